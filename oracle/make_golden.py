@@ -1,0 +1,176 @@
+"""Generate golden vectors from the REAL reference classes (run in the build container only).
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden.py
+
+Imports /root/reference/src with `nimblephysics` and `wandb` replaced by MagicMock (they are
+imported at module top by the reference but are not used by model / loss arithmetic; neither is
+installed here and there is no network).  Writes small .npz fixtures (data only: inputs are
+closed-form `det_fill` tensors, so only expected outputs are stored) into tests/golden/.
+The reference never travels to the GPU box; these fixtures do.
+
+TEST INFRASTRUCTURE ONLY.
+"""
+import argparse
+import os
+import sys
+from unittest.mock import MagicMock
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+from oracle.ref_cpu import K_COP, K_FORCE, K_TORQUE, K_WRENCH, det_fill  # noqa: E402
+from oracle.fixture_inputs import (FF_CASES, LOSS_SUBSETS, TL_CASES, det_state, ff_inputs,  # noqa: E402
+                                   ff_labels, loss_case_outputs)
+
+REF = os.environ.get("IB_REFERENCE", "/root/reference")
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def import_reference():
+    sys.modules["nimblephysics"] = MagicMock()
+    sys.modules["wandb"] = MagicMock()
+    sys.path.insert(0, os.path.join(REF, "src"))
+    from models.FeedForwardRegressionBaseline import FeedForwardBaseline
+    from models.TransformerBaseline import TransformerLayer
+    from loss.RegressionLossEvaluator import RegressionLossEvaluator
+    return FeedForwardBaseline, TransformerLayer, RegressionLossEvaluator
+
+
+def np_(t):
+    return t.detach().cpu().numpy().copy()
+
+
+def load_det_state(module, seed0=1.0):
+    sd = module.state_dict()
+    new = det_state({k: tuple(v.shape) for k, v in sd.items()}, seed0)
+    new = {k: v.to(sd[k].dtype) for k, v in new.items()}
+    module.load_state_dict(new)
+    return new
+
+
+def train_args(grf=range(6), cop=range(6), moment=range(6), wrench=range(12)):
+    a = argparse.Namespace()
+    a.predict_grf_components = list(grf)
+    a.predict_cop_components = list(cop)
+    a.predict_moment_components = list(moment)
+    a.predict_wrench_components = list(wrench)
+    return a
+
+
+def gen_feedforward(FF, RLE):
+    B, dofs, ncb = 4, 23, 2
+    for name, hist, stride, actn in FF_CASES:
+        F = hist // stride
+        model = FF(dofs, ncb, hist, "all_frames", actn, stride, 10, hidden_dims=[512, 512])
+        load_det_state(model)
+        inputs = ff_inputs(B, F, dofs, stride)
+        labels = ff_labels(B, F)
+        out = model({k: v.clone() for k, v in inputs.items()})
+        ev = RLE(dataset=None, split="train")
+        loss = ev({}, dict(out), {k: v.clone() for k, v in labels.items()}, [], [], train_args())
+        loss.backward()
+        d = {"meta_torch": np.array(torch.__version__), "loss": np_(loss)}
+        for k, v in out.items():
+            d["out/" + k] = np_(v)
+        d["metrics"] = np.array([ev.force_reported_metrics[0], ev.moment_reported_metrics[0],
+                                 ev.cop_reported_metrics[0], ev.wrench_reported_metrics[0],
+                                 ev.wrench_moment_reported_metrics[0], ev.com_acc_reported_metrics[0]])
+        for k, p in model.named_parameters():
+            d["gnorm/" + k] = np_(p.grad.norm())
+            d["gslice/" + k] = np_(p.grad.reshape(-1)[:64])
+        # one optimizer step of each kind the CLI offers (train.py:183-194), lr 1e-4 default (train.py:41)
+        sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+        grads = {k: p.grad.clone() for k, p in model.named_parameters()}
+        for opt_name, ctor in [("rmsprop", torch.optim.RMSprop), ("adam", torch.optim.Adam),
+                               ("sgd", torch.optim.SGD)]:
+            model.load_state_dict(sd0)
+            for k, p in model.named_parameters():
+                p.grad = grads[k].clone()
+            opt = ctor(model.parameters(), lr=1e-4)
+            opt.step()
+            for k, p in model.named_parameters():
+                d[f"step_{opt_name}/" + k] = np_(p.reshape(-1)[:64])
+        np.savez_compressed(os.path.join(OUT, f"ff_{name}.npz"), **d)
+        print("ff", name, float(loss.detach()))
+
+
+def gen_transformer_layer(TL):
+    for name, d, h, ffn, B, T, dt in TL_CASES:
+        layer = TL(d, h, ffn, 0.0, dtype=dt)
+        load_det_state(layer)
+        x = det_fill((B, T, d), 7, 1.0, dt).requires_grad_(True)
+        wout = det_fill((B, T, d), 8, 1.0, dt)
+        y = layer(x)
+        (y * wout).sum().backward()
+        dd = {"meta_torch": np.array(torch.__version__),
+              "y_sub": np_(y[:, ::7, ::5]), "y_sum": np_(y.sum()), "y_sq": np_((y * y).sum()),
+              "dx_sub": np_(x.grad[:, ::7, ::5]), "dx_norm": np_(x.grad.norm())}
+        if d <= 128:
+            dd["y_full"] = np_(y)
+            dd["dx_full"] = np_(x.grad)
+        for k, p in layer.named_parameters():
+            dd["gnorm/" + k] = np_(p.grad.norm())
+            dd["gslice/" + k] = np_(p.grad.reshape(-1)[:64])
+        np.savez_compressed(os.path.join(OUT, f"tl_{name}.npz"), **dd)
+        print("tl", name, float(y.sum()))
+
+
+def gen_loss(RLE):
+    B, F = 5, 7
+    outs = loss_case_outputs(B, F)
+    labels = ff_labels(B, F)
+    d = {"meta_torch": np.array(torch.__version__)}
+    subsets = {k: train_args(*v) for k, v in LOSS_SUBSETS.items()}
+    for name, a in subsets.items():
+        ev = RLE(dataset=None, split="dev")
+        o = {k: v.clone().requires_grad_(True) for k, v in outs.items()}
+        loss = ev({}, dict(o), {k: v.clone() for k, v in labels.items()}, [], [], a)
+        loss.backward()
+        d[f"{name}/loss"] = np_(loss)
+        d[f"{name}/force"] = np_(ev.force_losses[0])
+        d[f"{name}/moment"] = np_(ev.moment_losses[0])
+        d[f"{name}/wrench"] = np_(ev.wrench_losses[0])
+        d[f"{name}/cop"] = np_(ev.cop_losses[0])
+        d[f"{name}/metrics"] = np.array([ev.force_reported_metrics[0], ev.moment_reported_metrics[0],
+                                         ev.cop_reported_metrics[0], ev.wrench_reported_metrics[0],
+                                         ev.wrench_moment_reported_metrics[0], ev.com_acc_reported_metrics[0]])
+        for k, v in o.items():
+            d[f"{name}/grad/{k}"] = np_(v.grad if v.grad is not None else torch.zeros_like(v))
+    d["mask"] = np_(RLE.get_mask_by_threes(labels[K_FORCE], threshold=10.0))
+    np.savez_compressed(os.path.join(OUT, "loss_cases.npz"), **d)
+    print("loss ok")
+
+
+def gen_optim():
+    d = {"meta_torch": np.array(torch.__version__)}
+    ctors = {"sgd": torch.optim.SGD, "adam": torch.optim.Adam, "rmsprop": torch.optim.RMSprop,
+             "adagrad": torch.optim.Adagrad, "adadelta": torch.optim.Adadelta, "adamax": torch.optim.Adamax}
+    for name, ctor in ctors.items():
+        p = torch.nn.Parameter(det_fill((257,), 3, 0.5, torch.float64))
+        opt = ctor([p], lr=1e-2)
+        traj = []
+        for s in range(4):
+            p.grad = det_fill((257,), 20 + s, 0.3 * (s + 1), torch.float64)
+            opt.step()
+            traj.append(np_(p).copy())
+        d[name] = np.stack(traj)
+    np.savez_compressed(os.path.join(OUT, "optim_traj.npz"), **d)
+    print("optim ok")
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    torch.set_num_threads(4)
+    FF, TL, RLE = import_reference()
+    gen_feedforward(FF, RLE)
+    gen_transformer_layer(TL)
+    gen_loss(RLE)
+    gen_optim()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,473 @@
+"""CPU oracle: a torch-eager restatement of the reference's hot-path arithmetic.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``inferbiomechanics_amd/`` may import
+this module; only ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` do, and only as the checker / the timed
+CPU baseline, never as the product path.
+
+Every function is written as explicit tensor math (no ``torch.nn`` modules) and
+cites the reference file:line (relative to the reference repo root) whose
+arithmetic it restates.  Parity is PINNED: ``oracle/make_golden.py`` imports the
+real reference classes in the build container and writes golden vectors to
+``tests/golden/``; ``tests/test_oracle_golden.py`` checks this restatement
+against them.  The diffusion section (schedule, q_sample, eps-loss, DDIM,
+timestep embedding, denoiser wiring) has NO reference counterpart (SURVEY.md
+§0.1) -> "parity unpinned" by the reference for that section; it follows the
+DDPM (Ho et al. 2020) / DDIM (Song et al. 2021) definitions and is pinned only
+by literature known-answers in ``tests/test_oracle_golden.py``.
+
+All functions are dtype-generic: run in float64 for checking, float32 for the
+CPU-baseline timing.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+# --------------------------------------------------------------------------
+# tensor-dict contract (src/data/AddBiomechanicsDataset.py:9-42)
+# --------------------------------------------------------------------------
+INPUT_KEY_ORDER = [  # concat order: src/models/FeedForwardRegressionBaseline.py:97-107
+    "pos", "vel", "acc",
+    "rootLinearVelInRootFrame", "rootAngularVelInRootFrame",
+    "rootLinearAccInRootFrame", "rootAngularAccInRootFrame",
+    "jointCentersInRootFrame",
+    "rootPosHistoryInRootFrame", "rootEulerHistoryInRootFrame",
+]
+K_COP = "groundContactCenterOfPressureInRootFrame"
+K_FORCE = "groundContactForceInRootFrame"
+K_TORQUE = "groundContactTorqueInRootFrame"
+K_WRENCH = "groundContactWrenchesInRootFrame"
+
+
+def input_widths(num_dofs: int, stride: int) -> List[int]:
+    """Per-key channel widths asserted at FeedForwardRegressionBaseline.py:83-94."""
+    return [num_dofs, num_dofs, num_dofs, 3, 3, 3, 3, 36, 3 * stride, 3 * stride]
+
+
+def det_fill(shape: Sequence[int], seed: float, scale: float = 1.0,
+             dtype=torch.float64) -> torch.Tensor:
+    """Closed-form deterministic tensor (no RNG, no weight blobs in fixtures)."""
+    n = 1
+    for s in shape:
+        n *= int(s)
+    idx = torch.arange(n, dtype=torch.float64)
+    v = torch.sin(idx * 0.7390851332151607 + float(seed) * 1.6180339887498949)
+    v = v + 0.5 * torch.cos(idx * 0.2718281828459045 + float(seed))
+    return (scale * v).reshape(tuple(shape)).to(dtype)
+
+
+# --------------------------------------------------------------------------
+# activations (src/models/FeedForwardRegressionBaseline.py:7-11; silu is
+# BUILD-DEFINED, added for the diffusion blocks)
+# --------------------------------------------------------------------------
+def act(name: str, x: torch.Tensor) -> torch.Tensor:
+    if name == "relu":
+        return torch.clamp_min(x, 0)
+    if name == "tanh":
+        return torch.tanh(x)
+    if name == "sigmoid":
+        return 1.0 / (1.0 + torch.exp(-x))
+    if name == "silu":
+        return x / (1.0 + torch.exp(-x))
+    if name in ("none", "identity"):
+        return x
+    raise KeyError(name)
+
+
+def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor]) -> torch.Tensor:
+    """nn.Linear: y = x W^T + b, W is [out, in]."""
+    y = x @ w.transpose(-1, -2)
+    return y if b is None else y + b
+
+
+# --------------------------------------------------------------------------
+# FeedForwardBaseline (src/models/FeedForwardRegressionBaseline.py:20-121)
+# --------------------------------------------------------------------------
+def feedforward_sizes(num_dofs: int, num_contact_bodies: int, history_len: int, stride: int,
+                      output_data_format: str = "all_frames") -> Tuple[int, int, int]:
+    """input_size / output_size / num_output_frames: FeedForwardRegressionBaseline.py:52,61-62."""
+    frames = history_len // stride
+    input_size = (3 * num_dofs + 4 * 3 + 2 * stride * 3 + 12 * 3) * frames
+    nof = frames if output_data_format == "all_frames" else 1
+    output_size = num_contact_bodies * (3 * 3 + 6) * nof
+    return input_size, output_size, nof
+
+
+def feedforward_forward(layers: List[Tuple[torch.Tensor, torch.Tensor]],
+                        inputs: Dict[str, torch.Tensor], activation: str,
+                        num_output_frames: int) -> Dict[str, torch.Tensor]:
+    """forward(): FeedForwardRegressionBaseline.py:80-121 (no dropout / batchnorm: flags
+    default off, train.py:43,47).  ``layers`` = [(weight[out,in], bias[out]), ...]."""
+    x = torch.cat([inputs[k] for k in INPUT_KEY_ORDER], dim=-1)        # :97-107
+    B = x.shape[0]
+    x = x.reshape(B, -1)                                               # frame-major flatten
+    n = len(layers)
+    for i, (w, b) in enumerate(layers):                                # :68-75
+        x = linear(x, w, b)
+        if i < n - 1:
+            x = act(activation, x)
+    F = num_output_frames                                              # :116-121
+    return {
+        K_COP: x[:, 0 * F:6 * F].reshape(B, F, 6),
+        K_FORCE: x[:, 6 * F:12 * F].reshape(B, F, 6),
+        K_TORQUE: x[:, 12 * F:18 * F].reshape(B, F, 6),
+        K_WRENCH: x[:, 18 * F:30 * F].reshape(B, F, 12),
+    }
+
+
+# --------------------------------------------------------------------------
+# TransformerLayer (src/models/TransformerBaseline.py:8-38)
+# --------------------------------------------------------------------------
+def layer_norm(x: torch.Tensor, g: torch.Tensor, b: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    """nn.LayerNorm over the last dim, biased variance, eps 1e-5 (TransformerBaseline.py:21-22)."""
+    mu = x.mean(dim=-1, keepdim=True)
+    var = ((x - mu) ** 2).mean(dim=-1, keepdim=True)
+    return (x - mu) / torch.sqrt(var + eps) * g + b
+
+
+def mha_forward(x: torch.Tensor, in_w: torch.Tensor, in_b: torch.Tensor,
+                out_w: torch.Tensor, out_b: torch.Tensor, num_heads: int) -> torch.Tensor:
+    """nn.MultiheadAttention(batch_first=True) self-attention, no mask, dropout 0
+    (TransformerBaseline.py:12-13,29): packed in-proj [3d,d], per-head
+    softmax(QK^T/sqrt(d_h))V, out-proj."""
+    B, T, d = x.shape
+    dh = d // num_heads
+    qkv = linear(x, in_w, in_b)                                        # [B,T,3d]
+    q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
+    q = q.reshape(B, T, num_heads, dh).transpose(1, 2)                 # [B,H,T,dh]
+    k = k.reshape(B, T, num_heads, dh).transpose(1, 2)
+    v = v.reshape(B, T, num_heads, dh).transpose(1, 2)
+    s = (q @ k.transpose(-1, -2)) / math.sqrt(dh)
+    s = s - s.max(dim=-1, keepdim=True).values
+    p = torch.exp(s)
+    p = p / p.sum(dim=-1, keepdim=True)
+    o = (p @ v).transpose(1, 2).reshape(B, T, d)
+    return linear(o, out_w, out_b)
+
+
+TL_KEYS = [  # state_dict names of the reference TransformerLayer
+    "multihead_attention.in_proj_weight", "multihead_attention.in_proj_bias",
+    "multihead_attention.out_proj.weight", "multihead_attention.out_proj.bias",
+    "feedforward.0.weight", "feedforward.0.bias", "feedforward.2.weight", "feedforward.2.bias",
+    "norm1.weight", "norm1.bias", "norm2.weight", "norm2.bias",
+]
+
+
+def transformer_layer_forward(p: Dict[str, torch.Tensor], x: torch.Tensor, num_heads: int,
+                              prefix: str = "") -> torch.Tensor:
+    """TransformerLayer.forward: TransformerBaseline.py:24-38 (post-norm, ReLU FFN, dropout 0)."""
+    g = lambda k: p[prefix + k]
+    a = mha_forward(x, g("multihead_attention.in_proj_weight"), g("multihead_attention.in_proj_bias"),
+                    g("multihead_attention.out_proj.weight"), g("multihead_attention.out_proj.bias"),
+                    num_heads)
+    x = layer_norm(x + a, g("norm1.weight"), g("norm1.bias"))
+    f = linear(act("relu", linear(x, g("feedforward.0.weight"), g("feedforward.0.bias"))),
+               g("feedforward.2.weight"), g("feedforward.2.bias"))
+    return layer_norm(x + f, g("norm2.weight"), g("norm2.bias"))
+
+
+# --------------------------------------------------------------------------
+# RegressionLossEvaluator arithmetic (src/loss/RegressionLossEvaluator.py)
+# --------------------------------------------------------------------------
+def squared_diff_mean_vector(o: torch.Tensor, l: torch.Tensor) -> torch.Tensor:
+    """get_squared_diff_mean_vector: RegressionLossEvaluator.py:73-83."""
+    if o.shape != l.shape:
+        raise ValueError("Output and label tensors must have the same shape")
+    if o.dim() != 3:
+        raise ValueError("Output and label tensors must be 3-dimensional")
+    if o.numel() == 0:
+        raise ValueError("Output and label tensors must not be empty")
+    return ((o - l) ** 2).mean(dim=(0, 1))
+
+
+def mask_by_threes(t: torch.Tensor, threshold: float = 0.0) -> torch.Tensor:
+    """get_mask_by_threes: RegressionLossEvaluator.py:85-108 (strict '>')."""
+    if t.dim() != 3:
+        raise ValueError("Mask tensor must be 3-dimensional")
+    if t.numel() == 0:
+        raise ValueError("Mask tensor must not be empty")
+    if t.shape[-1] % 3 != 0:
+        raise ValueError("Mask tensor must have a final dimension divisible by 3")
+    with torch.no_grad():
+        r = t.reshape(t.shape[0], t.shape[1], -1, 3)
+        n = torch.sqrt((r * r).sum(dim=-1))
+        m = (n > threshold).to(t.dtype)
+        return m.unsqueeze(3).expand(-1, -1, -1, 3).reshape(t.shape)
+
+
+def mean_norm_error(o: torch.Tensor, l: torch.Tensor, vec_size: int = 3) -> torch.Tensor:
+    """get_mean_norm_error: RegressionLossEvaluator.py:119-141 (LAST FRAME ONLY, :136)."""
+    if o.shape != l.shape:
+        raise ValueError("Output and label tensors must have the same shape")
+    if o.dim() != 3:
+        raise ValueError("Output and label tensors must be 3-dimensional")
+    if o.numel() == 0:
+        raise ValueError("Output and label tensors must not be empty")
+    if o.shape[-1] % vec_size != 0:
+        raise ValueError("Tensors must have a final dimension divisible by vec_size=" + str(vec_size))
+    d = (o - l).reshape(o.shape[0], o.shape[1], -1, vec_size)[:, -1:, :, :]
+    return torch.sqrt((d * d).sum(dim=3)).mean()
+
+
+def com_acc_error(o: torch.Tensor, l: torch.Tensor) -> torch.Tensor:
+    """get_com_acc_error: RegressionLossEvaluator.py:143-158."""
+    if o.shape != l.shape:
+        raise ValueError("Output and label tensors must have the same shape")
+    if o.dim() != 3:
+        raise ValueError("Output and label tensors must be 3-dimensional")
+    if o.numel() == 0:
+        raise ValueError("Output and label tensors must not be empty")
+    if o.shape[-1] != 6:
+        raise ValueError("Output and label tensors must have a 6 dimensional final dimension")
+    return mean_norm_error(o[:, :, :3] + o[:, :, 3:], l[:, :, :3] + l[:, :, 3:], vec_size=3)
+
+
+def regression_loss(outputs: Dict[str, torch.Tensor], labels: Dict[str, torch.Tensor],
+                    grf: Sequence[int], cop: Sequence[int], moment: Sequence[int],
+                    wrench: Sequence[int]):
+    """RegressionLossEvaluator.__call__ steps 1-2.2: RegressionLossEvaluator.py:184-263.
+    Returns (loss, {force,moment,wrench,cop loss vectors}, {7 metrics})."""
+    force = squared_diff_mean_vector(outputs[K_FORCE], labels[K_FORCE])          # :184-188
+    mom = squared_diff_mean_vector(outputs[K_TORQUE], labels[K_TORQUE])          # :190-194
+    wr = squared_diff_mean_vector(outputs[K_WRENCH], labels[K_WRENCH])           # :198-202
+    mask = mask_by_threes(labels[K_FORCE], threshold=10.0)                       # :205-209
+    cp = squared_diff_mean_vector(outputs[K_COP] * mask, labels[K_COP] * mask)   # :210-214
+    idx = lambda v, i: v[list(i)].sum() if len(i) else v.new_zeros(())
+    loss = idx(force, grf) + idx(cp, cop) + idx(mom, moment) + idx(wr, wrench)   # :217-220
+    with torch.no_grad():                                                        # :230-263
+        m1 = mean_norm_error(outputs[K_WRENCH][:, :, :3], labels[K_WRENCH][:, :, :3], 3)
+        m2 = mean_norm_error(outputs[K_WRENCH][:, :, 6:9], labels[K_WRENCH][:, :, 6:9], 3)
+        metrics = {
+            "force": mean_norm_error(outputs[K_FORCE], labels[K_FORCE]),
+            "moment": mean_norm_error(outputs[K_TORQUE], labels[K_TORQUE]),
+            "cop": mean_norm_error(outputs[K_COP] * mask, labels[K_COP] * mask),
+            "wrench_moment": (m1 + m2) / 2.0,
+            "wrench": mean_norm_error(outputs[K_WRENCH], labels[K_WRENCH], vec_size=6),
+            "com_acc": com_acc_error(outputs[K_FORCE], labels[K_FORCE]),
+        }
+    return loss, {"force": force, "moment": mom, "wrench": wr, "cop": cp}, metrics
+
+
+# --------------------------------------------------------------------------
+# optimizers: torch.optim defaults with only lr set (src/cli/train.py:183-194).
+# The arithmetic lives in torch (third-party, torch~=2.1.0, requirements.txt:2);
+# restated from the published update rules and pinned by fixtures generated from
+# torch.optim itself.  state: dict of tensors, mutated in place; step is 1-based.
+# --------------------------------------------------------------------------
+def optim_init_state(opt: str, p: torch.Tensor) -> Dict[str, torch.Tensor]:
+    z = lambda: torch.zeros_like(p)
+    return {"sgd": {}, "adam": {"m": z(), "v": z()}, "rmsprop": {"sq": z()},
+            "adagrad": {"sum": z()}, "adadelta": {"sq": z(), "acc": z()},
+            "adamax": {"m": z(), "u": z()}}[opt]
+
+
+def optim_step(opt: str, p: torch.Tensor, g: torch.Tensor, st: Dict[str, torch.Tensor],
+               lr: float, step: int) -> torch.Tensor:
+    if opt == "sgd":
+        return p - lr * g
+    if opt == "adam":                       # betas (0.9, 0.999), eps 1e-8
+        b1, b2, eps = 0.9, 0.999, 1e-8
+        st["m"] = b1 * st["m"] + (1 - b1) * g
+        st["v"] = b2 * st["v"] + (1 - b2) * g * g
+        bc1, bc2 = 1 - b1 ** step, 1 - b2 ** step
+        denom = torch.sqrt(st["v"]) / math.sqrt(bc2) + eps
+        return p - (lr / bc1) * st["m"] / denom
+    if opt == "rmsprop":                    # alpha 0.99, eps 1e-8, momentum 0, not centered
+        a, eps = 0.99, 1e-8
+        st["sq"] = a * st["sq"] + (1 - a) * g * g
+        return p - lr * g / (torch.sqrt(st["sq"]) + eps)
+    if opt == "adagrad":                    # lr_decay 0, eps 1e-10, initial accumulator 0
+        st["sum"] = st["sum"] + g * g
+        return p - lr * g / (torch.sqrt(st["sum"]) + 1e-10)
+    if opt == "adadelta":                   # rho 0.9, eps 1e-6
+        rho, eps = 0.9, 1e-6
+        st["sq"] = rho * st["sq"] + (1 - rho) * g * g
+        delta = torch.sqrt(st["acc"] + eps) / torch.sqrt(st["sq"] + eps) * g
+        st["acc"] = rho * st["acc"] + (1 - rho) * delta * delta
+        return p - lr * delta
+    if opt == "adamax":                     # betas (0.9, 0.999), eps 1e-8
+        b1, b2, eps = 0.9, 0.999, 1e-8
+        st["m"] = b1 * st["m"] + (1 - b1) * g
+        st["u"] = torch.maximum(b2 * st["u"], g.abs() + eps)
+        return p - (lr / (1 - b1 ** step)) * st["m"] / st["u"]
+    raise KeyError(opt)
+
+
+# --------------------------------------------------------------------------
+# [BUILD-DEFINED] diffusion wrapper -- no reference counterpart.
+# DDPM linear schedule, eps-prediction loss, DDIM eta=0.
+# --------------------------------------------------------------------------
+def linear_beta_schedule(num_steps: int = 1000, beta_start: float = 1e-4,
+                         beta_end: float = 0.02) -> torch.Tensor:
+    return torch.linspace(beta_start, beta_end, num_steps, dtype=torch.float64)
+
+
+def alphas_cumprod(betas: torch.Tensor) -> torch.Tensor:
+    return torch.cumprod(1.0 - betas.to(torch.float64), dim=0)
+
+
+def schedule_tables(num_steps: int = 1000) -> Dict[str, torch.Tensor]:
+    """float64 tables; the product casts them ONCE to fp32 -> bit-exactness target."""
+    ab = alphas_cumprod(linear_beta_schedule(num_steps))
+    return {"alphas_cumprod": ab, "sqrt_ab": torch.sqrt(ab), "sqrt_1mab": torch.sqrt(1.0 - ab)}
+
+
+def ddim_timesteps(num_train_steps: int = 1000, num_sample_steps: int = 100) -> torch.Tensor:
+    """int64 descending subsequence: 990, 980, ..., 0 for (1000, 100)."""
+    stride = num_train_steps // num_sample_steps
+    return torch.arange(num_sample_steps - 1, -1, -1, dtype=torch.int64) * stride
+
+
+def q_sample(x0: torch.Tensor, t: torch.Tensor, eps: torch.Tensor,
+             tables: Dict[str, torch.Tensor]) -> torch.Tensor:
+    a = tables["sqrt_ab"].to(x0.dtype)[t].reshape(-1, 1, 1)
+    s = tables["sqrt_1mab"].to(x0.dtype)[t].reshape(-1, 1, 1)
+    return a * x0 + s * eps
+
+
+def timestep_embedding(t: torch.Tensor, dim: int, dtype=torch.float64,
+                       max_period: float = 10000.0) -> torch.Tensor:
+    """[sin(t*w_i), cos(t*w_i)], w_i = exp(-ln(max_period) * i / half), i = 0..half-1."""
+    half = dim // 2
+    w = torch.exp(-math.log(max_period) * torch.arange(half, dtype=torch.float64) / half)
+    a = t.to(torch.float64).reshape(-1, 1) * w.reshape(1, -1)
+    return torch.cat([torch.sin(a), torch.cos(a)], dim=-1).to(dtype)
+
+
+def eps_mse(pred: torch.Tensor, eps: torch.Tensor) -> torch.Tensor:
+    return ((pred - eps) ** 2).mean()
+
+
+def ddim_step(x_t: torch.Tensor, eps_pred: torch.Tensor, ab_t, ab_prev) -> torch.Tensor:
+    """eta = 0: x0 = (x_t - sqrt(1-ab_t) eps)/sqrt(ab_t);  x_prev = sqrt(ab_prev) x0 + sqrt(1-ab_prev) eps."""
+    ab_t = torch.as_tensor(ab_t, dtype=x_t.dtype)
+    ab_prev = torch.as_tensor(ab_prev, dtype=x_t.dtype)
+    x0 = (x_t - torch.sqrt(1 - ab_t) * eps_pred) / torch.sqrt(ab_t)
+    return torch.sqrt(ab_prev) * x0 + torch.sqrt(1 - ab_prev) * eps_pred
+
+
+def ddim_coeffs(num_train_steps: int = 1000, num_sample_steps: int = 100) -> torch.Tensor:
+    """Per-step (c_x, c_eps) so that x_prev = c_x * x_t + c_eps * eps (float64, [S,2])."""
+    ab = alphas_cumprod(linear_beta_schedule(num_train_steps))
+    ts = ddim_timesteps(num_train_steps, num_sample_steps)
+    out = []
+    for i, t in enumerate(ts.tolist()):
+        ab_t = ab[t]
+        ab_p = ab[ts[i + 1]] if i + 1 < len(ts) else torch.tensor(1.0, dtype=torch.float64)
+        cx = torch.sqrt(ab_p) / torch.sqrt(ab_t)
+        ce = torch.sqrt(1 - ab_p) - torch.sqrt(ab_p) * torch.sqrt(1 - ab_t) / torch.sqrt(ab_t)
+        out.append(torch.stack([cx, ce]))
+    return torch.stack(out)
+
+
+def time_mlp(p: Dict[str, torch.Tensor], t: torch.Tensor, temb_dim: int, dtype) -> torch.Tensor:
+    s = timestep_embedding(t, temb_dim, dtype)
+    u = act("silu", linear(s, p["time_mlp.0.weight"], p["time_mlp.0.bias"]))
+    return linear(u, p["time_mlp.2.weight"], p["time_mlp.2.bias"])
+
+
+def denoiser_mlp_forward(p: Dict[str, torch.Tensor], x_t: torch.Tensor, t: torch.Tensor,
+                         hidden: Sequence[int], temb_dim: int = 128) -> torch.Tensor:
+    """Token-wise MLP denoiser (BASELINE config 2):
+    e = time_mlp(t) [B, sum(hidden)]; per block i: h = LN(SiLU(W_i h + b_i + e[:, off_i:off_i+h_i]));
+    out = W_head h + b_head."""
+    e = time_mlp(p, t, temb_dim, x_t.dtype)
+    h, off = x_t, 0
+    for i, hd in enumerate(hidden):
+        z = linear(h, p[f"blocks.{i}.linear.weight"], p[f"blocks.{i}.linear.bias"]) \
+            + e[:, None, off:off + hd]
+        h = layer_norm(act("silu", z), p[f"blocks.{i}.norm.weight"], p[f"blocks.{i}.norm.bias"])
+        off += hd
+    return linear(h, p["head.weight"], p["head.bias"])
+
+
+def denoiser_transformer_forward(p: Dict[str, torch.Tensor], x_t: torch.Tensor, t: torch.Tensor,
+                                 num_layers: int, num_heads: int, temb_dim: int = 128) -> torch.Tensor:
+    """Transformer denoiser (BASELINE configs 3-5): in-proj over concat(x, pos_emb[frame]) (the
+    reference concatenates a learned per-frame embedding, TransformerBaseline.py:119-126) plus the
+    time embedding, `num_layers` reference TransformerLayers, out-proj."""
+    B, T, D = x_t.shape
+    e = time_mlp(p, t, temb_dim, x_t.dtype)                                  # [B, d_model]
+    pos = p["temporal_embedding.embedding.weight"][:T]                       # [T, pos_dim]
+    xin = torch.cat([x_t, pos.unsqueeze(0).expand(B, -1, -1)], dim=-1)
+    h = linear(xin, p["in_proj.weight"], p["in_proj.bias"]) + e[:, None, :]
+    for l in range(num_layers):
+        h = transformer_layer_forward(p, h, num_heads, prefix=f"transformer_layers.{l}.")
+    return linear(h, p["out_proj.weight"], p["out_proj.bias"])
+
+
+def denoiser_mlp_param_shapes(feat: int, hidden: Sequence[int], temb_dim: int = 128,
+                              temb_hidden: int = 512) -> Dict[str, Tuple[int, ...]]:
+    s: Dict[str, Tuple[int, ...]] = {
+        "time_mlp.0.weight": (temb_hidden, temb_dim), "time_mlp.0.bias": (temb_hidden,),
+        "time_mlp.2.weight": (sum(hidden), temb_hidden), "time_mlp.2.bias": (sum(hidden),),
+    }
+    prev = feat
+    for i, hd in enumerate(hidden):
+        s[f"blocks.{i}.linear.weight"] = (hd, prev)
+        s[f"blocks.{i}.linear.bias"] = (hd,)
+        s[f"blocks.{i}.norm.weight"] = (hd,)
+        s[f"blocks.{i}.norm.bias"] = (hd,)
+        prev = hd
+    s["head.weight"] = (feat, prev)
+    s["head.bias"] = (feat,)
+    return s
+
+
+def denoiser_transformer_param_shapes(feat: int, window: int, d_model: int = 512, ffn: int = 2048,
+                                      num_layers: int = 4, pos_dim: int = 30, temb_dim: int = 128,
+                                      temb_hidden: int = 512) -> Dict[str, Tuple[int, ...]]:
+    s: Dict[str, Tuple[int, ...]] = {
+        "time_mlp.0.weight": (temb_hidden, temb_dim), "time_mlp.0.bias": (temb_hidden,),
+        "time_mlp.2.weight": (d_model, temb_hidden), "time_mlp.2.bias": (d_model,),
+        "temporal_embedding.embedding.weight": (window, pos_dim),
+        "in_proj.weight": (d_model, feat + pos_dim), "in_proj.bias": (d_model,),
+    }
+    for l in range(num_layers):
+        pre = f"transformer_layers.{l}."
+        s[pre + "multihead_attention.in_proj_weight"] = (3 * d_model, d_model)
+        s[pre + "multihead_attention.in_proj_bias"] = (3 * d_model,)
+        s[pre + "multihead_attention.out_proj.weight"] = (d_model, d_model)
+        s[pre + "multihead_attention.out_proj.bias"] = (d_model,)
+        s[pre + "feedforward.0.weight"] = (ffn, d_model)
+        s[pre + "feedforward.0.bias"] = (ffn,)
+        s[pre + "feedforward.2.weight"] = (d_model, ffn)
+        s[pre + "feedforward.2.bias"] = (d_model,)
+        for n in ("norm1", "norm2"):
+            s[pre + n + ".weight"] = (d_model,)
+            s[pre + n + ".bias"] = (d_model,)
+    s["out_proj.weight"] = (feat, d_model)
+    s["out_proj.bias"] = (feat,)
+    return s
+
+
+def det_params(shapes: Dict[str, Tuple[int, ...]], dtype=torch.float64, seed0: float = 1.0
+               ) -> Dict[str, torch.Tensor]:
+    """Deterministic parameters: weights ~ det_fill scaled by 1/sqrt(fan_in), norm weights near 1."""
+    out = {}
+    for i, (k, shp) in enumerate(shapes.items()):
+        if k.endswith("norm.weight") or k.endswith("norm1.weight") or k.endswith("norm2.weight"):
+            out[k] = (1.0 + det_fill(shp, seed0 + i, 0.1)).to(dtype)
+        elif len(shp) == 1:
+            out[k] = det_fill(shp, seed0 + i, 0.05).to(dtype)
+        else:
+            out[k] = det_fill(shp, seed0 + i, 1.0 / math.sqrt(shp[-1])).to(dtype)
+    return out
+
+
+def ddim_sample(eps_fn, x_T: torch.Tensor, num_train_steps: int = 1000,
+                num_sample_steps: int = 100) -> torch.Tensor:
+    """The sampling loop: for t in ddim_timesteps: eps = eps_fn(x, t); x = ddim update."""
+    ab = alphas_cumprod(linear_beta_schedule(num_train_steps))
+    ts = ddim_timesteps(num_train_steps, num_sample_steps)
+    x = x_T
+    B = x.shape[0]
+    for i, t in enumerate(ts.tolist()):
+        tt = torch.full((B,), t, dtype=torch.int64)
+        eps = eps_fn(x, tt)
+        ab_p = ab[ts[i + 1]] if i + 1 < len(ts) else torch.tensor(1.0, dtype=torch.float64)
+        x = ddim_step(x, eps, ab[t].to(x.dtype), ab_p.to(x.dtype))
+    return x

@@ -1,0 +1,177 @@
+"""Pin the CPU oracle (oracle/ref_cpu.py) to golden vectors generated from the real reference
+classes by oracle/make_golden.py.  CPU only."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cpu as R
+from oracle.fixture_inputs import (FF_CASES, LOSS_SUBSETS, TL_CASES, det_state, ff_inputs, ff_labels,
+                                   loss_case_outputs)
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def close(a, b, rtol, atol=0.0):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = np.abs(a - b).max() if a.size else 0.0
+    tol = atol + rtol * max(np.abs(b).max(), 1e-30)
+    assert err <= tol, f"max err {err} > tol {tol}"
+
+
+def ff_state(hist, stride, dtype):
+    insz, outsz, _ = R.feedforward_sizes(23, 2, hist, stride)
+    dims = [insz, 512, 512, outsz]
+    shapes = {}
+    for i in range(3):
+        shapes[f"net.{2 * i}.weight"] = (dims[i + 1], dims[i])
+        shapes[f"net.{2 * i}.bias"] = (dims[i + 1],)
+    sd = det_state(shapes)
+    # the reference holds fp32 parameters: round through fp32 exactly as load_state_dict did
+    return {k: v.to(torch.float32).to(dtype) for k, v in sd.items()}
+
+
+@pytest.mark.parametrize("name,hist,stride,actn", FF_CASES)
+def test_feedforward_matches_reference(golden_dir, name, hist, stride, actn):
+    g = load(golden_dir, f"ff_{name}.npz")
+    dt = torch.float64
+    F = hist // stride
+    sd = {k: v.requires_grad_(True) for k, v in ff_state(hist, stride, dt).items()}
+    layers = [(sd[f"net.{2 * i}.weight"], sd[f"net.{2 * i}.bias"]) for i in range(3)]
+    inputs = {k: v.to(dt) for k, v in ff_inputs(4, F, 23, stride).items()}
+    labels = {k: v.to(dt) for k, v in ff_labels(4, F).items()}
+    out = R.feedforward_forward(layers, inputs, actn, F)
+    for k, v in out.items():
+        close(v.detach(), g["out/" + k], rtol=1e-4)  # fp32 reference vs f64 oracle
+    loss, parts, metrics = R.regression_loss(out, labels, range(6), range(6), range(6), range(12))
+    close(loss.detach(), g["loss"], rtol=2e-5)
+    close([metrics[k] for k in ("force", "moment", "cop", "wrench", "wrench_moment", "com_acc")],
+          g["metrics"], rtol=2e-5)
+    loss.backward()
+    for k, p in sd.items():
+        close(p.grad.norm(), g["gnorm/" + k], rtol=3e-4)
+        close(p.grad.reshape(-1)[:64], g["gslice/" + k], rtol=3e-4, atol=1e-6 * float(g["gnorm/" + k]))
+    for opt in ("rmsprop", "adam", "sgd"):
+        for k, p in sd.items():
+            p32 = p.detach().to(torch.float32)
+            g32 = p.grad.to(torch.float32)
+            st = R.optim_init_state(opt, p32)
+            new = R.optim_step(opt, p32, g32, st, 1e-4, 1)
+            close(new.reshape(-1)[:64], g[f"step_{opt}/" + k], rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize("name,d,h,ffn,B,T,dt", TL_CASES)
+def test_transformer_layer_matches_reference(golden_dir, name, d, h, ffn, B, T, dt):
+    g = load(golden_dir, f"tl_{name}.npz")
+    shapes = dict(zip(R.TL_KEYS, [(3 * d, d), (3 * d,), (d, d), (d,), (ffn, d), (ffn,), (d, ffn), (d,),
+                                  (d,), (d,), (d,), (d,)]))
+    sd = {k: v.to(dt).to(torch.float64).requires_grad_(True) for k, v in det_state(shapes).items()}
+    x = R.det_fill((B, T, d), 7, 1.0, dt).to(torch.float64).requires_grad_(True)
+    wout = R.det_fill((B, T, d), 8, 1.0, dt).to(torch.float64)
+    y = R.transformer_layer_forward(sd, x, h)
+    rt = 1e-9 if dt == torch.float64 else 3e-5
+    close(y.detach()[:, ::7, ::5], g["y_sub"], rtol=rt)
+    close(y.detach().sum(), g["y_sum"], rtol=rt, atol=rt * 100)
+    close((y * y).detach().sum(), g["y_sq"], rtol=rt)
+    (y * wout).sum().backward()
+    close(x.grad[:, ::7, ::5], g["dx_sub"], rtol=rt * 10)
+    close(x.grad.norm(), g["dx_norm"], rtol=rt * 10)
+    if "y_full" in g:
+        close(y.detach(), g["y_full"], rtol=rt)
+        close(x.grad, g["dx_full"], rtol=rt * 10)
+    for k, p in sd.items():
+        close(p.grad.norm(), g["gnorm/" + k], rtol=rt * 30)
+        close(p.grad.reshape(-1)[:64], g["gslice/" + k], rtol=rt * 30, atol=rt * 30 * float(g["gnorm/" + k]))
+
+
+@pytest.mark.parametrize("subset", list(LOSS_SUBSETS))
+def test_loss_evaluator_matches_reference(golden_dir, subset):
+    g = load(golden_dir, "loss_cases.npz")
+    dt = torch.float64
+    outs = {k: v.to(dt).requires_grad_(True) for k, v in loss_case_outputs().items()}
+    labels = {k: v.to(dt) for k, v in ff_labels(5, 7).items()}
+    grf, cop, mom, wr = LOSS_SUBSETS[subset]
+    loss, parts, metrics = R.regression_loss(outs, labels, grf, cop, mom, wr)
+    close(loss.detach(), g[f"{subset}/loss"], rtol=1e-5)
+    for k in ("force", "moment", "wrench", "cop"):
+        close(parts[k].detach(), g[f"{subset}/{k}"], rtol=1e-5)
+    close([metrics[k] for k in ("force", "moment", "cop", "wrench", "wrench_moment", "com_acc")],
+          g[f"{subset}/metrics"], rtol=1e-5)
+    loss.backward()
+    for k, v in outs.items():
+        gr = v.grad if v.grad is not None else torch.zeros_like(v)
+        close(gr, g[f"{subset}/grad/{k}"], rtol=1e-5, atol=1e-9)
+    close(R.mask_by_threes(labels[R.K_FORCE], 10.0), g["mask"], rtol=0)
+    # exact-threshold edge: norm == 10.0 is masked OUT, 10.0000001 is IN
+    m = R.mask_by_threes(labels[R.K_FORCE], 10.0)
+    assert m[0, 0, :3].sum() == 0 and m[0, 0, 3:].sum() == 3
+
+
+@pytest.mark.parametrize("opt", ["sgd", "adam", "rmsprop", "adagrad", "adadelta", "adamax"])
+def test_optimizers_match_torch_optim(golden_dir, opt):
+    g = load(golden_dir, "optim_traj.npz")
+    p = R.det_fill((257,), 3, 0.5)
+    st = R.optim_init_state(opt, p)
+    for s in range(4):
+        grad = R.det_fill((257,), 20 + s, 0.3 * (s + 1))
+        p = R.optim_step(opt, p, grad, st, 1e-2, s + 1)
+        close(p, g[opt][s], rtol=1e-12, atol=1e-14)
+
+
+# ---- diffusion known answers (no reference code: literature definitions) ----
+def test_schedule_known_answers():
+    ab = R.alphas_cumprod(R.linear_beta_schedule(1000))
+    assert ab.dtype == torch.float64
+    assert abs(ab[0].item() - 0.9999) < 1e-15
+    assert abs(ab[499].item() - 0.078587242881778235) < 1e-15
+    assert abs(ab[999].item() - 4.0358297653756761e-05) < 1e-18
+    ts = R.ddim_timesteps(1000, 100)
+    assert ts.dtype == torch.int64 and ts[0].item() == 990 and ts[-1].item() == 0 and len(ts) == 100
+    assert torch.equal(ts[:-1] - ts[1:], torch.full((99,), 10, dtype=torch.int64))
+
+
+def test_ddim_roundtrip_and_coeffs():
+    # with the true eps, one DDIM step to ab_prev = 1 returns x0 exactly
+    tabs = R.schedule_tables()
+    x0 = R.det_fill((2, 5, 7), 1)
+    eps = R.det_fill((2, 5, 7), 2)
+    t = torch.tensor([100, 900])
+    xt = R.q_sample(x0, t, eps, tabs)
+    for b in range(2):
+        back = R.ddim_step(xt[b], eps[b], tabs["alphas_cumprod"][t[b]], 1.0)
+        assert torch.allclose(back, x0[b], atol=1e-9)
+    co = R.ddim_coeffs(1000, 100)
+    ab = tabs["alphas_cumprod"]
+    xs = R.ddim_step(xt[0], eps[0], ab[990], ab[980])
+    assert torch.allclose(xs, co[0, 0] * xt[0] + co[0, 1] * eps[0], atol=1e-10)
+
+
+def test_timestep_embedding_known_answers():
+    e = R.timestep_embedding(torch.tensor([0, 1, 999]), 128)
+    assert e.shape == (3, 128)
+    assert torch.all(e[0, :64] == 0) and torch.all(e[0, 64:] == 1)
+    assert abs(e[1, 0].item() - math.sin(1.0)) < 1e-15 and abs(e[1, 64].item() - math.cos(1.0)) < 1e-15
+    w63 = math.exp(-math.log(10000.0) * 63 / 64)
+    assert abs(e[2, 63].item() - math.sin(999 * w63)) < 1e-12
+
+
+def test_denoisers_run_and_ddim_loop():
+    shp = R.denoiser_mlp_param_shapes(12, [16, 24], temb_dim=8, temb_hidden=16)
+    p = R.det_params(shp)
+    x = R.det_fill((3, 5, 12), 5)
+    t = torch.tensor([0, 10, 999])
+    y = R.denoiser_mlp_forward(p, x, t, [16, 24], temb_dim=8)
+    assert y.shape == x.shape and torch.isfinite(y).all()
+    shp = R.denoiser_transformer_param_shapes(12, 5, d_model=16, ffn=32, num_layers=2, pos_dim=3,
+                                              temb_dim=8, temb_hidden=16)
+    p2 = R.det_params(shp)
+    y2 = R.denoiser_transformer_forward(p2, x, t, 2, 4, temb_dim=8)
+    assert y2.shape == x.shape and torch.isfinite(y2).all()
+    out = R.ddim_sample(lambda xx, tt: R.denoiser_mlp_forward(p, xx, tt, [16, 24], temb_dim=8), x, 1000, 10)
+    assert out.shape == x.shape and torch.isfinite(out).all()
