@@ -1,0 +1,171 @@
+/* ib_hip.h -- C-ABI of the MI355X (gfx950) hot-path library `libib_hip.so`.
+ *
+ * The reference (jbejjani2022/InferBiomechanics) has NO FFI / native interface: its hot path is
+ * stock PyTorch ops called from Python.  Each entry point below therefore
+ * cites the reference call site whose torch op(s) it replaces (paths relative to the reference
+ * root).  Conventions ("[BUILD-DEFINED] C-ABI extension"):
+ *   - plain pointers + sizes only, no torch types; every pointer is a DEVICE pointer that the
+ *     caller (PyTorch) owns and that is only borrowed for the duration of the call;
+ *   - every call enqueues on `stream` (a hipStream_t; NULL = default stream) and returns without
+ *     synchronising; workspace is supplied by the caller; no global mutable state -> re-entrant;
+ *   - returns 0 on success, a negative IB_E_* code on error; never throws;
+ *   - `dtype` selects the STORAGE type of activations / weights operands: IB_F32 (parity mode,
+ *     exact-f32 MFMA) or IB_BF16 (throughput mode, bf16 storage, fp32 accumulate).  Bias, LayerNorm
+ *     affine, statistics, gradients of parameters, optimizer state are always fp32.
+ *   - all matrices are row-major with an explicit leading dimension (elements, not bytes).
+ */
+#ifndef IB_HIP_H
+#define IB_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* ib_stream_t; /* hipStream_t */
+
+enum { IB_F32 = 0, IB_BF16 = 1 };
+/* ACTIVATION_FUNCS: src/models/FeedForwardRegressionBaseline.py:7-11 (+ silu, build-defined) */
+enum { IB_ACT_NONE = 0, IB_ACT_RELU = 1, IB_ACT_TANH = 2, IB_ACT_SIGMOID = 3, IB_ACT_SILU = 4 };
+/* --opt-type choices: src/cli/train.py:183-194 */
+enum { IB_OPT_SGD = 0, IB_OPT_ADAM = 1, IB_OPT_RMSPROP = 2, IB_OPT_ADAGRAD = 3, IB_OPT_ADADELTA = 4,
+       IB_OPT_ADAMAX = 5 };
+enum { IB_OK = 0, IB_E_ARG = -1, IB_E_DTYPE = -2, IB_E_LAUNCH = -3, IB_E_WORKSPACE = -4,
+       IB_E_UNSUPPORTED = -5 };
+
+int ib_version(void);
+const char* ib_error_string(int code);
+
+/* ---- Linear family: nn.Linear fwd/bwd (FeedForwardRegressionBaseline.py:73,113;
+ *      TransformerBaseline.py:12-18,29,34) --------------------------------------------------- */
+
+/* y[M,N] = act( x[M,K] . w[N,K]^T + bias[N] + add_div[m / seg, :] + add_mod[m % seg, :] )
+ * bias / add_div / add_mod / z may be NULL.  z (if given) receives the pre-activation (needed for
+ * silu backward).  add_div broadcasts one row per window (the diffusion time embedding), add_mod one
+ * row per frame (the projected per-frame embedding, TransformerBaseline.py:119-126). */
+int ib_linear_fwd(const void* x, int64_t ldx, const void* w, int64_t ldw, const float* bias,
+                  const void* add_div, int64_t ld_add_div, const void* add_mod, int64_t ld_add_mod,
+                  int64_t seg, int act, void* y, int64_t ldy, void* z, int64_t ldz,
+                  int64_t M, int64_t N, int64_t K, int dtype, ib_stream_t stream);
+
+/* dx[M,K] = ( dz[M,N] . w[N,K] ) * act'(aux[M,K]) + addend[M,K]   (autograd of the layer BELOW and
+ * the residual-path gradient of the post-norm block fused in the epilogue).  aux = the lower layer's
+ * OUTPUT for relu/tanh/sigmoid, its PRE-activation for silu; ignored for IB_ACT_NONE.  addend may be
+ * NULL. */
+int ib_linear_dgrad(const void* dz, int64_t lddz, const void* w, int64_t ldw, int act_below,
+                    const void* aux, int64_t ldaux, const void* addend, int64_t ldadd, void* dx, int64_t lddx,
+                    int64_t M, int64_t N, int64_t K, int dtype, ib_stream_t stream);
+
+/* dw[N,K] (fp32) (+)= dz[M,N]^T . x[M,K]   split over M; partial slabs go to `workspace`
+ * (deterministic: slabs are summed in a fixed order by a second kernel, no float atomics). */
+size_t ib_linear_wgrad_workspace(int64_t M, int64_t N, int64_t K);
+int ib_linear_wgrad(const void* dz, int64_t lddz, const void* x, int64_t ldx, float* dw, int64_t lddw,
+                    int accumulate, void* workspace, size_t workspace_bytes,
+                    int64_t M, int64_t N, int64_t K, int dtype, ib_stream_t stream);
+
+/* out[s, n] (fp32) = sum over rows m of segment s of x[m, n]; mode 0: s = m / seg (M/seg segments,
+ * bias grads / per-window time-embedding grads), mode 1: s = m % seg (seg segments, per-frame
+ * embedding grads). */
+int ib_segment_colsum(const void* x, int64_t ldx, float* out, int64_t ldo, int64_t M, int64_t N,
+                      int64_t seg, int mode, int accumulate, int dtype, ib_stream_t stream);
+
+/* ---- LayerNorm (+ fused residual add / pre-activation): nn.LayerNorm, TransformerBaseline.py:21-22,31,36.
+ * v = act(x) (+ res);  y = (v - mean)/sqrt(var + eps) * gamma + beta;  mean/rstd [M] saved (fp32). */
+int ib_layernorm_fwd(const void* x, const void* res, int act, const float* gamma, const float* beta,
+                     void* y, float* mean, float* rstd, int64_t M, int64_t N, float eps, int dtype,
+                     ib_stream_t stream);
+/* dx = grad wrt x (through act), dres (optional, may alias nothing) = grad wrt res (= grad wrt v);
+ * dgamma/dbeta partials are written to `partial` [(2*nparts), N] fp32, then summed into dgamma/dbeta. */
+size_t ib_layernorm_bwd_workspace(int64_t M, int64_t N);
+int ib_layernorm_bwd(const void* dy, const void* x, const void* res, int act, const float* gamma,
+                     const float* mean, const float* rstd, void* dx, void* dres, float* dgamma,
+                     float* dbeta, int accumulate, void* workspace, size_t workspace_bytes,
+                     int64_t M, int64_t N, int dtype, ib_stream_t stream);
+
+/* ---- temporal self-attention: nn.MultiheadAttention core, TransformerBaseline.py:12-13,29.
+ * qkv [B, T, 3*H*dh] packed as the in-proj produces it (q | k | v, head h at columns h*dh..),
+ * out [B, T, H*dh];  softmax(q k^T / sqrt(dh)) v per (window, head); no mask.  lse [B,H,T] fp32. */
+int ib_attention_fwd(const void* qkv, void* out, float* lse, int64_t B, int64_t T, int64_t H,
+                     int64_t dh, int dtype, ib_stream_t stream);
+int ib_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
+                     int64_t B, int64_t T, int64_t H, int64_t dh, int dtype, ib_stream_t stream);
+
+/* ---- input packing: torch.concat x10 + reshape, FeedForwardRegressionBaseline.py:97-108.
+ * out[b, f, off_k + c] = cast(in_k[b, f, c]); inputs fp32 contiguous [B*F, width_k]. */
+int ib_concat_keys(const float* const* inputs, const int32_t* widths, int32_t nkeys, void* out,
+                   int64_t rows, int dtype_out, ib_stream_t stream);
+int ib_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, ib_stream_t stream);
+/* 2-D strided copy/cast (used to split the model output / refresh bf16 weight shadows) */
+int ib_cast2d(const void* src, int64_t lds, int src_dtype, void* dst, int64_t ldd, int dst_dtype,
+              int64_t rows, int64_t cols, ib_stream_t stream);
+
+/* ---- loss plugin: RegressionLossEvaluator.__call__ steps 1-2.2, src/loss/RegressionLossEvaluator.py:184-263.
+ * Each tensor is [B, F, C] with element (b,f,c) at ptr[b*bs + f*C + c] (bs = batch stride; the model
+ * output views of FeedForwardRegressionBaseline.py:116-121 have bs = 30*F).  C = 6,6,6,12 for
+ * cop, force, torque(moment), wrench; o_bs / g_bs are HOST arrays of the 4 batch strides in that order.  comp_w[30] = 0/1 selection of --predict-*-components in the
+ * order force[6], cop[6], moment[6], wrench[12] (RegressionLossEvaluator.py:217-220).
+ * result[64] fp32: [0] loss, [1..6] force vec, [7..12] cop vec, [13..18] moment vec, [19..30] wrench
+ * vec, [31..36] metrics force, moment, cop, wrench, wrench_moment, com_acc (last frame only, :136).
+ * grads (optional, same layout as the outputs, dtype `dtype`) = d loss / d output. */
+size_t ib_regression_loss_workspace(int64_t B, int64_t F);
+int ib_regression_loss(const void* o_cop, const void* o_force, const void* o_torque, const void* o_wrench,
+                       const int64_t* o_bs, const float* l_cop, const float* l_force, const float* l_torque,
+                       const float* l_wrench, const float* comp_w, float threshold, float* result,
+                       void* g_cop, void* g_force, void* g_torque, void* g_wrench, const int64_t* g_bs,
+                       void* workspace, size_t workspace_bytes, int64_t B, int64_t F, int dtype,
+                       ib_stream_t stream);
+
+/* diffusion eps-prediction loss [BUILD-DEFINED; no reference counterpart, SURVEY.md §0.1]:
+ * loss = mean((pred - target)^2) -> result[0]; dpred = 2 (pred - target) / n. */
+size_t ib_mse_loss_workspace(int64_t n);
+int ib_mse_loss(const void* pred, const void* target, void* dpred, float* result, void* workspace,
+                size_t workspace_bytes, int64_t n, int dtype, ib_stream_t stream);
+
+/* ---- optimizer step: torch.optim.{SGD,Adam,RMSprop,Adagrad,Adadelta,Adamax}(lr) defaults,
+ * src/cli/train.py:183-197,284.  One launch over a FLAT fp32 parameter buffer.  g is multiplied by
+ * grad_scale first (DDP mean = 1/world, train.py:175).  `step_dev` (optional, int32 device scalar)
+ * holds the 1-based step count (advance it with ib_counter_add BEFORE this call) and is used for
+ * the bias corrections, so a captured hipGraph replays correctly; if NULL, `step` (1-based) is used.  shadow (optional) receives bf16 copies of p. */
+int ib_optim_step(int opt, float* p, const float* g, float* s1, float* s2, int64_t n, float lr,
+                  float grad_scale, int32_t step, int32_t* step_dev, void* shadow_bf16,
+                  ib_stream_t stream);
+
+/* ---- diffusion wrapper [BUILD-DEFINED]: DDPM q_sample, DDIM eta=0 update, table gathers ----- */
+/* out[b, :] = table[idx[b], :]  (timestep-embedding rows; table computed in float64 on the host,
+ * cast once).  idx int64. */
+int ib_gather_rows(const float* table, const int64_t* idx, void* out, int64_t B, int64_t dim,
+                   int64_t table_rows, int dtype_out, ib_stream_t stream);
+/* x_t[b,:] = sqrt_ab[t[b]] * x0[b,:] + sqrt_1mab[t[b]] * eps[b,:]; per = T*D elements per window */
+int ib_q_sample(const void* x0, const void* eps, const int64_t* t, const float* sqrt_ab,
+                const float* sqrt_1mab, void* x_t, int64_t B, int64_t per, int64_t table_rows,
+                int dtype, ib_stream_t stream);
+/* x <- coef[s][0] * x + coef[s][1] * eps with s = *step_dev (or `step` if step_dev NULL).
+ * Also writes t_out[b] = timesteps[s+1] (the NEXT step's timestep, if t_out given) so a captured
+ * single-step graph can be replayed; ib_counter_add advances the counter. */
+int ib_ddim_step(void* x, const void* eps, const float* coef, const int64_t* timesteps,
+                 int64_t num_steps, int32_t step, const int32_t* step_dev, int64_t* t_out, int64_t B,
+                 int64_t n, int dtype, ib_stream_t stream);
+int ib_counter_add(int32_t* counter, int32_t delta, ib_stream_t stream);
+int ib_fill_i64(int64_t* dst, int64_t value, int64_t n, ib_stream_t stream);
+
+/* ---- hipGraph capture of a launch sequence (the captured denoise / train step) */
+int ib_graph_begin(ib_stream_t stream);
+int ib_graph_end(ib_stream_t stream, void** graph_exec_out);
+int ib_graph_launch(void* graph_exec, ib_stream_t stream);
+int ib_graph_destroy(void* graph_exec);
+
+/* ---- HIP-event timing on the launch stream (bench.py's roofline leg) ------------------------ */
+int ib_event_create(void** ev_out);
+int ib_event_record(void* ev, ib_stream_t stream);
+int ib_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms_out); /* synchronises on ev_stop */
+int ib_event_destroy(void* ev);
+
+/* ---- device self-tests of instruction-layout assumptions (tests only) ----------------------- */
+int ib_selftest_tr16(const void* in_bf16_64x16, void* out_bf16_64x4, ib_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IB_HIP_H */

@@ -1,0 +1,111 @@
+// [BUILD-DEFINED] diffusion wrapper kernels (no reference counterpart):
+// DDPM q_sample, DDIM (eta = 0) update, table gathers.  The schedule / coefficient / timestep-embedding
+// tables are computed in float64 on the host and cast ONCE to fp32 (bit-exactness target of §8c); these
+// kernels only index them, so noise-schedule and timestep indexing stay bit-exact.
+#include "ib_common.h"
+
+namespace {
+
+template <typename T>
+__global__ void gather_rows_kernel(const float* __restrict__ table, const int64_t* __restrict__ idx, T* __restrict__ out,
+                                   int64_t B, int64_t dim, int64_t table_rows) {
+  const int64_t n = B * dim;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = i / dim, d = i % dim;
+    int64_t r = idx[b];
+    r = r < 0 ? 0 : (r >= table_rows ? table_rows - 1 : r);
+    out[i] = ib_from_f32<T>(table[r * dim + d]);
+  }
+}
+
+template <typename T>
+__global__ void q_sample_kernel(const T* __restrict__ x0, const T* __restrict__ eps, const int64_t* __restrict__ t,
+                                const float* __restrict__ sqrt_ab, const float* __restrict__ sqrt_1mab, T* __restrict__ xt,
+                                int64_t B, int64_t per, int64_t table_rows) {
+  const int64_t n = B * per;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = i / per;
+    int64_t r = t[b];
+    r = r < 0 ? 0 : (r >= table_rows ? table_rows - 1 : r);
+    xt[i] = ib_from_f32<T>(sqrt_ab[r] * ib_to_f32(x0[i]) + sqrt_1mab[r] * ib_to_f32(eps[i]));
+  }
+}
+
+template <typename T>
+__global__ void ddim_step_kernel(T* __restrict__ x, const T* __restrict__ eps, const float* __restrict__ coef,
+                                 const int64_t* __restrict__ timesteps, int64_t num_steps, int step,
+                                 const int32_t* __restrict__ step_dev, int64_t* __restrict__ t_out, int64_t B, int64_t n) {
+  int s = step_dev ? *step_dev : step;
+  s = s < 0 ? 0 : (s >= num_steps ? (int)num_steps - 1 : s);
+  const float cx = coef[2 * s], ce = coef[2 * s + 1];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    x[i] = ib_from_f32<T>(cx * ib_to_f32(x[i]) + ce * ib_to_f32(eps[i]));
+  if (t_out && blockIdx.x == 0) {
+    const int64_t tn = (s + 1 < num_steps) ? timesteps[s + 1] : 0;
+    for (int64_t b = threadIdx.x; b < B; b += blockDim.x) t_out[b] = tn;
+  }
+}
+
+__global__ void counter_add_kernel(int32_t* c, int32_t d) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *c += d;
+}
+__global__ void fill_i64_kernel(int64_t* dst, int64_t v, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = v;
+}
+
+}  // namespace
+
+extern "C" int ib_gather_rows(const float* table, const int64_t* idx, void* out, int64_t B, int64_t dim,
+                              int64_t table_rows, int dtype_out, ib_stream_t stream) {
+  if (!table || !idx || !out || B <= 0 || dim <= 0 || table_rows <= 0) return IB_E_ARG;
+  const int grid = ib_grid_1d(B * dim, 256);
+  if (dtype_out == IB_F32)
+    hipLaunchKernelGGL((gather_rows_kernel<float>), dim3(grid), dim3(256), 0, ib_s(stream), table, idx, (float*)out, B, dim, table_rows);
+  else if (dtype_out == IB_BF16)
+    hipLaunchKernelGGL((gather_rows_kernel<bf16_t>), dim3(grid), dim3(256), 0, ib_s(stream), table, idx, (bf16_t*)out, B, dim, table_rows);
+  else return IB_E_DTYPE;
+  IB_CHECK_LAUNCH();
+  return IB_OK;
+}
+
+extern "C" int ib_q_sample(const void* x0, const void* eps, const int64_t* t, const float* sqrt_ab, const float* sqrt_1mab,
+                           void* x_t, int64_t B, int64_t per, int64_t table_rows, int dtype, ib_stream_t stream) {
+  if (!x0 || !eps || !t || !sqrt_ab || !sqrt_1mab || !x_t || B <= 0 || per <= 0 || table_rows <= 0) return IB_E_ARG;
+  const int grid = ib_grid_1d(B * per, 256);
+  if (dtype == IB_F32)
+    hipLaunchKernelGGL((q_sample_kernel<float>), dim3(grid), dim3(256), 0, ib_s(stream), (const float*)x0, (const float*)eps, t, sqrt_ab, sqrt_1mab, (float*)x_t, B, per, table_rows);
+  else if (dtype == IB_BF16)
+    hipLaunchKernelGGL((q_sample_kernel<bf16_t>), dim3(grid), dim3(256), 0, ib_s(stream), (const bf16_t*)x0, (const bf16_t*)eps, t, sqrt_ab, sqrt_1mab, (bf16_t*)x_t, B, per, table_rows);
+  else return IB_E_DTYPE;
+  IB_CHECK_LAUNCH();
+  return IB_OK;
+}
+
+extern "C" int ib_ddim_step(void* x, const void* eps, const float* coef, const int64_t* timesteps, int64_t num_steps,
+                            int32_t step, const int32_t* step_dev, int64_t* t_out, int64_t B, int64_t n, int dtype,
+                            ib_stream_t stream) {
+  if (!x || !eps || !coef || num_steps <= 0 || n <= 0) return IB_E_ARG;
+  if (t_out && (!timesteps || B <= 0)) return IB_E_ARG;
+  const int grid = ib_grid_1d(n, 256);
+  if (dtype == IB_F32)
+    hipLaunchKernelGGL((ddim_step_kernel<float>), dim3(grid), dim3(256), 0, ib_s(stream), (float*)x, (const float*)eps, coef, timesteps, num_steps, step, step_dev, t_out, B, n);
+  else if (dtype == IB_BF16)
+    hipLaunchKernelGGL((ddim_step_kernel<bf16_t>), dim3(grid), dim3(256), 0, ib_s(stream), (bf16_t*)x, (const bf16_t*)eps, coef, timesteps, num_steps, step, step_dev, t_out, B, n);
+  else return IB_E_DTYPE;
+  IB_CHECK_LAUNCH();
+  return IB_OK;
+}
+
+extern "C" int ib_counter_add(int32_t* counter, int32_t delta, ib_stream_t stream) {
+  if (!counter) return IB_E_ARG;
+  hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(64), 0, ib_s(stream), counter, delta);
+  IB_CHECK_LAUNCH();
+  return IB_OK;
+}
+
+extern "C" int ib_fill_i64(int64_t* dst, int64_t value, int64_t n, ib_stream_t stream) {
+  if (!dst || n <= 0) return IB_E_ARG;
+  hipLaunchKernelGGL(fill_i64_kernel, dim3(ib_grid_1d(n, 256)), dim3(256), 0, ib_s(stream), dst, value, n);
+  IB_CHECK_LAUNCH();
+  return IB_OK;
+}

@@ -1,0 +1,446 @@
+// Linear-layer GEMMs for gfx950: one LDS-tiled MFMA kernel family, three operand layouts.
+//
+//   C[i][j] = sum_k A(i,k) * B(j,k)            128 x 128 output tile per 256-thread workgroup,
+//                                              4 waves as 2x2, each wave 64x64 = 4x4 MFMA 16x16 tiles
+//   fwd   : A = x  [M,K]  (k-contiguous), B = w  [N,K] (k-contiguous)     y  = act(x w^T + ...)
+//   dgrad : A = dz [M,N]  (k-contiguous), B = w  [N,K] (k-STRIDED)        dx = (dz w) * act'(aux)
+//   wgrad : A = dz [M,N]  (k-STRIDED)   , B = x  [M,K] (k-STRIDED)        dw = dz^T x   (split over M)
+//
+// dtype f32  : v_mfma_f32_16x16x4_f32  (exact f32 fma chain -> the parity mode)
+// dtype bf16 : v_mfma_f32_16x16x32_bf16, fp32 accumulate (the throughput mode)
+//
+// LDS images keep the GLOBAL orientation of each operand (so staging is always 16-byte pieces,
+// coalesced along the contiguous dimension): k-contiguous operands as [row][k], k-strided operands
+// as [k][row].  bf16 fragments of a [k][row] image are read with ds_read_b64_tr_b16 (the hardware
+// transposing read), everything else with ds_read_b128 / ds_read_b32.
+// The MFMA is issued "swapped" (a = B-tile rows, b = A-tile rows) so that each lane ends up with
+// 4 CONSECUTIVE output columns of one output row -> 8/16-byte epilogue stores and bias loads.
+#include "ib_common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, NTHREADS = 256;
+constexpr int OPER_BYTES = 18432;  // one operand tile image (max over layouts / dtypes)
+
+template <typename T> struct Tile;
+template <> struct Tile<float> {
+  static constexpr int BK = 32, VW = 4, KC_STRIDE = 34, KS_STRIDE = 144;
+};
+template <> struct Tile<bf16_t> {
+  static constexpr int BK = 64, VW = 8, KC_STRIDE = 72, KS_STRIDE = 144;
+};
+
+enum { EPI_FWD = 0, EPI_DGRAD = 1, EPI_WGRAD = 2 };
+
+struct GemmParams {
+  const void* A; const void* B; int64_t lda, ldb;
+  int M, N, K;                 // C is [M,N]; K is the reduction length
+  void* C; int64_t ldc;
+  void* Z; int64_t ldz;        // fwd: optional pre-activation output
+  const float* bias;
+  const void* add_div; int64_t ld_add_div;
+  const void* add_mod; int64_t ld_add_mod;
+  int seg;
+  const void* aux; int64_t ldaux;  // dgrad: activation-derivative operand
+  const void* addend; int64_t ldadd;  // dgrad: residual-path gradient added in the epilogue
+  int act;
+  int vecA, vecB, vecC;
+  int tiles_n;
+  int k_chunk;                 // split over the reduction (wgrad): blockIdx.y * k_chunk
+  int64_t slab_stride;         // wgrad: elements between partial slabs (0 when not split)
+  int accumulate;
+};
+
+template <typename T>
+__device__ __forceinline__ uint4 load_piece(const T* p, int nvalid, bool vec) {
+  constexpr int VW = Tile<T>::VW;
+  uint4 r = make_uint4(0u, 0u, 0u, 0u);
+  if (nvalid >= VW && vec) {
+    __builtin_memcpy(&r, __builtin_assume_aligned(p, 4), 16);
+  } else if (nvalid > 0) {
+    T tmp[VW];
+#pragma unroll
+    for (int e = 0; e < VW; ++e) tmp[e] = static_cast<T>(0.f);
+#pragma unroll
+    for (int e = 0; e < VW; ++e)
+      if (e < nvalid) tmp[e] = p[e];
+    __builtin_memcpy(&r, tmp, 16);
+  }
+  return r;
+}
+
+// global -> registers: 4 x 16-byte pieces per thread per operand tile
+template <typename T, bool KC>
+__device__ __forceinline__ void load_tile(const T* base, int64_t ld, int row0, int rows_total, int k0,
+                                          int k_end, bool vec, uint4 (&r)[4], int tid) {
+  constexpr int VW = Tile<T>::VW;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int p = tid + NTHREADS * q;
+    if (KC) {
+      const int row = p >> 3, kc = p & 7;
+      const int gr = row0 + row, gk = k0 + kc * VW;
+      const int nvalid = (gr < rows_total) ? min(VW, k_end - gk) : 0;
+      r[q] = load_piece<T>(base + (int64_t)gr * ld + gk, nvalid, vec);
+    } else {
+      constexpr int RG = 128 / VW;
+      const int kk = p / RG, rg = p % RG;
+      const int gk = k0 + kk, gr = row0 + rg * VW;
+      const int nvalid = (gk < k_end) ? min(VW, rows_total - gr) : 0;
+      r[q] = load_piece<T>(base + (int64_t)gk * ld + gr, nvalid, vec);
+    }
+  }
+}
+
+// registers -> LDS image
+template <typename T, bool KC>
+__device__ __forceinline__ void store_tile(unsigned char* tile, const uint4 (&r)[4], int tid) {
+  constexpr int VW = Tile<T>::VW;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int p = tid + NTHREADS * q;
+    if (KC) {
+      const int row = p >> 3, kc = p & 7;
+      const int byte = (row * Tile<T>::KC_STRIDE + kc * VW) * (int)sizeof(T);
+      if (sizeof(T) == 2) {
+        *reinterpret_cast<uint4*>(tile + byte) = r[q];
+      } else {  // 136-byte rows: only 8-byte aligned
+        *reinterpret_cast<uint2*>(tile + byte) = make_uint2(r[q].x, r[q].y);
+        *reinterpret_cast<uint2*>(tile + byte + 8) = make_uint2(r[q].z, r[q].w);
+      }
+    } else {
+      constexpr int RG = 128 / VW;
+      const int kk = p / RG, rg = p % RG;
+      const int byte = (kk * Tile<T>::KS_STRIDE + rg * VW) * (int)sizeof(T);
+      *reinterpret_cast<uint4*>(tile + byte) = r[q];
+    }
+  }
+}
+
+typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
+
+// bf16 fragment: 8 consecutive k of tile row (rbase + lane%16), k = kbase + 8*(lane/16) + j
+template <bool KC>
+__device__ __forceinline__ bf16x8_t read_frag_bf16(const unsigned char* tile, int rbase, int kbase, int lane) {
+  if (KC) {
+    const int off = ((rbase + (lane & 15)) * Tile<bf16_t>::KC_STRIDE + kbase + 8 * (lane >> 4)) * 2;
+    return *reinterpret_cast<const bf16x8_t*>(tile + off);
+  } else {
+    // [k][row] image; transposing read: lane 4q+p of a 16-lane group addresses row (k) q,
+    // columns 4p..4p+3, and receives column (lane%16) of the 4 rows.
+    const int q = (lane & 15) >> 2, pp = lane & 3;
+    const int kr = kbase + 8 * (lane >> 4) + q;
+    const bf16_t* a0 = reinterpret_cast<const bf16_t*>(tile) + kr * Tile<bf16_t>::KS_STRIDE + rbase + 4 * pp;
+    s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(a0));
+    s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(a0 + 4 * Tile<bf16_t>::KS_STRIDE));
+    typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+    s16x8_t v;
+    v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+    v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+    return __builtin_bit_cast(bf16x8_t, v);
+  }
+}
+
+template <bool KC>
+__device__ __forceinline__ float read_frag_f32(const unsigned char* tile, int rbase, int kbase, int lane) {
+  const float* t = reinterpret_cast<const float*>(tile);
+  if (KC) return t[(rbase + (lane & 15)) * Tile<float>::KC_STRIDE + kbase + (lane >> 4)];
+  return t[(kbase + (lane >> 4)) * Tile<float>::KS_STRIDE + rbase + (lane & 15)];
+}
+
+template <typename T, bool A_KC, bool B_KC>
+__device__ __forceinline__ void compute_tile(const unsigned char* tA, const unsigned char* tB,
+                                             f32x4_t (&acc)[4][4], int lane, int wi, int wj) {
+  if constexpr (sizeof(T) == 2) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8_t fa[4], fb[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) fa[t] = read_frag_bf16<A_KC>(tA, wi * 64 + 16 * t, ks * 32, lane);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) fb[u] = read_frag_bf16<B_KC>(tB, wj * 64 + 16 * u, ks * 32, lane);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[u], fa[t], acc[t][u], 0, 0, 0);
+    }
+  } else {
+#pragma unroll
+    for (int kk = 0; kk < Tile<float>::BK / 4; ++kk) {
+      float fa[4], fb[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) fa[t] = read_frag_f32<A_KC>(tA, wi * 64 + 16 * t, kk * 4, lane);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) fb[u] = read_frag_f32<B_KC>(tB, wj * 64 + 16 * u, kk * 4, lane);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[u], fa[t], acc[t][u], 0, 0, 0);
+    }
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ void store4(T* p, const float (&v)[4], int nv, bool vec) {
+  if (nv == 4 && vec) {
+    if constexpr (sizeof(T) == 2) {
+      bf16x4_t o;
+      o[0] = static_cast<bf16_t>(v[0]); o[1] = static_cast<bf16_t>(v[1]);
+      o[2] = static_cast<bf16_t>(v[2]); o[3] = static_cast<bf16_t>(v[3]);
+      *reinterpret_cast<bf16x4_t*>(p) = o;
+    } else {
+      *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (r < nv) p[r] = ib_from_f32<T>(v[r]);
+  }
+}
+
+template <typename T, bool A_KC, bool B_KC, int EPI>
+__global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmParams p) {
+  constexpr int BK = Tile<T>::BK;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * OPER_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wi = wave >> 1, wj = wave & 1;
+  const int bid = ib_xcd_remap(blockIdx.x, gridDim.x);
+  const int ti = bid / p.tiles_n, tj = bid % p.tiles_n;
+  const int i0 = ti * BM, j0 = tj * BN;
+  const int kb = blockIdx.y * p.k_chunk;
+  const int ke = min(p.K, kb + p.k_chunk);
+  const int nk = (ke - kb + BK - 1) / BK;
+  const T* A = reinterpret_cast<const T*>(p.A);
+  const T* B = reinterpret_cast<const T*>(p.B);
+
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc[t][u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  uint4 ra[4], rb[4];
+  if (nk > 0) {
+    load_tile<T, A_KC>(A, p.lda, i0, p.M, kb, ke, p.vecA, ra, tid);
+    load_tile<T, B_KC>(B, p.ldb, j0, p.N, kb, ke, p.vecB, rb, tid);
+  }
+  for (int kt = 0; kt < nk; ++kt) {
+    unsigned char* tA = smem + (kt & 1) * 2 * OPER_BYTES;
+    unsigned char* tB = tA + OPER_BYTES;
+    store_tile<T, A_KC>(tA, ra, tid);
+    store_tile<T, B_KC>(tB, rb, tid);
+    __syncthreads();
+    if (kt + 1 < nk) {
+      const int k0 = kb + (kt + 1) * BK;
+      load_tile<T, A_KC>(A, p.lda, i0, p.M, k0, ke, p.vecA, ra, tid);
+      load_tile<T, B_KC>(B, p.ldb, j0, p.N, k0, ke, p.vecB, rb, tid);
+    }
+    compute_tile<T, A_KC, B_KC>(tA, tB, acc, lane, wi, wj);
+  }
+
+  // ---- epilogue: lane holds C[i][jb..jb+3] for 16 (t,u) sub-tiles
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int i = i0 + wi * 64 + 16 * t + (lane & 15);
+    if (i >= p.M) continue;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int jb = j0 + wj * 64 + 16 * u + 4 * (lane >> 4);
+      if (jb >= p.N) continue;
+      const int nv = min(4, p.N - jb);
+      float v[4] = {acc[t][u][0], acc[t][u][1], acc[t][u][2], acc[t][u][3]};
+      if constexpr (EPI == EPI_FWD) {
+        const T* ad = reinterpret_cast<const T*>(p.add_div);
+        const T* am = reinterpret_cast<const T*>(p.add_mod);
+        const int64_t rd = ad ? (int64_t)(i / p.seg) * p.ld_add_div : 0;
+        const int64_t rm = am ? (int64_t)(i % p.seg) * p.ld_add_mod : 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (r < nv) {
+            const int j = jb + r;
+            if (p.bias) v[r] += p.bias[j];
+            if (ad) v[r] += ib_to_f32(ad[rd + j]);
+            if (am) v[r] += ib_to_f32(am[rm + j]);
+          }
+        }
+        if (p.Z) store4<T>(reinterpret_cast<T*>(p.Z) + (int64_t)i * p.ldz + jb, v, nv, p.vecC);
+        if (p.act != IB_ACT_NONE) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = ib_act_fwd(p.act, v[r]);
+        }
+        store4<T>(reinterpret_cast<T*>(p.C) + (int64_t)i * p.ldc + jb, v, nv, p.vecC);
+      } else if constexpr (EPI == EPI_DGRAD) {
+        if (p.act != IB_ACT_NONE) {
+          const T* aux = reinterpret_cast<const T*>(p.aux) + (int64_t)i * p.ldaux + jb;
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (r < nv) v[r] *= ib_act_bwd(p.act, ib_to_f32(aux[r]));
+        }
+        if (p.addend) {
+          const T* ad = reinterpret_cast<const T*>(p.addend) + (int64_t)i * p.ldadd + jb;
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (r < nv) v[r] += ib_to_f32(ad[r]);
+        }
+        store4<T>(reinterpret_cast<T*>(p.C) + (int64_t)i * p.ldc + jb, v, nv, p.vecC);
+      } else {
+        float* c = reinterpret_cast<float*>(p.C) + (int64_t)blockIdx.y * p.slab_stride + (int64_t)i * p.ldc + jb;
+        if (p.accumulate && p.slab_stride == 0) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (r < nv) v[r] += c[r];
+        }
+        store4<float>(c, v, nv, p.vecC);
+      }
+    }
+  }
+}
+
+// out[e] (+)= sum_s slab[s][e]   (fixed order -> bitwise reproducible)
+__global__ void slab_reduce_kernel(const float* __restrict__ slabs, int nslab, int64_t slab_stride, float* out,
+                                   int64_t ldo, int rows, int cols, int accumulate) {
+  const int64_t n = (int64_t)rows * cols;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int k = 0; k < nslab; ++k) s += slabs[(int64_t)k * slab_stride + e];
+    const int r = (int)(e / cols), c = (int)(e % cols);
+    float* o = out + (int64_t)r * ldo + c;
+    *o = accumulate ? (*o + s) : s;
+  }
+}
+
+inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+template <typename T> bool vec_load_ok(const void* p, int64_t ld) {
+  return aligned(p, 4) && ((ld * (int64_t)sizeof(T)) % 4 == 0);
+}
+template <typename T> bool vec_store_ok(const void* p, int64_t ld) {
+  return aligned(p, 4 * sizeof(T)) && (ld % 4 == 0);
+}
+
+int wgrad_split(int64_t M, int64_t N, int64_t K, int bk, int* chunk_out) {
+  // reduction length is M; output tiles over [N, K]
+  const int64_t tiles = ((N + BM - 1) / BM) * ((K + BN - 1) / BN);
+  int64_t want = (512 + tiles - 1) / tiles;  // ~2 workgroups per CU
+  if (want < 1) want = 1;
+  if (want > 32) want = 32;
+  int64_t chunk = (M + want - 1) / want;
+  chunk = ((chunk + 63) / 64) * 64;  // multiple of both BKs
+  if (chunk < 64) chunk = 64;
+  const int64_t split = (M + chunk - 1) / chunk;
+  (void)bk;
+  *chunk_out = (int)chunk;
+  return (int)split;
+}
+
+template <typename T>
+int launch_fwd(GemmParams& p, hipStream_t s) {
+  p.vecA = vec_load_ok<T>(p.A, p.lda);
+  p.vecB = vec_load_ok<T>(p.B, p.ldb);
+  p.vecC = vec_store_ok<T>(p.C, p.ldc) && (!p.Z || vec_store_ok<T>(p.Z, p.ldz));
+  p.tiles_n = (p.N + BN - 1) / BN;
+  p.k_chunk = p.K; p.slab_stride = 0;
+  const int tiles = ((p.M + BM - 1) / BM) * p.tiles_n;
+  hipLaunchKernelGGL((gemm_kernel<T, true, true, EPI_FWD>), dim3(tiles, 1), dim3(NTHREADS), 0, s, p);
+  IB_CHECK_LAUNCH();
+  return IB_OK;
+}
+
+template <typename T>
+int launch_dgrad(GemmParams& p, hipStream_t s) {
+  p.vecA = vec_load_ok<T>(p.A, p.lda);
+  p.vecB = vec_load_ok<T>(p.B, p.ldb);
+  p.vecC = vec_store_ok<T>(p.C, p.ldc);
+  p.tiles_n = (p.N + BN - 1) / BN;
+  p.k_chunk = p.K; p.slab_stride = 0;
+  const int tiles = ((p.M + BM - 1) / BM) * p.tiles_n;
+  hipLaunchKernelGGL((gemm_kernel<T, true, false, EPI_DGRAD>), dim3(tiles, 1), dim3(NTHREADS), 0, s, p);
+  IB_CHECK_LAUNCH();
+  return IB_OK;
+}
+
+}  // namespace
+
+extern "C" int ib_linear_fwd(const void* x, int64_t ldx, const void* w, int64_t ldw, const float* bias,
+                             const void* add_div, int64_t ld_add_div, const void* add_mod,
+                             int64_t ld_add_mod, int64_t seg, int act, void* y, int64_t ldy, void* z,
+                             int64_t ldz, int64_t M, int64_t N, int64_t K, int dtype, ib_stream_t stream) {
+  if (!x || !w || !y || M <= 0 || N <= 0 || K <= 0 || ldx < K || ldw < K || ldy < N) return IB_E_ARG;
+  if ((add_div || add_mod) && seg <= 0) return IB_E_ARG;
+  if (z && ldz < N) return IB_E_ARG;
+  if (act < IB_ACT_NONE || act > IB_ACT_SILU) return IB_E_ARG;
+  GemmParams p{};
+  p.A = x; p.lda = ldx; p.B = w; p.ldb = ldw; p.M = (int)M; p.N = (int)N; p.K = (int)K;
+  p.C = y; p.ldc = ldy; p.Z = z; p.ldz = ldz; p.bias = bias;
+  p.add_div = add_div; p.ld_add_div = ld_add_div; p.add_mod = add_mod; p.ld_add_mod = ld_add_mod;
+  p.seg = (int)(seg > 0 ? seg : 1); p.act = act;
+  if (dtype == IB_F32) return launch_fwd<float>(p, ib_s(stream));
+  if (dtype == IB_BF16) return launch_fwd<bf16_t>(p, ib_s(stream));
+  return IB_E_DTYPE;
+}
+
+extern "C" int ib_linear_dgrad(const void* dz, int64_t lddz, const void* w, int64_t ldw, int act_below,
+                               const void* aux, int64_t ldaux, const void* addend, int64_t ldadd, void* dx,
+                               int64_t lddx, int64_t M, int64_t N, int64_t K, int dtype, ib_stream_t stream) {
+  if (!dz || !w || !dx || M <= 0 || N <= 0 || K <= 0 || lddz < N || ldw < K || lddx < K) return IB_E_ARG;
+  if (addend && ldadd < K) return IB_E_ARG;
+  if (act_below != IB_ACT_NONE && (!aux || ldaux < K)) return IB_E_ARG;
+  if (act_below < IB_ACT_NONE || act_below > IB_ACT_SILU) return IB_E_ARG;
+  // C[M,K] = sum_n dz[m][n] * w[n][k]:  reduction length N, B(j=k, kk=n) = w[n*ldw + k]  (k-strided)
+  GemmParams p{};
+  p.A = dz; p.lda = lddz; p.B = w; p.ldb = ldw; p.M = (int)M; p.N = (int)K; p.K = (int)N;
+  p.C = dx; p.ldc = lddx; p.aux = aux; p.ldaux = ldaux; p.act = act_below; p.seg = 1;
+  p.addend = addend; p.ldadd = ldadd;
+  if (dtype == IB_F32) return launch_dgrad<float>(p, ib_s(stream));
+  if (dtype == IB_BF16) return launch_dgrad<bf16_t>(p, ib_s(stream));
+  return IB_E_DTYPE;
+}
+
+extern "C" size_t ib_linear_wgrad_workspace(int64_t M, int64_t N, int64_t K) {
+  int chunk;
+  const int split = wgrad_split(M, N, K, 64, &chunk);
+  return split > 1 ? (size_t)split * (size_t)N * (size_t)K * sizeof(float) : 0;
+}
+
+extern "C" int ib_linear_wgrad(const void* dz, int64_t lddz, const void* x, int64_t ldx, float* dw,
+                               int64_t lddw, int accumulate, void* workspace, size_t workspace_bytes,
+                               int64_t M, int64_t N, int64_t K, int dtype, ib_stream_t stream) {
+  if (!dz || !x || !dw || M <= 0 || N <= 0 || K <= 0 || lddz < N || ldx < K || lddw < K) return IB_E_ARG;
+  if (dtype != IB_F32 && dtype != IB_BF16) return IB_E_DTYPE;
+  int chunk;
+  const int split = wgrad_split(M, N, K, 64, &chunk);
+  const size_t need = split > 1 ? (size_t)split * (size_t)N * (size_t)K * sizeof(float) : 0;
+  if (need > 0 && (!workspace || workspace_bytes < need)) return IB_E_WORKSPACE;
+  // C[N,K] = sum_m dz[m][n] * x[m][k]: A(i=n, kk=m) = dz[m*lddz + n], B(j=k, kk=m) = x[m*ldx + k]
+  GemmParams p{};
+  p.A = dz; p.lda = lddz; p.B = x; p.ldb = ldx; p.M = (int)N; p.N = (int)K; p.K = (int)M;
+  p.seg = 1; p.act = IB_ACT_NONE; p.accumulate = accumulate;
+  p.tiles_n = (p.N + BN - 1) / BN;
+  p.k_chunk = chunk;
+  const int tiles = ((p.M + BM - 1) / BM) * p.tiles_n;
+  hipStream_t s = ib_s(stream);
+  if (split > 1) {
+    p.C = workspace; p.ldc = K; p.slab_stride = (int64_t)N * K; p.accumulate = 0;
+  } else {
+    p.C = dw; p.ldc = lddw; p.slab_stride = 0;
+  }
+  p.vecC = aligned(p.C, 16) && (p.ldc % 4 == 0) && (p.slab_stride % 4 == 0);
+  if (dtype == IB_F32) {
+    p.vecA = vec_load_ok<float>(p.A, p.lda); p.vecB = vec_load_ok<float>(p.B, p.ldb);
+    hipLaunchKernelGGL((gemm_kernel<float, false, false, EPI_WGRAD>), dim3(tiles, split), dim3(NTHREADS), 0, s, p);
+  } else {
+    p.vecA = vec_load_ok<bf16_t>(p.A, p.lda); p.vecB = vec_load_ok<bf16_t>(p.B, p.ldb);
+    hipLaunchKernelGGL((gemm_kernel<bf16_t, false, false, EPI_WGRAD>), dim3(tiles, split), dim3(NTHREADS), 0, s, p);
+  }
+  IB_CHECK_LAUNCH();
+  if (split > 1) {
+    const int64_t n = (int64_t)N * K;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(ib_grid_1d(n, 256)), dim3(256), 0, s,
+                       reinterpret_cast<const float*>(workspace), split, (int64_t)N * K, dw, lddw, (int)N, (int)K,
+                       accumulate);
+    IB_CHECK_LAUNCH();
+  }
+  return IB_OK;
+}

@@ -1,0 +1,82 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels. wave = 64 lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ib_hip.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+
+#define IB_WAVE 64
+
+#define IB_CHECK_LAUNCH()                                    \
+  do {                                                       \
+    hipError_t e__ = hipGetLastError();                      \
+    if (e__ != hipSuccess) return IB_E_LAUNCH;               \
+  } while (0)
+
+static inline hipStream_t ib_s(ib_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+__device__ __forceinline__ float ib_to_f32(float v) { return v; }
+__device__ __forceinline__ float ib_to_f32(bf16_t v) { return static_cast<float>(v); }
+template <typename T> __device__ __forceinline__ T ib_from_f32(float v);
+template <> __device__ __forceinline__ float ib_from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t ib_from_f32<bf16_t>(float v) { return static_cast<bf16_t>(v); }
+
+// activation forward; accurate libm forms (parity mode must hold <= 1e-3 rel vs PyTorch CPU fp32)
+__device__ __forceinline__ float ib_act_fwd(int act, float v) {
+  switch (act) {
+    case IB_ACT_RELU: return v > 0.f ? v : 0.f;
+    case IB_ACT_TANH: return tanhf(v);
+    case IB_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
+    case IB_ACT_SILU: return v / (1.f + expf(-v));
+    default: return v;
+  }
+}
+// derivative factor given aux (= layer OUTPUT for relu/tanh/sigmoid, PRE-activation for silu)
+__device__ __forceinline__ float ib_act_bwd(int act, float aux) {
+  switch (act) {
+    case IB_ACT_RELU: return aux > 0.f ? 1.f : 0.f;
+    case IB_ACT_TANH: return 1.f - aux * aux;
+    case IB_ACT_SIGMOID: return aux * (1.f - aux);
+    case IB_ACT_SILU: {
+      float s = 1.f / (1.f + expf(-aux));
+      return s * (1.f + aux * (1.f - s));
+    }
+    default: return 1.f;
+  }
+}
+
+// 64-lane butterfly reductions (wave shuffles; no LDS)
+__device__ __forceinline__ float ib_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float ib_wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// XCD-aware bijective remap of a 1-D block id: blocks b and b+8 share an XCD (round-robin
+// dispatch), so give each XCD a contiguous chunk of the logical grid -> neighbouring tiles that
+// share an operand panel hit the same L2.  Speed only, never correctness.
+__device__ __forceinline__ int ib_xcd_remap(int bid, int nwg) {
+  const int nx = 8;
+  if (nwg < nx * 2) return bid;
+  int xcd = bid % nx, q = nwg / nx, r = nwg % nx;
+  int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + bid / nx;
+}
+
+static inline int ib_grid_1d(int64_t work_items, int per_block, int cap = 256 * 8) {
+  int64_t g = (work_items + per_block - 1) / per_block;
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return static_cast<int>(g);
+}

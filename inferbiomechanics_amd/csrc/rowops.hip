@@ -1,0 +1,441 @@
+// Row-wise HBM-bound kernels for gfx950: LayerNorm (+residual, +pre-activation) fwd/bwd with
+// wave-shuffle reductions, segmented column sums (bias / embedding grads), input packing, casts.
+// One wave (64 lanes) owns one row; a lane holds CH chunks of 4 consecutive elements in registers
+// (8- or 16-byte loads), so every tensor crosses HBM exactly once per kernel.
+#include "ib_common.h"
+
+namespace {
+
+__device__ __forceinline__ float act_bwd_pre(int act, float z) {
+  // derivative of act at pre-activation z
+  switch (act) {
+    case IB_ACT_RELU: return z > 0.f ? 1.f : 0.f;
+    case IB_ACT_TANH: { float t = tanhf(z); return 1.f - t * t; }
+    case IB_ACT_SIGMOID: { float s = 1.f / (1.f + expf(-z)); return s * (1.f - s); }
+    case IB_ACT_SILU: { float s = 1.f / (1.f + expf(-z)); return s * (1.f + z * (1.f - s)); }
+    default: return 1.f;
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ void load4(const T* p, int nv, bool vec, float (&v)[4]) {
+  if (nv == 4 && vec) {
+    if constexpr (sizeof(T) == 2) {
+      bf16x4_t t = *reinterpret_cast<const bf16x4_t*>(p);
+      v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3];
+    } else {
+      float4 t = *reinterpret_cast<const float4*>(p);
+      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (e < nv) ? ib_to_f32(p[e]) : 0.f;
+  }
+}
+template <typename T>
+__device__ __forceinline__ void store4(T* p, int nv, bool vec, const float (&v)[4]) {
+  if (nv == 4 && vec) {
+    if constexpr (sizeof(T) == 2) {
+      bf16x4_t o;
+      o[0] = (bf16_t)v[0]; o[1] = (bf16_t)v[1]; o[2] = (bf16_t)v[2]; o[3] = (bf16_t)v[3];
+      *reinterpret_cast<bf16x4_t*>(p) = o;
+    } else {
+      *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (e < nv) p[e] = ib_from_f32<T>(v[e]);
+  }
+}
+
+// ---------------------------------------------------------------- LayerNorm forward
+template <typename T, int CH>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res, int act,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, T* __restrict__ y,
+                                                            float* __restrict__ mean, float* __restrict__ rstd,
+                                                            int M, int N, float eps, int vec) {
+  const int lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6;
+  for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < M; row += gridDim.x * wpb) {
+    const T* xr = x + (int64_t)row * N;
+    const T* rr = res ? res + (int64_t)row * N : nullptr;
+    float v[CH][4];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int col = (c * 64 + lane) * 4;
+      const int nv = max(0, min(4, N - col));
+      load4<T>(xr + col, nv, vec, v[c]);
+      if (act != IB_ACT_NONE) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[c][e] = (e < nv) ? ib_act_fwd(act, v[c][e]) : 0.f;
+      }
+      if (rr) {
+        float r4[4];
+        load4<T>(rr + col, nv, vec, r4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[c][e] += r4[e];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s += v[c][e];
+    }
+    const float mu = ib_wave_sum(s) / (float)N;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int col = (c * 64 + lane) * 4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float d = (col + e < N) ? v[c][e] - mu : 0.f;
+        q += d * d;
+      }
+    }
+    const float var = ib_wave_sum(q) / (float)N;
+    const float rs = 1.f / sqrtf(var + eps);
+    if (lane == 0) {
+      if (mean) mean[row] = mu;
+      if (rstd) rstd[row] = rs;
+    }
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int col = (c * 64 + lane) * 4;
+      const int nv = max(0, min(4, N - col));
+      if (nv > 0) {
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          o[e] = (e < nv) ? (v[c][e] - mu) * rs * gamma[col + e] + beta[col + e] : 0.f;
+        store4<T>(y + (int64_t)row * N + col, nv, vec, o);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- LayerNorm backward
+// partial[blockIdx][0..N) = sum over this block's rows of dy*xhat ; partial[gridDim + blockIdx] = sum dy
+template <typename T, int CH>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                            const T* __restrict__ res, int act,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, T* __restrict__ dx,
+                                                            T* __restrict__ dres, float* __restrict__ partial,
+                                                            int M, int N, int vec) {
+  __shared__ float red[4][2][64 * 4 * CH / 4 + 0][4];  // [wave][dgamma|dbeta][chunk*64+lane][4]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wpb = blockDim.x >> 6;
+  float ag[CH][4], ab[CH][4];
+#pragma unroll
+  for (int c = 0; c < CH; ++c)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { ag[c][e] = 0.f; ab[c][e] = 0.f; }
+
+  for (int row = blockIdx.x * wpb + wave; row < M; row += gridDim.x * wpb) {
+    const int64_t ro = (int64_t)row * N;
+    const float mu = mean[row], rs = rstd[row];
+    float xh[CH][4], g[CH][4], zraw[CH][4];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int col = (c * 64 + lane) * 4;
+      const int nv = max(0, min(4, N - col));
+      float xv[4], dyv[4];
+      load4<T>(x + ro + col, nv, vec, xv);
+      load4<T>(dy + ro + col, nv, vec, dyv);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) zraw[c][e] = xv[e];
+      if (act != IB_ACT_NONE) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xv[e] = (e < nv) ? ib_act_fwd(act, xv[e]) : 0.f;
+      }
+      if (res) {
+        float r4[4];
+        load4<T>(res + ro + col, nv, vec, r4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xv[e] += r4[e];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const bool ok = e < nv;
+        const float h = ok ? (xv[e] - mu) * rs : 0.f;
+        const float gg = ok ? dyv[e] * gamma[col + e] : 0.f;
+        xh[c][e] = h; g[c][e] = gg;
+        s1 += gg; s2 += gg * h;
+        ag[c][e] += ok ? dyv[e] * h : 0.f;
+        ab[c][e] += ok ? dyv[e] : 0.f;
+      }
+    }
+    const float c1 = ib_wave_sum(s1) / (float)N;
+    const float c2 = ib_wave_sum(s2) / (float)N;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int col = (c * 64 + lane) * 4;
+      const int nv = max(0, min(4, N - col));
+      if (nv > 0) {
+        float dv[4], dxo[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          dv[e] = (g[c][e] - c1 - xh[c][e] * c2) * rs;
+          dxo[e] = (act != IB_ACT_NONE) ? dv[e] * act_bwd_pre(act, zraw[c][e]) : dv[e];
+        }
+        store4<T>(dx + ro + col, nv, vec, dxo);
+        if (dres) store4<T>(dres + ro + col, nv, vec, dv);
+      }
+    }
+  }
+  // cross-wave reduction of the affine-gradient partials, fixed order
+#pragma unroll
+  for (int c = 0; c < CH; ++c)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      red[wave][0][c * 64 + lane][e] = ag[c][e];
+      red[wave][1][c * 64 + lane][e] = ab[c][e];
+    }
+  __syncthreads();
+  for (int i = threadIdx.x; i < CH * 64 * 4; i += blockDim.x) {
+    const int col = i;  // (chunk*64+lane)*4+e == linear column index
+    if (col < N) {
+      float sg = 0.f, sb = 0.f;
+      for (int w = 0; w < wpb; ++w) {
+        sg += red[w][0][col >> 2][col & 3];
+        sb += red[w][1][col >> 2][col & 3];
+      }
+      partial[(int64_t)blockIdx.x * N + col] = sg;
+      partial[((int64_t)gridDim.x + blockIdx.x) * N + col] = sb;
+    }
+  }
+}
+
+// out[n] (+)= sum_{b < nparts} partial[b][n]   (fixed order)
+__global__ void partial_colsum_kernel(const float* __restrict__ partial, int nparts, int N, float* __restrict__ out,
+                                      int accumulate) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float s = 0.f;
+  for (int b = 0; b < nparts; ++b) s += partial[(int64_t)b * N + n];
+  out[n] = accumulate ? out[n] + s : s;
+}
+
+// ---------------------------------------------------------------- segmented column sum
+// rows of segment s: m = s*a + r*b, r in [0, cnt).  thread = 4 consecutive columns x one of 4 row lanes.
+template <typename T>
+__global__ __launch_bounds__(256) void segment_colsum_kernel(const T* __restrict__ x, int64_t ldx, float* __restrict__ out,
+                                                             int64_t ldo, int M, int N, int seg, int mode, int accumulate,
+                                                             int vec) {
+  __shared__ float red[4][64][4];
+  const int cg = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int s = blockIdx.y;
+  const int col = (blockIdx.x * 64 + cg) * 4;
+  const int nv = max(0, min(4, N - col));
+  int64_t a, b; int cnt;
+  if (mode == 0) { a = seg; b = 1; cnt = min(seg, M - s * seg); }
+  else { a = 1; b = seg; cnt = (M - s + seg - 1) / seg; }
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  if (nv > 0) {
+    for (int r = rl; r < cnt; r += 4) {
+      const int64_t m = (int64_t)s * a + (int64_t)r * b;
+      float v[4];
+      load4<T>(x + m * ldx + col, nv, vec, v);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] += v[e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) red[rl][cg][e] = acc[e];
+  __syncthreads();
+  if (rl == 0 && nv > 0) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (e < nv) {
+        const float t = ((red[0][cg][e] + red[1][cg][e]) + red[2][cg][e]) + red[3][cg][e];
+        float* o = out + (int64_t)s * ldo + col + e;
+        *o = accumulate ? *o + t : t;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- input packing / casts
+struct ConcatArgs {
+  const float* in[16];
+  int width[16];
+  int offset[16];
+  int nkeys;
+  int total;
+};
+template <typename T>
+__global__ void concat_keys_kernel(ConcatArgs a, T* __restrict__ out, int64_t rows) {
+  const int64_t n = rows * a.total;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / a.total;
+    const int col = (int)(i % a.total);
+    int k = 0;
+#pragma unroll
+    for (int j = 1; j < 16; ++j)
+      if (j < a.nkeys && col >= a.offset[j]) k = j;
+    out[i] = ib_from_f32<T>(a.in[k][row * a.width[k] + (col - a.offset[k])]);
+  }
+}
+
+template <typename S, typename D>
+__global__ void cast2d_kernel(const S* __restrict__ src, int64_t lds, D* __restrict__ dst, int64_t ldd, int64_t rows,
+                              int64_t cols) {
+  const int64_t n = rows * cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / cols, c = i % cols;
+    dst[r * ldd + c] = ib_from_f32<D>(ib_to_f32(src[r * lds + c]));
+  }
+}
+
+template <typename T, int CH>
+int launch_ln_fwd(const void* x, const void* res, int act, const float* gamma, const float* beta, void* y, float* mean,
+                  float* rstd, int64_t M, int64_t N, float eps, int vec, hipStream_t s) {
+  const int grid = ib_grid_1d(M, 4);
+  hipLaunchKernelGGL((layernorm_fwd_kernel<T, CH>), dim3(grid), dim3(256), 0, s, (const T*)x, (const T*)res, act, gamma,
+                     beta, (T*)y, mean, rstd, (int)M, (int)N, eps, vec);
+  IB_CHECK_LAUNCH();
+  return IB_OK;
+}
+
+int ln_bwd_parts(int64_t M) {
+  int64_t g = (M + 3) / 4;
+  if (g > 512) g = 512;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+template <typename T, int CH>
+int launch_ln_bwd(const void* dy, const void* x, const void* res, int act, const float* gamma, const float* mean,
+                  const float* rstd, void* dx, void* dres, float* partial, int64_t M, int64_t N, int vec, int parts,
+                  hipStream_t s) {
+  hipLaunchKernelGGL((layernorm_bwd_kernel<T, CH>), dim3(parts), dim3(256), 0, s, (const T*)dy, (const T*)x,
+                     (const T*)res, act, gamma, mean, rstd, (T*)dx, (T*)dres, partial, (int)M, (int)N, vec);
+  IB_CHECK_LAUNCH();
+  return IB_OK;
+}
+
+inline bool al(const void* p, size_t a) { return !p || (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+}  // namespace
+
+#define LN_DISPATCH(FN, T, ...)                                   \
+  (N <= 256 ? FN<T, 1>(__VA_ARGS__) : N <= 512 ? FN<T, 2>(__VA_ARGS__) \
+   : N <= 1024 ? FN<T, 4>(__VA_ARGS__) : FN<T, 8>(__VA_ARGS__))
+
+extern "C" int ib_layernorm_fwd(const void* x, const void* res, int act, const float* gamma, const float* beta, void* y,
+                                float* mean, float* rstd, int64_t M, int64_t N, float eps, int dtype,
+                                ib_stream_t stream) {
+  if (!x || !gamma || !beta || !y || M <= 0 || N <= 0) return IB_E_ARG;
+  if (N > 2048) return IB_E_UNSUPPORTED;
+  hipStream_t s = ib_s(stream);
+  if (dtype == IB_F32) {
+    const int vec = (N % 4 == 0) && al(x, 16) && al(res, 16) && al(y, 16);
+    return LN_DISPATCH(launch_ln_fwd, float, x, res, act, gamma, beta, y, mean, rstd, M, N, eps, vec, s);
+  }
+  if (dtype == IB_BF16) {
+    const int vec = (N % 4 == 0) && al(x, 8) && al(res, 8) && al(y, 8);
+    return LN_DISPATCH(launch_ln_fwd, bf16_t, x, res, act, gamma, beta, y, mean, rstd, M, N, eps, vec, s);
+  }
+  return IB_E_DTYPE;
+}
+
+extern "C" size_t ib_layernorm_bwd_workspace(int64_t M, int64_t N) {
+  return (size_t)2 * ln_bwd_parts(M) * (size_t)N * sizeof(float);
+}
+
+extern "C" int ib_layernorm_bwd(const void* dy, const void* x, const void* res, int act, const float* gamma,
+                                const float* mean, const float* rstd, void* dx, void* dres, float* dgamma,
+                                float* dbeta, int accumulate, void* workspace, size_t workspace_bytes, int64_t M,
+                                int64_t N, int dtype, ib_stream_t stream) {
+  if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || M <= 0 || N <= 0) return IB_E_ARG;
+  if (N > 2048) return IB_E_UNSUPPORTED;
+  const int parts = ln_bwd_parts(M);
+  if (!workspace || workspace_bytes < (size_t)2 * parts * N * sizeof(float)) return IB_E_WORKSPACE;
+  hipStream_t s = ib_s(stream);
+  float* partial = reinterpret_cast<float*>(workspace);
+  int rc;
+  if (dtype == IB_F32) {
+    const int vec = (N % 4 == 0) && al(x, 16) && al(res, 16) && al(dy, 16) && al(dx, 16) && al(dres, 16);
+    rc = LN_DISPATCH(launch_ln_bwd, float, dy, x, res, act, gamma, mean, rstd, dx, dres, partial, M, N, vec, parts, s);
+  } else if (dtype == IB_BF16) {
+    const int vec = (N % 4 == 0) && al(x, 8) && al(res, 8) && al(dy, 8) && al(dx, 8) && al(dres, 8);
+    rc = LN_DISPATCH(launch_ln_bwd, bf16_t, dy, x, res, act, gamma, mean, rstd, dx, dres, partial, M, N, vec, parts, s);
+  } else {
+    return IB_E_DTYPE;
+  }
+  if (rc != IB_OK) return rc;
+  const int g = (int)((N + 255) / 256);
+  hipLaunchKernelGGL(partial_colsum_kernel, dim3(g), dim3(256), 0, s, partial, parts, (int)N, dgamma, accumulate);
+  IB_CHECK_LAUNCH();
+  hipLaunchKernelGGL(partial_colsum_kernel, dim3(g), dim3(256), 0, s, partial + (int64_t)parts * N, parts, (int)N, dbeta,
+                     accumulate);
+  IB_CHECK_LAUNCH();
+  return IB_OK;
+}
+
+extern "C" int ib_segment_colsum(const void* x, int64_t ldx, float* out, int64_t ldo, int64_t M, int64_t N, int64_t seg,
+                                 int mode, int accumulate, int dtype, ib_stream_t stream) {
+  if (!x || !out || M <= 0 || N <= 0 || seg <= 0 || ldx < N || ldo < N || (mode != 0 && mode != 1)) return IB_E_ARG;
+  const int64_t nseg = (mode == 0) ? (M + seg - 1) / seg : (seg < M ? seg : M);
+  if (nseg > 65535) return IB_E_UNSUPPORTED;
+  dim3 grid((unsigned)((N + 255) / 256), (unsigned)nseg);
+  hipStream_t s = ib_s(stream);
+  if (dtype == IB_F32) {
+    const int vec = (ldx % 4 == 0) && al(x, 16);
+    hipLaunchKernelGGL((segment_colsum_kernel<float>), grid, dim3(256), 0, s, (const float*)x, ldx, out, ldo, (int)M,
+                       (int)N, (int)seg, mode, accumulate, vec);
+  } else if (dtype == IB_BF16) {
+    const int vec = (ldx % 4 == 0) && al(x, 8);
+    hipLaunchKernelGGL((segment_colsum_kernel<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)x, ldx, out, ldo, (int)M,
+                       (int)N, (int)seg, mode, accumulate, vec);
+  } else {
+    return IB_E_DTYPE;
+  }
+  IB_CHECK_LAUNCH();
+  return IB_OK;
+}
+
+extern "C" int ib_concat_keys(const float* const* inputs, const int32_t* widths, int32_t nkeys, void* out, int64_t rows,
+                              int dtype_out, ib_stream_t stream) {
+  if (!inputs || !widths || !out || nkeys <= 0 || nkeys > 16 || rows <= 0) return IB_E_ARG;
+  ConcatArgs a{};
+  a.nkeys = nkeys;
+  int off = 0;
+  for (int k = 0; k < nkeys; ++k) {
+    if (!inputs[k] || widths[k] <= 0) return IB_E_ARG;
+    a.in[k] = inputs[k]; a.width[k] = widths[k]; a.offset[k] = off; off += widths[k];
+  }
+  a.total = off;
+  const int grid = ib_grid_1d(rows * off, 256);
+  hipStream_t s = ib_s(stream);
+  if (dtype_out == IB_F32) hipLaunchKernelGGL((concat_keys_kernel<float>), dim3(grid), dim3(256), 0, s, a, (float*)out, rows);
+  else if (dtype_out == IB_BF16) hipLaunchKernelGGL((concat_keys_kernel<bf16_t>), dim3(grid), dim3(256), 0, s, a, (bf16_t*)out, rows);
+  else return IB_E_DTYPE;
+  IB_CHECK_LAUNCH();
+  return IB_OK;
+}
+
+extern "C" int ib_cast2d(const void* src, int64_t lds, int src_dtype, void* dst, int64_t ldd, int dst_dtype, int64_t rows,
+                         int64_t cols, ib_stream_t stream) {
+  if (!src || !dst || rows <= 0 || cols <= 0 || lds < cols || ldd < cols) return IB_E_ARG;
+  const int grid = ib_grid_1d(rows * cols, 256);
+  hipStream_t s = ib_s(stream);
+  if (src_dtype == IB_F32 && dst_dtype == IB_BF16)
+    hipLaunchKernelGGL((cast2d_kernel<float, bf16_t>), dim3(grid), dim3(256), 0, s, (const float*)src, lds, (bf16_t*)dst, ldd, rows, cols);
+  else if (src_dtype == IB_BF16 && dst_dtype == IB_F32)
+    hipLaunchKernelGGL((cast2d_kernel<bf16_t, float>), dim3(grid), dim3(256), 0, s, (const bf16_t*)src, lds, (float*)dst, ldd, rows, cols);
+  else if (src_dtype == IB_F32 && dst_dtype == IB_F32)
+    hipLaunchKernelGGL((cast2d_kernel<float, float>), dim3(grid), dim3(256), 0, s, (const float*)src, lds, (float*)dst, ldd, rows, cols);
+  else if (src_dtype == IB_BF16 && dst_dtype == IB_BF16)
+    hipLaunchKernelGGL((cast2d_kernel<bf16_t, bf16_t>), dim3(grid), dim3(256), 0, s, (const bf16_t*)src, lds, (bf16_t*)dst, ldd, rows, cols);
+  else
+    return IB_E_DTYPE;
+  IB_CHECK_LAUNCH();
+  return IB_OK;
+}
+
+extern "C" int ib_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, ib_stream_t stream) {
+  return ib_cast2d(src, n, src_dtype, dst, n, dst_dtype, 1, n, stream);
+}

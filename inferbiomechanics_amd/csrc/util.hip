@@ -1,0 +1,88 @@
+// Version / error strings, hipGraph capture helpers, HIP-event timing, instruction self-tests.
+#include "ib_common.h"
+
+extern "C" int ib_version(void) { return 100; }
+
+extern "C" const char* ib_error_string(int code) {
+  switch (code) {
+    case IB_OK: return "ok";
+    case IB_E_ARG: return "invalid argument (null pointer, non-positive size or leading dimension too small)";
+    case IB_E_DTYPE: return "unsupported dtype";
+    case IB_E_LAUNCH: return "HIP kernel launch failed";
+    case IB_E_WORKSPACE: return "workspace missing or too small";
+    case IB_E_UNSUPPORTED: return "shape not supported by this kernel";
+    default: return "unknown error";
+  }
+}
+
+extern "C" int ib_graph_begin(ib_stream_t stream) {
+  return hipStreamBeginCapture(ib_s(stream), hipStreamCaptureModeThreadLocal) == hipSuccess ? IB_OK : IB_E_LAUNCH;
+}
+extern "C" int ib_graph_end(ib_stream_t stream, void** graph_exec_out) {
+  if (!graph_exec_out) return IB_E_ARG;
+  hipGraph_t g = nullptr;
+  if (hipStreamEndCapture(ib_s(stream), &g) != hipSuccess || !g) return IB_E_LAUNCH;
+  hipGraphExec_t ge = nullptr;
+  hipError_t e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  if (e != hipSuccess) return IB_E_LAUNCH;
+  *graph_exec_out = ge;
+  return IB_OK;
+}
+extern "C" int ib_graph_launch(void* graph_exec, ib_stream_t stream) {
+  if (!graph_exec) return IB_E_ARG;
+  return hipGraphLaunch(reinterpret_cast<hipGraphExec_t>(graph_exec), ib_s(stream)) == hipSuccess ? IB_OK : IB_E_LAUNCH;
+}
+extern "C" int ib_graph_destroy(void* graph_exec) {
+  if (!graph_exec) return IB_E_ARG;
+  return hipGraphExecDestroy(reinterpret_cast<hipGraphExec_t>(graph_exec)) == hipSuccess ? IB_OK : IB_E_LAUNCH;
+}
+
+extern "C" int ib_event_create(void** ev_out) {
+  if (!ev_out) return IB_E_ARG;
+  hipEvent_t e;
+  if (hipEventCreate(&e) != hipSuccess) return IB_E_LAUNCH;
+  *ev_out = e;
+  return IB_OK;
+}
+extern "C" int ib_event_record(void* ev, ib_stream_t stream) {
+  if (!ev) return IB_E_ARG;
+  return hipEventRecord(reinterpret_cast<hipEvent_t>(ev), ib_s(stream)) == hipSuccess ? IB_OK : IB_E_LAUNCH;
+}
+extern "C" int ib_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms_out) {
+  if (!ev_start || !ev_stop || !ms_out) return IB_E_ARG;
+  if (hipEventSynchronize(reinterpret_cast<hipEvent_t>(ev_stop)) != hipSuccess) return IB_E_LAUNCH;
+  return hipEventElapsedTime(ms_out, reinterpret_cast<hipEvent_t>(ev_start), reinterpret_cast<hipEvent_t>(ev_stop)) ==
+                 hipSuccess ? IB_OK : IB_E_LAUNCH;
+}
+extern "C" int ib_event_destroy(void* ev) {
+  if (!ev) return IB_E_ARG;
+  return hipEventDestroy(reinterpret_cast<hipEvent_t>(ev)) == hipSuccess ? IB_OK : IB_E_LAUNCH;
+}
+
+// Probe of ds_read_b64_tr_b16 (the transposing LDS read the bf16 k-strided GEMM operands rely on):
+// input  in[64 rows][16 cols] bf16 (row-major, a [k][row] image of 64 k x 16 rows),
+// output out[lane][4]: what lane gets from ONE read whose address follows gemm.hip::read_frag_bf16
+// with kbase = 0, rbase = 0, i.e. expected out[lane][q] = in[8*(lane/16) + q][lane%16].
+namespace {
+typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
+__global__ void selftest_tr16_kernel(const short* __restrict__ in, short* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) short img[64 * 16];
+  for (int i = threadIdx.x; i < 64 * 16; i += blockDim.x) img[i] = in[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int q = (lane & 15) >> 2, pp = lane & 3;
+  const int kr = 8 * (lane >> 4) + q;
+  const short* a0 = img + kr * 16 + 4 * pp;
+  s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(a0));
+  for (int e = 0; e < 4; ++e) out[lane * 4 + e] = v[e];
+}
+}  // namespace
+
+extern "C" int ib_selftest_tr16(const void* in_bf16_64x16, void* out_bf16_64x4, ib_stream_t stream) {
+  if (!in_bf16_64x16 || !out_bf16_64x4) return IB_E_ARG;
+  hipLaunchKernelGGL(selftest_tr16_kernel, dim3(1), dim3(64), 0, ib_s(stream), (const short*)in_bf16_64x16,
+                     (short*)out_bf16_64x4);
+  IB_CHECK_LAUNCH();
+  return IB_OK;
+}

@@ -1,0 +1,630 @@
+"""ctypes binding of ``libib_hip.so`` (the C-ABI declared in ``include/ib_hip.h``).
+
+PyTorch is used here only for device memory and streams: every wrapper takes torch tensors, checks
+shape / dtype / contiguity on the host (a faulting kernel can reset the whole node), and passes raw
+device pointers + sizes + the current HIP stream to the library.  There is NO CPU or eager-PyTorch
+fallback: if the library is missing or a call fails, a ``HipError`` is raised.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libib_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "ib_hip.h")
+
+F32, BF16 = 0, 1
+ACT = {"none": 0, "identity": 0, None: 0, "relu": 1, "tanh": 2, "sigmoid": 3, "silu": 4}
+OPT = {"sgd": 0, "adam": 1, "rmsprop": 2, "adagrad": 3, "adadelta": 4, "adamax": 5}
+OPT_NUM_STATES = {"sgd": 0, "adam": 2, "rmsprop": 1, "adagrad": 1, "adadelta": 2, "adamax": 2}
+
+
+class HipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+_c = ctypes
+_vp, _i64, _i32, _f32, _sz = _c.c_void_p, _c.c_int64, _c.c_int32, _c.c_float, _c.c_size_t
+_SIGS = {
+    "ib_version": (_c.c_int, []),
+    "ib_error_string": (_c.c_char_p, [_c.c_int]),
+    "ib_linear_fwd": (_c.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _i64, _c.c_int, _vp, _i64, _vp,
+                                 _i64, _i64, _i64, _i64, _c.c_int, _vp]),
+    "ib_linear_dgrad": (_c.c_int, [_vp, _i64, _vp, _i64, _c.c_int, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64,
+                                   _c.c_int, _vp]),
+    "ib_linear_wgrad_workspace": (_sz, [_i64, _i64, _i64]),
+    "ib_linear_wgrad": (_c.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _c.c_int, _vp, _sz, _i64, _i64, _i64, _c.c_int, _vp]),
+    "ib_segment_colsum": (_c.c_int, [_vp, _i64, _vp, _i64, _i64, _i64, _i64, _c.c_int, _c.c_int, _c.c_int, _vp]),
+    "ib_layernorm_fwd": (_c.c_int, [_vp, _vp, _c.c_int, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _f32, _c.c_int, _vp]),
+    "ib_layernorm_bwd_workspace": (_sz, [_i64, _i64]),
+    "ib_layernorm_bwd": (_c.c_int, [_vp, _vp, _vp, _c.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _c.c_int, _vp, _sz,
+                                    _i64, _i64, _c.c_int, _vp]),
+    "ib_attention_fwd": (_c.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _c.c_int, _vp]),
+    "ib_attention_bwd": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _c.c_int, _vp]),
+    "ib_concat_keys": (_c.c_int, [_vp, _vp, _i32, _vp, _i64, _c.c_int, _vp]),
+    "ib_cast": (_c.c_int, [_vp, _c.c_int, _vp, _c.c_int, _i64, _vp]),
+    "ib_cast2d": (_c.c_int, [_vp, _i64, _c.c_int, _vp, _i64, _c.c_int, _i64, _i64, _vp]),
+    "ib_regression_loss_workspace": (_sz, [_i64, _i64]),
+    "ib_regression_loss": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp,
+                                      _vp, _vp, _vp, _sz, _i64, _i64, _c.c_int, _vp]),
+    "ib_mse_loss_workspace": (_sz, [_i64]),
+    "ib_mse_loss": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _sz, _i64, _c.c_int, _vp]),
+    "ib_optim_step": (_c.c_int, [_c.c_int, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _i32, _vp, _vp, _vp]),
+    "ib_gather_rows": (_c.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _c.c_int, _vp]),
+    "ib_q_sample": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _c.c_int, _vp]),
+    "ib_ddim_step": (_c.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i64, _i64, _c.c_int, _vp]),
+    "ib_counter_add": (_c.c_int, [_vp, _i32, _vp]),
+    "ib_fill_i64": (_c.c_int, [_vp, _i64, _i64, _vp]),
+    "ib_graph_begin": (_c.c_int, [_vp]),
+    "ib_graph_end": (_c.c_int, [_vp, _c.POINTER(_vp)]),
+    "ib_graph_launch": (_c.c_int, [_vp, _vp]),
+    "ib_graph_destroy": (_c.c_int, [_vp]),
+    "ib_event_create": (_c.c_int, [_c.POINTER(_vp)]),
+    "ib_event_record": (_c.c_int, [_vp, _vp]),
+    "ib_event_elapsed_ms": (_c.c_int, [_vp, _vp, _c.POINTER(_f32)]),
+    "ib_event_destroy": (_c.c_int, [_vp]),
+    "ib_selftest_tr16": (_c.c_int, [_vp, _vp, _vp]),
+}
+
+
+def declared_symbols() -> List[str]:
+    """Every function the public header declares (used by the CPU test that checks the exports)."""
+    src = open(HEADER_PATH).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ib_[a-z0-9_]+)\s*\(", src)))
+
+
+class _DryRunLib:
+    """TEST-ONLY stand-in (tests/test_plumbing_cpu.py): marshals every argument through the real ctypes
+    signature (so arity / type errors surface) and returns IB_OK without launching anything.  It computes
+    nothing -- outputs are left untouched -- and is never selected by product code."""
+
+    def __init__(self, real):
+        self._real = real
+        self.calls = []
+
+    def __getattr__(self, name):
+        res, args = _SIGS[name]
+        real = getattr(self._real, name)
+        if name.endswith("_workspace") or name in ("ib_version", "ib_error_string"):
+            return real
+
+        def call(*a):
+            if len(a) != len(args):
+                raise TypeError(f"{name}: expected {len(args)} arguments, got {len(a)}")
+            for v, t in zip(a, args):
+                if v is not None or t not in (_vp,):
+                    t.from_param(v) if hasattr(t, "from_param") else None
+            self.calls.append(name)
+            return 0
+        return call
+
+
+_dry_run = False
+
+
+def set_dry_run(on: bool):
+    """TEST-ONLY: see _DryRunLib."""
+    global _dry_run, _lib
+    _dry_run = bool(on)
+    _lib = None
+
+
+def lib():
+    """Load the library (once).  Raises HipError if it has not been built -- never falls back."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                           f"or `make -C inferbiomechanics_amd/csrc` (hipcc --offload-arch=gfx950). There is no fallback path.")
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = _DryRunLib(l) if _dry_run else l
+    return _lib
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        raise HipError(f"{what} failed: {lib().ib_error_string(rc).decode()} (code {rc})")
+
+
+def stream_ptr() -> int:
+    if _dry_run:
+        return 0
+    return torch.cuda.current_stream().cuda_stream
+
+
+def dtype_code(t: torch.dtype) -> int:
+    if t == torch.float32:
+        return F32
+    if t == torch.bfloat16:
+        return BF16
+    raise HipError(f"unsupported storage dtype {t}; the HIP path computes in float32 or bfloat16")
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _req(t: torch.Tensor, name: str, dtype: Optional[torch.dtype] = None, dim: Optional[int] = None):
+    if not isinstance(t, torch.Tensor) or not (t.is_cuda or _dry_run):
+        raise HipError(f"{name}: expected a tensor in device (HBM) memory")
+    if dtype is not None and t.dtype != dtype:
+        raise HipError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if dim is not None and t.dim() != dim:
+        raise HipError(f"{name}: expected {dim}-D, got shape {tuple(t.shape)}")
+
+
+def _mat(t: torch.Tensor, name: str, dtype: torch.dtype):
+    """2-D row-major view with unit inner stride -> (rows, cols, ld)."""
+    _req(t, name, dtype, 2)
+    if t.stride(1) != 1 and t.shape[1] != 1:
+        raise HipError(f"{name}: inner stride must be 1, got strides {t.stride()}")
+    ld = t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0))
+    if ld < t.shape[1]:
+        raise HipError(f"{name}: leading dimension {ld} < columns {t.shape[1]}")
+    return t.shape[0], t.shape[1], ld
+
+
+# --------------------------------------------------------------------------------------------
+# Linear family
+# --------------------------------------------------------------------------------------------
+def linear_fwd(x, w, bias, y, act="none", z=None, add_div=None, add_mod=None, seg=0):
+    dt = x.dtype
+    M, K, ldx = _mat(x, "x", dt)
+    N, Kw, ldw = _mat(w, "w", dt)
+    My, Ny, ldy = _mat(y, "y", dt)
+    if Kw != K or My != M or Ny != N:
+        raise HipError(f"linear_fwd shape mismatch: x{tuple(x.shape)} w{tuple(w.shape)} y{tuple(y.shape)}")
+    if bias is not None:
+        _req(bias, "bias", torch.float32, 1)
+        if bias.numel() != N or not bias.is_contiguous():
+            raise HipError("bias must be a contiguous fp32 vector of length N")
+    ldz = 0
+    if z is not None:
+        Mz, Nz, ldz = _mat(z, "z", dt)
+        if (Mz, Nz) != (M, N):
+            raise HipError("z shape mismatch")
+    ld_ad = ld_am = 0
+    if add_div is not None:
+        r, c, ld_ad = _mat(add_div, "add_div", dt)
+        if seg <= 0 or c != N or r * seg < M:
+            raise HipError(f"add_div must be [ceil(M/seg), N]; got {tuple(add_div.shape)} with seg={seg}, M={M}")
+    if add_mod is not None:
+        r, c, ld_am = _mat(add_mod, "add_mod", dt)
+        if seg <= 0 or c != N or r < min(seg, M):
+            raise HipError(f"add_mod must be [seg, N]; got {tuple(add_mod.shape)} with seg={seg}")
+    _check(lib().ib_linear_fwd(_ptr(x), ldx, _ptr(w), ldw, _ptr(bias), _ptr(add_div), ld_ad, _ptr(add_mod), ld_am,
+                               int(seg), ACT[act], _ptr(y), ldy, _ptr(z), ldz, M, N, K, dtype_code(dt), stream_ptr()),
+           "ib_linear_fwd")
+    return y
+
+
+def linear_dgrad(dz, w, dx, act_below="none", aux=None, addend=None):
+    dt = dz.dtype
+    M, N, lddz = _mat(dz, "dz", dt)
+    Nw, K, ldw = _mat(w, "w", dt)
+    Mx, Kx, lddx = _mat(dx, "dx", dt)
+    if Nw != N or Mx != M or Kx != K:
+        raise HipError(f"linear_dgrad shape mismatch: dz{tuple(dz.shape)} w{tuple(w.shape)} dx{tuple(dx.shape)}")
+    ldaux = 0
+    if ACT[act_below] != 0:
+        if aux is None:
+            raise HipError("linear_dgrad: activation below needs aux")
+        Ma, Ka, ldaux = _mat(aux, "aux", dt)
+        if (Ma, Ka) != (M, K):
+            raise HipError("aux shape mismatch")
+    ldadd = 0
+    if addend is not None:
+        Ma, Ka, ldadd = _mat(addend, "addend", dt)
+        if (Ma, Ka) != (M, K):
+            raise HipError("addend shape mismatch")
+    _check(lib().ib_linear_dgrad(_ptr(dz), lddz, _ptr(w), ldw, ACT[act_below], _ptr(aux), ldaux, _ptr(addend), ldadd,
+                                 _ptr(dx), lddx, M, N, K, dtype_code(dt), stream_ptr()), "ib_linear_dgrad")
+    return dx
+
+
+def linear_wgrad_workspace_bytes(M, N, K) -> int:
+    return int(lib().ib_linear_wgrad_workspace(M, N, K))
+
+
+def linear_wgrad(dz, x, dw, workspace, accumulate=False):
+    dt = dz.dtype
+    M, N, lddz = _mat(dz, "dz", dt)
+    Mx, K, ldx = _mat(x, "x", dt)
+    Nw, Kw, lddw = _mat(dw, "dw", torch.float32)
+    if Mx != M or Nw != N or Kw != K:
+        raise HipError(f"linear_wgrad shape mismatch: dz{tuple(dz.shape)} x{tuple(x.shape)} dw{tuple(dw.shape)}")
+    need = linear_wgrad_workspace_bytes(M, N, K)
+    wsb = 0 if workspace is None else workspace.numel() * workspace.element_size()
+    if need > wsb:
+        raise HipError(f"linear_wgrad: workspace of {need} bytes required, got {wsb}")
+    _check(lib().ib_linear_wgrad(_ptr(dz), lddz, _ptr(x), ldx, _ptr(dw), lddw, int(accumulate), _ptr(workspace), wsb,
+                                 M, N, K, dtype_code(dt), stream_ptr()), "ib_linear_wgrad")
+    return dw
+
+
+def segment_colsum(x, out, seg, mode=0, accumulate=False):
+    dt = x.dtype
+    M, N, ldx = _mat(x, "x", dt)
+    S, No, ldo = _mat(out, "out", torch.float32)
+    nseg = (M + seg - 1) // seg if mode == 0 else min(seg, M)
+    if No != N or S < nseg:
+        raise HipError(f"segment_colsum: out must be [{nseg}, {N}], got {tuple(out.shape)}")
+    _check(lib().ib_segment_colsum(_ptr(x), ldx, _ptr(out), ldo, M, N, int(seg), int(mode), int(accumulate),
+                                   dtype_code(dt), stream_ptr()), "ib_segment_colsum")
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# LayerNorm
+# --------------------------------------------------------------------------------------------
+def _rows(t: torch.Tensor, name: str, dt):
+    _req(t, name, dt)
+    if not t.is_contiguous():
+        raise HipError(f"{name} must be contiguous")
+    return t.numel() // t.shape[-1], t.shape[-1]
+
+
+def layernorm_fwd(x, gamma, beta, y, mean, rstd, res=None, act="none", eps=1e-5):
+    dt = x.dtype
+    M, N = _rows(x, "x", dt)
+    for t, n in ((y, "y"),) + (((res, "res"),) if res is not None else ()):
+        if _rows(t, n, dt) != (M, N):
+            raise HipError(f"{n} shape mismatch")
+    for t, n in ((gamma, "gamma"), (beta, "beta")):
+        _req(t, n, torch.float32, 1)
+        if t.numel() != N or not t.is_contiguous():
+            raise HipError(f"{n} must be contiguous fp32 [N]")
+    for t, n in ((mean, "mean"), (rstd, "rstd")):
+        _req(t, n, torch.float32)
+        if t.numel() != M or not t.is_contiguous():
+            raise HipError(f"{n} must be contiguous fp32 [M]")
+    _check(lib().ib_layernorm_fwd(_ptr(x), _ptr(res), ACT[act], _ptr(gamma), _ptr(beta), _ptr(y), _ptr(mean),
+                                  _ptr(rstd), M, N, float(eps), dtype_code(dt), stream_ptr()), "ib_layernorm_fwd")
+    return y
+
+
+def layernorm_bwd_workspace_bytes(M, N) -> int:
+    return int(lib().ib_layernorm_bwd_workspace(M, N))
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, res=None, dres=None, act="none",
+                  accumulate=False):
+    dt = x.dtype
+    M, N = _rows(x, "x", dt)
+    for t, n in ((dy, "dy"), (dx, "dx")) + (((res, "res"),) if res is not None else ()) + \
+            (((dres, "dres"),) if dres is not None else ()):
+        if _rows(t, n, dt) != (M, N):
+            raise HipError(f"{n} shape mismatch")
+    for t, n in ((gamma, "gamma"), (dgamma, "dgamma"), (dbeta, "dbeta")):
+        _req(t, n, torch.float32, 1)
+        if t.numel() != N or not t.is_contiguous():
+            raise HipError(f"{n} must be contiguous fp32 [N]")
+    for t, n in ((mean, "mean"), (rstd, "rstd")):
+        _req(t, n, torch.float32)
+        if t.numel() != M:
+            raise HipError(f"{n} must be fp32 [M]")
+    need = layernorm_bwd_workspace_bytes(M, N)
+    wsb = workspace.numel() * workspace.element_size()
+    if wsb < need:
+        raise HipError(f"layernorm_bwd: workspace of {need} bytes required, got {wsb}")
+    _check(lib().ib_layernorm_bwd(_ptr(dy), _ptr(x), _ptr(res), ACT[act], _ptr(gamma), _ptr(mean), _ptr(rstd),
+                                  _ptr(dx), _ptr(dres), _ptr(dgamma), _ptr(dbeta), int(accumulate), _ptr(workspace),
+                                  wsb, M, N, dtype_code(dt), stream_ptr()), "ib_layernorm_bwd")
+    return dx
+
+
+# --------------------------------------------------------------------------------------------
+# attention
+# --------------------------------------------------------------------------------------------
+def attention_fwd(qkv, out, lse, num_heads):
+    dt = qkv.dtype
+    _req(qkv, "qkv", dt, 3)
+    B, T, d3 = qkv.shape
+    d = d3 // 3
+    if d * 3 != d3 or d % num_heads or not qkv.is_contiguous():
+        raise HipError(f"qkv must be contiguous [B,T,3*H*dh], got {tuple(qkv.shape)}")
+    _req(out, "out", dt, 3)
+    if tuple(out.shape) != (B, T, d) or not out.is_contiguous():
+        raise HipError("out must be contiguous [B,T,H*dh]")
+    _req(lse, "lse", torch.float32)
+    if lse.numel() != B * num_heads * T or not lse.is_contiguous():
+        raise HipError("lse must be contiguous fp32 [B,H,T]")
+    _check(lib().ib_attention_fwd(_ptr(qkv), _ptr(out), _ptr(lse), B, T, num_heads, d // num_heads, dtype_code(dt),
+                                  stream_ptr()), "ib_attention_fwd")
+    return out
+
+
+def attention_bwd(qkv, out, dout, lse, dqkv, num_heads):
+    dt = qkv.dtype
+    B, T, d3 = qkv.shape
+    d = d3 // 3
+    for t, n, shp in ((qkv, "qkv", (B, T, d3)), (dqkv, "dqkv", (B, T, d3)), (out, "out", (B, T, d)),
+                      (dout, "dout", (B, T, d))):
+        _req(t, n, dt, 3)
+        if tuple(t.shape) != shp or not t.is_contiguous():
+            raise HipError(f"{n} must be contiguous {shp}")
+    _req(lse, "lse", torch.float32)
+    if lse.numel() != B * num_heads * T:
+        raise HipError("lse must be fp32 [B,H,T]")
+    _check(lib().ib_attention_bwd(_ptr(qkv), _ptr(out), _ptr(dout), _ptr(lse), _ptr(dqkv), B, T, num_heads,
+                                  d // num_heads, dtype_code(dt), stream_ptr()), "ib_attention_bwd")
+    return dqkv
+
+
+# --------------------------------------------------------------------------------------------
+# packing / casts
+# --------------------------------------------------------------------------------------------
+def concat_keys(tensors: Sequence[torch.Tensor], out: torch.Tensor):
+    rows = None
+    widths = []
+    for i, t in enumerate(tensors):
+        _req(t, f"input[{i}]", torch.float32)
+        if not t.is_contiguous():
+            raise HipError(f"input[{i}] must be contiguous")
+        r = t.numel() // t.shape[-1]
+        if rows is None:
+            rows = r
+        elif r != rows:
+            raise HipError("all keys must have the same [B,F] leading shape")
+        widths.append(t.shape[-1])
+    _req(out, "out")
+    if out.numel() != rows * sum(widths) or not out.is_contiguous():
+        raise HipError("concat_keys: out has the wrong size")
+    n = len(tensors)
+    ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in tensors])
+    ws = (ctypes.c_int32 * n)(*widths)
+    _check(lib().ib_concat_keys(ctypes.cast(ptrs, ctypes.c_void_p), ctypes.cast(ws, ctypes.c_void_p), n, _ptr(out),
+                                rows, dtype_code(out.dtype), stream_ptr()), "ib_concat_keys")
+    return out
+
+
+def cast(src: torch.Tensor, dst: torch.Tensor):
+    _req(src, "src")
+    _req(dst, "dst")
+    if src.numel() != dst.numel() or not src.is_contiguous() or not dst.is_contiguous():
+        raise HipError("cast: src/dst must be contiguous with equal numel")
+    _check(lib().ib_cast(_ptr(src), dtype_code(src.dtype), _ptr(dst), dtype_code(dst.dtype), src.numel(),
+                         stream_ptr()), "ib_cast")
+    return dst
+
+
+def cast2d(src: torch.Tensor, dst: torch.Tensor):
+    r, c, lds = _mat(src, "src", src.dtype)
+    r2, c2, ldd = _mat(dst, "dst", dst.dtype)
+    if (r, c) != (r2, c2):
+        raise HipError("cast2d shape mismatch")
+    _check(lib().ib_cast2d(_ptr(src), lds, dtype_code(src.dtype), _ptr(dst), ldd, dtype_code(dst.dtype), r, c,
+                           stream_ptr()), "ib_cast2d")
+    return dst
+
+
+# --------------------------------------------------------------------------------------------
+# losses
+# --------------------------------------------------------------------------------------------
+def regression_loss_workspace_bytes(B, F) -> int:
+    return int(lib().ib_regression_loss_workspace(B, F))
+
+
+def _bfc(t: torch.Tensor, name: str, dt, C: int):
+    """[B,F,C] tensor whose (F,C) block is contiguous -> batch stride."""
+    _req(t, name, dt, 3)
+    B, F, c = t.shape
+    if c != C or t.stride(2) != 1 or (F > 1 and t.stride(1) != C):
+        raise HipError(f"{name}: expected [B,F,{C}] with contiguous (F,C) block, got {tuple(t.shape)} strides {t.stride()}")
+    return t.stride(0) if B > 1 else F * C
+
+
+def regression_loss(outs, labels, comp_w, result, workspace, grads=None, threshold=10.0):
+    """outs/labels/grads: (cop, force, torque, wrench) tuples."""
+    dt = outs[0].dtype
+    B, F, _ = outs[0].shape
+    Cs = (6, 6, 6, 12)
+    obs = (ctypes.c_int64 * 4)(*[_bfc(t, f"out[{i}]", dt, Cs[i]) for i, t in enumerate(outs)])
+    for i, t in enumerate(outs):
+        if tuple(t.shape) != (B, F, Cs[i]):
+            raise HipError(f"out[{i}] must be [{B},{F},{Cs[i]}], got {tuple(t.shape)}")
+    for i, t in enumerate(labels):
+        _req(t, f"label[{i}]", torch.float32, 3)
+        if tuple(t.shape) != (B, F, Cs[i]) or not t.is_contiguous():
+            raise HipError(f"label[{i}] must be contiguous fp32 [{B},{F},{Cs[i]}], got {tuple(t.shape)}")
+    gbs = None
+    gp = [None] * 4
+    if grads is not None:
+        gbs = (ctypes.c_int64 * 4)(*[_bfc(t, f"grad[{i}]", dt, Cs[i]) for i, t in enumerate(grads)])
+        gp = [t.data_ptr() for t in grads]
+        for i, t in enumerate(grads):
+            if tuple(t.shape) != (B, F, Cs[i]):
+                raise HipError("grad shape mismatch")
+    _req(comp_w, "comp_w", torch.float32, 1)
+    _req(result, "result", torch.float32, 1)
+    if comp_w.numel() != 30 or result.numel() < 64:
+        raise HipError("comp_w must be [30], result [64]")
+    wsb = workspace.numel() * workspace.element_size()
+    if wsb < regression_loss_workspace_bytes(B, F):
+        raise HipError("regression_loss: workspace too small")
+    _check(lib().ib_regression_loss(_ptr(outs[0]), _ptr(outs[1]), _ptr(outs[2]), _ptr(outs[3]), ctypes.cast(obs, ctypes.c_void_p),
+                                    _ptr(labels[0]), _ptr(labels[1]), _ptr(labels[2]), _ptr(labels[3]), _ptr(comp_w),
+                                    float(threshold), _ptr(result), gp[0], gp[1], gp[2], gp[3],
+                                    None if gbs is None else ctypes.cast(gbs, ctypes.c_void_p), _ptr(workspace),
+                                    wsb, B, F, dtype_code(dt), stream_ptr()), "ib_regression_loss")
+    return result
+
+
+def mse_loss_workspace_bytes(n) -> int:
+    return int(lib().ib_mse_loss_workspace(n))
+
+
+def mse_loss(pred, target, result, workspace, dpred=None):
+    dt = pred.dtype
+    _req(pred, "pred", dt)
+    _req(target, "target", dt)
+    n = pred.numel()
+    if target.numel() != n or not pred.is_contiguous() or not target.is_contiguous():
+        raise HipError("mse_loss: pred/target must be contiguous with equal numel")
+    if dpred is not None and (dpred.dtype != dt or dpred.numel() != n or not dpred.is_contiguous()):
+        raise HipError("mse_loss: dpred mismatch")
+    _req(result, "result", torch.float32)
+    wsb = workspace.numel() * workspace.element_size()
+    if wsb < mse_loss_workspace_bytes(n):
+        raise HipError("mse_loss: workspace too small")
+    _check(lib().ib_mse_loss(_ptr(pred), _ptr(target), _ptr(dpred), _ptr(result), _ptr(workspace), wsb, n,
+                             dtype_code(dt), stream_ptr()), "ib_mse_loss")
+    return result
+
+
+# --------------------------------------------------------------------------------------------
+# optimizer
+# --------------------------------------------------------------------------------------------
+def optim_step(opt: str, p, g, s1, s2, lr, step=1, step_dev=None, grad_scale=1.0, shadow=None):
+    _req(p, "p", torch.float32, 1)
+    _req(g, "g", torch.float32, 1)
+    n = p.numel()
+    if g.numel() != n or not p.is_contiguous() or not g.is_contiguous():
+        raise HipError("optim_step: flat contiguous fp32 buffers of equal length required")
+    for t, nm in ((s1, "s1"), (s2, "s2")):
+        if t is not None:
+            _req(t, nm, torch.float32, 1)
+            if t.numel() != n:
+                raise HipError(f"{nm} length mismatch")
+    if shadow is not None:
+        _req(shadow, "shadow", torch.bfloat16, 1)
+        if shadow.numel() != n:
+            raise HipError("shadow length mismatch")
+    if step_dev is not None:
+        _req(step_dev, "step_dev", torch.int32)
+    _check(lib().ib_optim_step(OPT[opt], _ptr(p), _ptr(g), _ptr(s1), _ptr(s2), n, float(lr), float(grad_scale),
+                               int(step), _ptr(step_dev), _ptr(shadow), stream_ptr()), "ib_optim_step")
+
+
+# --------------------------------------------------------------------------------------------
+# diffusion
+# --------------------------------------------------------------------------------------------
+def gather_rows(table, idx, out):
+    _req(table, "table", torch.float32, 2)
+    _req(idx, "idx", torch.int64, 1)
+    _req(out, "out", None, 2)
+    B, dim = out.shape
+    if idx.numel() != B or table.shape[1] != dim or not table.is_contiguous() or not out.is_contiguous():
+        raise HipError("gather_rows shape mismatch")
+    _check(lib().ib_gather_rows(_ptr(table), _ptr(idx), _ptr(out), B, dim, table.shape[0], dtype_code(out.dtype),
+                                stream_ptr()), "ib_gather_rows")
+    return out
+
+
+def q_sample(x0, eps, t, sqrt_ab, sqrt_1mab, x_t):
+    dt = x0.dtype
+    for a, n in ((x0, "x0"), (eps, "eps"), (x_t, "x_t")):
+        _req(a, n, dt)
+        if a.shape != x0.shape or not a.is_contiguous():
+            raise HipError(f"{n}: contiguous tensors of one shape required")
+    _req(t, "t", torch.int64, 1)
+    B = x0.shape[0]
+    if t.numel() != B:
+        raise HipError("t must be int64 [B]")
+    _req(sqrt_ab, "sqrt_ab", torch.float32, 1)
+    _req(sqrt_1mab, "sqrt_1mab", torch.float32, 1)
+    _check(lib().ib_q_sample(_ptr(x0), _ptr(eps), _ptr(t), _ptr(sqrt_ab), _ptr(sqrt_1mab), _ptr(x_t), B,
+                             x0.numel() // B, sqrt_ab.numel(), dtype_code(dt), stream_ptr()), "ib_q_sample")
+    return x_t
+
+
+def ddim_step(x, eps, coef, timesteps, step=0, step_dev=None, t_out=None):
+    dt = x.dtype
+    _req(x, "x", dt)
+    _req(eps, "eps", dt)
+    if eps.shape != x.shape or not x.is_contiguous() or not eps.is_contiguous():
+        raise HipError("ddim_step: x/eps must be contiguous with one shape")
+    _req(coef, "coef", torch.float32, 2)
+    _req(timesteps, "timesteps", torch.int64, 1)
+    S = coef.shape[0]
+    if coef.shape[1] != 2 or timesteps.numel() != S or not coef.is_contiguous():
+        raise HipError("coef must be [S,2] fp32, timesteps [S] int64")
+    B = x.shape[0]
+    if t_out is not None:
+        _req(t_out, "t_out", torch.int64, 1)
+        if t_out.numel() != B:
+            raise HipError("t_out must be int64 [B]")
+    _check(lib().ib_ddim_step(_ptr(x), _ptr(eps), _ptr(coef), _ptr(timesteps), S, int(step), _ptr(step_dev),
+                              _ptr(t_out), B, x.numel(), dtype_code(dt), stream_ptr()), "ib_ddim_step")
+    return x
+
+
+def counter_add(counter, delta=1):
+    _req(counter, "counter", torch.int32)
+    _check(lib().ib_counter_add(_ptr(counter), int(delta), stream_ptr()), "ib_counter_add")
+
+
+def fill_i64(dst, value):
+    _req(dst, "dst", torch.int64)
+    _check(lib().ib_fill_i64(_ptr(dst), int(value), dst.numel(), stream_ptr()), "ib_fill_i64")
+
+
+# --------------------------------------------------------------------------------------------
+# graphs / events
+# --------------------------------------------------------------------------------------------
+class Graph:
+    """A hipGraph captured from the launches issued between begin() and end() on the current stream."""
+
+    def __init__(self):
+        self._exec = None
+
+    def begin(self):
+        _check(lib().ib_graph_begin(stream_ptr()), "ib_graph_begin")
+
+    def end(self):
+        h = ctypes.c_void_p()
+        _check(lib().ib_graph_end(stream_ptr(), ctypes.byref(h)), "ib_graph_end")
+        self._exec = h
+
+    def launch(self):
+        if self._exec is None:
+            raise HipError("graph has not been captured")
+        _check(lib().ib_graph_launch(self._exec, stream_ptr()), "ib_graph_launch")
+
+    def __del__(self):
+        try:
+            if self._exec is not None and _lib is not None:
+                _lib.ib_graph_destroy(self._exec)
+        except Exception:
+            pass
+
+
+class Event:
+    """hipEvent recorded on the CURRENT torch stream (the stream the kernels are launched on)."""
+
+    def __init__(self):
+        h = ctypes.c_void_p()
+        _check(lib().ib_event_create(ctypes.byref(h)), "ib_event_create")
+        self._h = h
+
+    def record(self):
+        _check(lib().ib_event_record(self._h, stream_ptr()), "ib_event_record")
+
+    def elapsed_ms(self, stop: "Event") -> float:
+        ms = ctypes.c_float()
+        _check(lib().ib_event_elapsed_ms(self._h, stop._h, ctypes.byref(ms)), "ib_event_elapsed_ms")
+        return ms.value
+
+    def __del__(self):
+        try:
+            if _lib is not None:
+                _lib.ib_event_destroy(self._h)
+        except Exception:
+            pass
+
+
+def selftest_tr16(inp: torch.Tensor, out: torch.Tensor):
+    _check(lib().ib_selftest_tr16(_ptr(inp), _ptr(out), stream_ptr()), "ib_selftest_tr16")
+    return out

@@ -1,0 +1,49 @@
+"""[BUILD-DEFINED] eps-prediction loss of the diffusion wrapper: loss = mean((eps_hat - eps)^2).
+
+One launch pair (per-block partials + fixed-order final sum) that also writes d loss/d eps_hat; the
+loss value stays on the device (no host sync per step)."""
+from typing import List
+
+import torch
+
+from .. import hip
+
+
+class _MSEFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target):
+        n = pred.numel()
+        result = torch.zeros(1, dtype=torch.float32, device=pred.device)
+        ws = torch.empty(hip.mse_loss_workspace_bytes(n), dtype=torch.uint8, device=pred.device)
+        dpred = torch.empty_like(pred) if pred.requires_grad else None
+        hip.mse_loss(pred, target, result, ws, dpred=dpred)
+        ctx.dpred = dpred
+        return result[0]
+
+    @staticmethod
+    def backward(ctx, dloss):
+        if ctx.dpred is None:
+            return None, None
+        return ctx.dpred * dloss.to(ctx.dpred.dtype), None
+
+
+class DiffusionLossEvaluator:
+    def __init__(self, split: str = 'train'):
+        self.split = split
+        self.losses: List[torch.Tensor] = []
+
+    def __call__(self, eps_pred: torch.Tensor, eps: torch.Tensor) -> torch.Tensor:
+        eps = eps.to(device=eps_pred.device, dtype=eps_pred.dtype).contiguous()
+        loss = _MSEFn.apply(eps_pred.contiguous(), eps)
+        self.losses.append(loss.detach())
+        return loss
+
+    def print_report(self, reset: bool = True):
+        if self.losses:
+            m = float(torch.stack(self.losses).mean().cpu())
+            print(f'\t[{self.split}] eps-MSE: {m}')
+        else:
+            m = None
+        if reset:
+            self.losses = []
+        return m

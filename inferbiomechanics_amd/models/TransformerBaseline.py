@@ -1,0 +1,81 @@
+"""TransformerLayer on gfx950 kernels (src/models/TransformerBaseline.py:8-38).
+
+Same constructor and state_dict names as the reference layer (``multihead_attention.in_proj_weight``,
+``...out_proj.weight``, ``feedforward.{0,2}.*``, ``norm{1,2}.*``).  The reference's whole-model
+``TransformerBaseline.forward`` is dead code (it needs data keys that no longer exist);
+its layer arithmetic is what the transformer denoiser is built from.
+dropout must be 0 (the only value the reference model passes, TransformerBaseline.py:79).
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from ..module import HipModule
+from ..plans import TransformerLayerPlan
+
+
+class _MHAParams(nn.Module):
+    """Parameter container with nn.MultiheadAttention's names and initialisation."""
+
+    def __init__(self, d: int, dtype, device=None):
+        super().__init__()
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * d, d, dtype=dtype, device=device))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * d, dtype=dtype, device=device))
+        self.out_proj = nn.Linear(d, d, dtype=dtype, device=device)
+        nn.init.xavier_uniform_(self.in_proj_weight)
+        nn.init.constant_(self.out_proj.bias, 0.0)
+
+
+def make_layer_params(d: int, ffn: int, dtype=torch.float32, device=None) -> nn.ModuleDict:
+    return nn.ModuleDict({
+        "multihead_attention": _MHAParams(d, dtype, device),
+        "feedforward": nn.ModuleDict({"0": nn.Linear(d, ffn, dtype=dtype, device=device),
+                                      "2": nn.Linear(ffn, d, dtype=dtype, device=device)}),
+        "norm1": nn.LayerNorm(d, dtype=dtype, device=device),
+        "norm2": nn.LayerNorm(d, dtype=dtype, device=device),
+    })
+
+
+class TransformerLayer(HipModule):
+    def __init__(self, timestep_vector_dim: int, num_heads: int, dim_feedforward: int, dropout: float = 0.0,
+                 dtype=torch.float32, device=None):
+        super().__init__(torch.bfloat16 if dtype == torch.bfloat16 else torch.float32)
+        if dropout != 0.0:
+            raise NotImplementedError("dropout != 0 is not on the HIP hot path (reference passes 0.0)")
+        if timestep_vector_dim % num_heads:
+            raise AssertionError("embed_dim must be divisible by num_heads")
+        self.d, self.h, self.ffn = timestep_vector_dim, num_heads, dim_feedforward
+        sub = make_layer_params(self.d, self.ffn, torch.float32, device)
+        self.multihead_attention = sub["multihead_attention"]
+        self.feedforward = sub["feedforward"]
+        self.norm1, self.norm2 = sub["norm1"], sub["norm2"]
+        self._plan = None
+
+    def _get_plan(self, device):
+        if self._plan is None or self._plan.buf.device != device or self._plan.dtype != self.compute_dtype:
+            self._plan = TransformerLayerPlan("", self.d, self.h, self.ffn, self.compute_dtype, device)
+        return self._plan
+
+    def _plan_forward(self, x):
+        out = torch.empty_like(x)
+        return self._get_plan(x.device).forward(x, self.param_source(), out=out)
+
+    def _plan_backward(self, dout, P, accumulate):
+        return {0: self._plan.backward(dout, P, accumulate).clone()}
+
+    def forward(self, x: torch.Tensor):
+        self.ensure_packed()
+        x = x.to(device=self._flat.device, dtype=self.compute_dtype).contiguous()
+        return self.run_plan(x)
+
+
+class TemporalEmbedding(nn.Module):
+    """Learned per-frame vector (src/models/TransformerBaseline.py:41-48); looked up with arange(T)."""
+
+    def __init__(self, window_size: int, embedding_dim: int, dtype=torch.float32, device=None):
+        super().__init__()
+        self.embedding = nn.Embedding(window_size, embedding_dim, dtype=dtype, device=device)
+
+    def forward(self, x):
+        return self.embedding(x)

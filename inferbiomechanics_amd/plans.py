@@ -1,0 +1,371 @@
+"""Explicit forward / backward launch plans over the HIP kernels.
+
+A *plan* is the MI355X-native replacement of "autograd over stock torch ops" for one model of the
+hot path: a fixed sequence of C-ABI launches over buffers that stay resident in HBM (allocated once
+per (plan, batch shape), so a warmed-up plan allocates nothing and can be captured into a hipGraph).
+Activations needed by the backward are kept in those buffers; nothing is re-derived by a tracing
+compiler.  Parameters are read through ``ParamSource`` (fp32 masters, or their bf16 shadows in
+throughput mode); gradients are written straight into caller-provided fp32 tensors (the flat grad
+buffer of the trainer, or scratch tensors handed to autograd).
+
+Reference arithmetic implemented here (file:line relative to the reference root):
+  * DenseStackPlan        -- FeedForwardBaseline.net, src/models/FeedForwardRegressionBaseline.py:65-77,113
+  * TransformerLayerPlan  -- TransformerLayer.forward, src/models/TransformerBaseline.py:24-38
+  * DenoiserMLPPlan / DenoiserTransformerPlan -- [BUILD-DEFINED] diffusion denoisers
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import hip
+
+
+class Buffers:
+    """Named HBM buffers, allocated on first use and reused afterwards (graph-capture safe)."""
+
+    def __init__(self, device):
+        self.device = device
+        self._b: Dict[tuple, torch.Tensor] = {}
+
+    def get(self, name: str, shape, dtype) -> torch.Tensor:
+        key = (name, tuple(int(s) for s in shape), dtype)
+        t = self._b.get(key)
+        if t is None:
+            t = torch.empty(key[1], dtype=dtype, device=self.device)
+            self._b[key] = t
+        return t
+
+    def bytes(self, name: str, nbytes: int) -> torch.Tensor:
+        n = max(int(nbytes), 16)
+        key = (name, "bytes")
+        t = self._b.get(key)
+        if t is None or t.numel() < n:
+            t = torch.empty(n, dtype=torch.uint8, device=self.device)
+            self._b[key] = t
+        return t
+
+    def nbytes(self) -> int:
+        return sum(t.numel() * t.element_size() for t in self._b.values())
+
+
+class ParamSource:
+    """name -> tensor in the plan's compute dtype for matrices (``w``), fp32 for vectors (``v``);
+    ``g`` -> the fp32 tensor that receives d loss / d param."""
+
+    def __init__(self, w: Callable[[str], torch.Tensor], v: Callable[[str], torch.Tensor],
+                 g: Optional[Callable[[str], torch.Tensor]] = None):
+        self.w, self.v, self.g = w, v, g
+
+
+def _colsum(buf: Buffers, tag: str, x2d: torch.Tensor, out_vec: torch.Tensor, accumulate: bool):
+    """out_vec[N] (+)= sum over all rows of x2d[M,N] -- one launch for short M, two for long M."""
+    M, N = x2d.shape
+    if M <= 512:
+        hip.segment_colsum(x2d, out_vec.view(1, N), seg=M, mode=0, accumulate=accumulate)
+    else:
+        chunk = 128
+        part = buf.get(tag + ".colsum", ((M + chunk - 1) // chunk, N), torch.float32)
+        hip.segment_colsum(x2d, part, seg=chunk, mode=0)
+        hip.segment_colsum(part, out_vec.view(1, N), seg=part.shape[0], mode=0, accumulate=accumulate)
+
+
+def _wgrad(buf: Buffers, dz: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, accumulate: bool):
+    M, N = dz.shape
+    K = x.shape[1]
+    ws = buf.bytes("wgrad.ws", hip.linear_wgrad_workspace_bytes(M, N, K))
+    hip.linear_wgrad(dz, x, dw, ws, accumulate=accumulate)
+
+
+def _as_dtype(buf: Buffers, tag: str, t32: torch.Tensor, dtype) -> torch.Tensor:
+    """fp32 reduction result -> GEMM operand in the compute dtype (no-op in parity mode)."""
+    if dtype == torch.float32:
+        return t32
+    o = buf.get(tag + ".cast", t32.shape, dtype)
+    hip.cast(t32, o)
+    return o
+
+
+# ------------------------------------------------------------------------------------------------
+class DenseStackPlan:
+    """[Linear act]* Linear over [M, K0] rows (FeedForwardRegressionBaseline.py:65-77)."""
+
+    def __init__(self, names: Sequence[Tuple[str, str]], activation: str, dtype, device, tag="ff"):
+        self.names, self.act, self.dtype, self.tag = list(names), activation, dtype, tag
+        self.buf = Buffers(device)
+        self.saved: List[torch.Tensor] = []
+
+    def forward(self, x: torch.Tensor, P: ParamSource, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        M = x.shape[0]
+        L = len(self.names)
+        self.saved = [x]
+        h = x
+        for i, (wn, bn) in enumerate(self.names):
+            w = P.w(wn)
+            last = i == L - 1
+            y = out if (last and out is not None) else self.buf.get(f"{self.tag}.y{i}", (M, w.shape[0]), self.dtype)
+            z = None
+            if not last and self.act == "silu":
+                z = self.buf.get(f"{self.tag}.z{i}", (M, w.shape[0]), self.dtype)
+            hip.linear_fwd(h, w, P.v(bn), y, act="none" if last else self.act, z=z)
+            self.saved.append(y if z is None else (y, z))
+            h = y
+        return h
+
+    def backward(self, dout: torch.Tensor, P: ParamSource, accumulate=False, need_dx=False):
+        L = len(self.names)
+        dz = dout
+        dx = None
+        for i in range(L - 1, -1, -1):
+            wn, bn = self.names[i]
+            xin = self.saved[i]
+            xin_y = xin[0] if isinstance(xin, tuple) else xin
+            _wgrad(self.buf, dz, xin_y, P.g(wn), accumulate)
+            _colsum(self.buf, f"{self.tag}.b{i}", dz, P.g(bn), accumulate)
+            if i > 0:
+                aux = xin[1] if isinstance(xin, tuple) else xin
+                nxt = self.buf.get(f"{self.tag}.dz{i - 1}", xin_y.shape, self.dtype)
+                hip.linear_dgrad(dz, P.w(wn), nxt, act_below=self.act, aux=aux)
+                dz = nxt
+            elif need_dx:
+                dx = self.buf.get(f"{self.tag}.dx", xin_y.shape, self.dtype)
+                hip.linear_dgrad(dz, P.w(wn), dx)
+        return dx
+
+
+# ------------------------------------------------------------------------------------------------
+class TransformerLayerPlan:
+    """Post-norm encoder layer (TransformerBaseline.py:24-38): x=LN1(x+MHA(x)); x=LN2(x+W2 relu(W1 x))."""
+
+    def __init__(self, prefix: str, d_model: int, num_heads: int, ffn: int, dtype, device, buf: Optional[Buffers] = None,
+                 tag="tl"):
+        self.p, self.d, self.h, self.ffn, self.dtype, self.tag = prefix, d_model, num_heads, ffn, dtype, tag
+        self.buf = buf if buf is not None else Buffers(device)
+        self.ctx = None
+
+    def forward(self, x3: torch.Tensor, P: ParamSource, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        B, T, d = x3.shape
+        M = B * T
+        g, dt, p, tg = self.buf.get, self.dtype, self.p, self.tag
+        x = x3.view(M, d)
+        qkv = g(tg + ".qkv", (B, T, 3 * d), dt)
+        hip.linear_fwd(x, P.w(p + "multihead_attention.in_proj_weight"), P.v(p + "multihead_attention.in_proj_bias"),
+                       qkv.view(M, 3 * d))
+        attn = g(tg + ".attn", (B, T, d), dt)
+        lse = g(tg + ".lse", (B, self.h, T), torch.float32)
+        hip.attention_fwd(qkv, attn, lse, self.h)
+        a = g(tg + ".a", (M, d), dt)
+        hip.linear_fwd(attn.view(M, d), P.w(p + "multihead_attention.out_proj.weight"),
+                       P.v(p + "multihead_attention.out_proj.bias"), a)
+        x1 = g(tg + ".x1", (M, d), dt)
+        m1, r1 = g(tg + ".m1", (M,), torch.float32), g(tg + ".r1", (M,), torch.float32)
+        hip.layernorm_fwd(a, P.v(p + "norm1.weight"), P.v(p + "norm1.bias"), x1, m1, r1, res=x)
+        f1 = g(tg + ".f1", (M, self.ffn), dt)
+        hip.linear_fwd(x1, P.w(p + "feedforward.0.weight"), P.v(p + "feedforward.0.bias"), f1, act="relu")
+        f2 = g(tg + ".f2", (M, d), dt)
+        hip.linear_fwd(f1, P.w(p + "feedforward.2.weight"), P.v(p + "feedforward.2.bias"), f2)
+        x2 = out if out is not None else g(tg + ".x2", (B, T, d), dt)
+        m2, r2 = g(tg + ".m2", (M,), torch.float32), g(tg + ".r2", (M,), torch.float32)
+        hip.layernorm_fwd(f2, P.v(p + "norm2.weight"), P.v(p + "norm2.bias"), x2.view(M, d), m2, r2, res=x1)
+        self.ctx = (x, qkv, attn, lse, a, x1, m1, r1, f1, f2, m2, r2, B, T)
+        return x2
+
+    def backward(self, dx2: torch.Tensor, P: ParamSource, accumulate=False) -> torch.Tensor:
+        x, qkv, attn, lse, a, x1, m1, r1, f1, f2, m2, r2, B, T = self.ctx
+        M, d = x.shape
+        g, dt, p, tg = self.buf.get, self.dtype, self.p, self.tag
+        lnws = self.buf.bytes("ln.ws", hip.layernorm_bwd_workspace_bytes(M, max(d, 1)))
+        # LN2: d(f2 + x1)
+        ds2 = g(tg + ".ds2", (M, d), dt)
+        hip.layernorm_bwd(dx2.view(M, d), f2, P.v(p + "norm2.weight"), m2, r2, ds2, P.g(p + "norm2.weight"),
+                          P.g(p + "norm2.bias"), lnws, res=x1, accumulate=accumulate)
+        _wgrad(self.buf, ds2, f1, P.g(p + "feedforward.2.weight"), accumulate)
+        _colsum(self.buf, tg + ".b2", ds2, P.g(p + "feedforward.2.bias"), accumulate)
+        dz1 = g(tg + ".dz1", (M, self.ffn), dt)
+        hip.linear_dgrad(ds2, P.w(p + "feedforward.2.weight"), dz1, act_below="relu", aux=f1)
+        _wgrad(self.buf, dz1, x1, P.g(p + "feedforward.0.weight"), accumulate)
+        _colsum(self.buf, tg + ".b1", dz1, P.g(p + "feedforward.0.bias"), accumulate)
+        dx1 = g(tg + ".dx1", (M, d), dt)
+        hip.linear_dgrad(dz1, P.w(p + "feedforward.0.weight"), dx1, addend=ds2)       # + residual path
+        # LN1: d(a + x)
+        ds1 = g(tg + ".ds1", (M, d), dt)
+        hip.layernorm_bwd(dx1, a, P.v(p + "norm1.weight"), m1, r1, ds1, P.g(p + "norm1.weight"),
+                          P.g(p + "norm1.bias"), lnws, res=x, accumulate=accumulate)
+        _wgrad(self.buf, ds1, attn.view(M, d), P.g(p + "multihead_attention.out_proj.weight"), accumulate)
+        _colsum(self.buf, tg + ".bo", ds1, P.g(p + "multihead_attention.out_proj.bias"), accumulate)
+        dattn = g(tg + ".dattn", (B, T, d), dt)
+        hip.linear_dgrad(ds1, P.w(p + "multihead_attention.out_proj.weight"), dattn.view(M, d))
+        dqkv = g(tg + ".dqkv", (B, T, 3 * d), dt)
+        hip.attention_bwd(qkv, attn, dattn, lse, dqkv, self.h)
+        dq2 = dqkv.view(M, 3 * d)
+        _wgrad(self.buf, dq2, x, P.g(p + "multihead_attention.in_proj_weight"), accumulate)
+        _colsum(self.buf, tg + ".bi", dq2, P.g(p + "multihead_attention.in_proj_bias"), accumulate)
+        dx = g(tg + ".dx", (B, T, d), dt)
+        hip.linear_dgrad(dq2, P.w(p + "multihead_attention.in_proj_weight"), dx.view(M, d), addend=ds1)
+        return dx
+
+
+# ------------------------------------------------------------------------------------------------
+class TimeMLPPlan:
+    """e = W2 silu(W1 sinus(t) + b1) + b2; sinus(t) is a row gather from a host-built fp32 table."""
+
+    def __init__(self, dtype, buf: Buffers, tag="tm"):
+        self.dtype, self.buf, self.tag = dtype, buf, tag
+        self.ctx = None
+
+    def forward(self, t: torch.Tensor, table: torch.Tensor, P: ParamSource) -> torch.Tensor:
+        B = t.shape[0]
+        g, dt, tg = self.buf.get, self.dtype, self.tag
+        w1, w2 = P.w("time_mlp.0.weight"), P.w("time_mlp.2.weight")
+        s = g(tg + ".s", (B, table.shape[1]), dt)
+        hip.gather_rows(table, t, s)
+        u = g(tg + ".u", (B, w1.shape[0]), dt)
+        zu = g(tg + ".zu", (B, w1.shape[0]), dt)
+        hip.linear_fwd(s, w1, P.v("time_mlp.0.bias"), u, act="silu", z=zu)
+        e = g(tg + ".e", (B, w2.shape[0]), dt)
+        hip.linear_fwd(u, w2, P.v("time_mlp.2.bias"), e)
+        self.ctx = (s, u, zu)
+        return e
+
+    def backward(self, de32: torch.Tensor, P: ParamSource, accumulate=False):
+        s, u, zu = self.ctx
+        B = s.shape[0]
+        tg = self.tag
+        de = _as_dtype(self.buf, tg + ".de", de32, self.dtype)
+        _wgrad(self.buf, de, u, P.g("time_mlp.2.weight"), accumulate)
+        _colsum(self.buf, tg + ".b2", de32, P.g("time_mlp.2.bias"), accumulate)
+        du = self.buf.get(tg + ".du", u.shape, self.dtype)
+        hip.linear_dgrad(de, P.w("time_mlp.2.weight"), du, act_below="silu", aux=zu)
+        _wgrad(self.buf, du, s, P.g("time_mlp.0.weight"), accumulate)
+        _colsum(self.buf, tg + ".b1", du, P.g("time_mlp.0.bias"), accumulate)
+
+
+class DenoiserMLPPlan:
+    """Token-wise MLP denoiser (BASELINE config 2): per block h = LN(silu(W h + b + e[window]))."""
+
+    def __init__(self, hidden: Sequence[int], dtype, device):
+        self.hidden, self.dtype = list(hidden), dtype
+        self.buf = Buffers(device)
+        self.time = TimeMLPPlan(dtype, self.buf)
+        self.ctx = None
+
+    def forward(self, x3: torch.Tensor, t: torch.Tensor, table: torch.Tensor, P: ParamSource,
+                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        B, T, D = x3.shape
+        M = B * T
+        g, dt = self.buf.get, self.dtype
+        e = self.time.forward(t, table, P)
+        h = x3.view(M, D)
+        saved = []
+        off = 0
+        for i, hd in enumerate(self.hidden):
+            z = g(f"dm.z{i}", (M, hd), dt)
+            hip.linear_fwd(h, P.w(f"blocks.{i}.linear.weight"), P.v(f"blocks.{i}.linear.bias"), z,
+                           add_div=e[:, off:off + hd], seg=T)
+            hn = g(f"dm.hn{i}", (M, hd), dt)
+            mu, rs = g(f"dm.mu{i}", (M,), torch.float32), g(f"dm.rs{i}", (M,), torch.float32)
+            hip.layernorm_fwd(z, P.v(f"blocks.{i}.norm.weight"), P.v(f"blocks.{i}.norm.bias"), hn, mu, rs, act="silu")
+            saved.append((h, z, mu, rs))
+            h = hn
+            off += hd
+        out = out if out is not None else g("dm.out", (B, T, D), dt)
+        hip.linear_fwd(h, P.w("head.weight"), P.v("head.bias"), out.view(M, D))
+        self.ctx = (saved, h, B, T)
+        return out
+
+    def backward(self, dout3: torch.Tensor, P: ParamSource, accumulate=False):
+        saved, hlast, B, T = self.ctx
+        M = B * T
+        g, dt = self.buf.get, self.dtype
+        dout = dout3.view(M, -1)
+        _wgrad(self.buf, dout, hlast, P.g("head.weight"), accumulate)
+        _colsum(self.buf, "dm.bh", dout, P.g("head.bias"), accumulate)
+        dh = g("dm.dh_last", hlast.shape, dt)
+        hip.linear_dgrad(dout, P.w("head.weight"), dh)
+        de32 = g("dm.de32", (B, sum(self.hidden)), torch.float32)
+        off = sum(self.hidden)
+        for i in range(len(self.hidden) - 1, -1, -1):
+            hd = self.hidden[i]
+            off -= hd
+            hin, z, mu, rs = saved[i]
+            lnws = self.buf.bytes("ln.ws", hip.layernorm_bwd_workspace_bytes(M, hd))
+            dz = g(f"dm.dz{i}", (M, hd), dt)
+            hip.layernorm_bwd(dh, z, P.v(f"blocks.{i}.norm.weight"), mu, rs, dz, P.g(f"blocks.{i}.norm.weight"),
+                              P.g(f"blocks.{i}.norm.bias"), lnws, act="silu", accumulate=accumulate)
+            _wgrad(self.buf, dz, hin, P.g(f"blocks.{i}.linear.weight"), accumulate)
+            # per-window sums of dz: the time-embedding gradient AND (summed over windows) the bias gradient
+            hip.segment_colsum(dz, de32[:, off:off + hd], seg=T, mode=0)
+            _colsum(self.buf, f"dm.b{i}", de32[:, off:off + hd], P.g(f"blocks.{i}.linear.bias"), accumulate)
+            if i > 0:
+                dh = g(f"dm.dh{i - 1}", hin.shape, dt)
+                hip.linear_dgrad(dz, P.w(f"blocks.{i}.linear.weight"), dh)
+        self.time.backward(de32, P, accumulate)
+
+
+class DenoiserTransformerPlan:
+    """Transformer denoiser (BASELINE configs 3-5): in-proj(x ++ frame-embedding) + time embedding,
+    N reference TransformerLayers, out-proj."""
+
+    def __init__(self, feat: int, pos_dim: int, d_model: int, num_heads: int, ffn: int, num_layers: int, dtype, device):
+        self.D, self.Pd, self.d, self.dtype = feat, pos_dim, d_model, dtype
+        self.buf = Buffers(device)
+        self.time = TimeMLPPlan(dtype, self.buf)
+        self.layers = [TransformerLayerPlan(f"transformer_layers.{l}.", d_model, num_heads, ffn, dtype, device,
+                                            buf=self.buf, tag=f"tl{l}") for l in range(num_layers)]
+        self.ctx = None
+
+    def forward(self, x3: torch.Tensor, t: torch.Tensor, table: torch.Tensor, P: ParamSource,
+                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        B, T, D = x3.shape
+        M = B * T
+        g, dt = self.buf.get, self.dtype
+        e = self.time.forward(t, table, P)                                   # [B, d]
+        w_in = P.w("in_proj.weight")                                         # [d, D + Pd]
+        pos = P.w("temporal_embedding.embedding.weight")[:T]                 # [T, Pd]
+        posproj = g("dt.posproj", (T, self.d), dt)
+        hip.linear_fwd(pos, w_in[:, D:], None, posproj)
+        h0 = g("dt.h0", (B, T, self.d), dt)
+        hip.linear_fwd(x3.view(M, D), w_in[:, :D], P.v("in_proj.bias"), h0.view(M, self.d), add_div=e,
+                       add_mod=posproj, seg=T)
+        h = h0
+        for lp in self.layers:
+            h = lp.forward(h, P)
+        out = out if out is not None else g("dt.out", (B, T, D), dt)
+        hip.linear_fwd(h.view(M, self.d), P.w("out_proj.weight"), P.v("out_proj.bias"), out.view(M, D))
+        self.ctx = (x3.view(M, D), pos, h, B, T)
+        return out
+
+    def backward(self, dout3: torch.Tensor, P: ParamSource, accumulate=False):
+        x, pos, hlast, B, T = self.ctx
+        M, D = x.shape
+        g, dt = self.buf.get, self.dtype
+        dout = dout3.view(M, D)
+        _wgrad(self.buf, dout, hlast.view(M, self.d), P.g("out_proj.weight"), accumulate)
+        _colsum(self.buf, "dt.bo", dout, P.g("out_proj.bias"), accumulate)
+        dh = g("dt.dh", (B, T, self.d), dt)
+        hip.linear_dgrad(dout, P.w("out_proj.weight"), dh.view(M, self.d))
+        for lp in reversed(self.layers):
+            dh = lp.backward(dh, P, accumulate)
+        dz0 = dh.view(M, self.d)
+        w_in, gw_in = P.w("in_proj.weight"), P.g("in_proj.weight")
+        _wgrad(self.buf, dz0, x, gw_in[:, :D], accumulate)
+        de32 = g("dt.de32", (B, self.d), torch.float32)
+        hip.segment_colsum(dz0, de32, seg=T, mode=0)                          # d e[window]
+        _colsum(self.buf, "dt.bi", de32, P.g("in_proj.bias"), accumulate)
+        dpp32 = g("dt.dpp32", (T, self.d), torch.float32)
+        hip.segment_colsum(dz0, dpp32, seg=T, mode=1)                         # d posproj[frame]
+        dpp = _as_dtype(self.buf, "dt.dpp", dpp32, dt)
+        _wgrad(self.buf, dpp, pos, gw_in[:, D:], accumulate)
+        # d embedding table rows [:T] = dposproj . W_p   (fp32 result via a cast of the compute-dtype GEMM)
+        dpos = g("dt.dpos", (T, self.Pd), dt)
+        hip.linear_dgrad(dpp, w_in[:, D:], dpos)
+        gpos = P.g("temporal_embedding.embedding.weight")
+        if gpos.shape[0] != T:
+            raise hip.HipError(f"window length {T} != frame-embedding table rows {gpos.shape[0]}")
+        dpos32 = dpos
+        if dt != torch.float32:
+            dpos32 = g("dt.dpos32", (T, self.Pd), torch.float32)
+            hip.cast2d(dpos, dpos32)
+        hip.segment_colsum(dpos32, gpos, seg=1, mode=0, accumulate=accumulate)   # row-wise copy / accumulate
+        self.time.backward(de32, P, accumulate)

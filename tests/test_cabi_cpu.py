@@ -1,0 +1,94 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/ib_hip.h declares (no
+compute calls without a GPU), host-side logic (flat layout, schedule tables bit-exact vs the oracle,
+component weights), the drop-in surface (state_dict names, registry), and loud failure off-GPU."""
+import argparse
+import ctypes
+
+import pytest
+import torch
+
+from oracle import ref_cpu as R
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from inferbiomechanics_amd import hip
+    lib = hip.lib()
+    names = hip.declared_symbols()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), f"libib_hip.so does not export {n}"
+        assert n in hip._SIGS, f"{n} has no ctypes signature"
+    assert lib.ib_version() >= 100
+    assert b"workspace" in lib.ib_error_string(-4)
+
+
+def test_null_arguments_return_error_codes_not_crashes():
+    from inferbiomechanics_amd import hip
+    lib = hip.lib()
+    assert lib.ib_linear_fwd(None, 0, None, 0, None, None, 0, None, 0, 0, 0, None, 0, None, 0, 4, 4, 4, 0, None) == -1
+    assert lib.ib_optim_step(9, None, None, None, None, 0, 0.0, 1.0, 1, None, None, None) == -1
+    assert lib.ib_linear_wgrad_workspace(12800, 512, 512) > 0
+    assert lib.ib_linear_wgrad_workspace(4, 8, 8) == 0
+
+
+def test_schedule_tables_bit_exact_vs_oracle():
+    from inferbiomechanics_amd.diffusion import schedule as S
+    ab = S.alphas_cumprod(1000)
+    assert torch.equal(ab, R.alphas_cumprod(R.linear_beta_schedule(1000)))
+    assert abs(ab[499].item() - 0.078587242881778235) < 1e-15
+    assert torch.equal(S.ddim_timesteps(1000, 100), R.ddim_timesteps(1000, 100))
+    assert torch.equal(S.ddim_coefficients(1000, 100), R.ddim_coeffs(1000, 100))
+    t = torch.arange(1000)
+    assert torch.equal(S.timestep_embedding_table(1000, 128), R.timestep_embedding(t, 128))
+    tabs = S.DiffusionTables(torch.device("cpu"))
+    assert tabs.sqrt_ab.dtype == torch.float32 and tabs.ddim_t.dtype == torch.int64
+    assert torch.equal(tabs.sqrt_ab, R.schedule_tables()["sqrt_ab"].to(torch.float32))
+
+
+def test_flat_layout_alignment():
+    from collections import OrderedDict
+    from inferbiomechanics_amd.module import flat_layout
+    lay, total = flat_layout(OrderedDict(a=(3, 5), b=(7,), c=(64, 2)))
+    assert lay["a"] == (0, 15) and lay["b"] == (64, 7) and lay["c"] == (128, 128) and total == 256
+
+
+def test_component_weights():
+    from inferbiomechanics_amd.loss.RegressionLossEvaluator import component_weights
+    a = argparse.Namespace(predict_grf_components=[1], predict_cop_components=[], predict_moment_components=[],
+                           predict_wrench_components=[])
+    w = component_weights(a)
+    assert sum(w) == 1.0 and w[1] == 1.0
+    a = argparse.Namespace(predict_grf_components=list(range(6)), predict_cop_components=list(range(6)),
+                           predict_moment_components=list(range(6)), predict_wrench_components=list(range(12)))
+    assert component_weights(a) == [1.0] * 30
+
+
+def test_drop_in_surface_names_match_reference():
+    from inferbiomechanics_amd.models.DiffusionDenoisers import DiffusionMLP, DiffusionTransformer
+    from inferbiomechanics_amd.models.FeedForwardRegressionBaseline import FeedForwardBaseline
+    from inferbiomechanics_amd.models.TransformerBaseline import TransformerLayer
+    m = FeedForwardBaseline(23, 2, 50, 'all_frames', 'sigmoid', 5, 10)
+    assert list(m.state_dict().keys()) == ['net.0.weight', 'net.0.bias', 'net.2.weight', 'net.2.bias',
+                                           'net.4.weight', 'net.4.bias']
+    assert m.input_size == 1470 and m.output_size == 300          # FeedForwardRegressionBaseline.py:52,63
+    assert sum(p.numel() for p in m.parameters()) == 1169708
+    assert list(TransformerLayer(512, 8, 2048).state_dict().keys()) == R.TL_KEYS
+    d = DiffusionMLP()
+    assert {k: tuple(v.shape) for k, v in d.state_dict().items()} == R.denoiser_mlp_param_shapes(300, [512, 512])
+    d2 = DiffusionTransformer()
+    assert {k: tuple(v.shape) for k, v in d2.state_dict().items()} == R.denoiser_transformer_param_shapes(300, 50)
+
+
+def test_no_cpu_fallback():
+    from inferbiomechanics_amd import hip
+    from inferbiomechanics_amd.loss.RegressionLossEvaluator import RegressionLossEvaluator
+    from inferbiomechanics_amd.models.FeedForwardRegressionBaseline import FeedForwardBaseline
+    from oracle.fixture_inputs import ff_inputs
+    m = FeedForwardBaseline(23, 2, 50, 'all_frames', 'sigmoid', 5, 10)
+    with pytest.raises(hip.HipError):
+        m(ff_inputs(2, 10, 23, 5))
+    with pytest.raises(hip.HipError):
+        hip.linear_fwd(torch.zeros(2, 2), torch.zeros(2, 2), None, torch.zeros(2, 2))
+    ev = RegressionLossEvaluator(None, 'train', device='cpu')
+    with pytest.raises(hip.HipError):
+        ev({}, {}, {}, [], [], argparse.Namespace())

@@ -1,0 +1,349 @@
+"""Kernel-level parity: every C-ABI entry point against float64 restatements (oracle / plain math)
+on seeded inputs.  Tolerances: fp32 mode <= 1e-3 relative (north_star; in practice ~1e-6), bf16 mode
+<= 3e-2 relative to the tensor's max magnitude (bf16 storage has 8 significant bits).  Index / table
+ops (gathers, schedule tables) are bit-exact.  GPU only."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ref_cpu as R  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def hip():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from inferbiomechanics_amd import hip as h
+    h.lib()
+    return h
+
+
+DEV = "cuda"
+TOL = {torch.float32: 1e-3, torch.bfloat16: 3e-2}
+TIGHT = {torch.float32: 2e-5, torch.bfloat16: 3e-2}
+
+
+def rnd(shape, seed, scale=1.0, dtype=torch.float32):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g, dtype=torch.float64) * scale).to(dtype)
+
+
+def close(actual, expected, rtol, what=""):
+    a = actual.detach().to("cpu", torch.float64)
+    e = expected.detach().to("cpu", torch.float64)
+    assert a.shape == e.shape, (what, a.shape, e.shape)
+    assert torch.isfinite(a).all(), f"{what}: non-finite values"
+    err = (a - e).abs().max().item()
+    ref = max(e.abs().max().item(), 1e-30)
+    assert err <= rtol * ref, f"{what}: max err {err:.3e} > {rtol:.1e} * {ref:.3e}"
+
+
+def test_tr16_transposing_read_layout(hip):
+    """ds_read_b64_tr_b16 must deliver in[8*(lane/16)+q][lane%16] as element q (what gemm.hip assumes)."""
+    img = torch.arange(64 * 16, dtype=torch.int16).reshape(64, 16)
+    out = torch.zeros(64, 4, dtype=torch.int16, device=DEV)
+    hip.selftest_tr16(img.to(DEV), out)
+    got = out.cpu()
+    exp = torch.empty(64, 4, dtype=torch.int16)
+    for lane in range(64):
+        for q in range(4):
+            exp[lane, q] = img[8 * (lane // 16) + q, lane % 16]
+    assert torch.equal(got, exp), f"tr16 layout differs:\n{got[:20]}\nvs\n{exp[:20]}"
+
+
+SHAPES = [(4, 512, 1470), (37, 300, 512), (256, 512, 128), (640, 512, 300), (130, 129, 67), (1, 5, 3),
+          (300, 1536, 512), (2560, 512, 300)]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", SHAPES)
+def test_linear_fwd(hip, dtype, M, N, K):
+    x = rnd((M, K), 1, 1.0, dtype)
+    w = rnd((N, K), 2, 1.0 / math.sqrt(K), dtype)
+    b = rnd((N,), 3, 0.1)
+    y = torch.empty(M, N, dtype=dtype, device=DEV)
+    hip.linear_fwd(x.to(DEV), w.to(DEV), b.to(DEV), y)
+    exp = x.double() @ w.double().T + b.double()
+    close(y, exp, TIGHT[dtype], "linear_fwd")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("act", ["relu", "tanh", "sigmoid", "silu"])
+def test_linear_fwd_epilogue(hip, dtype, act):
+    B, T, K, N = 5, 7, 44, 72
+    M = B * T
+    x = rnd((M, K), 1, 1.0, dtype)
+    w = rnd((N, K), 2, 1.0 / math.sqrt(K), dtype)
+    b = rnd((N,), 3, 0.1)
+    e_wide = rnd((B, N + 8), 4, 0.5, dtype)
+    e = e_wide[:, 4:4 + N]                               # strided row-broadcast operand
+    pm = rnd((T, N), 5, 0.5, dtype)
+    y = torch.empty(M, N, dtype=dtype, device=DEV)
+    z = torch.empty(M, N, dtype=dtype, device=DEV)
+    hip.linear_fwd(x.to(DEV), w.to(DEV), b.to(DEV), y, act=act, z=z, add_div=e_wide.to(DEV)[:, 4:4 + N], add_mod=pm.to(DEV), seg=T)
+    zz = x.double() @ w.double().T + b.double()
+    zz = (zz.reshape(B, T, N) + e.double()[:, None, :] + pm.double()[None, :, :]).reshape(M, N)
+    close(z, zz, TIGHT[dtype], "pre-activation")
+    close(y, R.act(act, zz), TIGHT[dtype], "activation " + act)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(4, 300, 512), (37, 512, 1470), (640, 300, 512), (130, 129, 67), (1, 5, 3),
+                                   (2560, 512, 300)])
+@pytest.mark.parametrize("act", ["none", "sigmoid", "silu", "relu", "tanh"])
+def test_linear_dgrad(hip, dtype, M, N, K, act):
+    dz = rnd((M, N), 1, 1.0, dtype)
+    w = rnd((N, K), 2, 1.0 / math.sqrt(N), dtype)
+    aux = rnd((M, K), 3, 1.0, dtype)
+    if act in ("sigmoid",):
+        aux = torch.sigmoid(aux.float()).to(dtype)
+    if act == "tanh":
+        aux = torch.tanh(aux.float()).to(dtype)
+    add = rnd((M, K), 4, 1.0, dtype)
+    dx = torch.empty(M, K, dtype=dtype, device=DEV)
+    hip.linear_dgrad(dz.to(DEV), w.to(DEV), dx, act_below=act, aux=aux.to(DEV) if act != "none" else None,
+                     addend=add.to(DEV))
+    exp = dz.double() @ w.double()
+    a = aux.double()
+    if act == "relu":
+        exp = exp * (a > 0)
+    elif act == "tanh":
+        exp = exp * (1 - a * a)
+    elif act == "sigmoid":
+        exp = exp * a * (1 - a)
+    elif act == "silu":
+        s = torch.sigmoid(a)
+        exp = exp * (s * (1 + a * (1 - s)))
+    exp = exp + add.double()
+    close(dx, exp, TIGHT[dtype], "dgrad")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(4, 300, 512), (64, 512, 1470), (12800, 512, 300), (130, 129, 67), (1, 5, 3),
+                                   (2500, 300, 512), (700, 1536, 512)])
+def test_linear_wgrad(hip, dtype, M, N, K):
+    dz = rnd((M, N), 1, 1.0, dtype)
+    x = rnd((M, K), 2, 1.0, dtype)
+    dw = torch.full((N, K), 7.0, dtype=torch.float32, device=DEV)
+    ws = torch.empty(max(hip.linear_wgrad_workspace_bytes(M, N, K), 16), dtype=torch.uint8, device=DEV)
+    hip.linear_wgrad(dz.to(DEV), x.to(DEV), dw, ws)
+    exp = dz.double().T @ x.double()
+    close(dw, exp, 2e-5 if dtype == torch.float32 else 1e-5 + 2e-2, "wgrad")
+    hip.linear_wgrad(dz.to(DEV), x.to(DEV), dw, ws, accumulate=True)
+    close(dw, 2 * exp, 2e-5 if dtype == torch.float32 else 2e-2, "wgrad accumulate")
+    # strided destination (a column block of a wider gradient matrix)
+    wide = torch.zeros(N, K + 30, dtype=torch.float32, device=DEV)
+    hip.linear_wgrad(dz.to(DEV), x.to(DEV), wide[:, :K], ws)
+    close(wide[:, :K], exp, 2e-5 if dtype == torch.float32 else 2e-2, "wgrad strided")
+    assert float(wide[:, K:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_wgrad_is_bitwise_reproducible(hip, dtype):
+    M, N, K = 3000, 300, 512
+    dz, x = rnd((M, N), 1, 1.0, dtype).to(DEV), rnd((M, K), 2, 1.0, dtype).to(DEV)
+    ws = torch.empty(hip.linear_wgrad_workspace_bytes(M, N, K), dtype=torch.uint8, device=DEV)
+    a = torch.empty(N, K, dtype=torch.float32, device=DEV)
+    b = torch.empty(N, K, dtype=torch.float32, device=DEV)
+    hip.linear_wgrad(dz, x, a, ws)
+    hip.linear_wgrad(dz, x, b, ws)
+    assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N", [(10, 512), (257, 108), (33, 2048), (5, 30), (100, 300)])
+@pytest.mark.parametrize("act,use_res", [("none", True), ("silu", False), ("none", False)])
+def test_layernorm_fwd_bwd(hip, dtype, M, N, act, use_res):
+    x = rnd((M, N), 1, 1.5, dtype)
+    res = rnd((M, N), 2, 1.0, dtype) if use_res else None
+    gamma = (1 + rnd((N,), 3, 0.1)).float()
+    beta = rnd((N,), 4, 0.1).float()
+    dy = rnd((M, N), 5, 1.0, dtype)
+    xd = x.double().requires_grad_(True)
+    rd = res.double().requires_grad_(True) if use_res else None
+    gd, bd = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    v = R.act(act, xd) + (rd if use_res else 0)
+    yd = R.layer_norm(v, gd, bd)
+    yd.backward(dy.double())
+    y = torch.empty(M, N, dtype=dtype, device=DEV)
+    mean = torch.empty(M, dtype=torch.float32, device=DEV)
+    rstd = torch.empty(M, dtype=torch.float32, device=DEV)
+    hip.layernorm_fwd(x.to(DEV), gamma.to(DEV), beta.to(DEV), y, mean, rstd, res=res.to(DEV) if use_res else None, act=act)
+    close(y, yd, TIGHT[dtype], "ln fwd")
+    close(mean, v.mean(-1), 1e-5, "ln mean")
+    dx = torch.empty(M, N, dtype=dtype, device=DEV)
+    dres = torch.empty(M, N, dtype=dtype, device=DEV) if (use_res or act != "none") else None
+    dg = torch.empty(N, dtype=torch.float32, device=DEV)
+    db = torch.empty(N, dtype=torch.float32, device=DEV)
+    ws = torch.empty(hip.layernorm_bwd_workspace_bytes(M, N), dtype=torch.uint8, device=DEV)
+    hip.layernorm_bwd(dy.to(DEV), x.to(DEV), gamma.to(DEV), mean, rstd, dx, dg, db, ws,
+                      res=res.to(DEV) if use_res else None, dres=dres, act=act)
+    close(dx, xd.grad, TOL[dtype] if dtype == torch.bfloat16 else 1e-4, "ln dx")
+    if use_res:
+        close(dres, rd.grad, TOL[dtype] if dtype == torch.bfloat16 else 1e-4, "ln dres")
+    close(dg, gd.grad, 1e-4 if dtype == torch.float32 else 2e-2, "ln dgamma")
+    close(db, bd.grad, 1e-4 if dtype == torch.float32 else 2e-2, "ln dbeta")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,T,H,dh", [(2, 50, 8, 64), (1, 200, 8, 64), (3, 10, 3, 36), (2, 37, 4, 32), (1, 1, 1, 8)])
+def test_attention_fwd_bwd(hip, dtype, B, T, H, dh):
+    d = H * dh
+    qkv = rnd((B, T, 3 * d), 1, 1.0, dtype)
+    dout = rnd((B, T, d), 2, 1.0, dtype)
+    q64 = qkv.double().requires_grad_(True)
+    q, k, v = q64[..., :d], q64[..., d:2 * d], q64[..., 2 * d:]
+    sp = lambda t: t.reshape(B, T, H, dh).transpose(1, 2)
+    s = (sp(q) @ sp(k).transpose(-1, -2)) / math.sqrt(dh)
+    p = torch.softmax(s, dim=-1)
+    o = (p @ sp(v)).transpose(1, 2).reshape(B, T, d)
+    o.backward(dout.double())
+    out = torch.empty(B, T, d, dtype=dtype, device=DEV)
+    lse = torch.empty(B, H, T, dtype=torch.float32, device=DEV)
+    hip.attention_fwd(qkv.to(DEV), out, lse, H)
+    close(out, o, TIGHT[dtype], "attention out")
+    close(lse, torch.logsumexp(s, dim=-1), 1e-4 if dtype == torch.float32 else 2e-2, "lse")
+    dqkv = torch.empty(B, T, 3 * d, dtype=dtype, device=DEV)
+    hip.attention_bwd(qkv.to(DEV), out, dout.to(DEV), lse, dqkv, H)
+    close(dqkv, q64.grad, 1e-4 if dtype == torch.float32 else 4e-2, "attention dqkv")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_segment_colsum(hip, dtype):
+    B, T, N = 6, 50, 300
+    x = rnd((B * T, N + 4), 1, 1.0, dtype).to(DEV)[:, 2:2 + N]
+    out = torch.zeros(B, N, dtype=torch.float32, device=DEV)
+    hip.segment_colsum(x, out, seg=T, mode=0)
+    close(out, x.double().reshape(B, T, N).sum(1), 1e-5 if dtype == torch.float32 else 1e-5, "div sum")
+    out2 = torch.ones(T, N, dtype=torch.float32, device=DEV)
+    hip.segment_colsum(x, out2, seg=T, mode=1, accumulate=True)
+    close(out2, x.double().reshape(B, T, N).sum(0) + 1, 1e-5, "mod sum accumulate")
+    out3 = torch.zeros(1, N, dtype=torch.float32, device=DEV)
+    hip.segment_colsum(x, out3, seg=B * T, mode=0)
+    close(out3, x.double().sum(0, keepdim=True), 1e-5, "full colsum")
+    # ragged last segment
+    out4 = torch.zeros(3, N, dtype=torch.float32, device=DEV)
+    hip.segment_colsum(x, out4, seg=128, mode=0)
+    xs = x.double()
+    close(out4, torch.stack([xs[:128].sum(0), xs[128:256].sum(0), xs[256:].sum(0)]), 1e-5, "ragged")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_concat_keys_and_casts(hip, dtype):
+    B, F = 3, 10
+    ws = R.input_widths(23, 5)
+    ts = [rnd((B, F, w), 10 + i) for i, w in enumerate(ws)]
+    out = torch.empty(B, F * sum(ws), dtype=dtype, device=DEV)
+    hip.concat_keys([t.to(DEV) for t in ts], out)
+    exp = torch.cat(ts, dim=-1).reshape(B, -1).to(dtype)
+    assert torch.equal(out.cpu(), exp)                       # pure data movement + RNE cast: bit-exact
+    src = rnd((1000,), 5)
+    dst = torch.empty(1000, dtype=torch.bfloat16, device=DEV)
+    hip.cast(src.to(DEV), dst)
+    assert torch.equal(dst.cpu(), src.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_diffusion_elementwise(hip, dtype):
+    from inferbiomechanics_amd.diffusion.schedule import DiffusionTables
+    tabs = DiffusionTables(torch.device(DEV), 1000, 100, 128)
+    otab = R.schedule_tables(1000)
+    # tables: float64 host math cast once -> bit-exact vs the oracle's float64 tables cast to fp32
+    assert torch.equal(tabs.sqrt_ab.cpu(), otab["sqrt_ab"].to(torch.float32))
+    assert torch.equal(tabs.sqrt_1mab.cpu(), otab["sqrt_1mab"].to(torch.float32))
+    assert torch.equal(tabs.ddim_t.cpu(), R.ddim_timesteps(1000, 100))
+    assert torch.equal(tabs.ddim_coef.cpu(), R.ddim_coeffs(1000, 100).to(torch.float32))
+    B, T, D = 5, 7, 12
+    t = torch.tensor([0, 1, 499, 999, 250], dtype=torch.int64)
+    emb = torch.empty(B, 128, dtype=dtype, device=DEV)
+    hip.gather_rows(tabs.temb, t.to(DEV), emb)
+    assert torch.equal(emb.cpu(), R.timestep_embedding(t, 128).to(torch.float32).to(dtype))   # bit-exact gather
+    x0, eps = rnd((B, T, D), 1, 1.0, dtype), rnd((B, T, D), 2, 1.0, dtype)
+    xt = torch.empty(B, T, D, dtype=dtype, device=DEV)
+    hip.q_sample(x0.to(DEV), eps.to(DEV), t.to(DEV), tabs.sqrt_ab, tabs.sqrt_1mab, xt)
+    close(xt, R.q_sample(x0.double(), t, eps.double(), otab), TIGHT[dtype], "q_sample")
+    x = rnd((B, T, D), 3, 1.0, dtype).to(DEV)
+    x_ref = x.double().cpu()
+    co = R.ddim_coeffs(1000, 100)
+    t_out = torch.zeros(B, dtype=torch.int64, device=DEV)
+    ctr = torch.tensor([17], dtype=torch.int32, device=DEV)
+    hip.ddim_step(x, eps.to(DEV), tabs.ddim_coef, tabs.ddim_t, step_dev=ctr, t_out=t_out)
+    close(x, co[17, 0] * x_ref + co[17, 1] * eps.double(), TIGHT[dtype], "ddim step")
+    assert torch.equal(t_out.cpu(), torch.full((B,), int(R.ddim_timesteps(1000, 100)[18]), dtype=torch.int64))
+    hip.counter_add(ctr, 1)
+    assert int(ctr.cpu()) == 18
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_mse_loss(hip, dtype):
+    n = 12345
+    p, t = rnd((n,), 1, 1.0, dtype), rnd((n,), 2, 1.0, dtype)
+    res = torch.zeros(1, dtype=torch.float32, device=DEV)
+    dp = torch.empty(n, dtype=dtype, device=DEV)
+    ws = torch.empty(hip.mse_loss_workspace_bytes(n), dtype=torch.uint8, device=DEV)
+    hip.mse_loss(p.to(DEV), t.to(DEV), res, ws, dpred=dp)
+    d = p.double() - t.double()
+    close(res, (d * d).mean().reshape(1), 1e-5, "mse")
+    close(dp, 2 * d / n, TIGHT[dtype], "dmse")
+
+
+@pytest.mark.parametrize("opt", ["sgd", "adam", "rmsprop", "adagrad", "adadelta", "adamax"])
+def test_optimizers_follow_torch_optim_trajectories(hip, golden_dir, opt):
+    import os
+    g = np.load(os.path.join(golden_dir, "optim_traj.npz"))
+    p = R.det_fill((257,), 3, 0.5).float().to(DEV)
+    s1 = torch.zeros_like(p)
+    s2 = torch.zeros_like(p)
+    shadow = torch.zeros(257, dtype=torch.bfloat16, device=DEV)
+    for s in range(4):
+        grad = R.det_fill((257,), 20 + s, 0.3 * (s + 1)).float().to(DEV)
+        hip.optim_step(opt, p, grad * 4.0, s1, s2, lr=1e-2, step=s + 1, grad_scale=0.25, shadow=shadow)
+        close(p, torch.from_numpy(g[opt][s]), 2e-5, f"{opt} step {s + 1}")
+        assert torch.equal(shadow.cpu(), p.cpu().to(torch.bfloat16))
+    # device-resident step counter (graph-replay form)
+    p2 = R.det_fill((257,), 3, 0.5).float().to(DEV)
+    s1.zero_(); s2.zero_()
+    ctr = torch.zeros(1, dtype=torch.int32, device=DEV)
+    for s in range(4):
+        grad = R.det_fill((257,), 20 + s, 0.3 * (s + 1)).float().to(DEV)
+        hip.counter_add(ctr, 1)
+        hip.optim_step(opt, p2, grad, s1, s2, lr=1e-2, step=0, step_dev=ctr)
+    close(p2, torch.from_numpy(g[opt][3]), 2e-5, f"{opt} via device counter")
+
+
+def test_hipgraph_capture_and_replay(hip):
+    x = rnd((64, 32), 1).to(DEV)
+    w = rnd((48, 32), 2, 0.2).to(DEV)
+    y = torch.zeros(64, 48, device=DEV)
+    hip.linear_fwd(x, w, None, y)                         # warm-up outside capture
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        g = hip.Graph()
+        g.begin()
+        hip.linear_fwd(x, w, None, y, act="relu")
+        g.end()
+        y.zero_()
+        e0, e1 = hip.Event(), hip.Event()
+        e0.record()
+        g.launch()
+        e1.record()
+        assert e0.elapsed_ms(e1) >= 0.0
+    torch.cuda.synchronize()
+    close(y, torch.relu(x.double() @ w.double().T), 2e-5, "graph replay")
+
+
+def test_bad_arguments_fail_loudly(hip):
+    x = torch.zeros(4, 8, device=DEV)
+    w = torch.zeros(5, 9, device=DEV)
+    y = torch.zeros(4, 5, device=DEV)
+    with pytest.raises(hip.HipError):
+        hip.linear_fwd(x, w, None, y)
+    with pytest.raises(hip.HipError):
+        hip.linear_fwd(x.cpu(), w, None, y)
+    with pytest.raises(hip.HipError):
+        hip.linear_fwd(x.to(torch.float16), w.to(torch.float16), None, y.to(torch.float16))
