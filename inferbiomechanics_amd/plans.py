@@ -55,8 +55,13 @@ class ParamSource:
     ``g`` -> the fp32 tensor that receives d loss / d param."""
 
     def __init__(self, w: Callable[[str], torch.Tensor], v: Callable[[str], torch.Tensor],
-                 g: Optional[Callable[[str], torch.Tensor]] = None):
+                 g: Optional[Callable[[str], torch.Tensor]] = None,
+                 ready: Optional[Callable[[str], None]] = None):
         self.w, self.v, self.g = w, v, g
+        # called by a plan's backward right after the launches that complete d loss / d param[name] are
+        # enqueued, in the order given by the plan's ready_order(): lets the trainer start the RCCL
+        # all-reduce of a gradient bucket while the rest of the backward is still running
+        self.ready = ready if ready is not None else (lambda name: None)
 
 
 def _colsum(buf: Buffers, tag: str, x2d: torch.Tensor, out_vec: torch.Tensor, accumulate: bool):
@@ -113,6 +118,9 @@ class DenseStackPlan:
             h = y
         return h
 
+    def ready_order(self) -> List[str]:
+        return [n for pair in reversed(self.names) for n in pair]
+
     def backward(self, dout: torch.Tensor, P: ParamSource, accumulate=False, need_dx=False):
         L = len(self.names)
         dz = dout
@@ -122,7 +130,9 @@ class DenseStackPlan:
             xin = self.saved[i]
             xin_y = xin[0] if isinstance(xin, tuple) else xin
             _wgrad(self.buf, dz, xin_y, P.g(wn), accumulate)
+            P.ready(wn)
             _colsum(self.buf, f"{self.tag}.b{i}", dz, P.g(bn), accumulate)
+            P.ready(bn)
             if i > 0:
                 aux = xin[1] if isinstance(xin, tuple) else xin
                 nxt = self.buf.get(f"{self.tag}.dz{i - 1}", xin_y.shape, self.dtype)
@@ -171,6 +181,13 @@ class TransformerLayerPlan:
         self.ctx = (x, qkv, attn, lse, a, x1, m1, r1, f1, f2, m2, r2, B, T)
         return x2
 
+    def ready_order(self) -> List[str]:
+        p = self.p
+        return [p + n for n in ("norm2.weight", "norm2.bias", "feedforward.2.weight", "feedforward.2.bias",
+                                "feedforward.0.weight", "feedforward.0.bias", "norm1.weight", "norm1.bias",
+                                "multihead_attention.out_proj.weight", "multihead_attention.out_proj.bias",
+                                "multihead_attention.in_proj_weight", "multihead_attention.in_proj_bias")]
+
     def backward(self, dx2: torch.Tensor, P: ParamSource, accumulate=False) -> torch.Tensor:
         x, qkv, attn, lse, a, x1, m1, r1, f1, f2, m2, r2, B, T = self.ctx
         M, d = x.shape
@@ -180,27 +197,37 @@ class TransformerLayerPlan:
         ds2 = g(tg + ".ds2", (M, d), dt)
         hip.layernorm_bwd(dx2.view(M, d), f2, P.v(p + "norm2.weight"), m2, r2, ds2, P.g(p + "norm2.weight"),
                           P.g(p + "norm2.bias"), lnws, res=x1, accumulate=accumulate)
+        P.ready(p + "norm2.weight"); P.ready(p + "norm2.bias")
         _wgrad(self.buf, ds2, f1, P.g(p + "feedforward.2.weight"), accumulate)
+        P.ready(p + "feedforward.2.weight")
         _colsum(self.buf, tg + ".b2", ds2, P.g(p + "feedforward.2.bias"), accumulate)
+        P.ready(p + "feedforward.2.bias")
         dz1 = g(tg + ".dz1", (M, self.ffn), dt)
         hip.linear_dgrad(ds2, P.w(p + "feedforward.2.weight"), dz1, act_below="relu", aux=f1)
         _wgrad(self.buf, dz1, x1, P.g(p + "feedforward.0.weight"), accumulate)
+        P.ready(p + "feedforward.0.weight")
         _colsum(self.buf, tg + ".b1", dz1, P.g(p + "feedforward.0.bias"), accumulate)
+        P.ready(p + "feedforward.0.bias")
         dx1 = g(tg + ".dx1", (M, d), dt)
         hip.linear_dgrad(dz1, P.w(p + "feedforward.0.weight"), dx1, addend=ds2)       # + residual path
         # LN1: d(a + x)
         ds1 = g(tg + ".ds1", (M, d), dt)
         hip.layernorm_bwd(dx1, a, P.v(p + "norm1.weight"), m1, r1, ds1, P.g(p + "norm1.weight"),
                           P.g(p + "norm1.bias"), lnws, res=x, accumulate=accumulate)
+        P.ready(p + "norm1.weight"); P.ready(p + "norm1.bias")
         _wgrad(self.buf, ds1, attn.view(M, d), P.g(p + "multihead_attention.out_proj.weight"), accumulate)
+        P.ready(p + "multihead_attention.out_proj.weight")
         _colsum(self.buf, tg + ".bo", ds1, P.g(p + "multihead_attention.out_proj.bias"), accumulate)
+        P.ready(p + "multihead_attention.out_proj.bias")
         dattn = g(tg + ".dattn", (B, T, d), dt)
         hip.linear_dgrad(ds1, P.w(p + "multihead_attention.out_proj.weight"), dattn.view(M, d))
         dqkv = g(tg + ".dqkv", (B, T, 3 * d), dt)
         hip.attention_bwd(qkv, attn, dattn, lse, dqkv, self.h)
         dq2 = dqkv.view(M, 3 * d)
         _wgrad(self.buf, dq2, x, P.g(p + "multihead_attention.in_proj_weight"), accumulate)
+        P.ready(p + "multihead_attention.in_proj_weight")
         _colsum(self.buf, tg + ".bi", dq2, P.g(p + "multihead_attention.in_proj_bias"), accumulate)
+        P.ready(p + "multihead_attention.in_proj_bias")
         dx = g(tg + ".dx", (B, T, d), dt)
         hip.linear_dgrad(dq2, P.w(p + "multihead_attention.in_proj_weight"), dx.view(M, d), addend=ds1)
         return dx
@@ -228,17 +255,25 @@ class TimeMLPPlan:
         self.ctx = (s, u, zu)
         return e
 
+    @staticmethod
+    def ready_order() -> List[str]:
+        return ["time_mlp.2.weight", "time_mlp.2.bias", "time_mlp.0.weight", "time_mlp.0.bias"]
+
     def backward(self, de32: torch.Tensor, P: ParamSource, accumulate=False):
         s, u, zu = self.ctx
         B = s.shape[0]
         tg = self.tag
         de = _as_dtype(self.buf, tg + ".de", de32, self.dtype)
         _wgrad(self.buf, de, u, P.g("time_mlp.2.weight"), accumulate)
+        P.ready("time_mlp.2.weight")
         _colsum(self.buf, tg + ".b2", de32, P.g("time_mlp.2.bias"), accumulate)
+        P.ready("time_mlp.2.bias")
         du = self.buf.get(tg + ".du", u.shape, self.dtype)
         hip.linear_dgrad(de, P.w("time_mlp.2.weight"), du, act_below="silu", aux=zu)
         _wgrad(self.buf, du, s, P.g("time_mlp.0.weight"), accumulate)
+        P.ready("time_mlp.0.weight")
         _colsum(self.buf, tg + ".b1", du, P.g("time_mlp.0.bias"), accumulate)
+        P.ready("time_mlp.0.bias")
 
 
 class DenoiserMLPPlan:
@@ -274,13 +309,22 @@ class DenoiserMLPPlan:
         self.ctx = (saved, h, B, T)
         return out
 
+    def ready_order(self) -> List[str]:
+        o = ["head.weight", "head.bias"]
+        for i in range(len(self.hidden) - 1, -1, -1):
+            o += [f"blocks.{i}.norm.weight", f"blocks.{i}.norm.bias", f"blocks.{i}.linear.weight",
+                  f"blocks.{i}.linear.bias"]
+        return o + TimeMLPPlan.ready_order()
+
     def backward(self, dout3: torch.Tensor, P: ParamSource, accumulate=False):
         saved, hlast, B, T = self.ctx
         M = B * T
         g, dt = self.buf.get, self.dtype
         dout = dout3.view(M, -1)
         _wgrad(self.buf, dout, hlast, P.g("head.weight"), accumulate)
+        P.ready("head.weight")
         _colsum(self.buf, "dm.bh", dout, P.g("head.bias"), accumulate)
+        P.ready("head.bias")
         dh = g("dm.dh_last", hlast.shape, dt)
         hip.linear_dgrad(dout, P.w("head.weight"), dh)
         de32 = g("dm.de32", (B, sum(self.hidden)), torch.float32)
@@ -293,10 +337,13 @@ class DenoiserMLPPlan:
             dz = g(f"dm.dz{i}", (M, hd), dt)
             hip.layernorm_bwd(dh, z, P.v(f"blocks.{i}.norm.weight"), mu, rs, dz, P.g(f"blocks.{i}.norm.weight"),
                               P.g(f"blocks.{i}.norm.bias"), lnws, act="silu", accumulate=accumulate)
+            P.ready(f"blocks.{i}.norm.weight"); P.ready(f"blocks.{i}.norm.bias")
             _wgrad(self.buf, dz, hin, P.g(f"blocks.{i}.linear.weight"), accumulate)
+            P.ready(f"blocks.{i}.linear.weight")
             # per-window sums of dz: the time-embedding gradient AND (summed over windows) the bias gradient
             hip.segment_colsum(dz, de32[:, off:off + hd], seg=T, mode=0)
             _colsum(self.buf, f"dm.b{i}", de32[:, off:off + hd], P.g(f"blocks.{i}.linear.bias"), accumulate)
+            P.ready(f"blocks.{i}.linear.bias")
             if i > 0:
                 dh = g(f"dm.dh{i - 1}", hin.shape, dt)
                 hip.linear_dgrad(dz, P.w(f"blocks.{i}.linear.weight"), dh)
@@ -336,13 +383,21 @@ class DenoiserTransformerPlan:
         self.ctx = (x3.view(M, D), pos, h, B, T)
         return out
 
+    def ready_order(self) -> List[str]:
+        o = ["out_proj.weight", "out_proj.bias"]
+        for lp in reversed(self.layers):
+            o += lp.ready_order()
+        return o + ["in_proj.bias", "in_proj.weight", "temporal_embedding.embedding.weight"] + TimeMLPPlan.ready_order()
+
     def backward(self, dout3: torch.Tensor, P: ParamSource, accumulate=False):
         x, pos, hlast, B, T = self.ctx
         M, D = x.shape
         g, dt = self.buf.get, self.dtype
         dout = dout3.view(M, D)
         _wgrad(self.buf, dout, hlast.view(M, self.d), P.g("out_proj.weight"), accumulate)
+        P.ready("out_proj.weight")
         _colsum(self.buf, "dt.bo", dout, P.g("out_proj.bias"), accumulate)
+        P.ready("out_proj.bias")
         dh = g("dt.dh", (B, T, self.d), dt)
         hip.linear_dgrad(dout, P.w("out_proj.weight"), dh.view(M, self.d))
         for lp in reversed(self.layers):
@@ -353,10 +408,12 @@ class DenoiserTransformerPlan:
         de32 = g("dt.de32", (B, self.d), torch.float32)
         hip.segment_colsum(dz0, de32, seg=T, mode=0)                          # d e[window]
         _colsum(self.buf, "dt.bi", de32, P.g("in_proj.bias"), accumulate)
+        P.ready("in_proj.bias")
         dpp32 = g("dt.dpp32", (T, self.d), torch.float32)
         hip.segment_colsum(dz0, dpp32, seg=T, mode=1)                         # d posproj[frame]
         dpp = _as_dtype(self.buf, "dt.dpp", dpp32, dt)
         _wgrad(self.buf, dpp, pos, gw_in[:, D:], accumulate)
+        P.ready("in_proj.weight")
         # d embedding table rows [:T] = dposproj . W_p   (fp32 result via a cast of the compute-dtype GEMM)
         dpos = g("dt.dpos", (T, self.Pd), dt)
         hip.linear_dgrad(dpp, w_in[:, D:], dpos)
@@ -368,4 +425,5 @@ class DenoiserTransformerPlan:
             dpos32 = g("dt.dpos32", (T, self.Pd), torch.float32)
             hip.cast2d(dpos, dpos32)
         hip.segment_colsum(dpos32, gpos, seg=1, mode=0, accumulate=accumulate)   # row-wise copy / accumulate
+        P.ready("temporal_embedding.embedding.weight")
         self.time.backward(de32, P, accumulate)
