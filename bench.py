@@ -1,0 +1,251 @@
+#!/usr/bin/env python3
+"""Headline benchmark of the hot path (driver contract: see the task statement / DESIGN.md §Measurement).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" = one fused training step (q_sample -> denoiser fwd -> eps-MSE -> bwd -> [RCCL grad all-reduce] ->
+fused optimizer) over one batch of synthetic motion windows already resident in HBM.  N = 1 workload =
+BASELINE.json configs[1]: token-wise MLP denoiser 300->512->512->300 (+ time MLP), T = 50, bf16 storage /
+fp32 accumulate, per-GPU batch 256 (weak scaling for N > 1).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}     # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+WORKLOADS = {
+    # name: (model kind, T, D, per-GPU batch)
+    "mlp_denoiser_T50": ("mlp", 50, 300, 256),
+    "transformer_denoiser_T50": ("transformer", 50, 300, 256),
+    "transformer_denoiser_T200": ("transformer", 200, 300, 64),
+}
+
+
+def build_model(kind, T, D, dtype, dev):
+    from inferbiomechanics_amd.models.DiffusionDenoisers import DiffusionMLP, DiffusionTransformer
+    torch.manual_seed(0)
+    if kind == "mlp":
+        return DiffusionMLP(D, [512, 512], device=dev, compute_dtype=dtype)
+    return DiffusionTransformer(D, T, d_model=512, num_heads=8, dim_feedforward=2048, num_layers=4, device=dev,
+                                compute_dtype=dtype)
+
+
+def train_flops_per_window(kind, T, D):
+    """algorithmic FLOPs (2*MAC, training = 3x forward GEMM FLOPs), SURVEY.md §8d"""
+    if kind == "mlp":
+        mac = D * 512 + 512 * 512 + 512 * D
+        return 3 * 2 * mac * T
+    d, ffn, L = 512, 2048, 4
+    per_tok = L * (4 * d * d + 2 * d * ffn + 2 * T * d) + (D + 30) * d + d * D
+    return 3 * 2 * per_tok * T
+
+
+def make_batches(nb, B, T, D, dtype, dev, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    out = []
+    for _ in range(nb):
+        x0 = torch.randn(B, T, D, generator=g).to(dev, dtype)
+        eps = torch.randn(B, T, D, generator=g).to(dev, dtype)
+        t = torch.randint(0, 1000, (B,), generator=g, dtype=torch.int64).to(dev)
+        out.append((x0, t, eps))
+    return out
+
+
+def cpu_baseline(kind, T, D, B, budget_s=15.0):
+    """The oracle (torch-eager CPU port of the reference arithmetic + build-defined diffusion wrapper),
+    fp32, all host cores, same workload shape; bounded sample."""
+    from oracle import ref_cpu as R
+    torch.set_num_threads(os.cpu_count() or 1)
+    torch.manual_seed(0)
+    if kind == "mlp":
+        shapes = R.denoiser_mlp_param_shapes(D, [512, 512])
+        fwd = lambda p, x, t: R.denoiser_mlp_forward(p, x, t, [512, 512])
+    else:
+        shapes = R.denoiser_transformer_param_shapes(D, T)
+        fwd = lambda p, x, t: R.denoiser_transformer_forward(p, x, t, 4, 8)
+    params = {k: (torch.randn(s) / (s[-1] ** 0.5 if len(s) > 1 else 10.0)).requires_grad_(True) for k, s in shapes.items()}
+    for k in params:
+        if k.endswith("norm.weight") or k.endswith("norm1.weight") or k.endswith("norm2.weight"):
+            params[k].data.fill_(1.0)
+    state = {k: R.optim_init_state("rmsprop", v.detach()) for k, v in params.items()}
+    tabs = {k: v.to(torch.float32) for k, v in R.schedule_tables().items()}
+    x0, eps = torch.randn(B, T, D), torch.randn(B, T, D)
+    t = torch.randint(0, 1000, (B,))
+
+    def step(i):
+        for v in params.values():
+            v.grad = None
+        xt = R.q_sample(x0, t, eps, tabs)
+        loss = R.eps_mse(fwd(params, xt, t), eps)
+        loss.backward()
+        with torch.no_grad():
+            for k, v in params.items():
+                v.copy_(R.optim_step("rmsprop", v, v.grad, state[k], 1e-4, i + 1))
+        return loss
+
+    for i in range(2):
+        step(i)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        step(n + 2)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 200:
+            break
+    return {"value": round(B * n / el, 1), "unit": "windows/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} training steps of batch {B} ({kind} denoiser, T={T}, D={D}, fp32, RMSprop) in {el:.1f} s"}
+
+
+def roofline_leg(trainer, batches, kind, B, T, D, dtype_name):
+    """Per-entry-point device time of one eager (un-captured) step, HIP events on the launch stream."""
+    from inferbiomechanics_amd import hip
+    saved = trainer.use_graph, trainer._rec
+    trainer.use_graph, trainer._rec = False, None
+    reps = 5
+    with hip.time_launches() as tl:
+        for i in range(reps):
+            trainer.step(batches[i % len(batches)])
+        torch.cuda.synchronize()
+        summ = tl.summary()
+    trainer.use_graph, trainer._rec = saved
+    gemm_flops = {"ib_linear_fwd": lambda a: 2 * a[-5] * a[-4] * a[-3], "ib_linear_dgrad": lambda a: 2 * a[-5] * a[-4] * a[-3],
+                  "ib_linear_wgrad": lambda a: 2 * a[-5] * a[-4] * a[-3]}
+    rows = []
+    for (name, ints), ms in summ.items():
+        rows.append((sum(ms) / reps, name, ints, sum(ms) / len(ms), len(ms) // reps))
+    rows.sort(reverse=True)
+    total = sum(r[0] for r in rows)
+    top = rows[0]
+    name, ints, avg_ms = top[1], top[2], top[3]
+    out = {"kernel": name, "launch_args": list(ints), "avg_launch_us": round(avg_ms * 1e3, 2),
+           "share_of_step_device_time": round(top[0] / total, 3), "traffic": None}
+    if name in gemm_flops:
+        fl = gemm_flops[name](ints)
+        ach = fl / (avg_ms * 1e-3) / 1e12
+        out.update({"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_TFLOPS[dtype_name], "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_TFLOPS[dtype_name], 4), "algorithmic_flops_per_launch": fl})
+    else:
+        out.update({"bound": "hbm", "achieved": None, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": None})
+    breakdown = [{"entry": r[1], "args": list(r[2]), "us_per_step": round(r[0] * 1e3, 2), "launches_per_step": r[4]}
+                 for r in rows[:12]]
+    return out, breakdown, total
+
+
+def ddim_leg(dev, dtype, B=16, T=200, D=300, steps=100):
+    """BASELINE config 5: T = 200 transformer denoiser, 100-step DDIM, one captured denoise step replayed."""
+    from inferbiomechanics_amd.diffusion.sampler import DDIMSampler
+    model = build_model("transformer", T, D, dtype, dev)
+    sampler = DDIMSampler(model, steps, use_graph=True)
+    xT = torch.randn(B, T, D, device=dev)
+    sampler.sample(xT, steps=3)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    sampler.sample(xT)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    return {"workload": f"transformer_denoiser_T{T} B={B} {steps}-step DDIM (hipGraph-replayed step)",
+            "steps_per_sec": round(steps / el, 1), "window_steps_per_sec": round(B * steps / el, 1),
+            "ms_per_sample_batch": round(el * 1e3, 2)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="mlp_denoiser_T50", choices=list(WORKLOADS))
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--opt-type", default="rmsprop")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ddim", action="store_true")
+    ap.add_argument("--bucket-mb", type=float, default=4.0)
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} needs `python -m torch.distributed.run --nproc-per-node {a.gpus} bench.py ...` "
+                         f"(WORLD_SIZE={world})")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from inferbiomechanics_amd import hip
+    from inferbiomechanics_amd.engine import HipTrainer
+    hip.lib()
+    kind, T, D, B = WORKLOADS[a.workload]
+    dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    model = build_model(kind, T, D, dtype, dev)
+    trainer = HipTrainer(model, "diffusion", a.opt_type, 1e-4, use_graph=not a.no_graph, bucket_mb=a.bucket_mb)
+    batches = make_batches(16, B, T, D, dtype, dev, seed=rank)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(4):                     # priming: eager warm-up + graph capture (not part of W)
+        trainer.step(batches[i % len(batches)])
+    for i in range(a.warmup):
+        trainer.step(batches[i % len(batches)])
+    sync()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        trainer.step(batches[i % len(batches)])
+    sync()
+    el = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.cpu())
+    loss = trainer.loss_value()
+
+    if rank == 0:
+        value = world * B * a.steps / el
+        line = {
+            "metric": "motion-windows/sec training (+ DDIM steps/sec)", "value": round(value, 1), "unit": "windows/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(el / a.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": f"{a.workload}_D{D}_B{B}_{a.dtype} (BASELINE.json configs[1])" if kind == "mlp"
+                       else f"{a.workload}_D{D}_B{B}_{a.dtype}",
+                       "per_gpu_batch": B, "global_batch": B * world, "window": T, "feat": D,
+                       "optimizer": a.opt_type, "hipgraph": not a.no_graph, "parallelism": f"dp{world}"},
+            "final_loss": round(loss, 6),
+            "train_tflops": round(value * train_flops_per_window(kind, T, D) / 1e12, 2),
+        }
+        rl, breakdown, dev_ms = roofline_leg(trainer, batches, kind, B, T, D, a.dtype)
+        line["roofline"] = rl
+        line["step_device_ms_eager"] = round(dev_ms, 4)
+        line["step_breakdown"] = breakdown
+        if not a.no_ddim:
+            line["ddim"] = ddim_leg(dev, dtype)
+        if not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(kind, T, D, B)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

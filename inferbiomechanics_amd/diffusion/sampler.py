@@ -1,0 +1,66 @@
+"""[BUILD-DEFINED] DDIM (eta = 0) sampling loop: N denoiser evaluations + updates.
+
+One denoise step = {time-embedding gather, denoiser forward plan, DDIM update, counter++}.  The step index
+lives in DEVICE memory (an int32 counter the update kernel reads), and the update kernel also writes the next
+step's timestep vector, so ONE captured hipGraph of a single step can be replayed for every step of the loop
+with no host involvement between steps (BASELINE config 5)."""
+from typing import Optional
+
+import torch
+
+from .. import hip
+from ..plans import ParamSource
+
+
+class DDIMSampler:
+    def __init__(self, model, num_sample_steps: int = 100, use_graph: bool = True):
+        self.model, self.S = model, num_sample_steps
+        self.use_graph = use_graph and not hip._dry_run
+        self._graph: Optional[hip.Graph] = None
+        self._sig = None
+        self._bufs = {}
+
+    def _step_launches(self, x, t_vec, ctr, tabs, P: ParamSource):
+        plan = self.model._get_plan(x.device)
+        eps = plan.forward(x, t_vec, tabs.temb, P)
+        hip.ddim_step(x, eps, tabs.ddim_coef, tabs.ddim_t, step_dev=ctr, t_out=t_vec)
+        hip.counter_add(ctr, 1)
+
+    @torch.no_grad()
+    def sample(self, x_T: torch.Tensor, steps: Optional[int] = None) -> torch.Tensor:
+        """x_T [B,T,D] ~ N(0,1) -> x_0.  `steps` (<= num_sample_steps) truncates the loop (benchmarks)."""
+        m = self.model
+        m.ensure_packed()
+        m.sync_shadow()
+        dev = m._flat.device
+        tabs = m.tables(dev)
+        if tabs.num_sample_steps != self.S:
+            tabs.set_sampler(self.S)
+        sig = (tuple(x_T.shape), m.compute_dtype)
+        if sig != self._sig:
+            self._sig, self._graph = sig, None
+            self._bufs = {"x": torch.empty(x_T.shape, dtype=m.compute_dtype, device=dev),
+                          "t": torch.empty(x_T.shape[0], dtype=torch.int64, device=dev),
+                          "ctr": torch.zeros(1, dtype=torch.int32, device=dev)}
+        x, t_vec, ctr = self._bufs["x"], self._bufs["t"], self._bufs["ctr"]
+        x.copy_(x_T.to(device=dev, dtype=m.compute_dtype))
+        ctr.zero_()
+        hip.fill_i64(t_vec, int(tabs.ddim_t[0]))
+        P = m.param_source()
+        n = self.S if steps is None else min(steps, self.S)
+        done = 0
+        if self.use_graph and self._graph is None:
+            self._step_launches(x, t_vec, ctr, tabs, P)          # eager warm-up step allocates plan buffers
+            done = 1
+            if n > 1:
+                g = hip.Graph()
+                g.begin()
+                self._step_launches(x, t_vec, ctr, tabs, P)
+                g.end()
+                self._graph = g
+        for _ in range(done, n):
+            if self._graph is not None:
+                self._graph.launch()
+            else:
+                self._step_launches(x, t_vec, ctr, tabs, P)
+        return x.clone()

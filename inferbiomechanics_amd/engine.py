@@ -1,0 +1,358 @@
+"""The fused training step and its data-parallel wiring (the MI355X-native replacement of the loop body
+``zero_grad -> model(inputs) -> loss -> backward -> optimizer.step`` at src/cli/train.py:240-284 and of the
+``DistributedDataParallel`` wrapper at train.py:175).
+
+One process per GPU.  A step is a fixed sequence of C-ABI launches over buffers resident in HBM:
+
+    [q_sample] -> plan.forward -> loss kernel (writes d loss/d out) -> plan.backward (grads straight into
+    ONE flat fp32 buffer) -> bucketed RCCL all-reduce of that buffer -> ONE fused optimizer launch
+    (also refreshes the bf16 weight shadow)
+
+* no autograd, no per-parameter tensors, no host synchronisation inside a step (the loss stays on the
+  device; read it with ``loss_value()`` when a report is due);
+* the flat buffers are laid out in the order the backward FINISHES gradients (``plan.ready_order()``), so a
+  gradient bucket is a contiguous slice that can be handed to RCCL while the rest of the backward is still
+  running (comm stream + events) -- DDP's overlap without DDP's hooks;
+* at steady state the launch sequence is replayed from hipGraphs (one graph per segment between two
+  collectives; a single graph when world_size == 1).
+
+Reference semantics kept: gradients are averaged over ranks (DDP mean), parameters are broadcast from rank 0
+at construction (DDP ctor), optimizer arithmetic = torch.optim defaults with only lr set (train.py:183-194).
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+from . import hip
+from .data.AddBiomechanicsDataset import INPUT_KEY_ORDER, LOSS_KEY_ORDER, LOSS_KEY_WIDTHS
+from .loss.RegressionLossEvaluator import component_weights
+from .module import HipModule, flat_layout
+from .plans import ParamSource
+
+
+class GradBuckets:
+    """Contiguous slices of the flat gradient buffer, all-reduced (SUM) as soon as every gradient inside a
+    slice has been produced.  The division by world_size is folded into the optimizer kernel."""
+
+    def __init__(self, flat_grad: torch.Tensor, layout: "OrderedDict[str, Tuple[int, int]]", bucket_bytes: int,
+                 group=None):
+        self.flat = flat_grad
+        self.group = group
+        self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.on_gpu = flat_grad.is_cuda
+        self.comm_stream = torch.cuda.Stream(device=flat_grad.device) if (self.on_gpu and self.world > 1) else None
+        names = list(layout.keys())
+        self.bucket_of: Dict[str, int] = {}
+        self.ranges: List[Tuple[int, int]] = []
+        self.members: List[List[str]] = []
+        lo, cur = 0, []
+        total = flat_grad.numel()
+        for i, n in enumerate(names):
+            cur.append(n)
+            end = layout[names[i + 1]][0] if i + 1 < len(names) else total
+            if (end - lo) * 4 >= bucket_bytes or i + 1 == len(names):
+                for m in cur:
+                    self.bucket_of[m] = len(self.ranges)
+                self.ranges.append((lo, end))
+                self.members.append(cur)
+                lo, cur = end, []
+        self._pending = [len(m) for m in self.members]
+        self._works: list = []
+
+    def reset(self):
+        self._pending = [len(m) for m in self.members]
+        self._works = []
+
+    def mark_ready(self, name: str) -> Optional[int]:
+        """returns the bucket index if `name` completed a bucket"""
+        b = self.bucket_of[name]
+        self._pending[b] -= 1
+        if self._pending[b] < 0:
+            raise hip.HipError(f"gradient of {name} reported ready twice in one step")
+        return b if self._pending[b] == 0 else None
+
+    def launch(self, b: int):
+        if self.world == 1:
+            return
+        lo, hi = self.ranges[b]
+        t = self.flat[lo:hi]
+        if self.on_gpu:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            with torch.cuda.stream(self.comm_stream):
+                self.comm_stream.wait_event(ev)
+                self._works.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            self._works.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self):
+        """make the compute stream wait for every outstanding bucket (no host block on the GPU path)"""
+        if self.on_gpu and self.comm_stream is not None:
+            for w in self._works:
+                with torch.cuda.stream(self.comm_stream):
+                    w.wait()
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        else:
+            for w in self._works:
+                w.wait()
+        self._works = []
+
+
+def broadcast_parameters(flat: torch.Tensor, group=None, src: int = 0):
+    """DDP-constructor semantics (train.py:175): every rank starts from rank 0's parameters."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.broadcast(flat, src=src, group=group)
+
+
+class _Recorder:
+    """Records a step as segments: hipGraphs (captured launch runs) interleaved with host actions
+    (collective launches), then replays them."""
+
+    def __init__(self):
+        self.actions: List[Tuple[str, object]] = []
+        self._g: Optional[hip.Graph] = None
+
+    def begin(self):
+        self._g = hip.Graph()
+        self._g.begin()
+
+    def cut(self, host_action: Callable[[], None]):
+        """close the current graph segment and schedule a host action (a collective launch) after it.
+        Nothing executes while recording; replay() runs segments and actions in order."""
+        self._g.end()
+        self.actions.append(("graph", self._g))
+        self.actions.append(("host", host_action))
+        self._g = hip.Graph()
+        self._g.begin()
+
+    def end(self):
+        self._g.end()
+        self.actions.append(("graph", self._g))
+        self._g = None
+
+    def replay(self):
+        for kind, a in self.actions:
+            if kind == "graph":
+                a.launch()
+            else:
+                a()
+
+
+class HipTrainer:
+    """Fused training step for one model on one GPU (+ data-parallel peers).
+
+    task = "diffusion": batch = (x0 [B,T,D], t [B] int64, eps [B,T,D]) -> q_sample -> denoiser -> eps-MSE
+    task = "regression": batch = (inputs dict of 10 keys, labels dict of 4 keys) -> FeedForwardBaseline ->
+                         RegressionLossEvaluator arithmetic (component selection from `args`)
+    """
+
+    def __init__(self, model: HipModule, task: str, opt_type: str = "rmsprop", lr: float = 1e-4, args=None,
+                 group=None, bucket_mb: float = 4.0, use_graph: bool = True):
+        if task not in ("diffusion", "regression"):
+            raise ValueError(task)
+        if opt_type not in hip.OPT:
+            raise ValueError("Invalid optimizer type: " + opt_type)          # train.py:195-197
+        self.model, self.task, self.opt_type, self.lr = model, task, opt_type, lr
+        self.group = group
+        self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.use_graph = use_graph and not hip._dry_run
+        dev = next(model.parameters()).device
+        self.device = dev
+        self.plan = self._plan_for(dev)
+        # ---- flat buffers in gradient-ready order
+        order = self.plan.ready_order()
+        params = OrderedDict(model.named_parameters())
+        if sorted(order) != sorted(params.keys()):
+            raise hip.HipError("plan.ready_order() does not cover the model's parameters")
+        shapes = OrderedDict((k, tuple(params[k].shape)) for k in order)
+        self.layout, total = flat_layout(shapes)
+        flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for k in order:
+                off, n = self.layout[k]
+                v = flat[off:off + n].view(shapes[k])
+                v.copy_(params[k].data)
+                params[k].data = v
+        model._flat, model._layout, model._shadow = flat, self.layout, None
+        self.flat = flat
+        broadcast_parameters(self.flat, group)
+        self.grad = torch.zeros_like(flat)
+        for k in order:
+            off, n = self.layout[k]
+            params[k].grad = self.grad[off:off + n].view(shapes[k])
+        ns = hip.OPT_NUM_STATES[opt_type]
+        self.s1 = torch.zeros_like(flat) if ns >= 1 else None
+        self.s2 = torch.zeros_like(flat) if ns >= 2 else None
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.steps_done = 0
+        model.sync_shadow()
+        model._shadow_fresh = True          # from here on the optimizer kernel keeps the shadow current
+        self._gviews = {k: params[k].grad for k in order}
+        self._params = params
+        self.buckets = GradBuckets(self.grad, self.layout, int(bucket_mb * (1 << 20)), group)
+        self.result = torch.zeros(64, dtype=torch.float32, device=dev)
+        self.comp_w = None
+        if task == "regression":
+            if args is None:
+                raise ValueError("regression task needs args with predict_*_components")
+            self.comp_w = torch.tensor(component_weights(args), dtype=torch.float32, device=dev)
+        self._static: Dict[str, torch.Tensor] = {}
+        self._rec: Optional[_Recorder] = None
+        self._sig = None
+        self._warm = 0
+        self._ready_seen: List[str] = []
+
+    # ------------------------------------------------------------------------------------------
+    def _plan_for(self, dev):
+        m = self.model
+        if self.task == "diffusion":
+            return m._get_plan(dev)
+        return m._get_plan(dev)
+
+    def _psrc(self, cut: Optional[Callable[[int], None]] = None) -> ParamSource:
+        m = self.model
+        params = self._params
+        if m.compute_dtype == torch.bfloat16:
+            w = lambda k: m.flat_view(m._shadow, k, params[k].shape)
+        else:
+            w = lambda k: params[k].data
+        v = lambda k: params[k].data
+        g = lambda k: self._gviews[k]
+
+        def ready(name: str):
+            self._ready_seen.append(name)
+            b = self.buckets.mark_ready(name)
+            if b is not None and self.world > 1:
+                if cut is not None:
+                    cut(b)
+                else:
+                    self.buckets.launch(b)
+        return ParamSource(w, v, g, ready)
+
+    def _sbuf(self, name: str, like: torch.Tensor, dtype=None) -> torch.Tensor:
+        dtype = dtype or like.dtype
+        key = (name, tuple(like.shape), dtype)
+        t = self._static.get(key)
+        if t is None:
+            t = torch.empty(like.shape, dtype=dtype, device=self.device)
+            self._static[key] = t
+        return t
+
+    # ---- the launch sequence ---------------------------------------------------------------------
+    def _launches(self, st: Dict[str, torch.Tensor], cut=None):
+        m, plan, dt = self.model, self.plan, self.model.compute_dtype
+        self.buckets.reset()
+        self._ready_seen = []
+        P = self._psrc(cut)
+        if self.task == "diffusion":
+            x0, t, eps = st["x0"], st["t"], st["eps"]
+            tabs = m.tables(self.device)
+            xt = plan.buf.get("tr.xt", x0.shape, dt)
+            hip.q_sample(x0, eps, t, tabs.sqrt_ab, tabs.sqrt_1mab, xt)
+            pred = plan.forward(xt, t, tabs.temb, P)
+            dpred = plan.buf.get("tr.dpred", pred.shape, dt)
+            ws = plan.buf.bytes("tr.mse", hip.mse_loss_workspace_bytes(pred.numel()))
+            hip.mse_loss(pred, eps, self.result, ws, dpred=dpred)
+            plan.backward(dpred, P, accumulate=False)
+        else:
+            B = st["in0"].shape[0]
+            x = plan.buf.get("ff.x", (B, m.input_size), dt)
+            hip.concat_keys([st[f"in{i}"] for i in range(len(INPUT_KEY_ORDER))], x)
+            out = plan.forward(x, P)
+            F = m.num_output_frames
+            views = m.split_output(out)
+            outs = tuple(views[k] for k in LOSS_KEY_ORDER)
+            G = plan.buf.get("tr.dout", out.shape, dt)
+            gv = m.split_output(G)
+            grads = tuple(gv[k] for k in LOSS_KEY_ORDER)
+            labs = tuple(st[f"lab{i}"] for i in range(4))
+            ws = plan.buf.bytes("tr.rl", hip.regression_loss_workspace_bytes(B, F))
+            hip.regression_loss(outs, labs, self.comp_w, self.result, ws, grads=grads, threshold=10.0)
+            plan.backward(G, P, accumulate=False)
+        if self.world > 1:
+            if cut is not None:
+                cut(-1)
+            else:
+                self.buckets.finish()
+        hip.counter_add(self.step_dev, 1)
+        hip.optim_step(self.opt_type, self.flat, self.grad, self.s1, self.s2, self.lr, step=0, step_dev=self.step_dev,
+                       grad_scale=1.0 / self.world, shadow=m._shadow if dt == torch.bfloat16 else None)
+
+    def _stage(self, batch) -> Dict[str, torch.Tensor]:
+        """copy the batch into the static input buffers the (captured) launch sequence reads"""
+        dt = self.model.compute_dtype
+        st: Dict[str, torch.Tensor] = {}
+        if self.task == "diffusion":
+            x0, t, eps = batch
+            for name, src, d in (("x0", x0, dt), ("eps", eps, dt), ("t", t, torch.int64)):
+                b = self._sbuf(name, src, d)
+                b.copy_(src, non_blocking=True)
+                st[name] = b
+        else:
+            inputs, labels = batch
+            for i, k in enumerate(INPUT_KEY_ORDER):
+                b = self._sbuf(f"in{i}", inputs[k], torch.float32)
+                b.copy_(inputs[k], non_blocking=True)
+                st[f"in{i}"] = b
+            for i, k in enumerate(LOSS_KEY_ORDER):
+                b = self._sbuf(f"lab{i}", labels[k], torch.float32)
+                b.copy_(labels[k], non_blocking=True)
+                st[f"lab{i}"] = b
+        return st
+
+    def step(self, batch) -> torch.Tensor:
+        """one fused training step; returns the DEVICE scalar holding this step's loss (no sync)."""
+        st = self._stage(batch)
+        sig = tuple((k, tuple(v.shape)) for k, v in st.items())
+        if sig != self._sig:
+            self._sig, self._rec, self._warm = sig, None, 0
+        if self._rec is not None:
+            self._rec.replay()
+        elif not self.use_graph or self._warm < 2:
+            self._launches(st)                  # eager (warm-up allocates every plan buffer)
+            if self._warm == 0 and self._ready_seen != list(self.layout.keys()):
+                raise hip.HipError("plan.backward() did not report gradients in ready_order()")
+            self._warm += 1
+        else:
+            rec = _Recorder()
+
+            def cut(b: int):
+                rec.cut((lambda: self.buckets.launch(b)) if b >= 0 else self.buckets.finish)
+            rec.begin()
+            self._launches(st, cut=cut if self.world > 1 else None)
+            rec.end()
+            self._rec = rec
+            rec.replay()                        # the capture itself executed nothing
+        self.steps_done += 1
+        return self.result[0]
+
+    def loss_value(self) -> float:
+        """host readback of the last step's loss (synchronises)"""
+        return float(self.result[0].cpu())
+
+    # ---- checkpoint payload (grammar of train.py:272-278) ------------------------------------------
+    def optimizer_state_dict(self) -> Dict:
+        return {"opt_type": self.opt_type, "lr": self.lr, "step": self.steps_done,
+                "layout": {k: list(v) for k, v in self.layout.items()},
+                "s1": None if self.s1 is None else self.s1.detach().cpu(),
+                "s2": None if self.s2 is None else self.s2.detach().cpu()}
+
+    def load_optimizer_state_dict(self, sd: Dict):
+        if sd.get("opt_type") != self.opt_type or {k: list(v) for k, v in self.layout.items()} != sd.get("layout"):
+            raise hip.HipError("optimizer state does not match this trainer (optimizer type or parameter layout)")
+        if self.s1 is not None:
+            self.s1.copy_(sd["s1"])
+        if self.s2 is not None:
+            self.s2.copy_(sd["s2"])
+        self.steps_done = int(sd["step"])
+        self.step_dev.fill_(self.steps_done)
+
+    def refresh_after_param_load(self):
+        """call after model.load_state_dict(): re-cast the bf16 shadow"""
+        self.model._shadow_fresh = False
+        self.model.sync_shadow()
+        self.model._shadow_fresh = True

@@ -107,6 +107,53 @@ class _DryRunLib:
         return call
 
 
+class _TimingLib:
+    """Brackets every C-ABI call with HIP events recorded on the launch stream (bench.py's roofline leg:
+    per-entry-point device time, measured live on the stream the kernels are launched on)."""
+
+    def __init__(self, real):
+        self._real = real
+        self.records = []      # (name, int_args, ev0, ev1)
+
+    def __getattr__(self, name):
+        real = getattr(self._real, name)
+        if not name.startswith("ib_") or name.startswith(("ib_event", "ib_graph")) or name.endswith("_workspace") \
+                or name in ("ib_version", "ib_error_string"):
+            return real
+
+        def call(*a):
+            e0, e1 = Event(), Event()
+            e0.record()
+            rc = real(*a)
+            e1.record()
+            self.records.append((name, tuple(v for v in a if isinstance(v, int) and not isinstance(v, bool) and 0 <= v < (1 << 31)), e0, e1))
+            return rc
+        return call
+
+    def summary(self):
+        """{(name, int_args): [ms, ...]} (synchronises)"""
+        out = {}
+        for name, ints, e0, e1 in self.records:
+            out.setdefault((name, ints), []).append(e0.elapsed_ms(e1))
+        return out
+
+
+class time_launches:
+    """context manager: `with hip.time_launches() as tl: ...; tl.summary()`"""
+
+    def __enter__(self):
+        global _lib
+        self._saved = lib()
+        self.tl = _TimingLib(self._saved)
+        _lib = self.tl
+        return self.tl
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self._saved
+        return False
+
+
 _dry_run = False
 
 
