@@ -1,0 +1,255 @@
+"""`main.py train` -- the DDP training driver (drop-in for src/cli/train.py).
+
+Flags and defaults are the reference's (train.py:24-69).  Control flow kept: per epoch a no-grad dev
+evaluation, a barrier, then the training loop with a report every 1000 batches and a rank-0 checkpoint
+``<checkpoint-dir>/epoch_{E}_batch_{i}.pt`` holding {'epoch', 'model_state_dict', 'optimizer_state_dict'}
+(train.py:201-291).  What differs is the loop BODY: ``zero_grad -> model -> loss -> backward -> step``
+(train.py:240-284) is one fused launch sequence (engine.HipTrainer): HIP kernels, gradients in one flat
+buffer, RCCL all-reduce in buckets overlapped with the backward, one optimizer launch, hipGraph replay, no
+per-step host sync (the reference syncs 8x per step through `.item()` and uploads to wandb every step).
+
+Reference defects fixed on the way: undefined DEV / mp / time (train.py:136,152,212), no
+--device flag, checkpoint keys saved with DDP's `module.` prefix, checkpoint dir join that drops the model
+type, `git_hash` storing the function object; wandb is optional.
+"""
+import argparse
+import logging
+import os
+from datetime import timedelta
+from typing import Dict, List
+
+import torch
+import torch.distributed as dist
+from torch.utils.data import DataLoader
+from torch.utils.data.distributed import DistributedSampler as DS
+
+from ..engine import HipTrainer
+from ..loss.DiffusionLossEvaluator import DiffusionLossEvaluator
+from ..loss.RegressionLossEvaluator import RegressionLossEvaluator
+from ._common import (add_additive_flags, add_component_flags, dtype_of, is_diffusion, open_dataset, pick_device)
+from .abstract_command import MODEL_TYPES, AbstractCommand
+from .utilities import get_git_hash, has_uncommitted_changes
+
+DEV = 'dev'   # the dev split directory (analyze.py:80); the reference train.py uses an undefined name here
+
+
+class TrainCommand(AbstractCommand):
+    def __init__(self):
+        super().__init__()
+
+    def register_subcommand(self, subparsers: argparse._SubParsersAction):
+        p = subparsers.add_parser('train', help='Train a model on the AddBiomechanics dataset')
+        p.add_argument('--dataset-home', type=str, default='../data', help='The path to the AddBiomechanics dataset.')
+        p.add_argument('--no-wandb', action='store_true', default=False, help='Do not log this run to Weights and Biases.')
+        p.add_argument('--model-type', type=str, default='feedforward', choices=MODEL_TYPES, help='The model to train.')
+        p.add_argument('--output-data-format', type=str, default='all_frames', choices=['all_frames', 'last_frame'],
+                       help='Output for all frames in a window or only the last frame.')
+        p.add_argument('--checkpoint-dir', type=str, default='../checkpoints',
+                       help='Where checkpoints are saved; training resumes from the latest one in this directory.')
+        p.add_argument('--geometry-folder', type=str, default=None, help='Path to the Geometry folder with bone mesh data.')
+        p.add_argument('--history-len', type=int, default=50, help='The number of timesteps of context in the inputs.')
+        p.add_argument('--stride', type=int, default=5, help='The timestep gap between frames in the context window.')
+        p.add_argument('--learning-rate', type=float, default=1e-4, help='The learning rate for weight updates.')
+        p.add_argument('--dropout', action='store_true', help='Apply dropout?')
+        p.add_argument('--dropout-prob', type=float, default=0.5, help='Dropout prob')
+        p.add_argument('--hidden-dims', type=int, nargs='+', default=[512, 512], help='Hidden dims across layers.')
+        p.add_argument('--batchnorm', action='store_true', help='Apply batchnorm?')
+        p.add_argument('--activation', type=str, default='sigmoid', help='Which activation func?')
+        p.add_argument('--epochs', type=int, default=10, help='The number of epochs to run training for.')
+        p.add_argument('--opt-type', type=str, default='rmsprop', help='The optimizer used to adapt the weights.')
+        p.add_argument('--batch-size', type=int, default=64, help='The batch size (per process).')
+        p.add_argument('--short', action='store_true', help='Use very short datasets to test quickly.')
+        p.add_argument('--data-loading-workers', type=int, default=1, help='Worker processes that load data.')
+        add_component_flags(p, train_defaults=True)
+        p.add_argument('--trial-filter', type=str, nargs='+', default=[""], help='What kind of trials to train/test on.')
+        p.add_argument('--compute-report', action='store_true', default=False,
+                       help='Compute inverse dynamics reports during loss evaluation.')
+        add_additive_flags(p)
+        p.add_argument('--max-steps', type=int, default=0, help='Stop each epoch after this many batches (0 = all).')
+        p.add_argument('--report-every', type=int, default=1000, help='Batches between reports / checkpoints.')
+        p.add_argument('--eager', action='store_true',
+                       help='Reference-style loop (autograd node + torch.optim + torch DDP) instead of the fused trainer.')
+        p.add_argument('--no-graph', action='store_true', help='Do not replay the step from hipGraphs.')
+        p.add_argument('--bucket-mb', type=float, default=4.0, help='Gradient all-reduce bucket size.')
+
+    # ------------------------------------------------------------------------------------------
+    def run(self, args: argparse.Namespace):
+        if 'command' in args and args.command != 'train':
+            return False
+        model_type: str = args.model_type
+        checkpoint_dir: str = os.path.join(os.path.abspath(args.checkpoint_dir), model_type)   # as analyze.py:57
+        history_len, stride = args.history_len, args.stride
+        log_to_wandb: bool = not args.no_wandb
+        diffusion = is_diffusion(model_type)
+
+        geometry = self.ensure_geometry(args.geometry_folder)
+        device = pick_device(args)
+        world_size = int(os.environ.get('WORLD_SIZE', '1'))
+        distributed = world_size > 1
+        if distributed:
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            dist.init_process_group(backend="nccl", timeout=timedelta(hours=1), device_id=device)   # RCCL (train.py:99)
+        rank = dist.get_rank() if distributed else 0
+        print(f"Running on {world_size} GPUs.")
+        print(f"Current device being used for model training and loss evaluation: {device}.")
+        if has_uncommitted_changes():
+            logging.error("UNCOMMITTED CHANGES IN REPO! This will make it hard to replicate this experiment later")
+
+        wandb = None
+        if log_to_wandb:
+            try:
+                import wandb as _wandb
+                wandb = _wandb
+                config = dict(args.__dict__)
+                config["git_hash"] = get_git_hash()
+                group = os.getenv('WANDB_RUN_GROUP', f'ddp_{wandb.util.generate_id()}')
+                wandb.init(project="addbiomechanics-baseline", config=config, group=group)
+            except ImportError:
+                logging.warning("wandb is not installed: continuing without uploads (same as --no-wandb)")
+                log_to_wandb = False
+
+        print("Initializing training set...")
+        train_dataset = open_dataset(args, 'train', history_len, stride, args.output_data_format, geometry)
+        print("Initializing dev set...")
+        dev_dataset = open_dataset(args, DEV, history_len, stride, args.output_data_format, geometry)
+        # DistributedSampler(shuffle=False, drop_last=True): rank r takes indices r, r+world, ... (train.py:143,149)
+        mk = lambda ds: DataLoader(ds, batch_size=args.batch_size, shuffle=False, num_workers=args.data_loading_workers,
+                                   persistent_workers=args.data_loading_workers > 0, pin_memory=True, drop_last=diffusion,
+                                   sampler=DS(ds, num_replicas=world_size, rank=rank, shuffle=False, drop_last=True))
+        train_dataloader, dev_dataloader = mk(train_dataset), mk(dev_dataset)
+
+        print("Initializing model...")
+        window = history_len // stride if stride > 1 else history_len
+        model = self.get_model(getattr(train_dataset, 'num_dofs', 23), getattr(train_dataset, 'num_contact_bodies', 2),
+                               model_type, history_len=history_len, stride=stride, hidden_dims=args.hidden_dims,
+                               activation=args.activation, batchnorm=args.batchnorm, dropout=args.dropout,
+                               dropout_prob=args.dropout_prob, root_history_len=10,
+                               output_data_format=args.output_data_format, device=device, compute_dtype=dtype_of(args),
+                               feat_dim=args.feat_dim, window=window).to(device)
+        if not any(p.requires_grad for p in model.parameters()):
+            print("No parameters to optimize. Skipping training loop.")
+            return False
+
+        if diffusion:
+            train_eval, dev_eval = DiffusionLossEvaluator('train'), DiffusionLossEvaluator(DEV)
+        else:
+            train_eval = RegressionLossEvaluator(dataset=train_dataset, split='train', device=device)
+            dev_eval = RegressionLossEvaluator(dataset=dev_dataset, split=DEV, device=device)
+
+        trainer, optimizer, ddp_model = None, None, model
+        if args.eager:
+            if distributed:
+                from torch.nn.parallel import DistributedDataParallel as DDP
+                model.ensure_packed()
+                ddp_model = DDP(model, device_ids=[device.index], output_device=device.index)
+            optimizer = make_torch_optimizer(args.opt_type, model.parameters(), args.learning_rate)
+        else:
+            trainer = HipTrainer(model, "diffusion" if diffusion else "regression", args.opt_type, args.learning_rate,
+                                 args=args, use_graph=not args.no_graph, bucket_mb=args.bucket_mb)
+
+        epoch_checkpoint, _ = self.load_latest_checkpoint(model, optimizer=trainer if trainer is not None else optimizer,
+                                                          checkpoint_dir=checkpoint_dir)
+        gen = torch.Generator().manual_seed(1234 + rank)
+
+        def diffusion_batch(x0):
+            B = x0.shape[0]
+            t = torch.randint(0, model.num_train_steps, (B,), generator=gen, dtype=torch.int64)
+            eps = torch.randn(x0.shape, generator=gen)
+            return x0, t, eps
+
+        for epoch in range(epoch_checkpoint + 1, args.epochs):
+            dev_dataloader.sampler.set_epoch(epoch)
+            train_dataloader.sampler.set_epoch(epoch)
+            print(f'[rank={rank}] Evaluating Dev Set Before Epoch {epoch}')
+            with torch.no_grad():
+                model.eval()
+                for i, batch in enumerate(dev_dataloader):
+                    if diffusion:
+                        x0, t, eps = diffusion_batch(batch)
+                        tabs = model.tables(device)
+                        from .. import hip
+                        xd = x0.to(device, model.compute_dtype)
+                        ed = eps.to(device, model.compute_dtype)
+                        xt = torch.empty_like(xd)
+                        hip.q_sample(xd, ed, t.to(device), tabs.sqrt_ab, tabs.sqrt_1mab, xt)
+                        dev_eval(model(xt, t), ed)
+                    else:
+                        inputs, labels, subj, trial = batch
+                        dev_eval(inputs, model(inputs), labels, subj, trial, args, compute_report=args.compute_report)
+                    if args.max_steps and i + 1 >= args.max_steps:
+                        break
+                print(f'[rank={rank}] Dev Set Evaluation: ')
+                dev_eval.print_report(args, log_to_wandb=log_to_wandb) if not diffusion else dev_eval.print_report()
+            if distributed:
+                dist.barrier()
+            print(f'[rank={rank}] Running Training Epoch {epoch}')
+            model.train()
+            n_batches = len(train_dataloader)
+            for i, batch in enumerate(train_dataloader):
+                if diffusion:
+                    x0, t, eps = diffusion_batch(batch)
+                    if trainer is not None:
+                        loss = trainer.step((x0.to(device, non_blocking=True), t.to(device, non_blocking=True),
+                                             eps.to(device, non_blocking=True)))
+                        train_eval.losses.append(loss.detach().clone())
+                    else:
+                        from .. import hip
+                        optimizer.zero_grad()
+                        tabs = model.tables(device)
+                        xd, ed = x0.to(device, model.compute_dtype), eps.to(device, model.compute_dtype)
+                        xt = torch.empty_like(xd)
+                        hip.q_sample(xd, ed, t.to(device), tabs.sqrt_ab, tabs.sqrt_1mab, xt)
+                        loss = train_eval(ddp_model(xt, t), ed)
+                        loss.backward()
+                        optimizer.step()
+                else:
+                    inputs, labels, subj, trial = batch
+                    if trainer is not None:
+                        trainer.step((inputs, labels))
+                        train_eval.record_result(trainer.result)
+                    else:
+                        optimizer.zero_grad()
+                        loss = train_eval(inputs, ddp_model(inputs), labels, subj, trial, args,
+                                          compute_report=args.compute_report and (i % 100 == 0))
+                        loss.backward()
+                        optimizer.step()
+                last = (i == n_batches - 1) or (args.max_steps and i + 1 >= args.max_steps)
+                if (i + 1) % 100 == 0 or last:
+                    logging.info(f'  - [rank={rank}] Batch {i + 1}/{n_batches}')
+                if (i + 1) % args.report_every == 0 or last:
+                    logging.info(f'[rank={rank}] Batch {i} Training Set Evaluation: ')
+                    train_eval.print_report(args, reset=False) if not diffusion else train_eval.print_report(reset=False)
+                    if rank == 0:
+                        save_checkpoint(checkpoint_dir, epoch, i, model, trainer if trainer is not None else optimizer)
+                if last:
+                    break
+            logging.info('-' * 80)
+            logging.info(f'[rank={rank}] Epoch {epoch}/{args.epochs} Training Set Evaluation: ')
+            train_eval.print_report(args, log_to_wandb=log_to_wandb) if not diffusion else train_eval.print_report()
+            logging.info('-' * 80)
+
+        if wandb is not None:
+            wandb.finish()
+        if distributed:
+            dist.destroy_process_group()
+        return True
+
+
+def make_torch_optimizer(opt_type: str, params, lr: float):
+    table = {'adagrad': torch.optim.Adagrad, 'adam': torch.optim.Adam, 'sgd': torch.optim.SGD,
+             'rmsprop': torch.optim.RMSprop, 'adadelta': torch.optim.Adadelta, 'adamax': torch.optim.Adamax}
+    if opt_type not in table:
+        logging.error('Invalid optimizer type: ' + opt_type)
+        assert (False)
+    return table[opt_type](params, lr=lr)
+
+
+def save_checkpoint(checkpoint_dir: str, epoch: int, batch: int, model, opt):
+    """file grammar of train.py:271-278; keys are saved WITHOUT DDP's `module.` prefix"""
+    os.makedirs(checkpoint_dir, exist_ok=True)
+    path = f"{checkpoint_dir}/epoch_{epoch}_batch_{batch}.pt"
+    osd = opt.optimizer_state_dict() if hasattr(opt, 'optimizer_state_dict') else opt.state_dict()
+    torch.save({'epoch': epoch,
+                'model_state_dict': {k: v.detach().cpu().clone() for k, v in model.state_dict().items()},
+                'optimizer_state_dict': osd}, path)
+    return path

@@ -45,6 +45,7 @@ struct GemmParams {
   const void* addend; int64_t ldadd;  // dgrad: residual-path gradient added in the epilogue
   int act;
   int vecA, vecB, vecC;
+  int vecBias, vecAdd, vecAux;   // 16-byte (fp32) / 8-byte (bf16) epilogue operand loads are legal
   int tiles_n;
   int k_chunk;                 // split over the reduction (wgrad): blockIdx.y * k_chunk
   int64_t slab_stride;         // wgrad: elements between partial slabs (0 when not split)
@@ -90,6 +91,34 @@ __device__ __forceinline__ void load_tile(const T* base, int64_t ld, int row0, i
       r[q] = load_piece<T>(base + (int64_t)gk * ld + gr, nvalid, vec);
     }
   }
+}
+
+// Hoisted form for the steady state: per-thread piece pointers are computed once per workgroup and
+// advanced by a constant per K step; no predicates (k-contiguous operands clamp out-of-range rows to the
+// last valid row -- those tile rows only feed outputs that are never stored; k-strided operands use this
+// path on interior tiles only).
+template <typename T, bool KC>
+__device__ __forceinline__ void init_ptrs(const T* base, int64_t ld, int row0, int rows_total, int k0,
+                                          const T* (&ptr)[4], int tid) {
+  constexpr int VW = Tile<T>::VW;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int p = tid + NTHREADS * q;
+    if (KC) {
+      const int row = p >> 3, kc = p & 7;
+      const int gr = min(row0 + row, rows_total - 1);
+      ptr[q] = base + (int64_t)gr * ld + k0 + kc * VW;
+    } else {
+      constexpr int RG = 128 / VW;
+      const int kk = p / RG, rg = p % RG;
+      ptr[q] = base + (int64_t)(k0 + kk) * ld + row0 + rg * VW;
+    }
+  }
+}
+template <typename T>
+__device__ __forceinline__ void load_tile_fast(const T* const (&ptr)[4], int64_t off, uint4 (&r)[4]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) __builtin_memcpy(&r[q], __builtin_assume_aligned(ptr[q] + off, 4), 16);
 }
 
 // registers -> LDS image
@@ -200,6 +229,110 @@ __device__ __forceinline__ void store4(T* p, const float (&v)[4], int nv, bool v
   }
 }
 
+// activation math with a compile-time selector.  fp32 storage (parity mode) uses the accurate libm
+// forms; bf16 storage uses the hardware exp (v_exp_f32) -- its error is far below bf16 resolution.
+template <typename T, int ACT>
+__device__ __forceinline__ float act_fwd_t(float v) {
+  if constexpr (ACT == IB_ACT_RELU) return v > 0.f ? v : 0.f;
+  else if constexpr (ACT == IB_ACT_TANH) return tanhf(v);
+  else if constexpr (ACT == IB_ACT_SIGMOID) return 1.f / (1.f + (sizeof(T) == 2 ? __expf(-v) : expf(-v)));
+  else if constexpr (ACT == IB_ACT_SILU) return v / (1.f + (sizeof(T) == 2 ? __expf(-v) : expf(-v)));
+  else return v;
+}
+template <typename T, int ACT>
+__device__ __forceinline__ float act_bwd_t(float aux) {
+  if constexpr (ACT == IB_ACT_RELU) return aux > 0.f ? 1.f : 0.f;
+  else if constexpr (ACT == IB_ACT_TANH) return 1.f - aux * aux;
+  else if constexpr (ACT == IB_ACT_SIGMOID) return aux * (1.f - aux);
+  else if constexpr (ACT == IB_ACT_SILU) {
+    const float sg = 1.f / (1.f + (sizeof(T) == 2 ? __expf(-aux) : expf(-aux)));
+    return sg * (1.f + aux * (1.f - sg));
+  } else return 1.f;
+}
+
+template <typename T>
+__device__ __forceinline__ void load4f(const T* p, int nv, bool vec, float (&v)[4]) {
+  if (nv == 4 && vec) {
+    if constexpr (sizeof(T) == 2) {
+      bf16x4_t t = *reinterpret_cast<const bf16x4_t*>(p);
+      v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3];
+    } else {
+      float4 t = *reinterpret_cast<const float4*>(p);
+      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = (r < nv) ? ib_to_f32(p[r]) : 0.f;
+  }
+}
+
+template <typename T, int EPI, int ACT>
+__device__ __forceinline__ void epilogue(const GemmParams& p, f32x4_t (&acc)[4][4], int i0, int j0, int wi, int wj,
+                                         int lane) {
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int i = i0 + wi * 64 + 16 * t + (lane & 15);
+    if (i >= p.M) continue;
+    [[maybe_unused]] int64_t rd = 0, rm = 0;
+    if constexpr (EPI == EPI_FWD) {
+      if (p.add_div) rd = (int64_t)(i / p.seg) * p.ld_add_div;
+      if (p.add_mod) rm = (int64_t)(i % p.seg) * p.ld_add_mod;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int jb = j0 + wj * 64 + 16 * u + 4 * (lane >> 4);
+      if (jb >= p.N) continue;
+      const int nv = min(4, p.N - jb);
+      float v[4] = {acc[t][u][0], acc[t][u][1], acc[t][u][2], acc[t][u][3]};
+      if constexpr (EPI == EPI_FWD) {
+        float w4[4];
+        if (p.bias) {
+          load4f<float>(p.bias + jb, nv, p.vecBias, w4);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += w4[r];
+        }
+        if (p.add_div) {
+          load4f<T>(reinterpret_cast<const T*>(p.add_div) + rd + jb, nv, p.vecAdd, w4);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += w4[r];
+        }
+        if (p.add_mod) {
+          load4f<T>(reinterpret_cast<const T*>(p.add_mod) + rm + jb, nv, p.vecAdd, w4);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += w4[r];
+        }
+        if (p.Z) store4<T>(reinterpret_cast<T*>(p.Z) + (int64_t)i * p.ldz + jb, v, nv, p.vecC);
+        if constexpr (ACT != IB_ACT_NONE) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = act_fwd_t<T, ACT>(v[r]);
+        }
+        store4<T>(reinterpret_cast<T*>(p.C) + (int64_t)i * p.ldc + jb, v, nv, p.vecC);
+      } else if constexpr (EPI == EPI_DGRAD) {
+        float w4[4];
+        if constexpr (ACT != IB_ACT_NONE) {
+          load4f<T>(reinterpret_cast<const T*>(p.aux) + (int64_t)i * p.ldaux + jb, nv, p.vecAux, w4);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] *= act_bwd_t<T, ACT>(w4[r]);
+        }
+        if (p.addend) {
+          load4f<T>(reinterpret_cast<const T*>(p.addend) + (int64_t)i * p.ldadd + jb, nv, p.vecAdd, w4);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += w4[r];
+        }
+        store4<T>(reinterpret_cast<T*>(p.C) + (int64_t)i * p.ldc + jb, v, nv, p.vecC);
+      } else {
+        float* c = reinterpret_cast<float*>(p.C) + (int64_t)blockIdx.y * p.slab_stride + (int64_t)i * p.ldc + jb;
+        if (p.accumulate && p.slab_stride == 0) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (r < nv) v[r] += c[r];
+        }
+        store4<float>(c, v, nv, p.vecC);
+      }
+    }
+  }
+}
+
 template <typename T, bool A_KC, bool B_KC, int EPI>
 __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmParams p) {
   constexpr int BK = Tile<T>::BK;
@@ -221,80 +354,47 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmParams p) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) acc[t][u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
+  // fast (unpredicated, pointer-bumped) staging where legal, generic predicated staging elsewhere
+  const bool fastA = p.vecA && (A_KC ? true : (i0 + BM <= p.M));
+  const bool fastB = p.vecB && (B_KC ? true : (j0 + BN <= p.N));
+  const T* pa[4]; const T* pb[4];
+  init_ptrs<T, A_KC>(A, p.lda, i0, p.M, kb, pa, tid);
+  init_ptrs<T, B_KC>(B, p.ldb, j0, p.N, kb, pb, tid);
+  const int64_t stepA = A_KC ? BK : (int64_t)BK * p.lda;
+  const int64_t stepB = B_KC ? BK : (int64_t)BK * p.ldb;
+
   uint4 ra[4], rb[4];
-  if (nk > 0) {
-    load_tile<T, A_KC>(A, p.lda, i0, p.M, kb, ke, p.vecA, ra, tid);
-    load_tile<T, B_KC>(B, p.ldb, j0, p.N, kb, ke, p.vecB, rb, tid);
-  }
+  auto stage = [&](int kt) {
+    const int k0 = kb + kt * BK;
+    const bool fullk = (k0 + BK <= ke);
+    if (fastA && fullk) load_tile_fast<T>(pa, stepA * kt, ra);
+    else load_tile<T, A_KC>(A, p.lda, i0, p.M, k0, ke, p.vecA, ra, tid);
+    if (fastB && fullk) load_tile_fast<T>(pb, stepB * kt, rb);
+    else load_tile<T, B_KC>(B, p.ldb, j0, p.N, k0, ke, p.vecB, rb, tid);
+  };
+  if (nk > 0) stage(0);
   for (int kt = 0; kt < nk; ++kt) {
     unsigned char* tA = smem + (kt & 1) * 2 * OPER_BYTES;
     unsigned char* tB = tA + OPER_BYTES;
     store_tile<T, A_KC>(tA, ra, tid);
     store_tile<T, B_KC>(tB, rb, tid);
     __syncthreads();
-    if (kt + 1 < nk) {
-      const int k0 = kb + (kt + 1) * BK;
-      load_tile<T, A_KC>(A, p.lda, i0, p.M, k0, ke, p.vecA, ra, tid);
-      load_tile<T, B_KC>(B, p.ldb, j0, p.N, k0, ke, p.vecB, rb, tid);
-    }
+    if (kt + 1 < nk) stage(kt + 1);
     compute_tile<T, A_KC, B_KC>(tA, tB, acc, lane, wi, wj);
   }
 
-  // ---- epilogue: lane holds C[i][jb..jb+3] for 16 (t,u) sub-tiles
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int i = i0 + wi * 64 + 16 * t + (lane & 15);
-    if (i >= p.M) continue;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int jb = j0 + wj * 64 + 16 * u + 4 * (lane >> 4);
-      if (jb >= p.N) continue;
-      const int nv = min(4, p.N - jb);
-      float v[4] = {acc[t][u][0], acc[t][u][1], acc[t][u][2], acc[t][u][3]};
-      if constexpr (EPI == EPI_FWD) {
-        const T* ad = reinterpret_cast<const T*>(p.add_div);
-        const T* am = reinterpret_cast<const T*>(p.add_mod);
-        const int64_t rd = ad ? (int64_t)(i / p.seg) * p.ld_add_div : 0;
-        const int64_t rm = am ? (int64_t)(i % p.seg) * p.ld_add_mod : 0;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if (r < nv) {
-            const int j = jb + r;
-            if (p.bias) v[r] += p.bias[j];
-            if (ad) v[r] += ib_to_f32(ad[rd + j]);
-            if (am) v[r] += ib_to_f32(am[rm + j]);
-          }
-        }
-        if (p.Z) store4<T>(reinterpret_cast<T*>(p.Z) + (int64_t)i * p.ldz + jb, v, nv, p.vecC);
-        if (p.act != IB_ACT_NONE) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = ib_act_fwd(p.act, v[r]);
-        }
-        store4<T>(reinterpret_cast<T*>(p.C) + (int64_t)i * p.ldc + jb, v, nv, p.vecC);
-      } else if constexpr (EPI == EPI_DGRAD) {
-        if (p.act != IB_ACT_NONE) {
-          const T* aux = reinterpret_cast<const T*>(p.aux) + (int64_t)i * p.ldaux + jb;
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (r < nv) v[r] *= ib_act_bwd(p.act, ib_to_f32(aux[r]));
-        }
-        if (p.addend) {
-          const T* ad = reinterpret_cast<const T*>(p.addend) + (int64_t)i * p.ldadd + jb;
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (r < nv) v[r] += ib_to_f32(ad[r]);
-        }
-        store4<T>(reinterpret_cast<T*>(p.C) + (int64_t)i * p.ldc + jb, v, nv, p.vecC);
-      } else {
-        float* c = reinterpret_cast<float*>(p.C) + (int64_t)blockIdx.y * p.slab_stride + (int64_t)i * p.ldc + jb;
-        if (p.accumulate && p.slab_stride == 0) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (r < nv) v[r] += c[r];
-        }
-        store4<float>(c, v, nv, p.vecC);
-      }
-    }
+  // ---- epilogue: lane holds C[i][jb..jb+3] for 16 (t,u) sub-tiles.  The activation is a compile-time
+  // parameter of the epilogue body (one uniform switch here), so only the selected math is executed.
+  if constexpr (EPI == EPI_WGRAD) {
+    epilogue<T, EPI, IB_ACT_NONE>(p, acc, i0, j0, wi, wj, lane);
+    return;
+  }
+  switch (p.act) {
+    case IB_ACT_RELU: epilogue<T, EPI, IB_ACT_RELU>(p, acc, i0, j0, wi, wj, lane); break;
+    case IB_ACT_TANH: epilogue<T, EPI, IB_ACT_TANH>(p, acc, i0, j0, wi, wj, lane); break;
+    case IB_ACT_SIGMOID: epilogue<T, EPI, IB_ACT_SIGMOID>(p, acc, i0, j0, wi, wj, lane); break;
+    case IB_ACT_SILU: epilogue<T, EPI, IB_ACT_SILU>(p, acc, i0, j0, wi, wj, lane); break;
+    default: epilogue<T, EPI, IB_ACT_NONE>(p, acc, i0, j0, wi, wj, lane); break;
   }
 }
 
@@ -340,6 +440,9 @@ int launch_fwd(GemmParams& p, hipStream_t s) {
   p.vecA = vec_load_ok<T>(p.A, p.lda);
   p.vecB = vec_load_ok<T>(p.B, p.ldb);
   p.vecC = vec_store_ok<T>(p.C, p.ldc) && (!p.Z || vec_store_ok<T>(p.Z, p.ldz));
+  p.vecBias = !p.bias || aligned(p.bias, 16);
+  p.vecAdd = (!p.add_div || vec_store_ok<T>(p.add_div, p.ld_add_div)) &&
+             (!p.add_mod || vec_store_ok<T>(p.add_mod, p.ld_add_mod));
   p.tiles_n = (p.N + BN - 1) / BN;
   p.k_chunk = p.K; p.slab_stride = 0;
   const int tiles = ((p.M + BM - 1) / BM) * p.tiles_n;
@@ -353,6 +456,8 @@ int launch_dgrad(GemmParams& p, hipStream_t s) {
   p.vecA = vec_load_ok<T>(p.A, p.lda);
   p.vecB = vec_load_ok<T>(p.B, p.ldb);
   p.vecC = vec_store_ok<T>(p.C, p.ldc);
+  p.vecAux = !p.aux || vec_store_ok<T>(p.aux, p.ldaux);
+  p.vecAdd = !p.addend || vec_store_ok<T>(p.addend, p.ldadd);
   p.tiles_n = (p.N + BN - 1) / BN;
   p.k_chunk = p.K; p.slab_stride = 0;
   const int tiles = ((p.M + BM - 1) / BM) * p.tiles_n;

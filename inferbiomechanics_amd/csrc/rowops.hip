@@ -208,36 +208,38 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
   }
 }
 
-// out[n] (+)= sum_{b < nparts} partial[b][n]   (fixed order)
-__global__ void partial_colsum_kernel(const float* __restrict__ partial, int nparts, int N, float* __restrict__ out,
-                                      int accumulate) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N) return;
-  float s = 0.f;
-  for (int b = 0; b < nparts; ++b) s += partial[(int64_t)b * N + n];
-  out[n] = accumulate ? out[n] + s : s;
-}
-
 // ---------------------------------------------------------------- segmented column sum
-// rows of segment s: m = s*a + r*b, r in [0, cnt).  thread = 4 consecutive columns x one of 4 row lanes.
-template <typename T>
+// rows of segment s: m = s*a + r*b, r in [0, cnt).  A 256-thread block = (256/RL) column groups of 4
+// consecutive columns x RL row lanes; the row lanes' partial sums are combined through LDS in a fixed
+// order.  RL = 4 for short segments, 16 for long ones (independent loads in flight instead of a serial chain).
+template <typename T, int RL>
 __global__ __launch_bounds__(256) void segment_colsum_kernel(const T* __restrict__ x, int64_t ldx, float* __restrict__ out,
                                                              int64_t ldo, int M, int N, int seg, int mode, int accumulate,
                                                              int vec) {
-  __shared__ float red[4][64][4];
-  const int cg = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  constexpr int CG = 256 / RL;
+  __shared__ float red[RL][CG][4];
+  const int cg = threadIdx.x % CG, rl = threadIdx.x / CG;
   const int s = blockIdx.y;
-  const int col = (blockIdx.x * 64 + cg) * 4;
+  const int col = (blockIdx.x * CG + cg) * 4;
   const int nv = max(0, min(4, N - col));
   int64_t a, b; int cnt;
   if (mode == 0) { a = seg; b = 1; cnt = min(seg, M - s * seg); }
   else { a = 1; b = seg; cnt = (M - s + seg - 1) / seg; }
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
   if (nv > 0) {
-    for (int r = rl; r < cnt; r += 4) {
-      const int64_t m = (int64_t)s * a + (int64_t)r * b;
+    int r = rl;
+    for (; r + 3 * RL < cnt; r += 4 * RL) {      // 4 independent loads in flight per lane
+      float v0[4], v1[4], v2[4], v3[4];
+      load4<T>(x + ((int64_t)s * a + (int64_t)r * b) * ldx + col, nv, vec, v0);
+      load4<T>(x + ((int64_t)s * a + (int64_t)(r + RL) * b) * ldx + col, nv, vec, v1);
+      load4<T>(x + ((int64_t)s * a + (int64_t)(r + 2 * RL) * b) * ldx + col, nv, vec, v2);
+      load4<T>(x + ((int64_t)s * a + (int64_t)(r + 3 * RL) * b) * ldx + col, nv, vec, v3);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] += (v0[e] + v1[e]) + (v2[e] + v3[e]);
+    }
+    for (; r < cnt; r += RL) {
       float v[4];
-      load4<T>(x + m * ldx + col, nv, vec, v);
+      load4<T>(x + ((int64_t)s * a + (int64_t)r * b) * ldx + col, nv, vec, v);
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc[e] += v[e];
     }
@@ -249,11 +251,27 @@ __global__ __launch_bounds__(256) void segment_colsum_kernel(const T* __restrict
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       if (e < nv) {
-        const float t = ((red[0][cg][e] + red[1][cg][e]) + red[2][cg][e]) + red[3][cg][e];
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < RL; ++w) t += red[w][cg][e];
         float* o = out + (int64_t)s * ldo + col + e;
         *o = accumulate ? *o + t : t;
       }
     }
+  }
+}
+
+template <typename T>
+void launch_segment_colsum(const T* x, int64_t ldx, float* out, int64_t ldo, int M, int N, int seg, int mode,
+                           int accumulate, int vec, int nseg, int rows_per_seg, hipStream_t s) {
+  if (rows_per_seg > 32) {
+    dim3 grid((unsigned)((N + 63) / 64), (unsigned)nseg);
+    hipLaunchKernelGGL((segment_colsum_kernel<T, 16>), grid, dim3(256), 0, s, x, ldx, out, ldo, M, N, seg, mode,
+                       accumulate, vec);
+  } else {
+    dim3 grid((unsigned)((N + 255) / 256), (unsigned)nseg);
+    hipLaunchKernelGGL((segment_colsum_kernel<T, 4>), grid, dim3(256), 0, s, x, ldx, out, ldo, M, N, seg, mode,
+                       accumulate, vec);
   }
 }
 
@@ -301,7 +319,7 @@ int launch_ln_fwd(const void* x, const void* res, int act, const float* gamma, c
 
 int ln_bwd_parts(int64_t M) {
   int64_t g = (M + 3) / 4;
-  if (g > 512) g = 512;
+  if (g > 256) g = 256;   // one block per CU; fewer partials to reduce
   if (g < 1) g = 1;
   return (int)g;
 }
@@ -366,11 +384,12 @@ extern "C" int ib_layernorm_bwd(const void* dy, const void* x, const void* res, 
     return IB_E_DTYPE;
   }
   if (rc != IB_OK) return rc;
-  const int g = (int)((N + 255) / 256);
-  hipLaunchKernelGGL(partial_colsum_kernel, dim3(g), dim3(256), 0, s, partial, parts, (int)N, dgamma, accumulate);
+  // fixed-order sums of the per-block partials: [parts, N] -> [N], twice
+  const int pvec = (N % 4 == 0);
+  launch_segment_colsum<float>(partial, N, dgamma, N, parts, (int)N, parts, 0, accumulate, pvec, 1, parts, s);
   IB_CHECK_LAUNCH();
-  hipLaunchKernelGGL(partial_colsum_kernel, dim3(g), dim3(256), 0, s, partial + (int64_t)parts * N, parts, (int)N, dbeta,
-                     accumulate);
+  launch_segment_colsum<float>(partial + (int64_t)parts * N, N, dbeta, N, parts, (int)N, parts, 0, accumulate, pvec, 1,
+                               parts, s);
   IB_CHECK_LAUNCH();
   return IB_OK;
 }
@@ -380,16 +399,16 @@ extern "C" int ib_segment_colsum(const void* x, int64_t ldx, float* out, int64_t
   if (!x || !out || M <= 0 || N <= 0 || seg <= 0 || ldx < N || ldo < N || (mode != 0 && mode != 1)) return IB_E_ARG;
   const int64_t nseg = (mode == 0) ? (M + seg - 1) / seg : (seg < M ? seg : M);
   if (nseg > 65535) return IB_E_UNSUPPORTED;
-  dim3 grid((unsigned)((N + 255) / 256), (unsigned)nseg);
   hipStream_t s = ib_s(stream);
+  const int rps = (int)((mode == 0) ? (seg < M ? seg : M) : (M + seg - 1) / seg);
   if (dtype == IB_F32) {
     const int vec = (ldx % 4 == 0) && al(x, 16);
-    hipLaunchKernelGGL((segment_colsum_kernel<float>), grid, dim3(256), 0, s, (const float*)x, ldx, out, ldo, (int)M,
-                       (int)N, (int)seg, mode, accumulate, vec);
+    launch_segment_colsum<float>((const float*)x, ldx, out, ldo, (int)M, (int)N, (int)seg, mode, accumulate, vec,
+                                 (int)nseg, rps, s);
   } else if (dtype == IB_BF16) {
     const int vec = (ldx % 4 == 0) && al(x, 8);
-    hipLaunchKernelGGL((segment_colsum_kernel<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)x, ldx, out, ldo, (int)M,
-                       (int)N, (int)seg, mode, accumulate, vec);
+    launch_segment_colsum<bf16_t>((const bf16_t*)x, ldx, out, ldo, (int)M, (int)N, (int)seg, mode, accumulate, vec,
+                                  (int)nseg, rps, s);
   } else {
     return IB_E_DTYPE;
   }

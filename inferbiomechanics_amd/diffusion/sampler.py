@@ -29,6 +29,21 @@ class DDIMSampler:
     @torch.no_grad()
     def sample(self, x_T: torch.Tensor, steps: Optional[int] = None) -> torch.Tensor:
         """x_T [B,T,D] ~ N(0,1) -> x_0.  `steps` (<= num_sample_steps) truncates the loop (benchmarks)."""
+        if not x_T.is_cuda and not hip._dry_run:
+            x_T = x_T.to(next(self.model.parameters()).device)
+        if hip._dry_run:
+            return self._sample(x_T, steps)
+        # hipGraph capture is not allowed on the legacy default stream -> run on a side stream
+        if getattr(self, "_stream", None) is None:
+            self._stream = torch.cuda.Stream(device=x_T.device)
+        cur = torch.cuda.current_stream()
+        self._stream.wait_stream(cur)
+        with torch.cuda.stream(self._stream):
+            out = self._sample(x_T, steps)
+        cur.wait_stream(self._stream)
+        return out
+
+    def _sample(self, x_T: torch.Tensor, steps: Optional[int] = None) -> torch.Tensor:
         m = self.model
         m.ensure_packed()
         m.sync_shadow()

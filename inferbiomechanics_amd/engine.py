@@ -200,6 +200,9 @@ class HipTrainer:
             if args is None:
                 raise ValueError("regression task needs args with predict_*_components")
             self.comp_w = torch.tensor(component_weights(args), dtype=torch.float32, device=dev)
+        # hipGraph capture is not allowed on the legacy default stream: the step runs on its own stream,
+        # ordered after / before the caller's current stream by events
+        self.stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         self._static: Dict[str, torch.Tensor] = {}
         self._rec: Optional[_Recorder] = None
         self._sig = None
@@ -306,6 +309,16 @@ class HipTrainer:
 
     def step(self, batch) -> torch.Tensor:
         """one fused training step; returns the DEVICE scalar holding this step's loss (no sync)."""
+        if self.stream is None:
+            return self._step(batch)
+        cur = torch.cuda.current_stream()
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            r = self._step(batch)
+        cur.wait_stream(self.stream)
+        return r
+
+    def _step(self, batch) -> torch.Tensor:
         st = self._stage(batch)
         sig = tuple((k, tuple(v.shape)) for k, v in st.items())
         if sig != self._sig:

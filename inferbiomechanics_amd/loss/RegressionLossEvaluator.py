@@ -207,6 +207,17 @@ class RegressionLossEvaluator:
             self._plot_force_error(outputs, labels, args, batch_subject_indices, batch_trial_indices, plot_path_root)
         return loss
 
+    def record_result(self, result: torch.Tensor):
+        """append one step's kernel result vector [64] (the fused trainer computes the loss itself and
+        hands over the device buffer; cloned, not read back)"""
+        r = result.detach().clone()
+        self.losses.append(r[0])
+        self.force_losses.append(r[1:7]); self.cop_losses.append(r[7:13])
+        self.moment_losses.append(r[13:19]); self.wrench_losses.append(r[19:31])
+        self.force_reported_metrics.append(r[31]); self.moment_reported_metrics.append(r[32])
+        self.cop_reported_metrics.append(r[33]); self.wrench_reported_metrics.append(r[34])
+        self.wrench_moment_reported_metrics.append(r[35]); self.com_acc_reported_metrics.append(r[36])
+
     def _inverse_dynamics_report(self, inputs, outputs, labels, batch_subject_indices) -> float:
         """per-element nimble inverse dynamics (RegressionLossEvaluator.py:265-286) -- needs the
         nimblephysics skeletons of a real AddBiomechanicsDataset; out of the hot path."""

@@ -65,3 +65,44 @@ def test_denoiser_plumbing(dry):
             loss.backward()
             assert all(p.grad is not None and p.grad.shape == p.shape for p in model.parameters()), \
                 [k for k, p in model.named_parameters() if p.grad is None]
+
+
+def test_cli_train_and_analyze_plumbing(dry, tmp_path, capsys):
+    """whole `main.py train` / `analyze` control flow (dataset -> sampler -> fused trainer -> report ->
+    checkpoint -> resume -> analyze CSV) with the kernels in dry-run"""
+    import os
+    from inferbiomechanics_amd.main import main
+    ck = str(tmp_path / "ck")
+    base = ['--no-wandb', '--synthetic-windows', '24', '--batch-size', '8', '--checkpoint-dir', ck,
+            '--data-loading-workers', '0']
+    assert main(['train', '--epochs', '2', '--max-steps', '2'] + base)
+    files = sorted(os.listdir(os.path.join(ck, 'feedforward')))
+    assert files == ['epoch_0_batch_1.pt', 'epoch_1_batch_1.pt']
+    sd = torch.load(os.path.join(ck, 'feedforward', files[-1]))
+    assert set(sd) == {'epoch', 'model_state_dict', 'optimizer_state_dict'} and sd['epoch'] == 1
+    assert list(sd['model_state_dict'])[0] == 'net.0.weight'            # no DDP `module.` prefix
+    assert main(['train', '--epochs', '3', '--max-steps', '1', '--eager', '--opt-type', 'adam'] + base[:-4] +
+                ['--checkpoint-dir', str(tmp_path / "ck2"), '--data-loading-workers', '0'])
+    assert main(['train', '--epochs', '3', '--max-steps', '1'] + base)   # resumes at epoch 2
+    assert 'epoch_2_batch_0.pt' in os.listdir(os.path.join(ck, 'feedforward'))
+    assert main(['analyze', '--no-wandb', '--synthetic-windows', '5', '--checkpoint-dir', ck,
+                 '--data-loading-workers', '0'])
+    rows = open(os.path.join(ck, 'feedforward', 'dev_analysis.csv')).read().strip().splitlines()
+    assert len(rows) == 5 and rows[0].startswith('synthetic_subject_0,window_')
+    assert main(['train', '--model-type', 'diffusion-mlp', '--epochs', '1', '--max-steps', '2', '--feat-dim', '24',
+                 '--hidden-dims', '32', '32', '--stride', '1', '--history-len', '6', '--compute-dtype', 'bf16'] + base)
+    assert main(['visualize', '--synthetic-windows', '4', '--checkpoint-dir', ck, '--num-frames', '2'])
+
+
+def test_checkpoint_loader_accepts_ddp_prefix_and_orders_files(dry, tmp_path):
+    import os
+    from inferbiomechanics_amd.cli.abstract_command import AbstractCommand
+    from inferbiomechanics_amd.models.FeedForwardRegressionBaseline import FeedForwardBaseline
+    m = FeedForwardBaseline(23, 2, 50, 'all_frames', 'sigmoid', 5, 10, hidden_dims=[8])
+    d = str(tmp_path)
+    for e, b, fill in ((0, 999, 1.0), (1, 5, 2.0), (0, 1000, 3.0)):
+        sd = {('module.' + k): torch.full_like(v, fill) for k, v in m.state_dict().items()}
+        torch.save({'epoch': e, 'model_state_dict': sd, 'optimizer_state_dict': None}, os.path.join(d, f'epoch_{e}_batch_{b}.pt'))
+    epoch, batch = AbstractCommand().load_latest_checkpoint(m, checkpoint_dir=d)
+    assert (epoch, batch) == (1, 5) and float(m.state_dict()['net.0.bias'][0]) == 2.0
+    assert AbstractCommand().load_latest_checkpoint(m, checkpoint_dir=os.path.join(d, 'nope')) == (-1, 0)
