@@ -18,28 +18,68 @@ __global__ void gather_rows_kernel(const float* __restrict__ table, const int64_
   }
 }
 
-template <typename T>
-__global__ void q_sample_kernel(const T* __restrict__ x0, const T* __restrict__ eps, const int64_t* __restrict__ t,
-                                const float* __restrict__ sqrt_ab, const float* __restrict__ sqrt_1mab, T* __restrict__ xt,
-                                int64_t B, int64_t per, int64_t table_rows) {
-  const int64_t n = B * per;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t b = i / per;
-    int64_t r = t[b];
-    r = r < 0 ? 0 : (r >= table_rows ? table_rows - 1 : r);
-    xt[i] = ib_from_f32<T>(sqrt_ab[r] * ib_to_f32(x0[i]) + sqrt_1mab[r] * ib_to_f32(eps[i]));
+// 8 elements per thread (16-byte bf16 / 2 x 16-byte fp32 accesses) when `per` is a multiple of 8
+template <typename T, int V>
+__device__ __forceinline__ void ldv(const T* p, float (&v)[V]) {
+  if constexpr (V == 1) { v[0] = ib_to_f32(p[0]); }
+  else if constexpr (sizeof(T) == 2) {
+    bf16x8_t t = *reinterpret_cast<const bf16x8_t*>(p);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (float)t[e];
+  } else {
+    float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  }
+}
+template <typename T, int V>
+__device__ __forceinline__ void stv(T* p, const float (&v)[V]) {
+  if constexpr (V == 1) { p[0] = ib_from_f32<T>(v[0]); }
+  else if constexpr (sizeof(T) == 2) {
+    bf16x8_t o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+    *reinterpret_cast<bf16x8_t*>(p) = o;
+  } else {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
   }
 }
 
-template <typename T>
+template <typename T, int V>
+__global__ void q_sample_kernel(const T* __restrict__ x0, const T* __restrict__ eps, const int64_t* __restrict__ t,
+                                const float* __restrict__ sqrt_ab, const float* __restrict__ sqrt_1mab, T* __restrict__ xt,
+                                int64_t B, int64_t per, int64_t table_rows) {
+  const int64_t n = B * per / V;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = (i * V) / per;
+    int64_t r = t[b];
+    r = r < 0 ? 0 : (r >= table_rows ? table_rows - 1 : r);
+    const float a = sqrt_ab[r], s = sqrt_1mab[r];
+    float x[V], e[V], o[V];
+    ldv<T, V>(x0 + i * V, x);
+    ldv<T, V>(eps + i * V, e);
+#pragma unroll
+    for (int k = 0; k < V; ++k) o[k] = a * x[k] + s * e[k];
+    stv<T, V>(xt + i * V, o);
+  }
+}
+
+template <typename T, int V>
 __global__ void ddim_step_kernel(T* __restrict__ x, const T* __restrict__ eps, const float* __restrict__ coef,
                                  const int64_t* __restrict__ timesteps, int64_t num_steps, int step,
                                  const int32_t* __restrict__ step_dev, int64_t* __restrict__ t_out, int64_t B, int64_t n) {
   int s = step_dev ? *step_dev : step;
   s = s < 0 ? 0 : (s >= num_steps ? (int)num_steps - 1 : s);
   const float cx = coef[2 * s], ce = coef[2 * s + 1];
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-    x[i] = ib_from_f32<T>(cx * ib_to_f32(x[i]) + ce * ib_to_f32(eps[i]));
+  const int64_t nv = n / V;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (int64_t)gridDim.x * blockDim.x) {
+    float a[V], e[V], o[V];
+    ldv<T, V>(x + i * V, a);
+    ldv<T, V>(eps + i * V, e);
+#pragma unroll
+    for (int k = 0; k < V; ++k) o[k] = cx * a[k] + ce * e[k];
+    stv<T, V>(x + i * V, o);
+  }
   if (t_out && blockIdx.x == 0) {
     const int64_t tn = (s + 1 < num_steps) ? timesteps[s + 1] : 0;
     for (int64_t b = threadIdx.x; b < B; b += blockDim.x) t_out[b] = tn;
@@ -71,12 +111,17 @@ extern "C" int ib_gather_rows(const float* table, const int64_t* idx, void* out,
 extern "C" int ib_q_sample(const void* x0, const void* eps, const int64_t* t, const float* sqrt_ab, const float* sqrt_1mab,
                            void* x_t, int64_t B, int64_t per, int64_t table_rows, int dtype, ib_stream_t stream) {
   if (!x0 || !eps || !t || !sqrt_ab || !sqrt_1mab || !x_t || B <= 0 || per <= 0 || table_rows <= 0) return IB_E_ARG;
-  const int grid = ib_grid_1d(B * per, 256);
-  if (dtype == IB_F32)
-    hipLaunchKernelGGL((q_sample_kernel<float>), dim3(grid), dim3(256), 0, ib_s(stream), (const float*)x0, (const float*)eps, t, sqrt_ab, sqrt_1mab, (float*)x_t, B, per, table_rows);
-  else if (dtype == IB_BF16)
-    hipLaunchKernelGGL((q_sample_kernel<bf16_t>), dim3(grid), dim3(256), 0, ib_s(stream), (const bf16_t*)x0, (const bf16_t*)eps, t, sqrt_ab, sqrt_1mab, (bf16_t*)x_t, B, per, table_rows);
-  else return IB_E_DTYPE;
+  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) % 16) == 0; };
+  const bool v8 = (per % 8 == 0) && al16(x0) && al16(eps) && al16(x_t);
+  const int grid = ib_grid_1d(B * per / (v8 ? 8 : 1), 256);
+  hipStream_t s = ib_s(stream);
+  if (dtype == IB_F32) {
+    if (v8) hipLaunchKernelGGL((q_sample_kernel<float, 8>), dim3(grid), dim3(256), 0, s, (const float*)x0, (const float*)eps, t, sqrt_ab, sqrt_1mab, (float*)x_t, B, per, table_rows);
+    else hipLaunchKernelGGL((q_sample_kernel<float, 1>), dim3(grid), dim3(256), 0, s, (const float*)x0, (const float*)eps, t, sqrt_ab, sqrt_1mab, (float*)x_t, B, per, table_rows);
+  } else if (dtype == IB_BF16) {
+    if (v8) hipLaunchKernelGGL((q_sample_kernel<bf16_t, 8>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x0, (const bf16_t*)eps, t, sqrt_ab, sqrt_1mab, (bf16_t*)x_t, B, per, table_rows);
+    else hipLaunchKernelGGL((q_sample_kernel<bf16_t, 1>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x0, (const bf16_t*)eps, t, sqrt_ab, sqrt_1mab, (bf16_t*)x_t, B, per, table_rows);
+  } else return IB_E_DTYPE;
   IB_CHECK_LAUNCH();
   return IB_OK;
 }
@@ -86,12 +131,17 @@ extern "C" int ib_ddim_step(void* x, const void* eps, const float* coef, const i
                             ib_stream_t stream) {
   if (!x || !eps || !coef || num_steps <= 0 || n <= 0) return IB_E_ARG;
   if (t_out && (!timesteps || B <= 0)) return IB_E_ARG;
-  const int grid = ib_grid_1d(n, 256);
-  if (dtype == IB_F32)
-    hipLaunchKernelGGL((ddim_step_kernel<float>), dim3(grid), dim3(256), 0, ib_s(stream), (float*)x, (const float*)eps, coef, timesteps, num_steps, step, step_dev, t_out, B, n);
-  else if (dtype == IB_BF16)
-    hipLaunchKernelGGL((ddim_step_kernel<bf16_t>), dim3(grid), dim3(256), 0, ib_s(stream), (bf16_t*)x, (const bf16_t*)eps, coef, timesteps, num_steps, step, step_dev, t_out, B, n);
-  else return IB_E_DTYPE;
+  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) % 16) == 0; };
+  const bool v8 = (n % 8 == 0) && al16(x) && al16(eps);
+  const int grid = ib_grid_1d(n / (v8 ? 8 : 1), 256);
+  hipStream_t s = ib_s(stream);
+  if (dtype == IB_F32) {
+    if (v8) hipLaunchKernelGGL((ddim_step_kernel<float, 8>), dim3(grid), dim3(256), 0, s, (float*)x, (const float*)eps, coef, timesteps, num_steps, step, step_dev, t_out, B, n);
+    else hipLaunchKernelGGL((ddim_step_kernel<float, 1>), dim3(grid), dim3(256), 0, s, (float*)x, (const float*)eps, coef, timesteps, num_steps, step, step_dev, t_out, B, n);
+  } else if (dtype == IB_BF16) {
+    if (v8) hipLaunchKernelGGL((ddim_step_kernel<bf16_t, 8>), dim3(grid), dim3(256), 0, s, (bf16_t*)x, (const bf16_t*)eps, coef, timesteps, num_steps, step, step_dev, t_out, B, n);
+    else hipLaunchKernelGGL((ddim_step_kernel<bf16_t, 1>), dim3(grid), dim3(256), 0, s, (bf16_t*)x, (const bf16_t*)eps, coef, timesteps, num_steps, step, step_dev, t_out, B, n);
+  } else return IB_E_DTYPE;
   IB_CHECK_LAUNCH();
   return IB_OK;
 }

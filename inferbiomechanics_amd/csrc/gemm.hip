@@ -96,10 +96,10 @@ __device__ __forceinline__ void load_tile(const T* base, int64_t ld, int row0, i
 // Hoisted form for the steady state: per-thread piece pointers are computed once per workgroup and
 // advanced by a constant per K step; no predicates (k-contiguous operands clamp out-of-range rows to the
 // last valid row -- those tile rows only feed outputs that are never stored; k-strided operands use this
-// path on interior tiles only).
+// path with a per-piece row count: full pieces load 16 bytes, edge pieces are zero-filled element-wise).
 template <typename T, bool KC>
 __device__ __forceinline__ void init_ptrs(const T* base, int64_t ld, int row0, int rows_total, int k0,
-                                          const T* (&ptr)[4], int tid) {
+                                          const T* (&ptr)[4], int (&nvr)[4], int tid) {
   constexpr int VW = Tile<T>::VW;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -108,17 +108,28 @@ __device__ __forceinline__ void init_ptrs(const T* base, int64_t ld, int row0, i
       const int row = p >> 3, kc = p & 7;
       const int gr = min(row0 + row, rows_total - 1);
       ptr[q] = base + (int64_t)gr * ld + k0 + kc * VW;
+      nvr[q] = VW;
     } else {
       constexpr int RG = 128 / VW;
       const int kk = p / RG, rg = p % RG;
-      ptr[q] = base + (int64_t)(k0 + kk) * ld + row0 + rg * VW;
+      const int gr = row0 + rg * VW;
+      ptr[q] = base + (int64_t)(k0 + kk) * ld + gr;
+      nvr[q] = max(0, min(VW, rows_total - gr));   // rows of this piece inside the matrix (loop-invariant)
     }
   }
 }
-template <typename T>
-__device__ __forceinline__ void load_tile_fast(const T* const (&ptr)[4], int64_t off, uint4 (&r)[4]) {
+template <typename T, bool KC>
+__device__ __forceinline__ void load_tile_fast(const T* const (&ptr)[4], const int (&nvr)[4], int64_t off,
+                                               uint4 (&r)[4]) {
+  constexpr int VW = Tile<T>::VW;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) __builtin_memcpy(&r[q], __builtin_assume_aligned(ptr[q] + off, 4), 16);
+  for (int q = 0; q < 4; ++q) {
+    if (KC || nvr[q] == VW) {
+      __builtin_memcpy(&r[q], __builtin_assume_aligned(ptr[q] + off, 4), 16);
+    } else {
+      r[q] = load_piece<T>(ptr[q] + off, nvr[q], false);   // edge piece of a k-strided operand: zero-filled
+    }
+  }
 }
 
 // registers -> LDS image
@@ -355,11 +366,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmParams p) {
     for (int u = 0; u < 4; ++u) acc[t][u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   // fast (unpredicated, pointer-bumped) staging where legal, generic predicated staging elsewhere
-  const bool fastA = p.vecA && (A_KC ? true : (i0 + BM <= p.M));
-  const bool fastB = p.vecB && (B_KC ? true : (j0 + BN <= p.N));
+  const bool fastA = p.vecA, fastB = p.vecB;
   const T* pa[4]; const T* pb[4];
-  init_ptrs<T, A_KC>(A, p.lda, i0, p.M, kb, pa, tid);
-  init_ptrs<T, B_KC>(B, p.ldb, j0, p.N, kb, pb, tid);
+  int na[4], nb[4];
+  init_ptrs<T, A_KC>(A, p.lda, i0, p.M, kb, pa, na, tid);
+  init_ptrs<T, B_KC>(B, p.ldb, j0, p.N, kb, pb, nb, tid);
   const int64_t stepA = A_KC ? BK : (int64_t)BK * p.lda;
   const int64_t stepB = B_KC ? BK : (int64_t)BK * p.ldb;
 
@@ -367,9 +378,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmParams p) {
   auto stage = [&](int kt) {
     const int k0 = kb + kt * BK;
     const bool fullk = (k0 + BK <= ke);
-    if (fastA && fullk) load_tile_fast<T>(pa, stepA * kt, ra);
+    if (fastA && fullk) load_tile_fast<T, A_KC>(pa, na, stepA * kt, ra);
     else load_tile<T, A_KC>(A, p.lda, i0, p.M, k0, ke, p.vecA, ra, tid);
-    if (fastB && fullk) load_tile_fast<T>(pb, stepB * kt, rb);
+    if (fastB && fullk) load_tile_fast<T, B_KC>(pb, nb, stepB * kt, rb);
     else load_tile<T, B_KC>(B, p.ldb, j0, p.N, k0, ke, p.vecB, rb, tid);
   };
   if (nk > 0) stage(0);

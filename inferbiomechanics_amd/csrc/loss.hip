@@ -134,16 +134,48 @@ __global__ void regression_loss_final_kernel(const float* __restrict__ partial, 
   }
 }
 
-template <typename T>
+template <typename T, int V>
 __global__ __launch_bounds__(256) void mse_partial_kernel(const T* __restrict__ pred, const T* __restrict__ target,
                                                           T* __restrict__ dpred, float* __restrict__ partial, int64_t n,
                                                           float gscale) {
   __shared__ float red[4];
   float s = 0.f;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const float d = ib_to_f32(pred[i]) - ib_to_f32(target[i]);
-    s += d * d;
-    if (dpred) dpred[i] = ib_from_f32<T>(gscale * d);
+  const int64_t nv = n / V;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (int64_t)gridDim.x * blockDim.x) {
+    float a[V], b[V], d[V];
+    if constexpr (V == 8) {
+      if constexpr (sizeof(T) == 2) {
+        bf16x8_t ta = *reinterpret_cast<const bf16x8_t*>(pred + i * 8), tb = *reinterpret_cast<const bf16x8_t*>(target + i * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { a[e] = (float)ta[e]; b[e] = (float)tb[e]; }
+      } else {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          float4 ta = *reinterpret_cast<const float4*>(pred + i * 8 + 4 * h), tb = *reinterpret_cast<const float4*>(target + i * 8 + 4 * h);
+          a[4 * h] = ta.x; a[4 * h + 1] = ta.y; a[4 * h + 2] = ta.z; a[4 * h + 3] = ta.w;
+          b[4 * h] = tb.x; b[4 * h + 1] = tb.y; b[4 * h + 2] = tb.z; b[4 * h + 3] = tb.w;
+        }
+      }
+    } else {
+      a[0] = ib_to_f32(pred[i]); b[0] = ib_to_f32(target[i]);
+    }
+#pragma unroll
+    for (int e = 0; e < V; ++e) { d[e] = a[e] - b[e]; s += d[e] * d[e]; d[e] *= gscale; }
+    if (dpred) {
+      if constexpr (V == 8) {
+        if constexpr (sizeof(T) == 2) {
+          bf16x8_t o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = (bf16_t)d[e];
+          *reinterpret_cast<bf16x8_t*>(dpred + i * 8) = o;
+        } else {
+          *reinterpret_cast<float4*>(dpred + i * 8) = make_float4(d[0], d[1], d[2], d[3]);
+          *reinterpret_cast<float4*>(dpred + i * 8 + 4) = make_float4(d[4], d[5], d[6], d[7]);
+        }
+      } else {
+        dpred[i] = ib_from_f32<T>(d[0]);
+      }
+    }
   }
   s = ib_wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
@@ -219,13 +251,15 @@ extern "C" int ib_mse_loss(const void* pred, const void* target, void* dpred, fl
   float* partial = reinterpret_cast<float*>(workspace);
   hipStream_t s = ib_s(stream);
   const float gscale = 2.f / (float)n;
-  if (dtype == IB_F32)
-    hipLaunchKernelGGL((mse_partial_kernel<float>), dim3(parts), dim3(256), 0, s, (const float*)pred, (const float*)target,
-                       (float*)dpred, partial, n, gscale);
-  else if (dtype == IB_BF16)
-    hipLaunchKernelGGL((mse_partial_kernel<bf16_t>), dim3(parts), dim3(256), 0, s, (const bf16_t*)pred,
-                       (const bf16_t*)target, (bf16_t*)dpred, partial, n, gscale);
-  else
+  auto al16 = [](const void* q) { return !q || (reinterpret_cast<uintptr_t>(q) % 16) == 0; };
+  const bool v8 = (n % 8 == 0) && al16(pred) && al16(target) && al16(dpred);
+  if (dtype == IB_F32) {
+    if (v8) hipLaunchKernelGGL((mse_partial_kernel<float, 8>), dim3(parts), dim3(256), 0, s, (const float*)pred, (const float*)target, (float*)dpred, partial, n, gscale);
+    else hipLaunchKernelGGL((mse_partial_kernel<float, 1>), dim3(parts), dim3(256), 0, s, (const float*)pred, (const float*)target, (float*)dpred, partial, n, gscale);
+  } else if (dtype == IB_BF16) {
+    if (v8) hipLaunchKernelGGL((mse_partial_kernel<bf16_t, 8>), dim3(parts), dim3(256), 0, s, (const bf16_t*)pred, (const bf16_t*)target, (bf16_t*)dpred, partial, n, gscale);
+    else hipLaunchKernelGGL((mse_partial_kernel<bf16_t, 1>), dim3(parts), dim3(256), 0, s, (const bf16_t*)pred, (const bf16_t*)target, (bf16_t*)dpred, partial, n, gscale);
+  } else
     return IB_E_DTYPE;
   IB_CHECK_LAUNCH();
   hipLaunchKernelGGL(mse_final_kernel, dim3(1), dim3(256), 0, s, partial, parts, result, 1.f / (float)n);

@@ -49,162 +49,229 @@ __device__ __forceinline__ void store4(T* p, int nv, bool vec, const float (&v)[
   }
 }
 
-// ---------------------------------------------------------------- LayerNorm forward
-template <typename T, int CH>
+// ---------------------------------------------------------------- LayerNorm
+// LPR lanes share a row (16 for N <= 512: four rows in flight per wave, 64 for wider rows); a lane owns
+// CH chunks of 8 consecutive elements (16-byte bf16 / 2 x 16-byte fp32 accesses) kept in registers, so x,
+// res, dy are read once and y / dx written once.  Row reductions are xor-shuffles inside the LPR-lane
+// group.  ACT is compile-time (IB_ACT_NONE / IB_ACT_SILU; -1 = runtime switch for the rare others).
+template <int ACT> __device__ __forceinline__ float ln_act(int act, float v) {
+  if constexpr (ACT == IB_ACT_NONE) return v;
+  else if constexpr (ACT == IB_ACT_SILU) return v / (1.f + expf(-v));
+  else return ib_act_fwd(act, v);
+}
+template <int ACT> __device__ __forceinline__ float ln_act_bwd(int act, float z) {
+  if constexpr (ACT == IB_ACT_NONE) return 1.f;
+  else if constexpr (ACT == IB_ACT_SILU) { const float s = 1.f / (1.f + expf(-z)); return s * (1.f + z * (1.f - s)); }
+  else return act_bwd_pre(act, z);
+}
+
+template <typename T>
+__device__ __forceinline__ void load8(const T* p, int nv, bool vec, float (&v)[8]) {
+  if (nv == 8 && vec) {
+    if constexpr (sizeof(T) == 2) {
+      bf16x8_t t = *reinterpret_cast<const bf16x8_t*>(p);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (float)t[e];
+    } else {
+      float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (e < nv) ? ib_to_f32(p[e]) : 0.f;
+  }
+}
+template <typename T>
+__device__ __forceinline__ void store8(T* p, int nv, bool vec, const float (&v)[8]) {
+  if (nv == 8 && vec) {
+    if constexpr (sizeof(T) == 2) {
+      bf16x8_t o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+      *reinterpret_cast<bf16x8_t*>(p) = o;
+    } else {
+      *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+      *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (e < nv) p[e] = ib_from_f32<T>(v[e]);
+  }
+}
+template <int LPR> __device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <typename T, int LPR, int CH, int ACT>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res, int act,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, T* __restrict__ y,
                                                             float* __restrict__ mean, float* __restrict__ rstd,
-                                                            int M, int N, float eps, int vec) {
-  const int lane = threadIdx.x & 63;
-  const int wpb = blockDim.x >> 6;
-  for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < M; row += gridDim.x * wpb) {
-    const T* xr = x + (int64_t)row * N;
-    const T* rr = res ? res + (int64_t)row * N : nullptr;
-    float v[CH][4];
+                                                            int M, int N, float eps, int vec, int vecp) {
+  constexpr int RPW = 64 / LPR;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane / LPR, l = lane % LPR;
+  const float invN = 1.f / (float)N;
+  for (int rb = (blockIdx.x * 4 + wave) * RPW; rb < M; rb += gridDim.x * 4 * RPW) {
+    const int row = rb + sub;
+    const bool live = row < M;
+    const int64_t ro = (int64_t)(live ? row : M - 1) * N;
+    float v[CH][8];
     float s = 0.f;
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
-      const int col = (c * 64 + lane) * 4;
-      const int nv = max(0, min(4, N - col));
-      load4<T>(xr + col, nv, vec, v[c]);
-      if (act != IB_ACT_NONE) {
+      const int col = (c * LPR + l) * 8;
+      const int nv = max(0, min(8, N - col));
+      load8<T>(x + ro + col, nv, vec, v[c]);
+      if constexpr (ACT != IB_ACT_NONE) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[c][e] = (e < nv) ? ib_act_fwd(act, v[c][e]) : 0.f;
+        for (int e = 0; e < 8; ++e) v[c][e] = (e < nv) ? ln_act<ACT>(act, v[c][e]) : 0.f;
       }
-      if (rr) {
-        float r4[4];
-        load4<T>(rr + col, nv, vec, r4);
+      if (res) {
+        float r8[8];
+        load8<T>(res + ro + col, nv, vec, r8);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[c][e] += r4[e];
+        for (int e = 0; e < 8; ++e) v[c][e] += r8[e];
       }
 #pragma unroll
-      for (int e = 0; e < 4; ++e) s += v[c][e];
+      for (int e = 0; e < 8; ++e) s += v[c][e];
     }
-    const float mu = ib_wave_sum(s) / (float)N;
+    const float mu = group_sum<LPR>(s) * invN;
     float q = 0.f;
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
-      const int col = (c * 64 + lane) * 4;
+      const int col = (c * LPR + l) * 8;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
+      for (int e = 0; e < 8; ++e) {
         const float d = (col + e < N) ? v[c][e] - mu : 0.f;
         q += d * d;
       }
     }
-    const float var = ib_wave_sum(q) / (float)N;
-    const float rs = 1.f / sqrtf(var + eps);
-    if (lane == 0) {
+    const float rs = 1.f / sqrtf(group_sum<LPR>(q) * invN + eps);
+    if (live && l == 0) {
       if (mean) mean[row] = mu;
       if (rstd) rstd[row] = rs;
     }
+    if (live) {
 #pragma unroll
-    for (int c = 0; c < CH; ++c) {
-      const int col = (c * 64 + lane) * 4;
-      const int nv = max(0, min(4, N - col));
-      if (nv > 0) {
-        float o[4];
+      for (int c = 0; c < CH; ++c) {
+        const int col = (c * LPR + l) * 8;
+        const int nv = max(0, min(8, N - col));
+        if (nv > 0) {
+          float gm[8], bt[8], o[8];
+          load8<float>(gamma + col, nv, vecp, gm);
+          load8<float>(beta + col, nv, vecp, bt);
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          o[e] = (e < nv) ? (v[c][e] - mu) * rs * gamma[col + e] + beta[col + e] : 0.f;
-        store4<T>(y + (int64_t)row * N + col, nv, vec, o);
+          for (int e = 0; e < 8; ++e) o[e] = (v[c][e] - mu) * rs * gm[e] + bt[e];
+          store8<T>(y + ro + col, nv, vec, o);
+        }
       }
     }
   }
 }
 
-// ---------------------------------------------------------------- LayerNorm backward
 // partial[blockIdx][0..N) = sum over this block's rows of dy*xhat ; partial[gridDim + blockIdx] = sum dy
-template <typename T, int CH>
+template <typename T, int LPR, int CH, int ACT>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                             const T* __restrict__ res, int act,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, T* __restrict__ dx,
                                                             T* __restrict__ dres, float* __restrict__ partial,
-                                                            int M, int N, int vec) {
-  __shared__ float red[4][2][64 * 4 * CH / 4 + 0][4];  // [wave][dgamma|dbeta][chunk*64+lane][4]
+                                                            int M, int N, int vec, int vecp) {
+  constexpr int RPW = 64 / LPR;
+  constexpr int NPAD = CH * LPR * 8;
+  __shared__ float red[4][2][NPAD];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wpb = blockDim.x >> 6;
-  float ag[CH][4], ab[CH][4];
+  const int sub = lane / LPR, l = lane % LPR;
+  const float invN = 1.f / (float)N;
+  float ag[CH][8], ab[CH][8], gm[CH][8];
 #pragma unroll
-  for (int c = 0; c < CH; ++c)
+  for (int c = 0; c < CH; ++c) {
+    const int col = (c * LPR + l) * 8;
+    load8<float>(gamma + col, max(0, min(8, N - col)), vecp, gm[c]);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { ag[c][e] = 0.f; ab[c][e] = 0.f; }
-
-  for (int row = blockIdx.x * wpb + wave; row < M; row += gridDim.x * wpb) {
-    const int64_t ro = (int64_t)row * N;
-    const float mu = mean[row], rs = rstd[row];
-    float xh[CH][4], g[CH][4], zraw[CH][4];
+    for (int e = 0; e < 8; ++e) { ag[c][e] = 0.f; ab[c][e] = 0.f; }
+  }
+  for (int rb = (blockIdx.x * 4 + wave) * RPW; rb < M; rb += gridDim.x * 4 * RPW) {
+    const int row = rb + sub;
+    const bool live = row < M;
+    const int64_t ro = (int64_t)(live ? row : M - 1) * N;
+    const float mu = mean[live ? row : M - 1], rs = rstd[live ? row : M - 1];
+    float xh[CH][8], g[CH][8], zr[CH][8];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
-      const int col = (c * 64 + lane) * 4;
-      const int nv = max(0, min(4, N - col));
-      float xv[4], dyv[4];
-      load4<T>(x + ro + col, nv, vec, xv);
-      load4<T>(dy + ro + col, nv, vec, dyv);
+      const int col = (c * LPR + l) * 8;
+      const int nv = live ? max(0, min(8, N - col)) : 0;
+      float xv[8], dyv[8];
+      load8<T>(x + ro + col, nv, vec, xv);
+      load8<T>(dy + ro + col, nv, vec, dyv);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) zraw[c][e] = xv[e];
-      if (act != IB_ACT_NONE) {
+      for (int e = 0; e < 8; ++e) zr[c][e] = xv[e];
+      if constexpr (ACT != IB_ACT_NONE) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) xv[e] = (e < nv) ? ib_act_fwd(act, xv[e]) : 0.f;
+        for (int e = 0; e < 8; ++e) xv[e] = (e < nv) ? ln_act<ACT>(act, xv[e]) : 0.f;
       }
       if (res) {
-        float r4[4];
-        load4<T>(res + ro + col, nv, vec, r4);
+        float r8[8];
+        load8<T>(res + ro + col, nv, vec, r8);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) xv[e] += r4[e];
+        for (int e = 0; e < 8; ++e) xv[e] += r8[e];
       }
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
+      for (int e = 0; e < 8; ++e) {
         const bool ok = e < nv;
         const float h = ok ? (xv[e] - mu) * rs : 0.f;
-        const float gg = ok ? dyv[e] * gamma[col + e] : 0.f;
+        const float gg = ok ? dyv[e] * gm[c][e] : 0.f;
         xh[c][e] = h; g[c][e] = gg;
         s1 += gg; s2 += gg * h;
         ag[c][e] += ok ? dyv[e] * h : 0.f;
         ab[c][e] += ok ? dyv[e] : 0.f;
       }
     }
-    const float c1 = ib_wave_sum(s1) / (float)N;
-    const float c2 = ib_wave_sum(s2) / (float)N;
+    const float c1 = group_sum<LPR>(s1) * invN;
+    const float c2 = group_sum<LPR>(s2) * invN;
+    if (live) {
 #pragma unroll
-    for (int c = 0; c < CH; ++c) {
-      const int col = (c * 64 + lane) * 4;
-      const int nv = max(0, min(4, N - col));
-      if (nv > 0) {
-        float dv[4], dxo[4];
+      for (int c = 0; c < CH; ++c) {
+        const int col = (c * LPR + l) * 8;
+        const int nv = max(0, min(8, N - col));
+        if (nv > 0) {
+          float dv[8], dxo[8];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          dv[e] = (g[c][e] - c1 - xh[c][e] * c2) * rs;
-          dxo[e] = (act != IB_ACT_NONE) ? dv[e] * act_bwd_pre(act, zraw[c][e]) : dv[e];
+          for (int e = 0; e < 8; ++e) {
+            dv[e] = (g[c][e] - c1 - xh[c][e] * c2) * rs;
+            dxo[e] = dv[e] * ln_act_bwd<ACT>(act, zr[c][e]);
+          }
+          store8<T>(dx + ro + col, nv, vec, dxo);
+          if (dres) store8<T>(dres + ro + col, nv, vec, dv);
         }
-        store4<T>(dx + ro + col, nv, vec, dxo);
-        if (dres) store4<T>(dres + ro + col, nv, vec, dv);
       }
     }
   }
-  // cross-wave reduction of the affine-gradient partials, fixed order
+  // rows of one wave that share columns (same l, different sub): fixed-order shuffle sum, then LDS across waves
 #pragma unroll
   for (int c = 0; c < CH; ++c)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      red[wave][0][c * 64 + lane][e] = ag[c][e];
-      red[wave][1][c * 64 + lane][e] = ab[c][e];
+    for (int e = 0; e < 8; ++e) {
+      float a = ag[c][e], b = ab[c][e];
+#pragma unroll
+      for (int o = LPR; o < 64; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+      if (sub == 0) {
+        red[wave][0][(c * LPR + l) * 8 + e] = a;
+        red[wave][1][(c * LPR + l) * 8 + e] = b;
+      }
     }
   __syncthreads();
-  for (int i = threadIdx.x; i < CH * 64 * 4; i += blockDim.x) {
-    const int col = i;  // (chunk*64+lane)*4+e == linear column index
-    if (col < N) {
-      float sg = 0.f, sb = 0.f;
-      for (int w = 0; w < wpb; ++w) {
-        sg += red[w][0][col >> 2][col & 3];
-        sb += red[w][1][col >> 2][col & 3];
-      }
-      partial[(int64_t)blockIdx.x * N + col] = sg;
-      partial[((int64_t)gridDim.x + blockIdx.x) * N + col] = sb;
-    }
+  for (int col = threadIdx.x; col < N; col += blockDim.x) {
+    const float sg = ((red[0][0][col] + red[1][0][col]) + red[2][0][col]) + red[3][0][col];
+    const float sb = ((red[0][1][col] + red[1][1][col]) + red[2][1][col]) + red[3][1][col];
+    partial[(int64_t)blockIdx.x * N + col] = sg;
+    partial[((int64_t)gridDim.x + blockIdx.x) * N + col] = sb;
   }
 }
 
@@ -307,29 +374,40 @@ __global__ void cast2d_kernel(const S* __restrict__ src, int64_t lds, D* __restr
   }
 }
 
-template <typename T, int CH>
+template <typename T, int LPR, int CH>
 int launch_ln_fwd(const void* x, const void* res, int act, const float* gamma, const float* beta, void* y, float* mean,
-                  float* rstd, int64_t M, int64_t N, float eps, int vec, hipStream_t s) {
-  const int grid = ib_grid_1d(M, 4);
-  hipLaunchKernelGGL((layernorm_fwd_kernel<T, CH>), dim3(grid), dim3(256), 0, s, (const T*)x, (const T*)res, act, gamma,
-                     beta, (T*)y, mean, rstd, (int)M, (int)N, eps, vec);
+                  float* rstd, int64_t M, int64_t N, float eps, int vec, int vecp, hipStream_t s) {
+  constexpr int RPB = 4 * (64 / LPR);
+  const int grid = ib_grid_1d(M, RPB);
+#define IB_LN_FWD(ACT)                                                                                              \
+  hipLaunchKernelGGL((layernorm_fwd_kernel<T, LPR, CH, ACT>), dim3(grid), dim3(256), 0, s, (const T*)x, (const T*)res, \
+                     act, gamma, beta, (T*)y, mean, rstd, (int)M, (int)N, eps, vec, vecp)
+  if (act == IB_ACT_NONE) IB_LN_FWD(IB_ACT_NONE);
+  else if (act == IB_ACT_SILU) IB_LN_FWD(IB_ACT_SILU);
+  else IB_LN_FWD(-1);
+#undef IB_LN_FWD
   IB_CHECK_LAUNCH();
   return IB_OK;
 }
 
 int ln_bwd_parts(int64_t M) {
-  int64_t g = (M + 3) / 4;
+  int64_t g = (M + 15) / 16;
   if (g > 256) g = 256;   // one block per CU; fewer partials to reduce
   if (g < 1) g = 1;
   return (int)g;
 }
 
-template <typename T, int CH>
+template <typename T, int LPR, int CH>
 int launch_ln_bwd(const void* dy, const void* x, const void* res, int act, const float* gamma, const float* mean,
-                  const float* rstd, void* dx, void* dres, float* partial, int64_t M, int64_t N, int vec, int parts,
-                  hipStream_t s) {
-  hipLaunchKernelGGL((layernorm_bwd_kernel<T, CH>), dim3(parts), dim3(256), 0, s, (const T*)dy, (const T*)x,
-                     (const T*)res, act, gamma, mean, rstd, (T*)dx, (T*)dres, partial, (int)M, (int)N, vec);
+                  const float* rstd, void* dx, void* dres, float* partial, int64_t M, int64_t N, int vec, int vecp,
+                  int parts, hipStream_t s) {
+#define IB_LN_BWD(ACT)                                                                                              \
+  hipLaunchKernelGGL((layernorm_bwd_kernel<T, LPR, CH, ACT>), dim3(parts), dim3(256), 0, s, (const T*)dy, (const T*)x, \
+                     (const T*)res, act, gamma, mean, rstd, (T*)dx, (T*)dres, partial, (int)M, (int)N, vec, vecp)
+  if (act == IB_ACT_NONE) IB_LN_BWD(IB_ACT_NONE);
+  else if (act == IB_ACT_SILU) IB_LN_BWD(IB_ACT_SILU);
+  else IB_LN_BWD(-1);
+#undef IB_LN_BWD
   IB_CHECK_LAUNCH();
   return IB_OK;
 }
@@ -338,9 +416,9 @@ inline bool al(const void* p, size_t a) { return !p || (reinterpret_cast<uintptr
 
 }  // namespace
 
-#define LN_DISPATCH(FN, T, ...)                                   \
-  (N <= 256 ? FN<T, 1>(__VA_ARGS__) : N <= 512 ? FN<T, 2>(__VA_ARGS__) \
-   : N <= 1024 ? FN<T, 4>(__VA_ARGS__) : FN<T, 8>(__VA_ARGS__))
+#define LN_DISPATCH(FN, T, ...)                                                              \
+  (N <= 128 ? FN<T, 16, 1>(__VA_ARGS__) : N <= 256 ? FN<T, 16, 2>(__VA_ARGS__)              \
+   : N <= 512 ? FN<T, 16, 4>(__VA_ARGS__) : N <= 1024 ? FN<T, 64, 2>(__VA_ARGS__) : FN<T, 64, 4>(__VA_ARGS__))
 
 extern "C" int ib_layernorm_fwd(const void* x, const void* res, int act, const float* gamma, const float* beta, void* y,
                                 float* mean, float* rstd, int64_t M, int64_t N, float eps, int dtype,
@@ -348,13 +426,14 @@ extern "C" int ib_layernorm_fwd(const void* x, const void* res, int act, const f
   if (!x || !gamma || !beta || !y || M <= 0 || N <= 0) return IB_E_ARG;
   if (N > 2048) return IB_E_UNSUPPORTED;
   hipStream_t s = ib_s(stream);
+  const int vecp = (N % 4 == 0) && al(gamma, 16) && al(beta, 16);
   if (dtype == IB_F32) {
     const int vec = (N % 4 == 0) && al(x, 16) && al(res, 16) && al(y, 16);
-    return LN_DISPATCH(launch_ln_fwd, float, x, res, act, gamma, beta, y, mean, rstd, M, N, eps, vec, s);
+    return LN_DISPATCH(launch_ln_fwd, float, x, res, act, gamma, beta, y, mean, rstd, M, N, eps, vec, vecp, s);
   }
   if (dtype == IB_BF16) {
-    const int vec = (N % 4 == 0) && al(x, 8) && al(res, 8) && al(y, 8);
-    return LN_DISPATCH(launch_ln_fwd, bf16_t, x, res, act, gamma, beta, y, mean, rstd, M, N, eps, vec, s);
+    const int vec = (N % 8 == 0) && al(x, 16) && al(res, 16) && al(y, 16);
+    return LN_DISPATCH(launch_ln_fwd, bf16_t, x, res, act, gamma, beta, y, mean, rstd, M, N, eps, vec, vecp, s);
   }
   return IB_E_DTYPE;
 }
@@ -374,12 +453,15 @@ extern "C" int ib_layernorm_bwd(const void* dy, const void* x, const void* res, 
   hipStream_t s = ib_s(stream);
   float* partial = reinterpret_cast<float*>(workspace);
   int rc;
+  const int vecp = (N % 4 == 0) && al(gamma, 16);
   if (dtype == IB_F32) {
     const int vec = (N % 4 == 0) && al(x, 16) && al(res, 16) && al(dy, 16) && al(dx, 16) && al(dres, 16);
-    rc = LN_DISPATCH(launch_ln_bwd, float, dy, x, res, act, gamma, mean, rstd, dx, dres, partial, M, N, vec, parts, s);
+    rc = LN_DISPATCH(launch_ln_bwd, float, dy, x, res, act, gamma, mean, rstd, dx, dres, partial, M, N, vec, vecp,
+                     parts, s);
   } else if (dtype == IB_BF16) {
-    const int vec = (N % 4 == 0) && al(x, 8) && al(res, 8) && al(dy, 8) && al(dx, 8) && al(dres, 8);
-    rc = LN_DISPATCH(launch_ln_bwd, bf16_t, dy, x, res, act, gamma, mean, rstd, dx, dres, partial, M, N, vec, parts, s);
+    const int vec = (N % 8 == 0) && al(x, 16) && al(res, 16) && al(dy, 16) && al(dx, 16) && al(dres, 16);
+    rc = LN_DISPATCH(launch_ln_bwd, bf16_t, dy, x, res, act, gamma, mean, rstd, dx, dres, partial, M, N, vec, vecp,
+                     parts, s);
   } else {
     return IB_E_DTYPE;
   }

@@ -17,24 +17,32 @@ from inferbiomechanics_amd import hip  # noqa: E402
 
 
 def timeit(fn, reps):
+    """`reps` launches captured into ONE hipGraph (no host launch overhead between kernels), replayed
+    3 times between two HIP events on the launch stream"""
     s = torch.cuda.Stream()
     with torch.cuda.stream(s):
-        for _ in range(5):
+        for _ in range(3):
             fn()
-        e0, e1 = hip.Event(), hip.Event()
-        e0.record()
+        g = hip.Graph()
+        g.begin()
         for _ in range(reps):
             fn()
+        g.end()
+        g.launch()
+        e0, e1 = hip.Event(), hip.Event()
+        e0.record()
+        for _ in range(3):
+            g.launch()
         e1.record()
         ms = e0.elapsed_ms(e1)
     torch.cuda.synchronize()
-    return ms * 1e3 / reps
+    return ms * 1e3 / (3 * reps)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--dtype", default="bf16")
-    ap.add_argument("--reps", type=int, default=50)
+    ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
