@@ -163,6 +163,8 @@ int ib_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms_out); /* synchr
 int ib_event_destroy(void* ev);
 
 /* ---- device self-tests of instruction-layout assumptions (tests only) ----------------------- */
+/* timing-only: bit mask of GEMM phases to skip (results are WRONG when non-zero; tools/kbench.py only) */
+int ib_debug_set_ablate(int mask);
 int ib_selftest_tr16(const void* in_bf16_64x16, void* out_bf16_64x4, ib_stream_t stream);
 
 #ifdef __cplusplus

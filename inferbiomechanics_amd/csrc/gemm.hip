@@ -32,6 +32,10 @@ template <> struct Tile<bf16_t> {
 
 enum { EPI_FWD = 0, EPI_DGRAD = 1, EPI_WGRAD = 2 };
 
+// TIMING-ONLY ablation switch (tools/kbench.py --ablate): bit0 skip steady-state global loads, bit1 skip LDS
+// stores, bit2 skip MFMAs, bit3 skip the epilogue stores.  Results are wrong when non-zero; never set by product code.
+int g_ablate = 0;
+
 struct GemmParams {
   const void* A; const void* B; int64_t lda, ldb;
   int M, N, K;                 // C is [M,N]; K is the reduction length
@@ -50,6 +54,7 @@ struct GemmParams {
   int k_chunk;                 // split over the reduction (wgrad): blockIdx.y * k_chunk
   int64_t slab_stride;         // wgrad: elements between partial slabs (0 when not split)
   int accumulate;
+  int ablate;
 };
 
 template <typename T>
@@ -387,12 +392,15 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmParams p) {
   for (int kt = 0; kt < nk; ++kt) {
     unsigned char* tA = smem + (kt & 1) * 2 * OPER_BYTES;
     unsigned char* tB = tA + OPER_BYTES;
-    store_tile<T, A_KC>(tA, ra, tid);
-    store_tile<T, B_KC>(tB, rb, tid);
+    if (!(p.ablate & 2) || kt == 0) {
+      store_tile<T, A_KC>(tA, ra, tid);
+      store_tile<T, B_KC>(tB, rb, tid);
+    }
     __syncthreads();
-    if (kt + 1 < nk) stage(kt + 1);
-    compute_tile<T, A_KC, B_KC>(tA, tB, acc, lane, wi, wj);
+    if (kt + 1 < nk && !(p.ablate & 1)) stage(kt + 1);
+    if (!(p.ablate & 4)) compute_tile<T, A_KC, B_KC>(tA, tB, acc, lane, wi, wj);
   }
+  if (p.ablate & 8) return;
 
   // ---- epilogue: lane holds C[i][jb..jb+3] for 16 (t,u) sub-tiles.  The activation is a compile-time
   // parameter of the epilogue body (one uniform switch here), so only the selected math is executed.
@@ -448,6 +456,7 @@ int wgrad_split(int64_t M, int64_t N, int64_t K, int bk, int* chunk_out) {
 
 template <typename T>
 int launch_fwd(GemmParams& p, hipStream_t s) {
+  p.ablate = g_ablate;
   p.vecA = vec_load_ok<T>(p.A, p.lda);
   p.vecB = vec_load_ok<T>(p.B, p.ldb);
   p.vecC = vec_store_ok<T>(p.C, p.ldc) && (!p.Z || vec_store_ok<T>(p.Z, p.ldz));
@@ -464,6 +473,7 @@ int launch_fwd(GemmParams& p, hipStream_t s) {
 
 template <typename T>
 int launch_dgrad(GemmParams& p, hipStream_t s) {
+  p.ablate = g_ablate;
   p.vecA = vec_load_ok<T>(p.A, p.lda);
   p.vecB = vec_load_ok<T>(p.B, p.ldb);
   p.vecC = vec_store_ok<T>(p.C, p.ldc);
@@ -478,6 +488,8 @@ int launch_dgrad(GemmParams& p, hipStream_t s) {
 }
 
 }  // namespace
+
+extern "C" int ib_debug_set_ablate(int mask) { g_ablate = mask; return IB_OK; }
 
 extern "C" int ib_linear_fwd(const void* x, int64_t ldx, const void* w, int64_t ldw, const float* bias,
                              const void* add_div, int64_t ld_add_div, const void* add_mod,
@@ -533,6 +545,7 @@ extern "C" int ib_linear_wgrad(const void* dz, int64_t lddz, const void* x, int6
   GemmParams p{};
   p.A = dz; p.lda = lddz; p.B = x; p.ldb = ldx; p.M = (int)N; p.N = (int)K; p.K = (int)M;
   p.seg = 1; p.act = IB_ACT_NONE; p.accumulate = accumulate;
+  p.ablate = g_ablate;
   p.tiles_n = (p.N + BN - 1) / BN;
   p.k_chunk = chunk;
   const int tiles = ((p.M + BM - 1) / BM) * p.tiles_n;

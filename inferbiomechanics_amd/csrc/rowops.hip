@@ -54,15 +54,22 @@ __device__ __forceinline__ void store4(T* p, int nv, bool vec, const float (&v)[
 // CH chunks of 8 consecutive elements (16-byte bf16 / 2 x 16-byte fp32 accesses) kept in registers, so x,
 // res, dy are read once and y / dx written once.  Row reductions are xor-shuffles inside the LPR-lane
 // group.  ACT is compile-time (IB_ACT_NONE / IB_ACT_SILU; -1 = runtime switch for the rare others).
-template <int ACT> __device__ __forceinline__ float ln_act(int act, float v) {
+// sigmoid: accurate libm form for fp32 storage (parity mode), hardware exp + rcp for bf16 storage (their
+// error is orders of magnitude below bf16 resolution; the accurate form made LN-backward VALU-bound)
+template <typename T> __device__ __forceinline__ float ln_sigmoid(float v) {
+  if constexpr (sizeof(T) == 2) return __frcp_rn(1.f + __expf(-v));
+  else return 1.f / (1.f + expf(-v));
+}
+template <typename T, int ACT> __device__ __forceinline__ float ln_act(int act, float v) {
   if constexpr (ACT == IB_ACT_NONE) return v;
-  else if constexpr (ACT == IB_ACT_SILU) return v / (1.f + expf(-v));
+  else if constexpr (ACT == IB_ACT_SILU) return v * ln_sigmoid<T>(v);
   else return ib_act_fwd(act, v);
 }
-template <int ACT> __device__ __forceinline__ float ln_act_bwd(int act, float z) {
-  if constexpr (ACT == IB_ACT_NONE) return 1.f;
-  else if constexpr (ACT == IB_ACT_SILU) { const float s = 1.f / (1.f + expf(-z)); return s * (1.f + z * (1.f - s)); }
-  else return act_bwd_pre(act, z);
+// activation value AND derivative from one sigmoid evaluation
+template <typename T, int ACT> __device__ __forceinline__ void ln_act_both(int act, float z, float& h, float& dh) {
+  if constexpr (ACT == IB_ACT_NONE) { h = z; dh = 1.f; }
+  else if constexpr (ACT == IB_ACT_SILU) { const float s = ln_sigmoid<T>(z); h = z * s; dh = s * (1.f + z * (1.f - s)); }
+  else { h = ib_act_fwd(act, z); dh = act_bwd_pre(act, z); }
 }
 
 template <typename T>
@@ -128,7 +135,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
       load8<T>(x + ro + col, nv, vec, v[c]);
       if constexpr (ACT != IB_ACT_NONE) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[c][e] = (e < nv) ? ln_act<ACT>(act, v[c][e]) : 0.f;
+        for (int e = 0; e < 8; ++e) v[c][e] = (e < nv) ? ln_act<T, ACT>(act, v[c][e]) : 0.f;
       }
       if (res) {
         float r8[8];
@@ -211,10 +218,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
       load8<T>(x + ro + col, nv, vec, xv);
       load8<T>(dy + ro + col, nv, vec, dyv);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) zr[c][e] = xv[e];
-      if constexpr (ACT != IB_ACT_NONE) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) xv[e] = (e < nv) ? ln_act<ACT>(act, xv[e]) : 0.f;
+      for (int e = 0; e < 8; ++e) {
+        float h, dh;
+        ln_act_both<T, ACT>(act, xv[e], h, dh);
+        xv[e] = (e < nv) ? h : 0.f;
+        zr[c][e] = dh;                 // activation derivative, reused for dx below
       }
       if (res) {
         float r8[8];
@@ -245,7 +253,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             dv[e] = (g[c][e] - c1 - xh[c][e] * c2) * rs;
-            dxo[e] = dv[e] * ln_act_bwd<ACT>(act, zr[c][e]);
+            dxo[e] = dv[e] * zr[c][e];
           }
           store8<T>(dx + ro + col, nv, vec, dxo);
           if (dres) store8<T>(dres + ro + col, nv, vec, dv);

@@ -71,6 +71,7 @@ _SIGS = {
     "ib_event_elapsed_ms": (_c.c_int, [_vp, _vp, _c.POINTER(_f32)]),
     "ib_event_destroy": (_c.c_int, [_vp]),
     "ib_selftest_tr16": (_c.c_int, [_vp, _vp, _vp]),
+    "ib_debug_set_ablate": (_c.c_int, [_c.c_int]),
 }
 
 
