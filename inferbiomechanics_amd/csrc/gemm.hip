@@ -15,6 +15,8 @@
 // transposing read), everything else with ds_read_b128 / ds_read_b32.
 // The MFMA is issued "swapped" (a = B-tile rows, b = A-tile rows) so that each lane ends up with
 // 4 CONSECUTIVE output columns of one output row -> 8/16-byte epilogue stores and bias loads.
+#include <type_traits>
+
 #include "ib_common.h"
 
 namespace {
@@ -282,38 +284,96 @@ __device__ __forceinline__ void load4f(const T* p, int nv, bool vec, float (&v)[
   }
 }
 
+// raw 4-element operand piece (8 B bf16 / 16 B fp32) kept in registers until all loads are in flight
+template <typename T> struct Raw4 { typename std::conditional<sizeof(T) == 2, uint2, uint4>::type v; };
+template <typename T>
+__device__ __forceinline__ Raw4<T> ldraw4(const T* __restrict__ p, int nv, bool vec) {
+  Raw4<T> r;
+  if (nv == 4 && vec) {
+    r.v = *reinterpret_cast<const decltype(r.v)*>(p);
+  } else {
+    T tmp[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) tmp[e] = (e < nv) ? p[e] : static_cast<T>(0.f);
+    __builtin_memcpy(&r.v, tmp, sizeof(r.v));
+  }
+  return r;
+}
+template <typename T>
+__device__ __forceinline__ void unraw4(const Raw4<T>& r, float (&v)[4]) {
+  T tmp[4];
+  __builtin_memcpy(tmp, &r.v, sizeof(r.v));
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = ib_to_f32(tmp[e]);
+}
+
+// Epilogue: a lane holds C[i][jb..jb+3] for 16 (t,u) sub-tiles.  Phase 1 issues EVERY operand load (bias,
+// row-broadcast adds, activation-derivative operand, residual) so they are all in flight together; phase 2
+// does the math and the stores.  (A per-sub-tile load->math->store chain serialises 16 L2 round trips.)
 template <typename T, int EPI, int ACT>
 __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4_t (&acc)[4][4], int i0, int j0, int wi, int wj,
                                          int lane) {
+  const int jb0 = j0 + wj * 64 + 4 * (lane >> 4);
+  const int ib0 = i0 + wi * 64 + (lane & 15);
+  [[maybe_unused]] Raw4<float> rb[4];
+  [[maybe_unused]] Raw4<T> r1[4][4], r2[4][4];
+  [[maybe_unused]] bool h1 = false, h2 = false;
+  if constexpr (EPI == EPI_FWD) {
+    h1 = p.add_div != nullptr; h2 = p.add_mod != nullptr;
+    if (p.bias) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int jb = jb0 + 16 * u;
+        rb[u] = ldraw4<float>(p.bias + jb, max(0, min(4, p.N - jb)), p.vecBias);
+      }
+    }
+  } else if constexpr (EPI == EPI_DGRAD) {
+    h1 = (ACT != IB_ACT_NONE); h2 = p.addend != nullptr;
+  }
+  if constexpr (EPI != EPI_WGRAD) {
+    if (h1 || h2) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int i = min(ib0 + 16 * t, p.M - 1);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int jb = jb0 + 16 * u;
+          const int nv = max(0, min(4, p.N - jb));
+          if constexpr (EPI == EPI_FWD) {
+            if (h1) r1[t][u] = ldraw4<T>(reinterpret_cast<const T*>(p.add_div) + (int64_t)(i / p.seg) * p.ld_add_div + jb, nv, p.vecAdd);
+            if (h2) r2[t][u] = ldraw4<T>(reinterpret_cast<const T*>(p.add_mod) + (int64_t)(i % p.seg) * p.ld_add_mod + jb, nv, p.vecAdd);
+          } else {
+            if (h1) r1[t][u] = ldraw4<T>(reinterpret_cast<const T*>(p.aux) + (int64_t)i * p.ldaux + jb, nv, p.vecAux);
+            if (h2) r2[t][u] = ldraw4<T>(reinterpret_cast<const T*>(p.addend) + (int64_t)i * p.ldadd + jb, nv, p.vecAdd);
+          }
+        }
+      }
+    }
+  }
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
-    const int i = i0 + wi * 64 + 16 * t + (lane & 15);
+    const int i = ib0 + 16 * t;
     if (i >= p.M) continue;
-    [[maybe_unused]] int64_t rd = 0, rm = 0;
-    if constexpr (EPI == EPI_FWD) {
-      if (p.add_div) rd = (int64_t)(i / p.seg) * p.ld_add_div;
-      if (p.add_mod) rm = (int64_t)(i % p.seg) * p.ld_add_mod;
-    }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int jb = j0 + wj * 64 + 16 * u + 4 * (lane >> 4);
+      const int jb = jb0 + 16 * u;
       if (jb >= p.N) continue;
       const int nv = min(4, p.N - jb);
       float v[4] = {acc[t][u][0], acc[t][u][1], acc[t][u][2], acc[t][u][3]};
+      float w4[4];
       if constexpr (EPI == EPI_FWD) {
-        float w4[4];
         if (p.bias) {
-          load4f<float>(p.bias + jb, nv, p.vecBias, w4);
+          unraw4<float>(rb[u], w4);
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] += w4[r];
         }
-        if (p.add_div) {
-          load4f<T>(reinterpret_cast<const T*>(p.add_div) + rd + jb, nv, p.vecAdd, w4);
+        if (h1) {
+          unraw4<T>(r1[t][u], w4);
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] += w4[r];
         }
-        if (p.add_mod) {
-          load4f<T>(reinterpret_cast<const T*>(p.add_mod) + rm + jb, nv, p.vecAdd, w4);
+        if (h2) {
+          unraw4<T>(r2[t][u], w4);
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] += w4[r];
         }
@@ -324,14 +384,13 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4_t (&acc)[4][
         }
         store4<T>(reinterpret_cast<T*>(p.C) + (int64_t)i * p.ldc + jb, v, nv, p.vecC);
       } else if constexpr (EPI == EPI_DGRAD) {
-        float w4[4];
         if constexpr (ACT != IB_ACT_NONE) {
-          load4f<T>(reinterpret_cast<const T*>(p.aux) + (int64_t)i * p.ldaux + jb, nv, p.vecAux, w4);
+          unraw4<T>(r1[t][u], w4);
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] *= act_bwd_t<T, ACT>(w4[r]);
         }
-        if (p.addend) {
-          load4f<T>(reinterpret_cast<const T*>(p.addend) + (int64_t)i * p.ldadd + jb, nv, p.vecAdd, w4);
+        if (h2) {
+          unraw4<T>(r2[t][u], w4);
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] += w4[r];
         }
@@ -350,7 +409,7 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4_t (&acc)[4][
 }
 
 template <typename T, bool A_KC, bool B_KC, int EPI>
-__global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmParams p) {
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmParams p) {
   constexpr int BK = Tile<T>::BK;
   __shared__ __attribute__((aligned(16))) unsigned char smem[4 * OPER_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -379,8 +438,12 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmParams p) {
   const int64_t stepA = A_KC ? BK : (int64_t)BK * p.lda;
   const int64_t stepB = B_KC ? BK : (int64_t)BK * p.ldb;
 
-  uint4 ra[4], rb[4];
-  auto stage = [&](int kt) {
+  // Depth-2 register prefetch: tile kt+2 is requested from HBM/L2 while tile kt is being multiplied and tile
+  // kt+1 is already in flight, so a K step never waits for a load issued in the same step (the loads of the
+  // previous structure had only one MFMA phase, ~0.3 us, to cover ~0.5+ us of memory latency).  Two named
+  // register sets (static indexing; a runtime-indexed set would go to scratch).
+  uint4 ra0[4], rb0[4], ra1[4], rb1[4];
+  auto stage = [&](int kt, uint4 (&ra)[4], uint4 (&rb)[4]) {
     const int k0 = kb + kt * BK;
     const bool fullk = (k0 + BK <= ke);
     if (fastA && fullk) load_tile_fast<T, A_KC>(pa, na, stepA * kt, ra);
@@ -388,19 +451,34 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmParams p) {
     if (fastB && fullk) load_tile_fast<T, B_KC>(pb, nb, stepB * kt, rb);
     else load_tile<T, B_KC>(B, p.ldb, j0, p.N, k0, ke, p.vecB, rb, tid);
   };
-  if (nk > 0) stage(0);
-  for (int kt = 0; kt < nk; ++kt) {
+  auto kstep = [&](int kt, uint4 (&ra)[4], uint4 (&rb)[4]) {
     unsigned char* tA = smem + (kt & 1) * 2 * OPER_BYTES;
     unsigned char* tB = tA + OPER_BYTES;
+#ifdef IB_ABLATE
     if (!(p.ablate & 2) || kt == 0) {
       store_tile<T, A_KC>(tA, ra, tid);
       store_tile<T, B_KC>(tB, rb, tid);
     }
     __syncthreads();
-    if (kt + 1 < nk && !(p.ablate & 1)) stage(kt + 1);
+    if (kt + 2 < nk && !(p.ablate & 1)) stage(kt + 2, ra, rb);
     if (!(p.ablate & 4)) compute_tile<T, A_KC, B_KC>(tA, tB, acc, lane, wi, wj);
+#else
+    store_tile<T, A_KC>(tA, ra, tid);
+    store_tile<T, B_KC>(tB, rb, tid);
+    __syncthreads();
+    if (kt + 2 < nk) stage(kt + 2, ra, rb);
+    compute_tile<T, A_KC, B_KC>(tA, tB, acc, lane, wi, wj);
+#endif
+  };
+  if (nk > 0) stage(0, ra0, rb0);
+  if (nk > 1) stage(1, ra1, rb1);
+  for (int kt = 0; kt < nk; kt += 2) {
+    kstep(kt, ra0, rb0);
+    if (kt + 1 < nk) kstep(kt + 1, ra1, rb1);
   }
+#ifdef IB_ABLATE
   if (p.ablate & 8) return;
+#endif
 
   // ---- epilogue: lane holds C[i][jb..jb+3] for 16 (t,u) sub-tiles.  The activation is a compile-time
   // parameter of the epilogue body (one uniform switch here), so only the selected math is executed.
