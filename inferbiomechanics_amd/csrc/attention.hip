@@ -211,10 +211,20 @@ size_t bwd_lds(int T, int dh) {
 
 }  // namespace
 
+// bf16 MFMA kernels (attention_mfma.hip); IB_E_UNSUPPORTED -> use the generic fp32-VALU kernels below
+int ib_attention_fwd_mfma_bf16(const void* qkv, void* out, float* lse, int64_t B, int64_t T, int64_t H, int64_t dh,
+                               hipStream_t s);
+int ib_attention_bwd_mfma_bf16(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
+                               int64_t B, int64_t T, int64_t H, int64_t dh, hipStream_t s);
+
 extern "C" int ib_attention_fwd(const void* qkv, void* out, float* lse, int64_t B, int64_t T, int64_t H, int64_t dh,
                                 int dtype, ib_stream_t stream) {
   if (!qkv || !out || B <= 0 || T <= 0 || H <= 0 || dh <= 0) return IB_E_ARG;
   if (T > MAX_T || dh > MAX_DH) return IB_E_UNSUPPORTED;
+  if (dtype == IB_BF16 && lse) {
+    const int rc = ib_attention_fwd_mfma_bf16(qkv, out, lse, B, T, H, dh, ib_s(stream));
+    if (rc != IB_E_UNSUPPORTED) return rc;
+  }
   const size_t lds = fwd_lds((int)T, (int)dh);
   if (lds > 160 * 1024) return IB_E_UNSUPPORTED;
   const float scale = 1.f / sqrtf((float)dh);
@@ -239,6 +249,10 @@ extern "C" int ib_attention_bwd(const void* qkv, const void* out, const void* do
                                 int64_t B, int64_t T, int64_t H, int64_t dh, int dtype, ib_stream_t stream) {
   if (!qkv || !out || !dout || !lse || !dqkv || B <= 0 || T <= 0 || H <= 0 || dh <= 0) return IB_E_ARG;
   if (T > MAX_T || dh > MAX_DH) return IB_E_UNSUPPORTED;
+  if (dtype == IB_BF16) {
+    const int rc = ib_attention_bwd_mfma_bf16(qkv, out, dout, lse, dqkv, B, T, H, dh, ib_s(stream));
+    if (rc != IB_E_UNSUPPORTED) return rc;
+  }
   const size_t lds = bwd_lds((int)T, (int)dh);
   if (lds > 160 * 1024) return IB_E_UNSUPPORTED;
   const float scale = 1.f / sqrtf((float)dh);

@@ -438,12 +438,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmParams p) {
   const int64_t stepA = A_KC ? BK : (int64_t)BK * p.lda;
   const int64_t stepB = B_KC ? BK : (int64_t)BK * p.ldb;
 
-  // Depth-2 register prefetch: tile kt+2 is requested from HBM/L2 while tile kt is being multiplied and tile
-  // kt+1 is already in flight, so a K step never waits for a load issued in the same step (the loads of the
-  // previous structure had only one MFMA phase, ~0.3 us, to cover ~0.5+ us of memory latency).  Two named
-  // register sets (static indexing; a runtime-indexed set would go to scratch).
-  uint4 ra0[4], rb0[4], ra1[4], rb1[4];
-  auto stage = [&](int kt, uint4 (&ra)[4], uint4 (&rb)[4]) {
+  // Register-staged double buffer: tile kt+1 is requested right after the barrier and lands while tile kt is
+  // multiplied.  (A depth-2 prefetch with two register sets was measured SLOWER for the k-strided operands:
+  // wgrad +25 %, dgrad +10 % -- see DESIGN.md.)
+  uint4 ra[4], rb[4];
+  auto stage = [&](int kt) {
     const int k0 = kb + kt * BK;
     const bool fullk = (k0 + BK <= ke);
     if (fastA && fullk) load_tile_fast<T, A_KC>(pa, na, stepA * kt, ra);
@@ -451,7 +450,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmParams p) {
     if (fastB && fullk) load_tile_fast<T, B_KC>(pb, nb, stepB * kt, rb);
     else load_tile<T, B_KC>(B, p.ldb, j0, p.N, k0, ke, p.vecB, rb, tid);
   };
-  auto kstep = [&](int kt, uint4 (&ra)[4], uint4 (&rb)[4]) {
+  if (nk > 0) stage(0);
+  for (int kt = 0; kt < nk; ++kt) {
     unsigned char* tA = smem + (kt & 1) * 2 * OPER_BYTES;
     unsigned char* tB = tA + OPER_BYTES;
 #ifdef IB_ABLATE
@@ -460,21 +460,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmParams p) {
       store_tile<T, B_KC>(tB, rb, tid);
     }
     __syncthreads();
-    if (kt + 2 < nk && !(p.ablate & 1)) stage(kt + 2, ra, rb);
+    if (kt + 1 < nk && !(p.ablate & 1)) stage(kt + 1);
     if (!(p.ablate & 4)) compute_tile<T, A_KC, B_KC>(tA, tB, acc, lane, wi, wj);
 #else
     store_tile<T, A_KC>(tA, ra, tid);
     store_tile<T, B_KC>(tB, rb, tid);
     __syncthreads();
-    if (kt + 2 < nk) stage(kt + 2, ra, rb);
+    if (kt + 1 < nk) stage(kt + 1);
     compute_tile<T, A_KC, B_KC>(tA, tB, acc, lane, wi, wj);
 #endif
-  };
-  if (nk > 0) stage(0, ra0, rb0);
-  if (nk > 1) stage(1, ra1, rb1);
-  for (int kt = 0; kt < nk; kt += 2) {
-    kstep(kt, ra0, rb0);
-    if (kt + 1 < nk) kstep(kt + 1, ra1, rb1);
   }
 #ifdef IB_ABLATE
   if (p.ablate & 8) return;

@@ -195,14 +195,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane / LPR, l = lane % LPR;
   const float invN = 1.f / (float)N;
-  float ag[CH][8], ab[CH][8], gm[CH][8];
+  float ag[CH][8], ab[CH][8];
 #pragma unroll
-  for (int c = 0; c < CH; ++c) {
-    const int col = (c * LPR + l) * 8;
-    load8<float>(gamma + col, max(0, min(8, N - col)), vecp, gm[c]);
+  for (int c = 0; c < CH; ++c)
 #pragma unroll
     for (int e = 0; e < 8; ++e) { ag[c][e] = 0.f; ab[c][e] = 0.f; }
-  }
   for (int rb = (blockIdx.x * 4 + wave) * RPW; rb < M; rb += gridDim.x * 4 * RPW) {
     const int row = rb + sub;
     const bool live = row < M;
@@ -214,9 +211,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
     for (int c = 0; c < CH; ++c) {
       const int col = (c * LPR + l) * 8;
       const int nv = live ? max(0, min(8, N - col)) : 0;
-      float xv[8], dyv[8];
+      float xv[8], dyv[8], gm[8];
       load8<T>(x + ro + col, nv, vec, xv);
       load8<T>(dy + ro + col, nv, vec, dyv);
+      load8<float>(gamma + col, max(0, min(8, N - col)), vecp, gm);   // L1/L2 resident; not worth 8 registers per chunk
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         float h, dh;
@@ -234,7 +232,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
       for (int e = 0; e < 8; ++e) {
         const bool ok = e < nv;
         const float h = ok ? (xv[e] - mu) * rs : 0.f;
-        const float gg = ok ? dyv[e] * gm[c][e] : 0.f;
+        const float gg = ok ? dyv[e] * gm[e] : 0.f;
         xh[c][e] = h; g[c][e] = gg;
         s1 += gg; s2 += gg * h;
         ag[c][e] += ok ? dyv[e] * h : 0.f;
@@ -399,8 +397,8 @@ int launch_ln_fwd(const void* x, const void* res, int act, const float* gamma, c
 }
 
 int ln_bwd_parts(int64_t M) {
-  int64_t g = (M + 15) / 16;
-  if (g > 256) g = 256;   // one block per CU; fewer partials to reduce
+  int64_t g = (M + 7) / 8;
+  if (g > 768) g = 768;   // 3 blocks (12 waves) per CU: enough waves in flight to cover HBM latency
   if (g < 1) g = 1;
   return (int)g;
 }
@@ -424,6 +422,11 @@ inline bool al(const void* p, size_t a) { return !p || (reinterpret_cast<uintptr
 
 }  // namespace
 
+// backward keeps 5 per-lane arrays of CH*8 floats: use more lanes per row (fewer elements per lane) so the kernel
+// stays near 128 VGPRs (>= 3 waves per SIMD); at 256 VGPRs it ran at 1 wave per SIMD and 4x off the HBM roofline
+#define LN_DISPATCH_BWD(FN, T, ...)                                                          \
+  (N <= 128 ? FN<T, 16, 1>(__VA_ARGS__) : N <= 256 ? FN<T, 16, 2>(__VA_ARGS__)              \
+   : N <= 512 ? FN<T, 32, 2>(__VA_ARGS__) : N <= 1024 ? FN<T, 64, 2>(__VA_ARGS__) : FN<T, 64, 4>(__VA_ARGS__))
 #define LN_DISPATCH(FN, T, ...)                                                              \
   (N <= 128 ? FN<T, 16, 1>(__VA_ARGS__) : N <= 256 ? FN<T, 16, 2>(__VA_ARGS__)              \
    : N <= 512 ? FN<T, 16, 4>(__VA_ARGS__) : N <= 1024 ? FN<T, 64, 2>(__VA_ARGS__) : FN<T, 64, 4>(__VA_ARGS__))
@@ -464,11 +467,11 @@ extern "C" int ib_layernorm_bwd(const void* dy, const void* x, const void* res, 
   const int vecp = (N % 4 == 0) && al(gamma, 16);
   if (dtype == IB_F32) {
     const int vec = (N % 4 == 0) && al(x, 16) && al(res, 16) && al(dy, 16) && al(dx, 16) && al(dres, 16);
-    rc = LN_DISPATCH(launch_ln_bwd, float, dy, x, res, act, gamma, mean, rstd, dx, dres, partial, M, N, vec, vecp,
+    rc = LN_DISPATCH_BWD(launch_ln_bwd, float, dy, x, res, act, gamma, mean, rstd, dx, dres, partial, M, N, vec, vecp,
                      parts, s);
   } else if (dtype == IB_BF16) {
     const int vec = (N % 8 == 0) && al(x, 16) && al(res, 16) && al(dy, 16) && al(dx, 16) && al(dres, 16);
-    rc = LN_DISPATCH(launch_ln_bwd, bf16_t, dy, x, res, act, gamma, mean, rstd, dx, dres, partial, M, N, vec, vecp,
+    rc = LN_DISPATCH_BWD(launch_ln_bwd, bf16_t, dy, x, res, act, gamma, mean, rstd, dx, dres, partial, M, N, vec, vecp,
                      parts, s);
   } else {
     return IB_E_DTYPE;
