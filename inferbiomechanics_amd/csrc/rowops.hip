@@ -181,8 +181,10 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
 }
 
 // partial[blockIdx][0..N) = sum over this block's rows of dy*xhat ; partial[gridDim + blockIdx] = sum dy
+constexpr int LN_BWD_WPB = 8;   // waves per block in the backward: 256 blocks x 8 waves cover the chip with <= 256 partial rows
+
 template <typename T, int LPR, int CH, int ACT>
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+__global__ __launch_bounds__(LN_BWD_WPB * 64) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                             const T* __restrict__ res, int act,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ mean,
@@ -191,7 +193,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
                                                             int M, int N, int vec, int vecp) {
   constexpr int RPW = 64 / LPR;
   constexpr int NPAD = CH * LPR * 8;
-  __shared__ float red[4][2][NPAD];
+  constexpr int WPB = LN_BWD_WPB;
+  __shared__ float red[WPB][2][NPAD];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane / LPR, l = lane % LPR;
   const float invN = 1.f / (float)N;
@@ -200,7 +203,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
   for (int c = 0; c < CH; ++c)
 #pragma unroll
     for (int e = 0; e < 8; ++e) { ag[c][e] = 0.f; ab[c][e] = 0.f; }
-  for (int rb = (blockIdx.x * 4 + wave) * RPW; rb < M; rb += gridDim.x * 4 * RPW) {
+  for (int rb = (blockIdx.x * WPB + wave) * RPW; rb < M; rb += gridDim.x * WPB * RPW) {
     const int row = rb + sub;
     const bool live = row < M;
     const int64_t ro = (int64_t)(live ? row : M - 1) * N;
@@ -274,8 +277,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
     }
   __syncthreads();
   for (int col = threadIdx.x; col < N; col += blockDim.x) {
-    const float sg = ((red[0][0][col] + red[1][0][col]) + red[2][0][col]) + red[3][0][col];
-    const float sb = ((red[0][1][col] + red[1][1][col]) + red[2][1][col]) + red[3][1][col];
+    float sg = 0.f, sb = 0.f;
+#pragma unroll
+    for (int w = 0; w < WPB; ++w) { sg += red[w][0][col]; sb += red[w][1][col]; }
     partial[(int64_t)blockIdx.x * N + col] = sg;
     partial[((int64_t)gridDim.x + blockIdx.x) * N + col] = sb;
   }
@@ -288,7 +292,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
 template <typename T, int RL>
 __global__ __launch_bounds__(256) void segment_colsum_kernel(const T* __restrict__ x, int64_t ldx, float* __restrict__ out,
                                                              int64_t ldo, int M, int N, int seg, int mode, int accumulate,
-                                                             int vec) {
+                                                             int vec, float* __restrict__ out1) {
   constexpr int CG = 256 / RL;
   __shared__ float red[RL][CG][4];
   const int cg = threadIdx.x % CG, rl = threadIdx.x / CG;
@@ -327,7 +331,7 @@ __global__ __launch_bounds__(256) void segment_colsum_kernel(const T* __restrict
         float t = 0.f;
 #pragma unroll
         for (int w = 0; w < RL; ++w) t += red[w][cg][e];
-        float* o = out + (int64_t)s * ldo + col + e;
+        float* o = (out1 && s == 1) ? out1 + col + e : out + (int64_t)s * ldo + col + e;   // out1: segment 1 elsewhere
         *o = accumulate ? *o + t : t;
       }
     }
@@ -336,15 +340,15 @@ __global__ __launch_bounds__(256) void segment_colsum_kernel(const T* __restrict
 
 template <typename T>
 void launch_segment_colsum(const T* x, int64_t ldx, float* out, int64_t ldo, int M, int N, int seg, int mode,
-                           int accumulate, int vec, int nseg, int rows_per_seg, hipStream_t s) {
+                           int accumulate, int vec, int nseg, int rows_per_seg, hipStream_t s, float* out1 = nullptr) {
   if (rows_per_seg > 32) {
     dim3 grid((unsigned)((N + 63) / 64), (unsigned)nseg);
     hipLaunchKernelGGL((segment_colsum_kernel<T, 16>), grid, dim3(256), 0, s, x, ldx, out, ldo, M, N, seg, mode,
-                       accumulate, vec);
+                       accumulate, vec, out1);
   } else {
     dim3 grid((unsigned)((N + 255) / 256), (unsigned)nseg);
     hipLaunchKernelGGL((segment_colsum_kernel<T, 4>), grid, dim3(256), 0, s, x, ldx, out, ldo, M, N, seg, mode,
-                       accumulate, vec);
+                       accumulate, vec, out1);
   }
 }
 
@@ -397,8 +401,8 @@ int launch_ln_fwd(const void* x, const void* res, int act, const float* gamma, c
 }
 
 int ln_bwd_parts(int64_t M) {
-  int64_t g = (M + 7) / 8;
-  if (g > 768) g = 768;   // 3 blocks (12 waves) per CU: enough waves in flight to cover HBM latency
+  int64_t g = (M + 15) / 16;
+  if (g > 256) g = 256;   // one 8-wave block per CU; the fixed-order reduction over the partial rows stays short
   if (g < 1) g = 1;
   return (int)g;
 }
@@ -408,7 +412,7 @@ int launch_ln_bwd(const void* dy, const void* x, const void* res, int act, const
                   const float* rstd, void* dx, void* dres, float* partial, int64_t M, int64_t N, int vec, int vecp,
                   int parts, hipStream_t s) {
 #define IB_LN_BWD(ACT)                                                                                              \
-  hipLaunchKernelGGL((layernorm_bwd_kernel<T, LPR, CH, ACT>), dim3(parts), dim3(256), 0, s, (const T*)dy, (const T*)x, \
+  hipLaunchKernelGGL((layernorm_bwd_kernel<T, LPR, CH, ACT>), dim3(parts), dim3(LN_BWD_WPB * 64), 0, s, (const T*)dy, (const T*)x, \
                      (const T*)res, act, gamma, mean, rstd, (T*)dx, (T*)dres, partial, (int)M, (int)N, vec, vecp)
   if (act == IB_ACT_NONE) IB_LN_BWD(IB_ACT_NONE);
   else if (act == IB_ACT_SILU) IB_LN_BWD(IB_ACT_SILU);
@@ -477,12 +481,10 @@ extern "C" int ib_layernorm_bwd(const void* dy, const void* x, const void* res, 
     return IB_E_DTYPE;
   }
   if (rc != IB_OK) return rc;
-  // fixed-order sums of the per-block partials: [parts, N] -> [N], twice
+  // fixed-order sums of the per-block partials in ONE launch: [2*parts, N] as two segments of `parts` rows,
+  // segment 0 -> dgamma, segment 1 -> dbeta
   const int pvec = (N % 4 == 0);
-  launch_segment_colsum<float>(partial, N, dgamma, N, parts, (int)N, parts, 0, accumulate, pvec, 1, parts, s);
-  IB_CHECK_LAUNCH();
-  launch_segment_colsum<float>(partial + (int64_t)parts * N, N, dbeta, N, parts, (int)N, parts, 0, accumulate, pvec, 1,
-                               parts, s);
+  launch_segment_colsum<float>(partial, N, dgamma, N, 2 * parts, (int)N, parts, 0, accumulate, pvec, 2, parts, s, dbeta);
   IB_CHECK_LAUNCH();
   return IB_OK;
 }

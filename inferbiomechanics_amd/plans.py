@@ -64,6 +64,36 @@ class ParamSource:
         self.ready = ready if ready is not None else (lambda name: None)
 
 
+class Branch:
+    """A side stream forked from / joined into the current stream with events.  Launches issued inside `run`
+    execute concurrently with what the main stream does next; under hipGraph capture the same event edges
+    become a parallel branch of the graph.  Disabled (runs inline) off-GPU and when `enabled` is False."""
+
+    def __init__(self, device, enabled: bool = True):
+        self.on = enabled and torch.device(device).type == "cuda" and not hip._dry_run
+        if self.on:
+            self.stream = torch.cuda.Stream(device=device)
+            self.ev_fork, self.ev_join = torch.cuda.Event(), torch.cuda.Event()
+        self._pending = False
+
+    def run(self, fn):
+        if not self.on:
+            fn()
+            return
+        main = torch.cuda.current_stream()
+        self.ev_fork.record(main)
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_event(self.ev_fork)
+            fn()
+            self.ev_join.record(self.stream)
+        self._pending = True
+
+    def join(self):
+        if self.on and self._pending:
+            torch.cuda.current_stream().wait_event(self.ev_join)
+            self._pending = False
+
+
 def _colsum(buf: Buffers, tag: str, x2d: torch.Tensor, out_vec: torch.Tensor, accumulate: bool):
     """out_vec[N] (+)= sum over all rows of x2d[M,N] -- one launch for short M, two for long M."""
     M, N = x2d.shape
@@ -76,10 +106,11 @@ def _colsum(buf: Buffers, tag: str, x2d: torch.Tensor, out_vec: torch.Tensor, ac
         hip.segment_colsum(part, out_vec.view(1, N), seg=part.shape[0], mode=0, accumulate=accumulate)
 
 
-def _wgrad(buf: Buffers, dz: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, accumulate: bool):
+def _wgrad(buf: Buffers, dz: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, accumulate: bool, ws_tag: str = "wgrad.ws"):
+    """`ws_tag`: launches that may run concurrently (different branches) must not share a slab workspace"""
     M, N = dz.shape
     K = x.shape[1]
-    ws = buf.bytes("wgrad.ws", hip.linear_wgrad_workspace_bytes(M, N, K))
+    ws = buf.bytes(ws_tag, hip.linear_wgrad_workspace_bytes(M, N, K))
     hip.linear_wgrad(dz, x, dw, ws, accumulate=accumulate)
 
 
@@ -264,13 +295,13 @@ class TimeMLPPlan:
         B = s.shape[0]
         tg = self.tag
         de = _as_dtype(self.buf, tg + ".de", de32, self.dtype)
-        _wgrad(self.buf, de, u, P.g("time_mlp.2.weight"), accumulate)
+        _wgrad(self.buf, de, u, P.g("time_mlp.2.weight"), accumulate, ws_tag=tg + ".wgrad.ws")
         P.ready("time_mlp.2.weight")
         _colsum(self.buf, tg + ".b2", de32, P.g("time_mlp.2.bias"), accumulate)
         P.ready("time_mlp.2.bias")
         du = self.buf.get(tg + ".du", u.shape, self.dtype)
         hip.linear_dgrad(de, P.w("time_mlp.2.weight"), du, act_below="silu", aux=zu)
-        _wgrad(self.buf, du, s, P.g("time_mlp.0.weight"), accumulate)
+        _wgrad(self.buf, du, s, P.g("time_mlp.0.weight"), accumulate, ws_tag=tg + ".wgrad.ws")
         P.ready("time_mlp.0.weight")
         _colsum(self.buf, tg + ".b1", du, P.g("time_mlp.0.bias"), accumulate)
         P.ready("time_mlp.0.bias")
@@ -284,6 +315,10 @@ class DenoiserMLPPlan:
         self.buf = Buffers(device)
         self.time = TimeMLPPlan(dtype, self.buf)
         self.ctx = None
+        # the time-MLP backward (5 small latency-bound launches) runs on a forked stream next to the first
+        # block's weight gradient; the trainer disables this under data parallelism (bucket events are
+        # recorded on ONE stream)
+        self.branch = Branch(device)
 
     def forward(self, x3: torch.Tensor, t: torch.Tensor, table: torch.Tensor, P: ParamSource,
                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -311,10 +346,11 @@ class DenoiserMLPPlan:
 
     def ready_order(self) -> List[str]:
         o = ["head.weight", "head.bias"]
-        for i in range(len(self.hidden) - 1, -1, -1):
+        for i in range(len(self.hidden) - 1, 0, -1):
             o += [f"blocks.{i}.norm.weight", f"blocks.{i}.norm.bias", f"blocks.{i}.linear.weight",
                   f"blocks.{i}.linear.bias"]
-        return o + TimeMLPPlan.ready_order()
+        return o + ["blocks.0.norm.weight", "blocks.0.norm.bias"] + TimeMLPPlan.ready_order() + \
+            ["blocks.0.linear.weight", "blocks.0.linear.bias"]
 
     def backward(self, dout3: torch.Tensor, P: ParamSource, accumulate=False):
         saved, hlast, B, T = self.ctx
@@ -338,16 +374,19 @@ class DenoiserMLPPlan:
             hip.layernorm_bwd(dh, z, P.v(f"blocks.{i}.norm.weight"), mu, rs, dz, P.g(f"blocks.{i}.norm.weight"),
                               P.g(f"blocks.{i}.norm.bias"), lnws, act="silu", accumulate=accumulate)
             P.ready(f"blocks.{i}.norm.weight"); P.ready(f"blocks.{i}.norm.bias")
-            _wgrad(self.buf, dz, hin, P.g(f"blocks.{i}.linear.weight"), accumulate)
-            P.ready(f"blocks.{i}.linear.weight")
             # per-window sums of dz: the time-embedding gradient AND (summed over windows) the bias gradient
             hip.segment_colsum(dz, de32[:, off:off + hd], seg=T, mode=0)
+            if i == 0:
+                # de32 is complete: fork the time-MLP backward beside this block's weight gradient
+                self.branch.run(lambda: self.time.backward(de32, P, accumulate))
+            _wgrad(self.buf, dz, hin, P.g(f"blocks.{i}.linear.weight"), accumulate)
+            P.ready(f"blocks.{i}.linear.weight")
             _colsum(self.buf, f"dm.b{i}", de32[:, off:off + hd], P.g(f"blocks.{i}.linear.bias"), accumulate)
             P.ready(f"blocks.{i}.linear.bias")
             if i > 0:
                 dh = g(f"dm.dh{i - 1}", hin.shape, dt)
                 hip.linear_dgrad(dz, P.w(f"blocks.{i}.linear.weight"), dh)
-        self.time.backward(de32, P, accumulate)
+        self.branch.join()
 
 
 class DenoiserTransformerPlan:
