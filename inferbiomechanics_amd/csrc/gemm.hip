@@ -51,6 +51,7 @@ struct GemmParams {
   const void* addend; int64_t ldadd;  // dgrad: residual-path gradient added in the epilogue
   int act;
   int vecA, vecB, vecC;
+  int gldsA, gldsB;            // operand pieces are 16-byte aligned: direct-to-LDS staging is legal (bf16)
   int vecBias, vecAdd, vecAux;   // 16-byte (fp32) / 8-byte (bf16) epilogue operand loads are legal
   int tiles_n;
   int k_chunk;                 // split over the reduction (wgrad): blockIdx.y * k_chunk
@@ -161,6 +162,41 @@ __device__ __forceinline__ void store_tile(unsigned char* tile, const uint4 (&r)
       const int byte = (kk * Tile<T>::KS_STRIDE + rg * VW) * (int)sizeof(T);
       *reinterpret_cast<uint4*>(tile + byte) = r[q];
     }
+  }
+}
+
+// ---- direct-to-LDS staging (bf16): global_load_lds_dwordx4 writes 16 B per lane straight into the LDS
+// image (no VGPR round trip, no ds_write: VGPR->LDS stores run at ~80 B/clk/CU and were ~1/3 of a K step).
+// One wave-instruction fills 1 KiB of the image at (wave-uniform base + lane*16), so the 18 KiB image
+// (128 rows x 144 B, or 64 k-rows x 288 B) is 18 chunks; wave w issues chunks w, w+4, ...  Each lane derives
+// WHICH global piece belongs at its LDS slot from the slot's byte offset; lanes that fall into the row padding
+// fetch a duplicate piece (the pad bytes are never read).
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void glb_void_t;
+constexpr int GLDS_CHUNKS = OPER_BYTES / 1024;   // 18
+
+template <bool KC>
+__device__ __forceinline__ void glds_offsets(int64_t ld, int row0, int rows_total, int wave, int lane, int64_t (&off)[5]) {
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    const int chunk = wave + 4 * j;
+    const int o = (chunk < GLDS_CHUNKS ? chunk : 0) * 1024 + lane * 16;
+    if (KC) {
+      const int row = o / 144, c = min((o % 144) / 16, 7);
+      off[j] = (int64_t)min(row0 + row, rows_total - 1) * ld + 8 * c;
+    } else {
+      const int kk = o / 288, c = min((o % 288) / 16, 15);
+      off[j] = (int64_t)kk * ld + row0 + 8 * c;
+    }
+  }
+}
+__device__ __forceinline__ void glds_issue(const bf16_t* base, const int64_t (&off)[5], int64_t koff, unsigned char* tile,
+                                           int wave) {
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    const int chunk = wave + 4 * j;
+    if (chunk < GLDS_CHUNKS)
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(base + off[j] + koff), (lds_void_t*)(tile + chunk * 1024), 16, 0, 0);
   }
 }
 
@@ -438,37 +474,69 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmParams p) {
   const int64_t stepA = A_KC ? BK : (int64_t)BK * p.lda;
   const int64_t stepB = B_KC ? BK : (int64_t)BK * p.ldb;
 
-  // Register-staged double buffer: tile kt+1 is requested right after the barrier and lands while tile kt is
-  // multiplied.  (A depth-2 prefetch with two register sets was measured SLOWER for the k-strided operands:
-  // wgrad +25 %, dgrad +10 % -- see DESIGN.md.)
+  // Double-buffered LDS, one barrier per K step.  Per operand and K step the tile is staged either
+  //  (g) directly HBM/L2 -> LDS by global_load_lds (bf16, 16-byte-aligned pieces, full K step, and -- for
+  //      k-strided operands -- an interior tile), issued BEFORE the MFMA phase of the previous tile, or
+  //  (r) through registers (predicated / zero-filled: K tails, edge tiles, unaligned or fp32 operands), loaded
+  //      before the MFMA phase and written to LDS after it.
+  // (A depth-2 register prefetch was measured slower for the k-strided operands: wgrad +25 %, dgrad +10 %.)
+  bool gA = false, gB = false;
+  [[maybe_unused]] int64_t oa[5], ob[5];
+  if constexpr (sizeof(T) == 2) {
+    gA = p.gldsA && (A_KC || i0 + BM <= p.M);
+    gB = p.gldsB && (B_KC || j0 + BN <= p.N);
+    if (gA) glds_offsets<A_KC>(p.lda, i0, p.M, wave, lane, oa);
+    if (gB) glds_offsets<B_KC>(p.ldb, j0, p.N, wave, lane, ob);
+  }
   uint4 ra[4], rb[4];
-  auto stage = [&](int kt) {
+  // returns bit0: A staged through registers, bit1: B staged through registers
+  auto stage_issue = [&](int kt, unsigned char* tA, unsigned char* tB) -> int {
     const int k0 = kb + kt * BK;
     const bool fullk = (k0 + BK <= ke);
-    if (fastA && fullk) load_tile_fast<T, A_KC>(pa, na, stepA * kt, ra);
-    else load_tile<T, A_KC>(A, p.lda, i0, p.M, k0, ke, p.vecA, ra, tid);
-    if (fastB && fullk) load_tile_fast<T, B_KC>(pb, nb, stepB * kt, rb);
-    else load_tile<T, B_KC>(B, p.ldb, j0, p.N, k0, ke, p.vecB, rb, tid);
+    int viaregs = 0;
+    if constexpr (sizeof(T) == 2) {
+      if (gA && fullk) glds_issue(reinterpret_cast<const bf16_t*>(A), oa, A_KC ? (int64_t)k0 : (int64_t)k0 * p.lda, tA, wave);
+      else viaregs |= 1;
+      if (gB && fullk) glds_issue(reinterpret_cast<const bf16_t*>(B), ob, B_KC ? (int64_t)k0 : (int64_t)k0 * p.ldb, tB, wave);
+      else viaregs |= 2;
+    } else {
+      viaregs = 3;
+    }
+    if (viaregs & 1) {
+      if (fastA && fullk) load_tile_fast<T, A_KC>(pa, na, stepA * kt, ra);
+      else load_tile<T, A_KC>(A, p.lda, i0, p.M, k0, ke, p.vecA, ra, tid);
+    }
+    if (viaregs & 2) {
+      if (fastB && fullk) load_tile_fast<T, B_KC>(pb, nb, stepB * kt, rb);
+      else load_tile<T, B_KC>(B, p.ldb, j0, p.N, k0, ke, p.vecB, rb, tid);
+    }
+    return viaregs;
   };
-  if (nk > 0) stage(0);
+  auto stage_commit = [&](int viaregs, unsigned char* tA, unsigned char* tB) {
+    if (viaregs & 1) store_tile<T, A_KC>(tA, ra, tid);
+    if (viaregs & 2) store_tile<T, B_KC>(tB, rb, tid);
+  };
+  if (nk > 0) {
+    const int v = stage_issue(0, smem, smem + OPER_BYTES);
+    stage_commit(v, smem, smem + OPER_BYTES);
+    __syncthreads();
+  }
   for (int kt = 0; kt < nk; ++kt) {
     unsigned char* tA = smem + (kt & 1) * 2 * OPER_BYTES;
     unsigned char* tB = tA + OPER_BYTES;
+    unsigned char* nA = smem + ((kt + 1) & 1) * 2 * OPER_BYTES;
+    unsigned char* nB = nA + OPER_BYTES;
+    int v = 0;
 #ifdef IB_ABLATE
-    if (!(p.ablate & 2) || kt == 0) {
-      store_tile<T, A_KC>(tA, ra, tid);
-      store_tile<T, B_KC>(tB, rb, tid);
-    }
-    __syncthreads();
-    if (kt + 1 < nk && !(p.ablate & 1)) stage(kt + 1);
+    if (kt + 1 < nk && !(p.ablate & 1)) v = stage_issue(kt + 1, nA, nB);
     if (!(p.ablate & 4)) compute_tile<T, A_KC, B_KC>(tA, tB, acc, lane, wi, wj);
+    if (kt + 1 < nk && !(p.ablate & 2)) stage_commit(v, nA, nB);
 #else
-    store_tile<T, A_KC>(tA, ra, tid);
-    store_tile<T, B_KC>(tB, rb, tid);
-    __syncthreads();
-    if (kt + 1 < nk) stage(kt + 1);
+    if (kt + 1 < nk) v = stage_issue(kt + 1, nA, nB);
     compute_tile<T, A_KC, B_KC>(tA, tB, acc, lane, wi, wj);
+    if (kt + 1 < nk) stage_commit(v, nA, nB);
 #endif
+    __syncthreads();   // also drains the in-flight global_load_lds (hipcc emits vmcnt(0) before the barrier)
   }
 #ifdef IB_ABLATE
   if (p.ablate & 8) return;
@@ -507,6 +575,9 @@ inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_
 template <typename T> bool vec_load_ok(const void* p, int64_t ld) {
   return aligned(p, 4) && ((ld * (int64_t)sizeof(T)) % 4 == 0);
 }
+template <typename T> bool glds_ok(const void* p, int64_t ld) {
+  return sizeof(T) == 2 && aligned(p, 16) && (ld % 8 == 0);
+}
 template <typename T> bool vec_store_ok(const void* p, int64_t ld) {
   return aligned(p, 4 * sizeof(T)) && (ld % 4 == 0);
 }
@@ -531,6 +602,7 @@ int launch_fwd(GemmParams& p, hipStream_t s) {
   p.ablate = g_ablate;
   p.vecA = vec_load_ok<T>(p.A, p.lda);
   p.vecB = vec_load_ok<T>(p.B, p.ldb);
+  p.gldsA = glds_ok<T>(p.A, p.lda); p.gldsB = glds_ok<T>(p.B, p.ldb);
   p.vecC = vec_store_ok<T>(p.C, p.ldc) && (!p.Z || vec_store_ok<T>(p.Z, p.ldz));
   p.vecBias = !p.bias || aligned(p.bias, 16);
   p.vecAdd = (!p.add_div || vec_store_ok<T>(p.add_div, p.ld_add_div)) &&
@@ -548,6 +620,7 @@ int launch_dgrad(GemmParams& p, hipStream_t s) {
   p.ablate = g_ablate;
   p.vecA = vec_load_ok<T>(p.A, p.lda);
   p.vecB = vec_load_ok<T>(p.B, p.ldb);
+  p.gldsA = glds_ok<T>(p.A, p.lda); p.gldsB = glds_ok<T>(p.B, p.ldb);
   p.vecC = vec_store_ok<T>(p.C, p.ldc);
   p.vecAux = !p.aux || vec_store_ok<T>(p.aux, p.ldaux);
   p.vecAdd = !p.addend || vec_store_ok<T>(p.addend, p.ldadd);
@@ -633,6 +706,7 @@ extern "C" int ib_linear_wgrad(const void* dz, int64_t lddz, const void* x, int6
     hipLaunchKernelGGL((gemm_kernel<float, false, false, EPI_WGRAD>), dim3(tiles, split), dim3(NTHREADS), 0, s, p);
   } else {
     p.vecA = vec_load_ok<bf16_t>(p.A, p.lda); p.vecB = vec_load_ok<bf16_t>(p.B, p.ldb);
+    p.gldsA = glds_ok<bf16_t>(p.A, p.lda); p.gldsB = glds_ok<bf16_t>(p.B, p.ldb);
     hipLaunchKernelGGL((gemm_kernel<bf16_t, false, false, EPI_WGRAD>), dim3(tiles, split), dim3(NTHREADS), 0, s, p);
   }
   IB_CHECK_LAUNCH();
