@@ -483,8 +483,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmParams p) {
   bool gA = false, gB = false;
   [[maybe_unused]] int64_t oa[5], ob[5];
   if constexpr (sizeof(T) == 2) {
-    gA = p.gldsA && (A_KC || i0 + BM <= p.M);
-    gB = p.gldsB && (B_KC || j0 + BN <= p.N);
+    // measured (tools/kbench.py): direct-to-LDS staging pays for long reductions (K = 2048 forward: 48 -> 41 us)
+    // and is neutral-to-slightly-negative below ~16 K steps, where prologue/epilogue dominate
+    const bool longk = nk >= 16;
+    gA = longk && p.gldsA && (A_KC || i0 + BM <= p.M);
+    gB = longk && p.gldsB && (B_KC || j0 + BN <= p.N);
     if (gA) glds_offsets<A_KC>(p.lda, i0, p.M, wave, lane, oa);
     if (gB) glds_offsets<B_KC>(p.ldb, j0, p.N, wave, lane, ob);
   }

@@ -139,6 +139,69 @@ class _TimingLib:
         return out
 
 
+class _RecordingLib:
+    """Records every C-ABI call (name + raw arguments) of one eager step so bench.py can re-issue each distinct
+    call back-to-back inside a hipGraph and time it with HIP events (no host launch overhead in the number)."""
+
+    SKIP = ("ib_optim_step", "ib_counter_add")       # mutate state when repeated
+
+    def __init__(self, real):
+        self._real = real
+        self.calls = []      # (name, args)
+
+    def __getattr__(self, name):
+        real = getattr(self._real, name)
+        if not name.startswith("ib_") or name.startswith(("ib_event", "ib_graph")) or name.endswith("_workspace") \
+                or name in ("ib_version", "ib_error_string"):
+            return real
+
+        def call(*a):
+            self.calls.append((name, a))
+            return real(*a)
+        return call
+
+
+class record_launches:
+    def __enter__(self):
+        global _lib
+        self._saved = lib()
+        self.rec = _RecordingLib(self._saved)
+        _lib = self.rec
+        return self.rec
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self._saved
+        return False
+
+
+def time_recorded_call(name: str, args, reps: int = 20, rounds: int = 3) -> float:
+    """average device time (us) of one launch of a recorded call: `reps` launches captured in a graph on a side
+    stream, replayed `rounds` times between two HIP events recorded on that stream"""
+    fn = getattr(lib(), name)
+    s = torch.cuda.Stream()
+    sp = ctypes.c_void_p(s.cuda_stream)
+    a = list(args)
+    a[-1] = sp                                   # every entry point takes the stream last
+    with torch.cuda.stream(s):
+        for _ in range(2):
+            _check(fn(*a), name)
+        g = Graph()
+        g.begin()
+        for _ in range(reps):
+            _check(fn(*a), name)
+        g.end()
+        g.launch()
+        e0, e1 = Event(), Event()
+        e0.record()
+        for _ in range(rounds):
+            g.launch()
+        e1.record()
+        ms = e0.elapsed_ms(e1)
+    torch.cuda.synchronize()
+    return ms * 1e3 / (reps * rounds)
+
+
 class time_launches:
     """context manager: `with hip.time_launches() as tl: ...; tl.summary()`"""
 
