@@ -68,7 +68,9 @@ def cpu_baseline(kind, T, D, B, budget_s=15.0):
     """The oracle (torch-eager CPU port of the reference arithmetic + build-defined diffusion wrapper),
     fp32, all host cores, same workload shape; bounded sample."""
     from oracle import ref_cpu as R
-    torch.set_num_threads(os.cpu_count() or 1)
+    # one GPU's share of the host (the GPU box gives 16 worker CPUs per GPU); all 256 logical CPUs of the box
+    # on these small GEMMs is 80x SLOWER (thread oversubscription: 9.8 windows/s measured)
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
     torch.manual_seed(0)
     if kind == "mlp":
         shapes = R.denoiser_mlp_param_shapes(D, [512, 512])
@@ -149,26 +151,52 @@ def roofline_leg(trainer, batches, dtype_name):
                      "us_per_step": round(us * count, 2)})
     rows.sort(key=lambda r: -r["us_per_step"])
     total = sum(r["us_per_step"] for r in rows)
-    top = rows[0]
-    out = {"kernel": KERNEL_OF.get(top["entry"], top["entry"]), "entry": top["entry"], "dims": top["dims"],
-           "avg_launch_us": top["avg_launch_us"], "launches_per_step": top["launches_per_step"],
-           "share_of_step_device_time": round(top["us_per_step"] / total, 3), "traffic": None}
     es = 2 if dtype_name == "bf16" else 4
-    if top["entry"] in ("ib_linear_fwd", "ib_linear_dgrad", "ib_linear_wgrad"):
-        M, N, K = top["dims"][-5], top["dims"][-4], top["dims"][-3]      # (..., M, N, K, dtype, stream)
-        fl = 2 * M * N * K
-        ach = fl / (top["avg_launch_us"] * 1e-6) / 1e12
+
+    def work(r):
+        """(algorithmic flops, algorithmic bytes) of ONE launch; dims = the call's small-integer arguments, which
+        for every entry point end with (..., M, N, K, dtype) or (..., M, N, dtype)"""
+        d, e = r["dims"], r["entry"]
+        if e in ("ib_linear_fwd", "ib_linear_dgrad", "ib_linear_wgrad"):
+            M, N, K = d[-4], d[-3], d[-2]
+            return 2 * M * N * K, (M * K + N * K) * es + M * N * (4 if e.endswith("wgrad") else es)
+        if e in ("ib_layernorm_fwd", "ib_layernorm_bwd"):
+            M, N = d[-3], d[-2]
+            return 0, (2 if e.endswith("fwd") else 3) * M * N * es
+        return 0, 0
+
+    # the dominant KERNEL = the entry point with the largest share of the step (all its shapes together)
+    fam = {}
+    for r in rows:
+        f = fam.setdefault(r["entry"], {"us": 0.0, "launches": 0, "flops": 0, "bytes": 0})
+        fl, by = work(r)
+        f["us"] += r["us_per_step"]; f["launches"] += r["launches_per_step"]
+        f["flops"] += fl * r["launches_per_step"]; f["bytes"] += by * r["launches_per_step"]
+    top_e, top = max(fam.items(), key=lambda kv: kv[1]["us"])
+    avg_us = top["us"] / top["launches"]
+    out = {"kernel": KERNEL_OF.get(top_e, top_e), "entry": top_e, "launches_per_step": top["launches"],
+           "avg_launch_us": round(avg_us, 2), "share_of_step_device_time": round(top["us"] / total, 3),
+           "shapes": [r["dims"][-4:-1] for r in rows if r["entry"] == top_e], "traffic": None}
+    if top["flops"]:
+        ach = top["flops"] / (top["us"] * 1e-6) / 1e12
         out.update({"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_TFLOPS[dtype_name], "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_TFLOPS[dtype_name], 4), "algorithmic_flops_per_launch": fl,
-                    "algorithmic_bytes_per_launch": (M * K + N * K) * es + M * N * (4 if top["entry"].endswith("wgrad") else es)})
-    elif top["entry"] in ("ib_layernorm_fwd", "ib_layernorm_bwd"):
-        M, N = top["dims"][-4], top["dims"][-3]
-        by = (2 if top["entry"].endswith("fwd") else 3) * M * N * es
-        ach = by / (top["avg_launch_us"] * 1e-6) / 1e9
+                    "frac": round(ach / PEAK_TFLOPS[dtype_name], 4),
+                    "algorithmic_flops_per_launch": top["flops"] // top["launches"],
+                    "algorithmic_bytes_per_launch": top["bytes"] // top["launches"]})
+    elif top["bytes"]:
+        ach = top["bytes"] / (top["us"] * 1e-6) / 1e9
         out.update({"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                    "frac": round(ach / PEAK_HBM_GBS, 4), "algorithmic_bytes_per_launch": by})
+                    "frac": round(ach / PEAK_HBM_GBS, 4), "algorithmic_bytes_per_launch": top["bytes"] // top["launches"]})
     else:
         out.update({"bound": "hbm", "achieved": None, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": None})
+    # HBM traffic per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE),
+    # written by tools/summarize_profile.py; null if no profile of this kernel has been summarised
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            out["traffic"] = json.load(open(tpath)).get(top_e)
+        except Exception:
+            pass
     return out, rows[:14], total
 
 

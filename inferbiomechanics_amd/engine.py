@@ -163,8 +163,9 @@ class HipTrainer:
         dev = next(model.parameters()).device
         self.device = dev
         self.plan = self._plan_for(dev)
-        if self.world > 1 and hasattr(self.plan, "branch"):
-            self.plan.branch.on = False     # gradient-bucket events are recorded on one stream only
+        if self.world > 1 and hasattr(self.plan, "branches"):
+            for br in self.plan.branches():
+                br.on = False               # gradient-bucket events are recorded on one stream only
         # ---- flat buffers in gradient-ready order
         order = self.plan.ready_order()
         params = OrderedDict(model.named_parameters())

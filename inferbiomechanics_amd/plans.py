@@ -308,25 +308,40 @@ class TimeMLPPlan:
 
 
 class DenoiserMLPPlan:
-    """Token-wise MLP denoiser (BASELINE config 2): per block h = LN(silu(W h + b + e[window]))."""
+    """Token-wise MLP denoiser (BASELINE config 2): per block h = LN(silu(W h + b + e[window])).
+
+    Backward = a critical chain (head dgrad -> LN bwd -> dgrad -> LN bwd -> time-MLP bwd) plus work that only
+    hangs off it (the weight-gradient GEMMs and bias sums).  The hangers run on forked streams (`Branch`), so
+    these individually latency-bound launches overlap; under hipGraph capture they become parallel graph
+    branches.  Every concurrent wgrad owns its slab workspace."""
 
     def __init__(self, hidden: Sequence[int], dtype, device):
         self.hidden, self.dtype = list(hidden), dtype
         self.buf = Buffers(device)
         self.time = TimeMLPPlan(dtype, self.buf)
         self.ctx = None
-        # the time-MLP backward (5 small latency-bound launches) runs on a forked stream next to the first
-        # block's weight gradient; the trainer disables this under data parallelism (bucket events are
-        # recorded on ONE stream)
-        self.branch = Branch(device)
+        # the trainer switches the branches off under data parallelism (gradient-bucket events are recorded on
+        # ONE stream)
+        self.br_head = Branch(device)
+        self.br_blk = [Branch(device) for _ in self.hidden]
+        self.branch = Branch(device)            # time-MLP backward
 
-    def forward(self, x3: torch.Tensor, t: torch.Tensor, table: torch.Tensor, P: ParamSource,
-                out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        B, T, D = x3.shape
+    def branches(self) -> List[Branch]:
+        return [self.br_head, self.branch] + self.br_blk
+
+    def forward(self, x, t: torch.Tensor, table: torch.Tensor, P: ParamSource,
+                out: Optional[torch.Tensor] = None, BT: Optional[Tuple[int, int]] = None) -> torch.Tensor:
+        """x: [B,T,D] contiguous, or a (possibly row-padded) 2-D [B*T, D] view with BT=(B,T)"""
+        if x.dim() == 3:
+            B, T, D = x.shape
+            h = x.view(B * T, D)
+        else:
+            B, T = BT
+            D = x.shape[1]
+            h = x
         M = B * T
         g, dt = self.buf.get, self.dtype
         e = self.time.forward(t, table, P)
-        h = x3.view(M, D)
         saved = []
         off = 0
         for i, hd in enumerate(self.hidden):
@@ -339,8 +354,10 @@ class DenoiserMLPPlan:
             saved.append((h, z, mu, rs))
             h = hn
             off += hd
-        out = out if out is not None else g("dm.out", (B, T, D), dt)
-        hip.linear_fwd(h, P.w("head.weight"), P.v("head.bias"), out.view(M, D))
+        if out is None:
+            out = g("dm.out", (B, T, D), dt)
+        out2 = out.view(M, D) if out.dim() == 3 else out
+        hip.linear_fwd(h, P.w("head.weight"), P.v("head.bias"), out2)
         self.ctx = (saved, h, B, T)
         return out
 
@@ -352,15 +369,18 @@ class DenoiserMLPPlan:
         return o + ["blocks.0.norm.weight", "blocks.0.norm.bias"] + TimeMLPPlan.ready_order() + \
             ["blocks.0.linear.weight", "blocks.0.linear.bias"]
 
-    def backward(self, dout3: torch.Tensor, P: ParamSource, accumulate=False):
+    def backward(self, dout, P: ParamSource, accumulate=False):
         saved, hlast, B, T = self.ctx
         M = B * T
         g, dt = self.buf.get, self.dtype
-        dout = dout3.view(M, -1)
-        _wgrad(self.buf, dout, hlast, P.g("head.weight"), accumulate)
-        P.ready("head.weight")
-        _colsum(self.buf, "dm.bh", dout, P.g("head.bias"), accumulate)
-        P.ready("head.bias")
+        dout = dout.view(M, -1) if dout.dim() == 3 else dout
+
+        def head_grads():
+            _wgrad(self.buf, dout, hlast, P.g("head.weight"), accumulate, ws_tag="dm.wsH")
+            P.ready("head.weight")
+            _colsum(self.buf, "dm.bh", dout, P.g("head.bias"), accumulate)
+            P.ready("head.bias")
+        self.br_head.run(head_grads)
         dh = g("dm.dh_last", hlast.shape, dt)
         hip.linear_dgrad(dout, P.w("head.weight"), dh)
         de32 = g("dm.de32", (B, sum(self.hidden)), torch.float32)
@@ -374,19 +394,26 @@ class DenoiserMLPPlan:
             hip.layernorm_bwd(dh, z, P.v(f"blocks.{i}.norm.weight"), mu, rs, dz, P.g(f"blocks.{i}.norm.weight"),
                               P.g(f"blocks.{i}.norm.bias"), lnws, act="silu", accumulate=accumulate)
             P.ready(f"blocks.{i}.norm.weight"); P.ready(f"blocks.{i}.norm.bias")
+            sl = de32[:, off:off + hd]
+
+            def blk_grads(i=i, dz=dz, hin=hin, sl=sl):
+                _wgrad(self.buf, dz, hin, P.g(f"blocks.{i}.linear.weight"), accumulate, ws_tag=f"dm.ws{i}")
+                P.ready(f"blocks.{i}.linear.weight")
+                _colsum(self.buf, f"dm.b{i}", sl, P.g(f"blocks.{i}.linear.bias"), accumulate)
+                P.ready(f"blocks.{i}.linear.bias")
+
             # per-window sums of dz: the time-embedding gradient AND (summed over windows) the bias gradient
-            hip.segment_colsum(dz, de32[:, off:off + hd], seg=T, mode=0)
-            if i == 0:
-                # de32 is complete: fork the time-MLP backward beside this block's weight gradient
-                self.branch.run(lambda: self.time.backward(de32, P, accumulate))
-            _wgrad(self.buf, dz, hin, P.g(f"blocks.{i}.linear.weight"), accumulate)
-            P.ready(f"blocks.{i}.linear.weight")
-            _colsum(self.buf, f"dm.b{i}", de32[:, off:off + hd], P.g(f"blocks.{i}.linear.bias"), accumulate)
-            P.ready(f"blocks.{i}.linear.bias")
+            hip.segment_colsum(dz, sl, seg=T, mode=0)
             if i > 0:
+                self.br_blk[i].run(blk_grads)
                 dh = g(f"dm.dh{i - 1}", hin.shape, dt)
                 hip.linear_dgrad(dz, P.w(f"blocks.{i}.linear.weight"), dh)
-        self.branch.join()
+            else:
+                # de32 is complete: the time-MLP backward forks off, block 0's weight gradient stays on the main stream
+                self.branch.run(lambda: self.time.backward(de32, P, accumulate))
+                blk_grads()
+        for b in self.branches():
+            b.join()
 
 
 class DenoiserTransformerPlan:

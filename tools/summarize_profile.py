@@ -1,0 +1,105 @@
+#!/usr/bin/env python3
+"""Turn a tools/profile_round.sh collection (gpurun_out/prof_<tag>/) into the committed evidence under profiles/:
+
+  profiles/<tag>_kernel_stats.csv     rocprofv3 --kernel-trace --stats summary (verbatim)
+  profiles/<tag>_per_kernel.md        per (kernel, grid) average duration joined with the HBM counters
+  profiles/traffic.json               {C-ABI entry: {"hbm_bytes_per_launch": ..., ...}} read by bench.py's roofline leg
+
+HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024: FETCH_SIZE / WRITE_SIZE are in KiB and come from SEPARATE
+--pmc passes; on gfx950 FETCH_SIZE reports half of the bytes of a wide coalesced read stream (MI355X_MICROARCH.md §HBM).
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ENTRY_OF = [("gemm_kernel", "Lb1ELb1ELi0", "ib_linear_fwd"), ("gemm_kernel", "Lb1ELb0ELi1", "ib_linear_dgrad"),
+            ("gemm_kernel", "Lb0ELb0ELi2", "ib_linear_wgrad"), ("layernorm_fwd_kernel", "", "ib_layernorm_fwd"),
+            ("layernorm_bwd_kernel", "", "ib_layernorm_bwd"), ("attn_fwd_mfma", "", "ib_attention_fwd"),
+            ("attn_bwd_mfma", "", "ib_attention_bwd")]
+
+
+def entry_of(name):
+    for a, b, e in ENTRY_OF:
+        if a in name and b in name:
+            return e
+    # demangled form of the template kernels
+    if "gemm_kernel" in name:
+        if "true, true" in name or ", true, 0>" in name:
+            return "ib_linear_fwd"
+        if "false, 1>" in name:
+            return "ib_linear_dgrad"
+    return None
+
+
+def first(pattern):
+    g = glob.glob(pattern)
+    return g[0] if g else None
+
+
+def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
+    dst = os.path.join(ROOT, "profiles")
+    os.makedirs(dst, exist_ok=True)
+    stats = first(os.path.join(src, "trace", "*", "*kernel_stats.csv"))
+    shutil.copy(stats, os.path.join(dst, f"{tag}_kernel_stats.csv"))
+    trace = list(csv.DictReader(open(first(os.path.join(src, "trace", "*", "*kernel_trace.csv")))))
+
+    def counters(sub):
+        f = first(os.path.join(src, sub, "*", "*counter_collection.csv"))
+        a = collections.defaultdict(list)
+        if f:
+            for r in csv.DictReader(open(f)):
+                a[(r["Kernel_Name"], r["Grid_Size"])].append(float(r["Counter_Value"]))
+        return a
+    F, W = counters("pmc_fetch"), counters("pmc_write")
+    T = collections.defaultdict(list)
+    n = len(trace)
+    for r in trace[n // 4:]:                         # skip process start-up / warm-up dispatches
+        gs = int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])
+        T[(r["Kernel_Name"], str(gs))].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    rows = []
+    for k, v in T.items():
+        f, w = F.get(k), W.get(k)
+        fk = sum(f) / len(f) if f else None
+        wk = sum(w) / len(w) if w else None
+        rows.append({"kernel": k[0], "grid_threads": int(k[1]), "dispatches": len(v), "avg_us": sum(v) / len(v) / 1e3,
+                     "total_ms": sum(v) / 1e6, "FETCH_SIZE_KiB": fk, "WRITE_SIZE_KiB": wk,
+                     "hbm_bytes": None if fk is None or wk is None else (2 * fk + wk) * 1024})
+    rows.sort(key=lambda r: -r["total_ms"])
+    with open(os.path.join(dst, f"{tag}_per_kernel.md"), "w") as f:
+        f.write(f"# {tag}: per-kernel durations (rocprofv3 --kernel-trace, un-graphed bench.py) joined with HBM counters\n\n"
+                "`hbm MB/launch` = (2 x FETCH_SIZE + WRITE_SIZE) KiB from separate `--pmc` passes (gfx950 FETCH_SIZE correction).\n"
+                "Durations of sub-10 us kernels are inflated in the un-graphed run (the GPU idles between host launches);\n"
+                "tools/kbench.py / bench.py's roofline leg time launches back-to-back inside a hipGraph.\n\n"
+                "| kernel | grid (threads) | dispatches | avg us | total ms | FETCH KiB | WRITE KiB | hbm MB/launch |\n|---|---|---|---|---|---|---|---|\n")
+        for r in rows[:40]:
+            name = r["kernel"].split("(")[0][-70:]
+            f.write(f"| `{name}` | {r['grid_threads']} | {r['dispatches']} | {r['avg_us']:.1f} | {r['total_ms']:.2f} | "
+                    f"{'' if r['FETCH_SIZE_KiB'] is None else round(r['FETCH_SIZE_KiB'])} | "
+                    f"{'' if r['WRITE_SIZE_KiB'] is None else round(r['WRITE_SIZE_KiB'])} | "
+                    f"{'' if r['hbm_bytes'] is None else round(r['hbm_bytes'] / 1e6, 1)} |\n")
+    traffic = {}
+    fam = collections.defaultdict(lambda: {"bytes": 0.0, "n": 0, "us": 0.0})
+    for r in rows:
+        e = entry_of(r["kernel"])
+        if e and r["hbm_bytes"] is not None:
+            fam[e]["bytes"] += r["hbm_bytes"] * r["dispatches"]
+            fam[e]["n"] += r["dispatches"]
+            fam[e]["us"] += r["avg_us"] * r["dispatches"]
+    for e, v in fam.items():
+        traffic[e] = {"hbm_bytes_per_launch": round(v["bytes"] / v["n"]), "avg_launch_us_in_profile": round(v["us"] / v["n"], 2),
+                      "dispatches": v["n"], "source": f"profiles/{tag}_per_kernel.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+                      "separate passes; bytes = (2*FETCH + WRITE) KiB)"}
+    json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
+    print(open(os.path.join(dst, f"{tag}_per_kernel.md")).read()[:3000])
+    print(json.dumps(traffic, indent=1))
+
+
+if __name__ == "__main__":
+    main()
