@@ -66,32 +66,35 @@ class ParamSource:
 
 class Branch:
     """A side stream forked from / joined into the current stream with events.  Launches issued inside `run`
-    execute concurrently with what the main stream does next; under hipGraph capture the same event edges
-    become a parallel branch of the graph.  Disabled (runs inline) off-GPU and when `enabled` is False."""
+    execute concurrently with what the main stream does next (successive `run`s of one Branch are ordered among
+    themselves); under hipGraph capture the same event edges become a parallel branch of the graph.  Disabled
+    (runs inline) off-GPU and when `on` is False."""
 
     def __init__(self, device, enabled: bool = True):
         self.on = enabled and torch.device(device).type == "cuda" and not hip._dry_run
-        if self.on:
-            self.stream = torch.cuda.Stream(device=device)
-            self.ev_fork, self.ev_join = torch.cuda.Event(), torch.cuda.Event()
-        self._pending = False
+        self.stream = torch.cuda.Stream(device=device) if self.on else None
+        self._forks: List = []
+        self._join = torch.cuda.Event() if self.on else None
+        self._n = 0
 
     def run(self, fn):
         if not self.on:
             fn()
             return
-        main = torch.cuda.current_stream()
-        self.ev_fork.record(main)
+        if self._n == len(self._forks):
+            self._forks.append(torch.cuda.Event())
+        ev = self._forks[self._n]
+        self._n += 1
+        ev.record(torch.cuda.current_stream())
         with torch.cuda.stream(self.stream):
-            self.stream.wait_event(self.ev_fork)
+            self.stream.wait_event(ev)
             fn()
-            self.ev_join.record(self.stream)
-        self._pending = True
+            self._join.record(self.stream)
 
     def join(self):
-        if self.on and self._pending:
-            torch.cuda.current_stream().wait_event(self.ev_join)
-            self._pending = False
+        if self.on and self._n:
+            torch.cuda.current_stream().wait_event(self._join)
+        self._n = 0
 
 
 def _colsum(buf: Buffers, tag: str, x2d: torch.Tensor, out_vec: torch.Tensor, accumulate: bool):
@@ -184,6 +187,13 @@ class TransformerLayerPlan:
         self.p, self.d, self.h, self.ffn, self.dtype, self.tag = prefix, d_model, num_heads, ffn, dtype, tag
         self.buf = buf if buf is not None else Buffers(device)
         self.ctx = None
+        # the four weight-gradient GEMMs (+ bias sums) hang off the critical dgrad / LayerNorm / attention chain:
+        # they run on this layer's side stream (each with its own slab workspace)
+        self.branch = Branch(device)
+        self.join_on_exit = True     # a parent plan sets this False and joins all layers once at the end
+
+    def branches(self) -> List["Branch"]:
+        return [self.branch]
 
     def forward(self, x3: torch.Tensor, P: ParamSource, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         B, T, d = x3.shape
@@ -229,16 +239,22 @@ class TransformerLayerPlan:
         hip.layernorm_bwd(dx2.view(M, d), f2, P.v(p + "norm2.weight"), m2, r2, ds2, P.g(p + "norm2.weight"),
                           P.g(p + "norm2.bias"), lnws, res=x1, accumulate=accumulate)
         P.ready(p + "norm2.weight"); P.ready(p + "norm2.bias")
-        _wgrad(self.buf, ds2, f1, P.g(p + "feedforward.2.weight"), accumulate)
-        P.ready(p + "feedforward.2.weight")
-        _colsum(self.buf, tg + ".b2", ds2, P.g(p + "feedforward.2.bias"), accumulate)
-        P.ready(p + "feedforward.2.bias")
+
+        def g_ffn2():
+            _wgrad(self.buf, ds2, f1, P.g(p + "feedforward.2.weight"), accumulate, ws_tag=tg + ".ws2")
+            P.ready(p + "feedforward.2.weight")
+            _colsum(self.buf, tg + ".b2", ds2, P.g(p + "feedforward.2.bias"), accumulate)
+            P.ready(p + "feedforward.2.bias")
+        self.branch.run(g_ffn2)
         dz1 = g(tg + ".dz1", (M, self.ffn), dt)
         hip.linear_dgrad(ds2, P.w(p + "feedforward.2.weight"), dz1, act_below="relu", aux=f1)
-        _wgrad(self.buf, dz1, x1, P.g(p + "feedforward.0.weight"), accumulate)
-        P.ready(p + "feedforward.0.weight")
-        _colsum(self.buf, tg + ".b1", dz1, P.g(p + "feedforward.0.bias"), accumulate)
-        P.ready(p + "feedforward.0.bias")
+
+        def g_ffn1():
+            _wgrad(self.buf, dz1, x1, P.g(p + "feedforward.0.weight"), accumulate, ws_tag=tg + ".ws1")
+            P.ready(p + "feedforward.0.weight")
+            _colsum(self.buf, tg + ".b1", dz1, P.g(p + "feedforward.0.bias"), accumulate)
+            P.ready(p + "feedforward.0.bias")
+        self.branch.run(g_ffn1)
         dx1 = g(tg + ".dx1", (M, d), dt)
         hip.linear_dgrad(dz1, P.w(p + "feedforward.0.weight"), dx1, addend=ds2)       # + residual path
         # LN1: d(a + x)
@@ -246,21 +262,30 @@ class TransformerLayerPlan:
         hip.layernorm_bwd(dx1, a, P.v(p + "norm1.weight"), m1, r1, ds1, P.g(p + "norm1.weight"),
                           P.g(p + "norm1.bias"), lnws, res=x, accumulate=accumulate)
         P.ready(p + "norm1.weight"); P.ready(p + "norm1.bias")
-        _wgrad(self.buf, ds1, attn.view(M, d), P.g(p + "multihead_attention.out_proj.weight"), accumulate)
-        P.ready(p + "multihead_attention.out_proj.weight")
-        _colsum(self.buf, tg + ".bo", ds1, P.g(p + "multihead_attention.out_proj.bias"), accumulate)
-        P.ready(p + "multihead_attention.out_proj.bias")
+
+        def g_out():
+            _wgrad(self.buf, ds1, attn.view(M, d), P.g(p + "multihead_attention.out_proj.weight"), accumulate,
+                   ws_tag=tg + ".wso")
+            P.ready(p + "multihead_attention.out_proj.weight")
+            _colsum(self.buf, tg + ".bo", ds1, P.g(p + "multihead_attention.out_proj.bias"), accumulate)
+            P.ready(p + "multihead_attention.out_proj.bias")
+        self.branch.run(g_out)
         dattn = g(tg + ".dattn", (B, T, d), dt)
         hip.linear_dgrad(ds1, P.w(p + "multihead_attention.out_proj.weight"), dattn.view(M, d))
         dqkv = g(tg + ".dqkv", (B, T, 3 * d), dt)
         hip.attention_bwd(qkv, attn, dattn, lse, dqkv, self.h)
         dq2 = dqkv.view(M, 3 * d)
-        _wgrad(self.buf, dq2, x, P.g(p + "multihead_attention.in_proj_weight"), accumulate)
-        P.ready(p + "multihead_attention.in_proj_weight")
-        _colsum(self.buf, tg + ".bi", dq2, P.g(p + "multihead_attention.in_proj_bias"), accumulate)
-        P.ready(p + "multihead_attention.in_proj_bias")
+
+        def g_in():
+            _wgrad(self.buf, dq2, x, P.g(p + "multihead_attention.in_proj_weight"), accumulate, ws_tag=tg + ".wsi")
+            P.ready(p + "multihead_attention.in_proj_weight")
+            _colsum(self.buf, tg + ".bi", dq2, P.g(p + "multihead_attention.in_proj_bias"), accumulate)
+            P.ready(p + "multihead_attention.in_proj_bias")
+        self.branch.run(g_in)
         dx = g(tg + ".dx", (B, T, d), dt)
         hip.linear_dgrad(dq2, P.w(p + "multihead_attention.in_proj_weight"), dx.view(M, d), addend=ds1)
+        if self.join_on_exit:
+            self.branch.join()
         return dx
 
 
@@ -426,7 +451,12 @@ class DenoiserTransformerPlan:
         self.time = TimeMLPPlan(dtype, self.buf)
         self.layers = [TransformerLayerPlan(f"transformer_layers.{l}.", d_model, num_heads, ffn, dtype, device,
                                             buf=self.buf, tag=f"tl{l}") for l in range(num_layers)]
+        for lp in self.layers:
+            lp.join_on_exit = False          # joined once, at the end of the whole backward
         self.ctx = None
+
+    def branches(self) -> List[Branch]:
+        return [lp.branch for lp in self.layers]
 
     def forward(self, x3: torch.Tensor, t: torch.Tensor, table: torch.Tensor, P: ParamSource,
                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -493,3 +523,5 @@ class DenoiserTransformerPlan:
         hip.segment_colsum(dpos32, gpos, seg=1, mode=0, accumulate=accumulate)   # row-wise copy / accumulate
         P.ready("temporal_embedding.embedding.weight")
         self.time.backward(de32, P, accumulate)
+        for lp in self.layers:
+            lp.branch.join()
