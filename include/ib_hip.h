@@ -72,16 +72,19 @@ int ib_segment_colsum(const void* x, int64_t ldx, float* out, int64_t ldo, int64
                       int64_t seg, int mode, int accumulate, int dtype, ib_stream_t stream);
 
 /* ---- LayerNorm (+ fused residual add / pre-activation): nn.LayerNorm, TransformerBaseline.py:21-22,31,36.
- * v = act(x) (+ res);  y = (v - mean)/sqrt(var + eps) * gamma + beta;  mean/rstd [M] saved (fp32). */
+ * v = act(x + add_div[m / seg, :]) (+ res);  y = (v - mean)/sqrt(var + eps) * gamma + beta;  mean/rstd [M] saved
+ * (fp32).  add_div (optional, may be NULL) broadcasts one row per window BEFORE the activation (the diffusion
+ * time embedding; having it here instead of in the GEMM epilogue takes the time-MLP off the critical path). */
 int ib_layernorm_fwd(const void* x, const void* res, int act, const float* gamma, const float* beta,
-                     void* y, float* mean, float* rstd, int64_t M, int64_t N, float eps, int dtype,
-                     ib_stream_t stream);
+                     void* y, float* mean, float* rstd, const void* add_div, int64_t ld_add_div, int64_t seg,
+                     int64_t M, int64_t N, float eps, int dtype, ib_stream_t stream);
 /* dx = grad wrt x (through act), dres (optional, may alias nothing) = grad wrt res (= grad wrt v);
  * dgamma/dbeta partials are written to `partial` [(2*nparts), N] fp32, then summed into dgamma/dbeta. */
 size_t ib_layernorm_bwd_workspace(int64_t M, int64_t N);
 int ib_layernorm_bwd(const void* dy, const void* x, const void* res, int act, const float* gamma,
                      const float* mean, const float* rstd, void* dx, void* dres, float* dgamma,
                      float* dbeta, int accumulate, void* workspace, size_t workspace_bytes,
+                     const void* add_div, int64_t ld_add_div, int64_t seg,
                      int64_t M, int64_t N, int dtype, ib_stream_t stream);
 
 /* ---- temporal self-attention: nn.MultiheadAttention core, TransformerBaseline.py:12-13,29.
@@ -122,6 +125,11 @@ int ib_regression_loss(const void* o_cop, const void* o_force, const void* o_tor
 size_t ib_mse_loss_workspace(int64_t n);
 int ib_mse_loss(const void* pred, const void* target, void* dpred, float* result, void* workspace,
                 size_t workspace_bytes, int64_t n, int dtype, ib_stream_t stream);
+/* the same in two halves, so the scalar reduction can run off the critical path (a forked stream): the first
+ * writes dpred and the per-block partial sums into `workspace`, the second reduces them into result[0]. */
+int ib_mse_loss_partial(const void* pred, const void* target, void* dpred, void* workspace, size_t workspace_bytes,
+                        int64_t n, int dtype, ib_stream_t stream);
+int ib_mse_loss_finalize(const void* workspace, size_t workspace_bytes, float* result, int64_t n, ib_stream_t stream);
 
 /* ---- optimizer step: torch.optim.{SGD,Adam,RMSprop,Adagrad,Adadelta,Adamax}(lr) defaults,
  * src/cli/train.py:183-197,284.  One launch over a FLAT fp32 parameter buffer.  g is multiplied by

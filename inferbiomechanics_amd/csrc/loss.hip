@@ -243,9 +243,9 @@ extern "C" int ib_regression_loss(const void* o_cop, const void* o_force, const 
 
 extern "C" size_t ib_mse_loss_workspace(int64_t n) { return (size_t)mse_parts(n) * sizeof(float); }
 
-extern "C" int ib_mse_loss(const void* pred, const void* target, void* dpred, float* result, void* workspace,
-                           size_t workspace_bytes, int64_t n, int dtype, ib_stream_t stream) {
-  if (!pred || !target || !result || n <= 0) return IB_E_ARG;
+extern "C" int ib_mse_loss_partial(const void* pred, const void* target, void* dpred, void* workspace,
+                                   size_t workspace_bytes, int64_t n, int dtype, ib_stream_t stream) {
+  if (!pred || !target || n <= 0) return IB_E_ARG;
   const int parts = mse_parts(n);
   if (!workspace || workspace_bytes < (size_t)parts * sizeof(float)) return IB_E_WORKSPACE;
   float* partial = reinterpret_cast<float*>(workspace);
@@ -262,7 +262,24 @@ extern "C" int ib_mse_loss(const void* pred, const void* target, void* dpred, fl
   } else
     return IB_E_DTYPE;
   IB_CHECK_LAUNCH();
-  hipLaunchKernelGGL(mse_final_kernel, dim3(1), dim3(256), 0, s, partial, parts, result, 1.f / (float)n);
+  return IB_OK;
+}
+
+extern "C" int ib_mse_loss_finalize(const void* workspace, size_t workspace_bytes, float* result, int64_t n,
+                                    ib_stream_t stream) {
+  if (!workspace || !result || n <= 0) return IB_E_ARG;
+  const int parts = mse_parts(n);
+  if (workspace_bytes < (size_t)parts * sizeof(float)) return IB_E_WORKSPACE;
+  hipLaunchKernelGGL(mse_final_kernel, dim3(1), dim3(256), 0, ib_s(stream), reinterpret_cast<const float*>(workspace),
+                     parts, result, 1.f / (float)n);
   IB_CHECK_LAUNCH();
   return IB_OK;
+}
+
+extern "C" int ib_mse_loss(const void* pred, const void* target, void* dpred, float* result, void* workspace,
+                           size_t workspace_bytes, int64_t n, int dtype, ib_stream_t stream) {
+  if (!result) return IB_E_ARG;
+  const int rc = ib_mse_loss_partial(pred, target, dpred, workspace, workspace_bytes, n, dtype, stream);
+  if (rc != IB_OK) return rc;
+  return ib_mse_loss_finalize(workspace, workspace_bytes, result, n, stream);
 }

@@ -117,7 +117,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, T* __restrict__ y,
                                                             float* __restrict__ mean, float* __restrict__ rstd,
-                                                            int M, int N, float eps, int vec, int vecp) {
+                                                            int M, int N, float eps, int vec, int vecp,
+                                                            const T* __restrict__ add_div, int64_t ld_add, int seg) {
   constexpr int RPW = 64 / LPR;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane / LPR, l = lane % LPR;
@@ -133,6 +134,12 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
       const int col = (c * LPR + l) * 8;
       const int nv = max(0, min(8, N - col));
       load8<T>(x + ro + col, nv, vec, v[c]);
+      if (add_div) {        // per-window row added BEFORE the activation (the diffusion time embedding)
+        float a8[8];
+        load8<T>(add_div + (int64_t)((live ? row : M - 1) / seg) * ld_add + col, nv, vec, a8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[c][e] += a8[e];
+      }
       if constexpr (ACT != IB_ACT_NONE) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[c][e] = (e < nv) ? ln_act<T, ACT>(act, v[c][e]) : 0.f;
@@ -190,7 +197,8 @@ __global__ __launch_bounds__(LN_BWD_WPB * 64) void layernorm_bwd_kernel(const T*
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, T* __restrict__ dx,
                                                             T* __restrict__ dres, float* __restrict__ partial,
-                                                            int M, int N, int vec, int vecp) {
+                                                            int M, int N, int vec, int vecp,
+                                                            const T* __restrict__ add_div, int64_t ld_add, int seg) {
   constexpr int RPW = 64 / LPR;
   constexpr int NPAD = CH * LPR * 8;
   constexpr int WPB = LN_BWD_WPB;
@@ -218,6 +226,12 @@ __global__ __launch_bounds__(LN_BWD_WPB * 64) void layernorm_bwd_kernel(const T*
       load8<T>(x + ro + col, nv, vec, xv);
       load8<T>(dy + ro + col, nv, vec, dyv);
       load8<float>(gamma + col, max(0, min(8, N - col)), vecp, gm);   // L1/L2 resident; not worth 8 registers per chunk
+      if (add_div) {
+        float a8[8];
+        load8<T>(add_div + (int64_t)((live ? row : M - 1) / seg) * ld_add + col, nv, vec, a8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xv[e] += a8[e];
+      }
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         float h, dh;
@@ -386,12 +400,13 @@ __global__ void cast2d_kernel(const S* __restrict__ src, int64_t lds, D* __restr
 
 template <typename T, int LPR, int CH>
 int launch_ln_fwd(const void* x, const void* res, int act, const float* gamma, const float* beta, void* y, float* mean,
-                  float* rstd, int64_t M, int64_t N, float eps, int vec, int vecp, hipStream_t s) {
+                  float* rstd, int64_t M, int64_t N, float eps, int vec, int vecp, const void* add_div, int64_t ld_add,
+                  int seg, hipStream_t s) {
   constexpr int RPB = 4 * (64 / LPR);
   const int grid = ib_grid_1d(M, RPB);
 #define IB_LN_FWD(ACT)                                                                                              \
   hipLaunchKernelGGL((layernorm_fwd_kernel<T, LPR, CH, ACT>), dim3(grid), dim3(256), 0, s, (const T*)x, (const T*)res, \
-                     act, gamma, beta, (T*)y, mean, rstd, (int)M, (int)N, eps, vec, vecp)
+                     act, gamma, beta, (T*)y, mean, rstd, (int)M, (int)N, eps, vec, vecp, (const T*)add_div, ld_add, seg)
   if (act == IB_ACT_NONE) IB_LN_FWD(IB_ACT_NONE);
   else if (act == IB_ACT_SILU) IB_LN_FWD(IB_ACT_SILU);
   else IB_LN_FWD(-1);
@@ -410,10 +425,11 @@ int ln_bwd_parts(int64_t M) {
 template <typename T, int LPR, int CH>
 int launch_ln_bwd(const void* dy, const void* x, const void* res, int act, const float* gamma, const float* mean,
                   const float* rstd, void* dx, void* dres, float* partial, int64_t M, int64_t N, int vec, int vecp,
-                  int parts, hipStream_t s) {
+                  int parts, const void* add_div, int64_t ld_add, int seg, hipStream_t s) {
 #define IB_LN_BWD(ACT)                                                                                              \
   hipLaunchKernelGGL((layernorm_bwd_kernel<T, LPR, CH, ACT>), dim3(parts), dim3(LN_BWD_WPB * 64), 0, s, (const T*)dy, (const T*)x, \
-                     (const T*)res, act, gamma, mean, rstd, (T*)dx, (T*)dres, partial, (int)M, (int)N, vec, vecp)
+                     (const T*)res, act, gamma, mean, rstd, (T*)dx, (T*)dres, partial, (int)M, (int)N, vec, vecp,           \
+                     (const T*)add_div, ld_add, seg)
   if (act == IB_ACT_NONE) IB_LN_BWD(IB_ACT_NONE);
   else if (act == IB_ACT_SILU) IB_LN_BWD(IB_ACT_SILU);
   else IB_LN_BWD(-1);
@@ -436,19 +452,22 @@ inline bool al(const void* p, size_t a) { return !p || (reinterpret_cast<uintptr
    : N <= 512 ? FN<T, 16, 4>(__VA_ARGS__) : N <= 1024 ? FN<T, 64, 2>(__VA_ARGS__) : FN<T, 64, 4>(__VA_ARGS__))
 
 extern "C" int ib_layernorm_fwd(const void* x, const void* res, int act, const float* gamma, const float* beta, void* y,
-                                float* mean, float* rstd, int64_t M, int64_t N, float eps, int dtype,
-                                ib_stream_t stream) {
+                                float* mean, float* rstd, const void* add_div, int64_t ld_add, int64_t seg, int64_t M,
+                                int64_t N, float eps, int dtype, ib_stream_t stream) {
   if (!x || !gamma || !beta || !y || M <= 0 || N <= 0) return IB_E_ARG;
+  if (add_div && (seg <= 0 || ld_add < N)) return IB_E_ARG;
   if (N > 2048) return IB_E_UNSUPPORTED;
   hipStream_t s = ib_s(stream);
   const int vecp = (N % 4 == 0) && al(gamma, 16) && al(beta, 16);
   if (dtype == IB_F32) {
-    const int vec = (N % 4 == 0) && al(x, 16) && al(res, 16) && al(y, 16);
-    return LN_DISPATCH(launch_ln_fwd, float, x, res, act, gamma, beta, y, mean, rstd, M, N, eps, vec, vecp, s);
+    const int vec = (N % 4 == 0) && al(x, 16) && al(res, 16) && al(y, 16) && al(add_div, 16) && (ld_add % 4 == 0);
+    return LN_DISPATCH(launch_ln_fwd, float, x, res, act, gamma, beta, y, mean, rstd, M, N, eps, vec, vecp, add_div,
+                       ld_add, (int)seg, s);
   }
   if (dtype == IB_BF16) {
-    const int vec = (N % 8 == 0) && al(x, 16) && al(res, 16) && al(y, 16);
-    return LN_DISPATCH(launch_ln_fwd, bf16_t, x, res, act, gamma, beta, y, mean, rstd, M, N, eps, vec, vecp, s);
+    const int vec = (N % 8 == 0) && al(x, 16) && al(res, 16) && al(y, 16) && al(add_div, 16) && (ld_add % 8 == 0);
+    return LN_DISPATCH(launch_ln_fwd, bf16_t, x, res, act, gamma, beta, y, mean, rstd, M, N, eps, vec, vecp, add_div,
+                       ld_add, (int)seg, s);
   }
   return IB_E_DTYPE;
 }
@@ -459,9 +478,11 @@ extern "C" size_t ib_layernorm_bwd_workspace(int64_t M, int64_t N) {
 
 extern "C" int ib_layernorm_bwd(const void* dy, const void* x, const void* res, int act, const float* gamma,
                                 const float* mean, const float* rstd, void* dx, void* dres, float* dgamma,
-                                float* dbeta, int accumulate, void* workspace, size_t workspace_bytes, int64_t M,
-                                int64_t N, int dtype, ib_stream_t stream) {
+                                float* dbeta, int accumulate, void* workspace, size_t workspace_bytes,
+                                const void* add_div, int64_t ld_add, int64_t seg, int64_t M, int64_t N, int dtype,
+                                ib_stream_t stream) {
   if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || M <= 0 || N <= 0) return IB_E_ARG;
+  if (add_div && (seg <= 0 || ld_add < N)) return IB_E_ARG;
   if (N > 2048) return IB_E_UNSUPPORTED;
   const int parts = ln_bwd_parts(M);
   if (!workspace || workspace_bytes < (size_t)2 * parts * N * sizeof(float)) return IB_E_WORKSPACE;
@@ -470,13 +491,15 @@ extern "C" int ib_layernorm_bwd(const void* dy, const void* x, const void* res, 
   int rc;
   const int vecp = (N % 4 == 0) && al(gamma, 16);
   if (dtype == IB_F32) {
-    const int vec = (N % 4 == 0) && al(x, 16) && al(res, 16) && al(dy, 16) && al(dx, 16) && al(dres, 16);
+    const int vec = (N % 4 == 0) && al(x, 16) && al(res, 16) && al(dy, 16) && al(dx, 16) && al(dres, 16) &&
+                    al(add_div, 16) && (ld_add % 4 == 0);
     rc = LN_DISPATCH_BWD(launch_ln_bwd, float, dy, x, res, act, gamma, mean, rstd, dx, dres, partial, M, N, vec, vecp,
-                     parts, s);
+                     parts, add_div, ld_add, (int)seg, s);
   } else if (dtype == IB_BF16) {
-    const int vec = (N % 8 == 0) && al(x, 16) && al(res, 16) && al(dy, 16) && al(dx, 16) && al(dres, 16);
+    const int vec = (N % 8 == 0) && al(x, 16) && al(res, 16) && al(dy, 16) && al(dx, 16) && al(dres, 16) &&
+                    al(add_div, 16) && (ld_add % 8 == 0);
     rc = LN_DISPATCH_BWD(launch_ln_bwd, bf16_t, dy, x, res, act, gamma, mean, rstd, dx, dres, partial, M, N, vec, vecp,
-                     parts, s);
+                     parts, add_div, ld_add, (int)seg, s);
   } else {
     return IB_E_DTYPE;
   }

@@ -206,6 +206,8 @@ class HipTrainer:
         # hipGraph capture is not allowed on the legacy default stream: the step runs on its own stream,
         # ordered after / before the caller's current stream by events
         self.stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+        from .plans import Branch
+        self._br_loss = Branch(dev, enabled=(self.world == 1))
         self._static: Dict[str, torch.Tensor] = {}
         self._rec: Optional[_Recorder] = None
         self._sig = None
@@ -262,8 +264,11 @@ class HipTrainer:
             pred = plan.forward(xt, t, tabs.temb, P)
             dpred = plan.buf.get("tr.dpred", pred.shape, dt)
             ws = plan.buf.bytes("tr.mse", hip.mse_loss_workspace_bytes(pred.numel()))
-            hip.mse_loss(pred, eps, self.result, ws, dpred=dpred)
+            hip.mse_loss_partial(pred, eps, ws, dpred=dpred)          # dL/dpred + per-block partial sums
+            n = pred.numel()
+            self._br_loss.run(lambda: hip.mse_loss_finalize(ws, self.result, n))   # the scalar: off the chain
             plan.backward(dpred, P, accumulate=False)
+            self._br_loss.join()
         else:
             B = st["in0"].shape[0]
             x = plan.buf.get("ff.x", (B, m.input_size), dt)

@@ -42,10 +42,11 @@ _SIGS = {
     "ib_linear_wgrad_workspace": (_sz, [_i64, _i64, _i64]),
     "ib_linear_wgrad": (_c.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _c.c_int, _vp, _sz, _i64, _i64, _i64, _c.c_int, _vp]),
     "ib_segment_colsum": (_c.c_int, [_vp, _i64, _vp, _i64, _i64, _i64, _i64, _c.c_int, _c.c_int, _c.c_int, _vp]),
-    "ib_layernorm_fwd": (_c.c_int, [_vp, _vp, _c.c_int, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _f32, _c.c_int, _vp]),
+    "ib_layernorm_fwd": (_c.c_int, [_vp, _vp, _c.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _f32,
+                                    _c.c_int, _vp]),
     "ib_layernorm_bwd_workspace": (_sz, [_i64, _i64]),
     "ib_layernorm_bwd": (_c.c_int, [_vp, _vp, _vp, _c.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _c.c_int, _vp, _sz,
-                                    _i64, _i64, _c.c_int, _vp]),
+                                    _vp, _i64, _i64, _i64, _i64, _c.c_int, _vp]),
     "ib_attention_fwd": (_c.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _c.c_int, _vp]),
     "ib_attention_bwd": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _c.c_int, _vp]),
     "ib_concat_keys": (_c.c_int, [_vp, _vp, _i32, _vp, _i64, _c.c_int, _vp]),
@@ -56,6 +57,8 @@ _SIGS = {
                                       _vp, _vp, _vp, _sz, _i64, _i64, _c.c_int, _vp]),
     "ib_mse_loss_workspace": (_sz, [_i64]),
     "ib_mse_loss": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _sz, _i64, _c.c_int, _vp]),
+    "ib_mse_loss_partial": (_c.c_int, [_vp, _vp, _vp, _vp, _sz, _i64, _c.c_int, _vp]),
+    "ib_mse_loss_finalize": (_c.c_int, [_vp, _sz, _vp, _i64, _vp]),
     "ib_optim_step": (_c.c_int, [_c.c_int, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _i32, _vp, _vp, _vp]),
     "ib_gather_rows": (_c.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _c.c_int, _vp]),
     "ib_q_sample": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _c.c_int, _vp]),
@@ -387,7 +390,16 @@ def _rows(t: torch.Tensor, name: str, dt):
     return t.numel() // t.shape[-1], t.shape[-1]
 
 
-def layernorm_fwd(x, gamma, beta, y, mean, rstd, res=None, act="none", eps=1e-5):
+def _add_div(add_div, seg, M, N, dt):
+    if add_div is None:
+        return None, 0, 0
+    r, c, ld = _mat(add_div, "add_div", dt)
+    if seg <= 0 or c != N or r * seg < M:
+        raise HipError(f"add_div must be [ceil(M/seg), N]; got {tuple(add_div.shape)} with seg={seg}, M={M}")
+    return add_div.data_ptr(), ld, int(seg)
+
+
+def layernorm_fwd(x, gamma, beta, y, mean, rstd, res=None, act="none", eps=1e-5, add_div=None, seg=0):
     dt = x.dtype
     M, N = _rows(x, "x", dt)
     for t, n in ((y, "y"),) + (((res, "res"),) if res is not None else ()):
@@ -401,8 +413,10 @@ def layernorm_fwd(x, gamma, beta, y, mean, rstd, res=None, act="none", eps=1e-5)
         _req(t, n, torch.float32)
         if t.numel() != M or not t.is_contiguous():
             raise HipError(f"{n} must be contiguous fp32 [M]")
+    ap, ald, aseg = _add_div(add_div, seg, M, N, dt)
     _check(lib().ib_layernorm_fwd(_ptr(x), _ptr(res), ACT[act], _ptr(gamma), _ptr(beta), _ptr(y), _ptr(mean),
-                                  _ptr(rstd), M, N, float(eps), dtype_code(dt), stream_ptr()), "ib_layernorm_fwd")
+                                  _ptr(rstd), ap, ald, aseg, M, N, float(eps), dtype_code(dt), stream_ptr()),
+           "ib_layernorm_fwd")
     return y
 
 
@@ -411,7 +425,7 @@ def layernorm_bwd_workspace_bytes(M, N) -> int:
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, res=None, dres=None, act="none",
-                  accumulate=False):
+                  accumulate=False, add_div=None, seg=0):
     dt = x.dtype
     M, N = _rows(x, "x", dt)
     for t, n in ((dy, "dy"), (dx, "dx")) + (((res, "res"),) if res is not None else ()) + \
@@ -430,9 +444,10 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, res=No
     wsb = workspace.numel() * workspace.element_size()
     if wsb < need:
         raise HipError(f"layernorm_bwd: workspace of {need} bytes required, got {wsb}")
+    ap, ald, aseg = _add_div(add_div, seg, M, N, dt)
     _check(lib().ib_layernorm_bwd(_ptr(dy), _ptr(x), _ptr(res), ACT[act], _ptr(gamma), _ptr(mean), _ptr(rstd),
                                   _ptr(dx), _ptr(dres), _ptr(dgamma), _ptr(dbeta), int(accumulate), _ptr(workspace),
-                                  wsb, M, N, dtype_code(dt), stream_ptr()), "ib_layernorm_bwd")
+                                  wsb, ap, ald, aseg, M, N, dtype_code(dt), stream_ptr()), "ib_layernorm_bwd")
     return dx
 
 
@@ -593,6 +608,28 @@ def mse_loss(pred, target, result, workspace, dpred=None):
     _check(lib().ib_mse_loss(_ptr(pred), _ptr(target), _ptr(dpred), _ptr(result), _ptr(workspace), wsb, n,
                              dtype_code(dt), stream_ptr()), "ib_mse_loss")
     return result
+
+
+def mse_loss_partial(pred, target, workspace, dpred=None):
+    dt = pred.dtype
+    _req(pred, "pred", dt)
+    _req(target, "target", dt)
+    n = pred.numel()
+    if target.numel() != n or not pred.is_contiguous() or not target.is_contiguous():
+        raise HipError("mse_loss: pred/target must be contiguous with equal numel")
+    if dpred is not None and (dpred.dtype != dt or dpred.numel() != n or not dpred.is_contiguous()):
+        raise HipError("mse_loss: dpred mismatch")
+    wsb = workspace.numel() * workspace.element_size()
+    if wsb < mse_loss_workspace_bytes(n):
+        raise HipError("mse_loss: workspace too small")
+    _check(lib().ib_mse_loss_partial(_ptr(pred), _ptr(target), _ptr(dpred), _ptr(workspace), wsb, n, dtype_code(dt),
+                                     stream_ptr()), "ib_mse_loss_partial")
+
+
+def mse_loss_finalize(workspace, result, n):
+    _req(result, "result", torch.float32)
+    wsb = workspace.numel() * workspace.element_size()
+    _check(lib().ib_mse_loss_finalize(_ptr(workspace), wsb, _ptr(result), int(n), stream_ptr()), "ib_mse_loss_finalize")
 
 
 # --------------------------------------------------------------------------------------------

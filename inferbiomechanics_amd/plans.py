@@ -296,6 +296,7 @@ class TimeMLPPlan:
     def __init__(self, dtype, buf: Buffers, tag="tm"):
         self.dtype, self.buf, self.tag = dtype, buf, tag
         self.ctx = None
+        self.br = Branch(buf.device)     # backward: the output layer's weight/bias gradients beside the dgrad chain
 
     def forward(self, t: torch.Tensor, table: torch.Tensor, P: ParamSource) -> torch.Tensor:
         B = t.shape[0]
@@ -320,16 +321,20 @@ class TimeMLPPlan:
         B = s.shape[0]
         tg = self.tag
         de = _as_dtype(self.buf, tg + ".de", de32, self.dtype)
-        _wgrad(self.buf, de, u, P.g("time_mlp.2.weight"), accumulate, ws_tag=tg + ".wgrad.ws")
-        P.ready("time_mlp.2.weight")
-        _colsum(self.buf, tg + ".b2", de32, P.g("time_mlp.2.bias"), accumulate)
-        P.ready("time_mlp.2.bias")
+
+        def out_layer_grads():
+            _wgrad(self.buf, de, u, P.g("time_mlp.2.weight"), accumulate, ws_tag=tg + ".ws2")
+            P.ready("time_mlp.2.weight")
+            _colsum(self.buf, tg + ".b2", de32, P.g("time_mlp.2.bias"), accumulate)
+            P.ready("time_mlp.2.bias")
+        self.br.run(out_layer_grads)
         du = self.buf.get(tg + ".du", u.shape, self.dtype)
         hip.linear_dgrad(de, P.w("time_mlp.2.weight"), du, act_below="silu", aux=zu)
-        _wgrad(self.buf, du, s, P.g("time_mlp.0.weight"), accumulate, ws_tag=tg + ".wgrad.ws")
+        _wgrad(self.buf, du, s, P.g("time_mlp.0.weight"), accumulate, ws_tag=tg + ".ws0")
         P.ready("time_mlp.0.weight")
         _colsum(self.buf, tg + ".b1", du, P.g("time_mlp.0.bias"), accumulate)
         P.ready("time_mlp.0.bias")
+        self.br.join()
 
 
 class DenoiserMLPPlan:
@@ -350,9 +355,10 @@ class DenoiserMLPPlan:
         self.br_head = Branch(device)
         self.br_blk = [Branch(device) for _ in self.hidden]
         self.branch = Branch(device)            # time-MLP backward
+        self.br_tfwd = Branch(device)           # time-MLP forward (beside q_sample + the first block's GEMM)
 
     def branches(self) -> List[Branch]:
-        return [self.br_head, self.branch] + self.br_blk
+        return [self.br_head, self.branch, self.br_tfwd, self.time.br] + self.br_blk
 
     def forward(self, x, t: torch.Tensor, table: torch.Tensor, P: ParamSource,
                 out: Optional[torch.Tensor] = None, BT: Optional[Tuple[int, int]] = None) -> torch.Tensor:
@@ -366,24 +372,31 @@ class DenoiserMLPPlan:
             h = x
         M = B * T
         g, dt = self.buf.get, self.dtype
-        e = self.time.forward(t, table, P)
+        # the time embedding is added in the LayerNorm prologue (not the GEMM epilogue), so the time-MLP runs on a
+        # forked stream beside the first GEMM; it is joined right before the first LayerNorm
+        eref = {}
+        self.br_tfwd.run(lambda: eref.__setitem__("e", self.time.forward(t, table, P)))
         saved = []
         off = 0
         for i, hd in enumerate(self.hidden):
             z = g(f"dm.z{i}", (M, hd), dt)
-            hip.linear_fwd(h, P.w(f"blocks.{i}.linear.weight"), P.v(f"blocks.{i}.linear.bias"), z,
-                           add_div=e[:, off:off + hd], seg=T)
+            hip.linear_fwd(h, P.w(f"blocks.{i}.linear.weight"), P.v(f"blocks.{i}.linear.bias"), z)
+            if i == 0:
+                self.br_tfwd.join()
+            e = eref["e"]
             hn = g(f"dm.hn{i}", (M, hd), dt)
             mu, rs = g(f"dm.mu{i}", (M,), torch.float32), g(f"dm.rs{i}", (M,), torch.float32)
-            hip.layernorm_fwd(z, P.v(f"blocks.{i}.norm.weight"), P.v(f"blocks.{i}.norm.bias"), hn, mu, rs, act="silu")
+            hip.layernorm_fwd(z, P.v(f"blocks.{i}.norm.weight"), P.v(f"blocks.{i}.norm.bias"), hn, mu, rs, act="silu",
+                              add_div=e[:, off:off + hd], seg=T)
             saved.append((h, z, mu, rs))
             h = hn
             off += hd
+        e = eref["e"]
         if out is None:
             out = g("dm.out", (B, T, D), dt)
         out2 = out.view(M, D) if out.dim() == 3 else out
         hip.linear_fwd(h, P.w("head.weight"), P.v("head.bias"), out2)
-        self.ctx = (saved, h, B, T)
+        self.ctx = (saved, h, B, T, e)
         return out
 
     def ready_order(self) -> List[str]:
@@ -395,7 +408,7 @@ class DenoiserMLPPlan:
             ["blocks.0.linear.weight", "blocks.0.linear.bias"]
 
     def backward(self, dout, P: ParamSource, accumulate=False):
-        saved, hlast, B, T = self.ctx
+        saved, hlast, B, T, e = self.ctx
         M = B * T
         g, dt = self.buf.get, self.dtype
         dout = dout.view(M, -1) if dout.dim() == 3 else dout
@@ -417,7 +430,8 @@ class DenoiserMLPPlan:
             lnws = self.buf.bytes("ln.ws", hip.layernorm_bwd_workspace_bytes(M, hd))
             dz = g(f"dm.dz{i}", (M, hd), dt)
             hip.layernorm_bwd(dh, z, P.v(f"blocks.{i}.norm.weight"), mu, rs, dz, P.g(f"blocks.{i}.norm.weight"),
-                              P.g(f"blocks.{i}.norm.bias"), lnws, act="silu", accumulate=accumulate)
+                              P.g(f"blocks.{i}.norm.bias"), lnws, act="silu", accumulate=accumulate,
+                              add_div=e[:, off:off + hd], seg=T)
             P.ready(f"blocks.{i}.norm.weight"); P.ready(f"blocks.{i}.norm.bias")
             sl = de32[:, off:off + hd]
 

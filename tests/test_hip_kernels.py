@@ -347,3 +347,35 @@ def test_bad_arguments_fail_loudly(hip):
         hip.linear_fwd(x.cpu(), w, None, y)
     with pytest.raises(hip.HipError):
         hip.linear_fwd(x.to(torch.float16), w.to(torch.float16), None, y.to(torch.float16))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_layernorm_with_per_window_add(hip, dtype):
+    """v = silu(x + e[window]) -> LN: the time-embedding add fused into the LayerNorm prologue (fwd + bwd)"""
+    B, T, N = 5, 7, 512
+    M = B * T
+    x = rnd((M, N), 1, 1.5, dtype)
+    e_wide = rnd((B, 2 * N), 2, 1.0, dtype)
+    e = e_wide[:, N:]                                       # strided slice, as the plans pass it
+    gamma = (1 + rnd((N,), 3, 0.1)).float()
+    beta = rnd((N,), 4, 0.1).float()
+    dy = rnd((M, N), 5, 1.0, dtype)
+    xd = x.double().requires_grad_(True)
+    gd, bd = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    v = R.act("silu", (xd.reshape(B, T, N) + e.double()[:, None, :]).reshape(M, N))
+    yd = R.layer_norm(v, gd, bd)
+    yd.backward(dy.double())
+    y = torch.empty(M, N, dtype=dtype, device=DEV)
+    mean = torch.empty(M, dtype=torch.float32, device=DEV)
+    rstd = torch.empty(M, dtype=torch.float32, device=DEV)
+    ed = e_wide.to(DEV)[:, N:]
+    hip.layernorm_fwd(x.to(DEV), gamma.to(DEV), beta.to(DEV), y, mean, rstd, act="silu", add_div=ed, seg=T)
+    close(y, yd, TIGHT[dtype], "ln(+e) fwd")
+    dx = torch.empty(M, N, dtype=dtype, device=DEV)
+    dg = torch.empty(N, dtype=torch.float32, device=DEV)
+    db = torch.empty(N, dtype=torch.float32, device=DEV)
+    ws = torch.empty(hip.layernorm_bwd_workspace_bytes(M, N), dtype=torch.uint8, device=DEV)
+    hip.layernorm_bwd(dy.to(DEV), x.to(DEV), gamma.to(DEV), mean, rstd, dx, dg, db, ws, act="silu", add_div=ed, seg=T)
+    close(dx, xd.grad, 1e-4 if dtype == torch.float32 else 3e-2, "ln(+e) dx")
+    close(dg, gd.grad, 1e-4 if dtype == torch.float32 else 2e-2, "ln(+e) dgamma")
+    close(db, bd.grad, 1e-4 if dtype == torch.float32 else 2e-2, "ln(+e) dbeta")
