@@ -68,8 +68,9 @@ int ib_linear_wgrad(const void* dz, int64_t lddz, const void* x, int64_t ldx, fl
 /* out[s, n] (fp32) = sum over rows m of segment s of x[m, n]; mode 0: s = m / seg (M/seg segments,
  * bias grads / per-window time-embedding grads), mode 1: s = m % seg (seg segments, per-frame
  * embedding grads). */
-int ib_segment_colsum(const void* x, int64_t ldx, float* out, int64_t ldo, int64_t M, int64_t N,
-                      int64_t seg, int mode, int accumulate, int dtype, ib_stream_t stream);
+int ib_segment_colsum(const void* x, int64_t ldx, float* out, int64_t ldo, void* out_bf16, int64_t ld_bf16,
+                      int64_t M, int64_t N, int64_t seg, int mode, int accumulate, int dtype, ib_stream_t stream);
+/* out_bf16 (optional): a bf16 copy of the sums, i.e. the operand of the GEMM that consumes them (saves a cast launch) */
 
 /* ---- LayerNorm (+ fused residual add / pre-activation): nn.LayerNorm, TransformerBaseline.py:21-22,31,36.
  * v = act(x + add_div[m / seg, :]) (+ res);  y = (v - mean)/sqrt(var + eps) * gamma + beta;  mean/rstd [M] saved
@@ -80,7 +81,11 @@ int ib_layernorm_fwd(const void* x, const void* res, int act, const float* gamma
                      int64_t M, int64_t N, float eps, int dtype, ib_stream_t stream);
 /* dx = grad wrt x (through act), dres (optional, may alias nothing) = grad wrt res (= grad wrt v);
  * dgamma/dbeta partials are written to `partial` [(2*nparts), N] fp32, then summed into dgamma/dbeta. */
+/* dgamma == dbeta == NULL defers the fixed-order reduction of the parameter-gradient partials (they stay in
+ * `workspace`); ib_layernorm_bwd_reduce finishes it later, e.g. on a forked stream off the critical path. */
 size_t ib_layernorm_bwd_workspace(int64_t M, int64_t N);
+int ib_layernorm_bwd_reduce(const void* workspace, size_t workspace_bytes, float* dgamma, float* dbeta,
+                            int accumulate, int64_t M, int64_t N, ib_stream_t stream);
 int ib_layernorm_bwd(const void* dy, const void* x, const void* res, int act, const float* gamma,
                      const float* mean, const float* rstd, void* dx, void* dres, float* dgamma,
                      float* dbeta, int accumulate, void* workspace, size_t workspace_bytes,
@@ -137,8 +142,10 @@ int ib_mse_loss_finalize(const void* workspace, size_t workspace_bytes, float* r
  * holds the 1-based step count (advance it with ib_counter_add BEFORE this call) and is used for
  * the bias corrections, so a captured hipGraph replays correctly; if NULL, `step` (1-based) is used.  shadow (optional) receives bf16 copies of p. */
 int ib_optim_step(int opt, float* p, const float* g, float* s1, float* s2, int64_t n, float lr,
-                  float grad_scale, int32_t step, int32_t* step_dev, void* shadow_bf16,
+                  float grad_scale, int32_t step, int32_t* step_dev, int32_t* ticket, void* shadow_bf16,
                   ib_stream_t stream);
+/* ticket (optional, zero-initialised int32 device word): self-counting mode -- *step_dev then holds the number of
+ * COMPLETED steps, the kernel uses *step_dev + 1 and its last-exiting block publishes it (no separate counter launch). */
 
 /* ---- diffusion wrapper [BUILD-DEFINED]: DDPM q_sample, DDIM eta=0 update, table gathers ----- */
 /* out[b, :] = table[idx[b], :]  (timestep-embedding rows; table computed in float64 on the host,

@@ -9,7 +9,7 @@ namespace {
 
 struct OptArgs {
   float* p; const float* g; float* s1; float* s2; bf16_t* shadow;
-  int64_t n; float lr; float gscale; int step; const int32_t* step_dev; int opt;
+  int64_t n; float lr; float gscale; int step; int32_t* step_dev; int32_t* ticket; int opt;
 };
 
 __device__ __forceinline__ float opt_update(const OptArgs& a, float p, float g, float& s1, float& s2, float bc1,
@@ -46,7 +46,10 @@ __device__ __forceinline__ float opt_update(const OptArgs& a, float p, float g, 
 }
 
 __global__ __launch_bounds__(256) void optim_kernel(OptArgs a) {
-  const int step = a.step_dev ? *a.step_dev : a.step;
+  // self-counting mode (ticket != NULL): *step_dev holds the number of COMPLETED steps; every block reads it on
+  // entry, and the block that draws the last exit ticket publishes step and resets the ticket -- it exits after
+  // every other block has entered (and therefore read the old value), so no block can see the new count.
+  const int step = a.step_dev ? (a.ticket ? *(volatile int32_t*)a.step_dev + 1 : *a.step_dev) : a.step;
   // bias corrections in double (torch computes them as Python floats)
   const float bc1 = (float)(1.0 - pow(0.9, (double)step));
   const float bc2s = (float)sqrt(1.0 - pow(0.999, (double)step));
@@ -80,13 +83,25 @@ __global__ __launch_bounds__(256) void optim_kernel(OptArgs a) {
     if (has2) a.s2[i] = s2;
     if (a.shadow) a.shadow[i] = (bf16_t)p;
   }
+  if (a.ticket) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int t = atomicAdd(a.ticket, 1);
+      if (t == (int)gridDim.x - 1) {
+        *a.step_dev = step;
+        *a.ticket = 0;
+      }
+    }
+  }
 }
 
 }  // namespace
 
 extern "C" int ib_optim_step(int opt, float* p, const float* g, float* s1, float* s2, int64_t n, float lr,
-                             float grad_scale, int32_t step, int32_t* step_dev, void* shadow_bf16, ib_stream_t stream) {
+                             float grad_scale, int32_t step, int32_t* step_dev, int32_t* ticket, void* shadow_bf16,
+                             ib_stream_t stream) {
   if (!p || !g || n <= 0 || opt < IB_OPT_SGD || opt > IB_OPT_ADAMAX) return IB_E_ARG;
+  if (ticket && !step_dev) return IB_E_ARG;
   const bool need1 = opt != IB_OPT_SGD;
   const bool need2 = (opt == IB_OPT_ADAM || opt == IB_OPT_ADADELTA || opt == IB_OPT_ADAMAX);
   if ((need1 && !s1) || (need2 && !s2)) return IB_E_ARG;
@@ -94,7 +109,7 @@ extern "C" int ib_optim_step(int opt, float* p, const float* g, float* s1, float
   if (!al16(p) || !al16(g) || !al16(s1) || !al16(s2) || (shadow_bf16 && reinterpret_cast<uintptr_t>(shadow_bf16) % 8))
     return IB_E_ARG;
   OptArgs a{p, g, need1 ? s1 : nullptr, need2 ? s2 : nullptr, reinterpret_cast<bf16_t*>(shadow_bf16),
-            n, lr, grad_scale, step, step_dev, opt};
+            n, lr, grad_scale, step, step_dev, ticket, opt};
   hipLaunchKernelGGL(optim_kernel, dim3(ib_grid_1d(n / 4 + 1, 256)), dim3(256), 0, ib_s(stream), a);
   IB_CHECK_LAUNCH();
   return IB_OK;

@@ -306,7 +306,8 @@ __global__ __launch_bounds__(LN_BWD_WPB * 64) void layernorm_bwd_kernel(const T*
 template <typename T, int RL>
 __global__ __launch_bounds__(256) void segment_colsum_kernel(const T* __restrict__ x, int64_t ldx, float* __restrict__ out,
                                                              int64_t ldo, int M, int N, int seg, int mode, int accumulate,
-                                                             int vec, float* __restrict__ out1) {
+                                                             int vec, float* __restrict__ out1, bf16_t* __restrict__ out_lp,
+                                                             int64_t ld_lp) {
   constexpr int CG = 256 / RL;
   __shared__ float red[RL][CG][4];
   const int cg = threadIdx.x % CG, rl = threadIdx.x / CG;
@@ -346,7 +347,9 @@ __global__ __launch_bounds__(256) void segment_colsum_kernel(const T* __restrict
 #pragma unroll
         for (int w = 0; w < RL; ++w) t += red[w][cg][e];
         float* o = (out1 && s == 1) ? out1 + col + e : out + (int64_t)s * ldo + col + e;   // out1: segment 1 elsewhere
-        *o = accumulate ? *o + t : t;
+        const float r = accumulate ? *o + t : t;
+        *o = r;
+        if (out_lp) out_lp[(int64_t)s * ld_lp + col + e] = (bf16_t)r;   // bf16 copy = next GEMM's operand (no cast launch)
       }
     }
   }
@@ -354,15 +357,16 @@ __global__ __launch_bounds__(256) void segment_colsum_kernel(const T* __restrict
 
 template <typename T>
 void launch_segment_colsum(const T* x, int64_t ldx, float* out, int64_t ldo, int M, int N, int seg, int mode,
-                           int accumulate, int vec, int nseg, int rows_per_seg, hipStream_t s, float* out1 = nullptr) {
+                           int accumulate, int vec, int nseg, int rows_per_seg, hipStream_t s, float* out1 = nullptr,
+                           bf16_t* out_lp = nullptr, int64_t ld_lp = 0) {
   if (rows_per_seg > 32) {
     dim3 grid((unsigned)((N + 63) / 64), (unsigned)nseg);
     hipLaunchKernelGGL((segment_colsum_kernel<T, 16>), grid, dim3(256), 0, s, x, ldx, out, ldo, M, N, seg, mode,
-                       accumulate, vec, out1);
+                       accumulate, vec, out1, out_lp, ld_lp);
   } else {
     dim3 grid((unsigned)((N + 255) / 256), (unsigned)nseg);
     hipLaunchKernelGGL((segment_colsum_kernel<T, 4>), grid, dim3(256), 0, s, x, ldx, out, ldo, M, N, seg, mode,
-                       accumulate, vec, out1);
+                       accumulate, vec, out1, out_lp, ld_lp);
   }
 }
 
@@ -481,7 +485,8 @@ extern "C" int ib_layernorm_bwd(const void* dy, const void* x, const void* res, 
                                 float* dbeta, int accumulate, void* workspace, size_t workspace_bytes,
                                 const void* add_div, int64_t ld_add, int64_t seg, int64_t M, int64_t N, int dtype,
                                 ib_stream_t stream) {
-  if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || M <= 0 || N <= 0) return IB_E_ARG;
+  if (!dy || !x || !gamma || !mean || !rstd || !dx || M <= 0 || N <= 0) return IB_E_ARG;
+  if ((dgamma == nullptr) != (dbeta == nullptr)) return IB_E_ARG;   // both NULL = leave the partials in the workspace
   if (add_div && (seg <= 0 || ld_add < N)) return IB_E_ARG;
   if (N > 2048) return IB_E_UNSUPPORTED;
   const int parts = ln_bwd_parts(M);
@@ -504,6 +509,7 @@ extern "C" int ib_layernorm_bwd(const void* dy, const void* x, const void* res, 
     return IB_E_DTYPE;
   }
   if (rc != IB_OK) return rc;
+  if (!dgamma) return IB_OK;        // deferred: ib_layernorm_bwd_reduce() finishes the parameter gradients later
   // fixed-order sums of the per-block partials in ONE launch: [2*parts, N] as two segments of `parts` rows,
   // segment 0 -> dgamma, segment 1 -> dbeta
   const int pvec = (N % 4 == 0);
@@ -512,9 +518,23 @@ extern "C" int ib_layernorm_bwd(const void* dy, const void* x, const void* res, 
   return IB_OK;
 }
 
-extern "C" int ib_segment_colsum(const void* x, int64_t ldx, float* out, int64_t ldo, int64_t M, int64_t N, int64_t seg,
-                                 int mode, int accumulate, int dtype, ib_stream_t stream) {
+extern "C" int ib_layernorm_bwd_reduce(const void* workspace, size_t workspace_bytes, float* dgamma, float* dbeta,
+                                       int accumulate, int64_t M, int64_t N, ib_stream_t stream) {
+  if (!workspace || !dgamma || !dbeta || M <= 0 || N <= 0) return IB_E_ARG;
+  const int parts = ln_bwd_parts(M);
+  if (workspace_bytes < (size_t)2 * parts * N * sizeof(float)) return IB_E_WORKSPACE;
+  const float* partial = reinterpret_cast<const float*>(workspace);
+  launch_segment_colsum<float>(partial, N, dgamma, N, 2 * parts, (int)N, parts, 0, accumulate, (N % 4 == 0), 2, parts,
+                               ib_s(stream), dbeta);
+  IB_CHECK_LAUNCH();
+  return IB_OK;
+}
+
+extern "C" int ib_segment_colsum(const void* x, int64_t ldx, float* out, int64_t ldo, void* out_bf16, int64_t ld_bf16,
+                                 int64_t M, int64_t N, int64_t seg, int mode, int accumulate, int dtype,
+                                 ib_stream_t stream) {
   if (!x || !out || M <= 0 || N <= 0 || seg <= 0 || ldx < N || ldo < N || (mode != 0 && mode != 1)) return IB_E_ARG;
+  if (out_bf16 && ld_bf16 < N) return IB_E_ARG;
   const int64_t nseg = (mode == 0) ? (M + seg - 1) / seg : (seg < M ? seg : M);
   if (nseg > 65535) return IB_E_UNSUPPORTED;
   hipStream_t s = ib_s(stream);
@@ -522,11 +542,11 @@ extern "C" int ib_segment_colsum(const void* x, int64_t ldx, float* out, int64_t
   if (dtype == IB_F32) {
     const int vec = (ldx % 4 == 0) && al(x, 16);
     launch_segment_colsum<float>((const float*)x, ldx, out, ldo, (int)M, (int)N, (int)seg, mode, accumulate, vec,
-                                 (int)nseg, rps, s);
+                                 (int)nseg, rps, s, nullptr, (bf16_t*)out_bf16, ld_bf16);
   } else if (dtype == IB_BF16) {
     const int vec = (ldx % 4 == 0) && al(x, 8);
     launch_segment_colsum<bf16_t>((const bf16_t*)x, ldx, out, ldo, (int)M, (int)N, (int)seg, mode, accumulate, vec,
-                                  (int)nseg, rps, s);
+                                  (int)nseg, rps, s, nullptr, (bf16_t*)out_bf16, ld_bf16);
   } else {
     return IB_E_DTYPE;
   }

@@ -190,7 +190,8 @@ class HipTrainer:
         ns = hip.OPT_NUM_STATES[opt_type]
         self.s1 = torch.zeros_like(flat) if ns >= 1 else None
         self.s2 = torch.zeros_like(flat) if ns >= 2 else None
-        self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)      # completed steps (device-resident)
+        self.ticket = torch.zeros(1, dtype=torch.int32, device=dev)        # exit-ticket word of the optimizer kernel
         self.steps_done = 0
         model.sync_shadow()
         model._shadow_fresh = True          # from here on the optimizer kernel keeps the shadow current
@@ -207,7 +208,7 @@ class HipTrainer:
         # ordered after / before the caller's current stream by events
         self.stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         from .plans import Branch
-        self._br_loss = Branch(dev, enabled=(self.world == 1))
+        self._br_loss = Branch(dev, enabled=(self.world == 1), name="loss")
         self._static: Dict[str, torch.Tensor] = {}
         self._rec: Optional[_Recorder] = None
         self._sig = None
@@ -289,9 +290,10 @@ class HipTrainer:
                 cut(-1)
             else:
                 self.buckets.finish()
-        hip.counter_add(self.step_dev, 1)
+        # self-counting optimizer launch: uses *step_dev + 1 and publishes it itself (no separate counter launch)
         hip.optim_step(self.opt_type, self.flat, self.grad, self.s1, self.s2, self.lr, step=0, step_dev=self.step_dev,
-                       grad_scale=1.0 / self.world, shadow=m._shadow if dt == torch.bfloat16 else None)
+                       ticket=self.ticket, grad_scale=1.0 / self.world,
+                       shadow=m._shadow if dt == torch.bfloat16 else None)
 
     def _stage(self, batch) -> Dict[str, torch.Tensor]:
         """copy the batch into the static input buffers the (captured) launch sequence reads"""

@@ -41,7 +41,8 @@ _SIGS = {
                                    _c.c_int, _vp]),
     "ib_linear_wgrad_workspace": (_sz, [_i64, _i64, _i64]),
     "ib_linear_wgrad": (_c.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _c.c_int, _vp, _sz, _i64, _i64, _i64, _c.c_int, _vp]),
-    "ib_segment_colsum": (_c.c_int, [_vp, _i64, _vp, _i64, _i64, _i64, _i64, _c.c_int, _c.c_int, _c.c_int, _vp]),
+    "ib_segment_colsum": (_c.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _c.c_int, _c.c_int, _c.c_int, _vp]),
+    "ib_layernorm_bwd_reduce": (_c.c_int, [_vp, _sz, _vp, _vp, _c.c_int, _i64, _i64, _vp]),
     "ib_layernorm_fwd": (_c.c_int, [_vp, _vp, _c.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _f32,
                                     _c.c_int, _vp]),
     "ib_layernorm_bwd_workspace": (_sz, [_i64, _i64]),
@@ -59,7 +60,7 @@ _SIGS = {
     "ib_mse_loss": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _sz, _i64, _c.c_int, _vp]),
     "ib_mse_loss_partial": (_c.c_int, [_vp, _vp, _vp, _vp, _sz, _i64, _c.c_int, _vp]),
     "ib_mse_loss_finalize": (_c.c_int, [_vp, _sz, _vp, _i64, _vp]),
-    "ib_optim_step": (_c.c_int, [_c.c_int, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _i32, _vp, _vp, _vp]),
+    "ib_optim_step": (_c.c_int, [_c.c_int, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _i32, _vp, _vp, _vp, _vp]),
     "ib_gather_rows": (_c.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _c.c_int, _vp]),
     "ib_q_sample": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _c.c_int, _vp]),
     "ib_ddim_step": (_c.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i64, _i64, _c.c_int, _vp]),
@@ -368,15 +369,20 @@ def linear_wgrad(dz, x, dw, workspace, accumulate=False):
     return dw
 
 
-def segment_colsum(x, out, seg, mode=0, accumulate=False):
+def segment_colsum(x, out, seg, mode=0, accumulate=False, out_bf16=None):
     dt = x.dtype
     M, N, ldx = _mat(x, "x", dt)
     S, No, ldo = _mat(out, "out", torch.float32)
     nseg = (M + seg - 1) // seg if mode == 0 else min(seg, M)
     if No != N or S < nseg:
         raise HipError(f"segment_colsum: out must be [{nseg}, {N}], got {tuple(out.shape)}")
-    _check(lib().ib_segment_colsum(_ptr(x), ldx, _ptr(out), ldo, M, N, int(seg), int(mode), int(accumulate),
-                                   dtype_code(dt), stream_ptr()), "ib_segment_colsum")
+    ldl = 0
+    if out_bf16 is not None:
+        Sl, Nl, ldl = _mat(out_bf16, "out_bf16", torch.bfloat16)
+        if Nl != N or Sl < nseg:
+            raise HipError("segment_colsum: out_bf16 shape mismatch")
+    _check(lib().ib_segment_colsum(_ptr(x), ldx, _ptr(out), ldo, _ptr(out_bf16), ldl, M, N, int(seg), int(mode),
+                                   int(accumulate), dtype_code(dt), stream_ptr()), "ib_segment_colsum")
     return out
 
 
@@ -432,7 +438,9 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, res=No
             (((dres, "dres"),) if dres is not None else ()):
         if _rows(t, n, dt) != (M, N):
             raise HipError(f"{n} shape mismatch")
-    for t, n in ((gamma, "gamma"), (dgamma, "dgamma"), (dbeta, "dbeta")):
+    if (dgamma is None) != (dbeta is None):
+        raise HipError("layernorm_bwd: dgamma and dbeta are given together or deferred together")
+    for t, n in ((gamma, "gamma"),) + (((dgamma, "dgamma"), (dbeta, "dbeta")) if dgamma is not None else ()):
         _req(t, n, torch.float32, 1)
         if t.numel() != N or not t.is_contiguous():
             raise HipError(f"{n} must be contiguous fp32 [N]")
@@ -449,6 +457,16 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, workspace, res=No
                                   _ptr(dx), _ptr(dres), _ptr(dgamma), _ptr(dbeta), int(accumulate), _ptr(workspace),
                                   wsb, ap, ald, aseg, M, N, dtype_code(dt), stream_ptr()), "ib_layernorm_bwd")
     return dx
+
+
+def layernorm_bwd_reduce(workspace, dgamma, dbeta, M, N, accumulate=False):
+    for t, n in ((dgamma, "dgamma"), (dbeta, "dbeta")):
+        _req(t, n, torch.float32, 1)
+        if t.numel() != N or not t.is_contiguous():
+            raise HipError(f"{n} must be contiguous fp32 [N]")
+    wsb = workspace.numel() * workspace.element_size()
+    _check(lib().ib_layernorm_bwd_reduce(_ptr(workspace), wsb, _ptr(dgamma), _ptr(dbeta), int(accumulate), int(M), int(N),
+                                         stream_ptr()), "ib_layernorm_bwd_reduce")
 
 
 # --------------------------------------------------------------------------------------------
@@ -635,7 +653,7 @@ def mse_loss_finalize(workspace, result, n):
 # --------------------------------------------------------------------------------------------
 # optimizer
 # --------------------------------------------------------------------------------------------
-def optim_step(opt: str, p, g, s1, s2, lr, step=1, step_dev=None, grad_scale=1.0, shadow=None):
+def optim_step(opt: str, p, g, s1, s2, lr, step=1, step_dev=None, grad_scale=1.0, shadow=None, ticket=None):
     _req(p, "p", torch.float32, 1)
     _req(g, "g", torch.float32, 1)
     n = p.numel()
@@ -652,8 +670,10 @@ def optim_step(opt: str, p, g, s1, s2, lr, step=1, step_dev=None, grad_scale=1.0
             raise HipError("shadow length mismatch")
     if step_dev is not None:
         _req(step_dev, "step_dev", torch.int32)
+    if ticket is not None:
+        _req(ticket, "ticket", torch.int32)
     _check(lib().ib_optim_step(OPT[opt], _ptr(p), _ptr(g), _ptr(s1), _ptr(s2), n, float(lr), float(grad_scale),
-                               int(step), _ptr(step_dev), _ptr(shadow), stream_ptr()), "ib_optim_step")
+                               int(step), _ptr(step_dev), _ptr(ticket), _ptr(shadow), stream_ptr()), "ib_optim_step")
 
 
 # --------------------------------------------------------------------------------------------

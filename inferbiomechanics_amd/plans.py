@@ -70,7 +70,11 @@ class Branch:
     themselves); under hipGraph capture the same event edges become a parallel branch of the graph.  Disabled
     (runs inline) off-GPU and when `on` is False."""
 
-    def __init__(self, device, enabled: bool = True):
+    def __init__(self, device, enabled: bool = True, name: str = ""):
+        import os
+        self.name = name
+        off = [n for n in os.environ.get("IB_NO_BRANCH", "").split(",") if n]
+        enabled = enabled and name not in off and "all" not in off
         self.on = enabled and torch.device(device).type == "cuda" and not hip._dry_run
         self.stream = torch.cuda.Stream(device=device) if self.on else None
         self._forks: List = []
@@ -189,7 +193,7 @@ class TransformerLayerPlan:
         self.ctx = None
         # the four weight-gradient GEMMs (+ bias sums) hang off the critical dgrad / LayerNorm / attention chain:
         # they run on this layer's side stream (each with its own slab workspace)
-        self.branch = Branch(device)
+        self.branch = Branch(device, name="layer")
         self.join_on_exit = True     # a parent plan sets this False and joins all layers once at the end
 
     def branches(self) -> List["Branch"]:
@@ -296,7 +300,6 @@ class TimeMLPPlan:
     def __init__(self, dtype, buf: Buffers, tag="tm"):
         self.dtype, self.buf, self.tag = dtype, buf, tag
         self.ctx = None
-        self.br = Branch(buf.device)     # backward: the output layer's weight/bias gradients beside the dgrad chain
 
     def forward(self, t: torch.Tensor, table: torch.Tensor, P: ParamSource) -> torch.Tensor:
         B = t.shape[0]
@@ -316,25 +319,35 @@ class TimeMLPPlan:
     def ready_order() -> List[str]:
         return ["time_mlp.2.weight", "time_mlp.2.bias", "time_mlp.0.weight", "time_mlp.0.bias"]
 
-    def backward(self, de32: torch.Tensor, P: ParamSource, accumulate=False):
-        s, u, zu = self.ctx
-        B = s.shape[0]
-        tg = self.tag
-        de = _as_dtype(self.buf, tg + ".de", de32, self.dtype)
+    def _de(self, de32: torch.Tensor, de_lp: Optional[torch.Tensor]) -> torch.Tensor:
+        if self.dtype == torch.float32:
+            return de32
+        return de_lp if de_lp is not None else _as_dtype(self.buf, self.tag + ".de", de32, self.dtype)
 
-        def out_layer_grads():
-            _wgrad(self.buf, de, u, P.g("time_mlp.2.weight"), accumulate, ws_tag=tg + ".ws2")
-            P.ready("time_mlp.2.weight")
-            _colsum(self.buf, tg + ".b2", de32, P.g("time_mlp.2.bias"), accumulate)
-            P.ready("time_mlp.2.bias")
-        self.br.run(out_layer_grads)
+    def backward_out_layer(self, de32, de_lp, P: ParamSource, accumulate=False):
+        """gradients of the output layer (time_mlp.2): independent of the dgrad chain below"""
+        s, u, zu = self.ctx
+        tg = self.tag
+        _wgrad(self.buf, self._de(de32, de_lp), u, P.g("time_mlp.2.weight"), accumulate, ws_tag=tg + ".ws2")
+        P.ready("time_mlp.2.weight")
+        _colsum(self.buf, tg + ".b2", de32, P.g("time_mlp.2.bias"), accumulate)
+        P.ready("time_mlp.2.bias")
+
+    def backward_hidden(self, de32, de_lp, P: ParamSource, accumulate=False):
+        s, u, zu = self.ctx
+        tg = self.tag
         du = self.buf.get(tg + ".du", u.shape, self.dtype)
-        hip.linear_dgrad(de, P.w("time_mlp.2.weight"), du, act_below="silu", aux=zu)
+        hip.linear_dgrad(self._de(de32, de_lp), P.w("time_mlp.2.weight"), du, act_below="silu", aux=zu)
         _wgrad(self.buf, du, s, P.g("time_mlp.0.weight"), accumulate, ws_tag=tg + ".ws0")
         P.ready("time_mlp.0.weight")
         _colsum(self.buf, tg + ".b1", du, P.g("time_mlp.0.bias"), accumulate)
         P.ready("time_mlp.0.bias")
-        self.br.join()
+
+    def backward(self, de32: torch.Tensor, P: ParamSource, accumulate=False, de_lp: Optional[torch.Tensor] = None):
+        """both halves on the current stream (callers that want them concurrent fork the halves as SIBLING
+        branches of the main stream: a fork nested inside a forked stream crashes hipStreamEndCapture)"""
+        self.backward_out_layer(de32, de_lp, P, accumulate)
+        self.backward_hidden(de32, de_lp, P, accumulate)
 
 
 class DenoiserMLPPlan:
@@ -352,13 +365,14 @@ class DenoiserMLPPlan:
         self.ctx = None
         # the trainer switches the branches off under data parallelism (gradient-bucket events are recorded on
         # ONE stream)
-        self.br_head = Branch(device)
-        self.br_blk = [Branch(device) for _ in self.hidden]
-        self.branch = Branch(device)            # time-MLP backward
-        self.br_tfwd = Branch(device)           # time-MLP forward (beside q_sample + the first block's GEMM)
+        self.br_head = Branch(device, name="head")
+        self.br_blk = [Branch(device, name="blk") for _ in self.hidden]
+        self.branch = Branch(device, name="time_bwd")   # time-MLP backward: hidden-layer chain
+        self.br_tout = Branch(device, name="time_out")  # time-MLP backward: output-layer gradients
+        self.br_tfwd = Branch(device, name="time_fwd")  # time-MLP forward (beside q_sample + the first block's GEMM)
 
     def branches(self) -> List[Branch]:
-        return [self.br_head, self.branch, self.br_tfwd, self.time.br] + self.br_blk
+        return [self.br_head, self.branch, self.br_tout, self.br_tfwd] + self.br_blk
 
     def forward(self, x, t: torch.Tensor, table: torch.Tensor, P: ParamSource,
                 out: Optional[torch.Tensor] = None, BT: Optional[Tuple[int, int]] = None) -> torch.Tensor:
@@ -404,8 +418,8 @@ class DenoiserMLPPlan:
         for i in range(len(self.hidden) - 1, 0, -1):
             o += [f"blocks.{i}.norm.weight", f"blocks.{i}.norm.bias", f"blocks.{i}.linear.weight",
                   f"blocks.{i}.linear.bias"]
-        return o + ["blocks.0.norm.weight", "blocks.0.norm.bias"] + TimeMLPPlan.ready_order() + \
-            ["blocks.0.linear.weight", "blocks.0.linear.bias"]
+        return o + TimeMLPPlan.ready_order() + ["blocks.0.norm.weight", "blocks.0.norm.bias",
+                                                "blocks.0.linear.weight", "blocks.0.linear.bias"]
 
     def backward(self, dout, P: ParamSource, accumulate=False):
         saved, hlast, B, T, e = self.ctx
@@ -421,35 +435,42 @@ class DenoiserMLPPlan:
         self.br_head.run(head_grads)
         dh = g("dm.dh_last", hlast.shape, dt)
         hip.linear_dgrad(dout, P.w("head.weight"), dh)
-        de32 = g("dm.de32", (B, sum(self.hidden)), torch.float32)
-        off = sum(self.hidden)
+        H = sum(self.hidden)
+        de32 = g("dm.de32", (B, H), torch.float32)
+        de_lp = g("dm.de_lp", (B, H), torch.bfloat16) if dt == torch.bfloat16 else None
+        off = H
         for i in range(len(self.hidden) - 1, -1, -1):
             hd = self.hidden[i]
             off -= hd
             hin, z, mu, rs = saved[i]
-            lnws = self.buf.bytes("ln.ws", hip.layernorm_bwd_workspace_bytes(M, hd))
+            # the LayerNorm parameter-gradient reduction is deferred to the block's side work (own workspace)
+            lnws = self.buf.bytes(f"dm.lnws{i}", hip.layernorm_bwd_workspace_bytes(M, hd))
             dz = g(f"dm.dz{i}", (M, hd), dt)
-            hip.layernorm_bwd(dh, z, P.v(f"blocks.{i}.norm.weight"), mu, rs, dz, P.g(f"blocks.{i}.norm.weight"),
-                              P.g(f"blocks.{i}.norm.bias"), lnws, act="silu", accumulate=accumulate,
+            hip.layernorm_bwd(dh, z, P.v(f"blocks.{i}.norm.weight"), mu, rs, dz, None, None, lnws, act="silu",
                               add_div=e[:, off:off + hd], seg=T)
-            P.ready(f"blocks.{i}.norm.weight"); P.ready(f"blocks.{i}.norm.bias")
             sl = de32[:, off:off + hd]
 
-            def blk_grads(i=i, dz=dz, hin=hin, sl=sl):
+            def blk_grads(i=i, dz=dz, hin=hin, sl=sl, lnws=lnws, hd=hd):
+                hip.layernorm_bwd_reduce(lnws, P.g(f"blocks.{i}.norm.weight"), P.g(f"blocks.{i}.norm.bias"), M, hd,
+                                         accumulate=accumulate)
+                P.ready(f"blocks.{i}.norm.weight"); P.ready(f"blocks.{i}.norm.bias")
                 _wgrad(self.buf, dz, hin, P.g(f"blocks.{i}.linear.weight"), accumulate, ws_tag=f"dm.ws{i}")
                 P.ready(f"blocks.{i}.linear.weight")
                 _colsum(self.buf, f"dm.b{i}", sl, P.g(f"blocks.{i}.linear.bias"), accumulate)
                 P.ready(f"blocks.{i}.linear.bias")
 
-            # per-window sums of dz: the time-embedding gradient AND (summed over windows) the bias gradient
-            hip.segment_colsum(dz, sl, seg=T, mode=0)
+            # per-window sums of dz: the time-embedding gradient AND (summed over windows) the bias gradient;
+            # the bf16 copy is the time-MLP backward's GEMM operand
+            hip.segment_colsum(dz, sl, seg=T, mode=0, out_bf16=None if de_lp is None else de_lp[:, off:off + hd])
             if i > 0:
                 self.br_blk[i].run(blk_grads)
                 dh = g(f"dm.dh{i - 1}", hin.shape, dt)
                 hip.linear_dgrad(dz, P.w(f"blocks.{i}.linear.weight"), dh)
             else:
-                # de32 is complete: the time-MLP backward forks off, block 0's weight gradient stays on the main stream
-                self.branch.run(lambda: self.time.backward(de32, P, accumulate))
+                # de32 is complete: the two halves of the time-MLP backward fork off as siblings; block 0's own
+                # gradients stay on the main stream
+                self.br_tout.run(lambda: self.time.backward_out_layer(de32, de_lp, P, accumulate))
+                self.branch.run(lambda: self.time.backward_hidden(de32, de_lp, P, accumulate))
                 blk_grads()
         for b in self.branches():
             b.join()

@@ -26,7 +26,7 @@ def test_null_arguments_return_error_codes_not_crashes():
     from inferbiomechanics_amd import hip
     lib = hip.lib()
     assert lib.ib_linear_fwd(None, 0, None, 0, None, None, 0, None, 0, 0, 0, None, 0, None, 0, 4, 4, 4, 0, None) == -1
-    assert lib.ib_optim_step(9, None, None, None, None, 0, 0.0, 1.0, 1, None, None, None) == -1
+    assert lib.ib_optim_step(9, None, None, None, None, 0, 0.0, 1.0, 1, None, None, None, None) == -1
     assert lib.ib_linear_wgrad_workspace(12800, 512, 512) > 0
     assert lib.ib_linear_wgrad_workspace(4, 8, 8) == 0
 

@@ -379,3 +379,53 @@ def test_layernorm_with_per_window_add(hip, dtype):
     close(dx, xd.grad, 1e-4 if dtype == torch.float32 else 3e-2, "ln(+e) dx")
     close(dg, gd.grad, 1e-4 if dtype == torch.float32 else 2e-2, "ln(+e) dgamma")
     close(db, bd.grad, 1e-4 if dtype == torch.float32 else 2e-2, "ln(+e) dbeta")
+
+
+@pytest.mark.parametrize("opt", ["adam", "rmsprop"])
+def test_optimizer_self_counting_mode(hip, golden_dir, opt):
+    """ticket mode: the kernel uses *step_dev + 1 and its last-exiting block publishes it (graph-replay form
+    without a separate counter launch); must follow the same torch.optim trajectory"""
+    import os
+    g = np.load(os.path.join(golden_dir, "optim_traj.npz"))
+    n = 257
+    p = R.det_fill((n,), 3, 0.5).float().to(DEV)
+    s1, s2 = torch.zeros_like(p), torch.zeros_like(p)
+    ctr = torch.zeros(1, dtype=torch.int32, device=DEV)
+    tick = torch.zeros(1, dtype=torch.int32, device=DEV)
+    for s in range(4):
+        grad = R.det_fill((n,), 20 + s, 0.3 * (s + 1)).float().to(DEV)
+        hip.optim_step(opt, p, grad, s1, s2, lr=1e-2, step=0, step_dev=ctr, ticket=tick)
+        close(p, torch.from_numpy(g[opt][s]), 2e-5, f"{opt} self-counting step {s + 1}")
+        assert int(ctr.cpu()) == s + 1 and int(tick.cpu()) == 0
+    # many blocks: the ticket logic must hold with a multi-block grid
+    big = torch.zeros(300_000, device=DEV)
+    gb = torch.ones_like(big)
+    sb = torch.zeros_like(big)
+    ctr.zero_()
+    for s in range(3):
+        hip.optim_step("adagrad", big, gb, sb, None, lr=1.0, step=0, step_dev=ctr, ticket=tick)
+    assert int(ctr.cpu()) == 3 and int(tick.cpu()) == 0
+    close(big[:5], -torch.tensor([1.0 + 2 ** -0.5 + 3 ** -0.5] * 5), 1e-5, "adagrad 3 steps")
+
+
+def test_segment_colsum_bf16_side_output_and_deferred_ln_reduce(hip):
+    B, T, N = 4, 9, 64
+    x = rnd((B * T, N), 1, 1.0, torch.bfloat16).to(DEV)
+    out = torch.zeros(B, N, dtype=torch.float32, device=DEV)
+    lp = torch.zeros(B, 2 * N, dtype=torch.bfloat16, device=DEV)
+    hip.segment_colsum(x, out, seg=T, mode=0, out_bf16=lp[:, N:])
+    assert torch.equal(lp[:, N:].cpu(), out.cpu().to(torch.bfloat16)) and float(lp[:, :N].abs().max()) == 0.0
+    # deferred LayerNorm parameter-gradient reduction == immediate one
+    M = 40
+    xx, dy = rnd((M, N), 2, 1.0, torch.float32).to(DEV), rnd((M, N), 3, 1.0, torch.float32).to(DEV)
+    gm, bt = torch.ones(N, device=DEV), torch.zeros(N, device=DEV)
+    y = torch.empty_like(xx)
+    mu, rs = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    hip.layernorm_fwd(xx, gm, bt, y, mu, rs)
+    ws = torch.empty(hip.layernorm_bwd_workspace_bytes(M, N), dtype=torch.uint8, device=DEV)
+    dx1, dx2 = torch.empty_like(xx), torch.empty_like(xx)
+    dg1, db1, dg2, db2 = (torch.empty(N, device=DEV) for _ in range(4))
+    hip.layernorm_bwd(dy, xx, gm, mu, rs, dx1, dg1, db1, ws)
+    hip.layernorm_bwd(dy, xx, gm, mu, rs, dx2, None, None, ws)
+    hip.layernorm_bwd_reduce(ws, dg2, db2, M, N)
+    assert torch.equal(dx1, dx2) and torch.equal(dg1, dg2) and torch.equal(db1, db2)
