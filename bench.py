@@ -241,8 +241,12 @@ def main():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    selftest = os.environ.get("IB_DDP_SELFTEST") == "1"      # 1-rank run of the whole RCCL / bucket / segment path
+    if world > 1 or selftest:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
     from inferbiomechanics_amd import hip
@@ -256,7 +260,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 or selftest:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -285,7 +289,8 @@ def main():
             "config": {"workload": f"{a.workload}_D{D}_B{B}_{a.dtype} (BASELINE.json configs[1])" if kind == "mlp"
                        else f"{a.workload}_D{D}_B{B}_{a.dtype}",
                        "per_gpu_batch": B, "global_batch": B * world, "window": T, "feat": D,
-                       "optimizer": a.opt_type, "hipgraph": not a.no_graph, "parallelism": f"dp{world}"},
+                       "optimizer": a.opt_type, "hipgraph": not a.no_graph, "parallelism": f"dp{world}",
+                       "grad_buckets": len(trainer.buckets.ranges) if trainer.ddp else 0},
             "final_loss": round(loss, 6),
             "train_tflops": round(value * train_flops_per_window(kind, T, D) / 1e12, 2),
         }
@@ -298,7 +303,7 @@ def main():
         if not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(kind, T, D, B)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or selftest:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -39,12 +39,15 @@ class GradBuckets:
     slice has been produced.  The division by world_size is folded into the optimizer kernel."""
 
     def __init__(self, flat_grad: torch.Tensor, layout: "OrderedDict[str, Tuple[int, int]]", bucket_bytes: int,
-                 group=None):
+                 group=None, active: Optional[bool] = None):
         self.flat = flat_grad
         self.group = group
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        # `active`: collectives are issued.  Defaults to world > 1; the 1-rank self-test (IB_DDP_SELFTEST=1 with
+        # an initialised process group) forces it so the whole comm path runs on a single GPU.
+        self.active = (self.world > 1) if active is None else bool(active)
         self.on_gpu = flat_grad.is_cuda
-        self.comm_stream = torch.cuda.Stream(device=flat_grad.device) if (self.on_gpu and self.world > 1) else None
+        self.comm_stream = torch.cuda.Stream(device=flat_grad.device) if (self.on_gpu and self.active) else None
         names = list(layout.keys())
         self.bucket_of: Dict[str, int] = {}
         self.ranges: List[Tuple[int, int]] = []
@@ -76,7 +79,7 @@ class GradBuckets:
         return b if self._pending[b] == 0 else None
 
     def launch(self, b: int):
-        if self.world == 1:
+        if not self.active:
             return
         lo, hi = self.ranges[b]
         t = self.flat[lo:hi]
@@ -159,11 +162,15 @@ class HipTrainer:
         self.model, self.task, self.opt_type, self.lr = model, task, opt_type, lr
         self.group = group
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        import os
+        # data-parallel machinery on: several ranks, or the 1-rank self-test of the comm path
+        self.ddp = self.world > 1 or (os.environ.get("IB_DDP_SELFTEST") == "1" and dist.is_available()
+                                      and dist.is_initialized())
         self.use_graph = use_graph and not hip._dry_run
         dev = next(model.parameters()).device
         self.device = dev
         self.plan = self._plan_for(dev)
-        if self.world > 1 and hasattr(self.plan, "branches"):
+        if self.ddp and hasattr(self.plan, "branches"):
             for br in self.plan.branches():
                 br.on = False               # gradient-bucket events are recorded on one stream only
         # ---- flat buffers in gradient-ready order
@@ -197,7 +204,7 @@ class HipTrainer:
         model._shadow_fresh = True          # from here on the optimizer kernel keeps the shadow current
         self._gviews = {k: params[k].grad for k in order}
         self._params = params
-        self.buckets = GradBuckets(self.grad, self.layout, int(bucket_mb * (1 << 20)), group)
+        self.buckets = GradBuckets(self.grad, self.layout, int(bucket_mb * (1 << 20)), group, active=self.ddp)
         self.result = torch.zeros(64, dtype=torch.float32, device=dev)
         self.comp_w = None
         if task == "regression":
@@ -208,7 +215,7 @@ class HipTrainer:
         # ordered after / before the caller's current stream by events
         self.stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         from .plans import Branch
-        self._br_loss = Branch(dev, enabled=(self.world == 1), name="loss")
+        self._br_loss = Branch(dev, enabled=not self.ddp, name="loss")
         self._static: Dict[str, torch.Tensor] = {}
         self._rec: Optional[_Recorder] = None
         self._sig = None
@@ -235,7 +242,7 @@ class HipTrainer:
         def ready(name: str):
             self._ready_seen.append(name)
             b = self.buckets.mark_ready(name)
-            if b is not None and self.world > 1:
+            if b is not None and self.ddp:
                 if cut is not None:
                     cut(b)
                 else:
@@ -285,7 +292,7 @@ class HipTrainer:
             ws = plan.buf.bytes("tr.rl", hip.regression_loss_workspace_bytes(B, F))
             hip.regression_loss(outs, labs, self.comp_w, self.result, ws, grads=grads, threshold=10.0)
             plan.backward(G, P, accumulate=False)
-        if self.world > 1:
+        if self.ddp:
             if cut is not None:
                 cut(-1)
             else:
@@ -346,7 +353,7 @@ class HipTrainer:
             def cut(b: int):
                 rec.cut((lambda: self.buckets.launch(b)) if b >= 0 else self.buckets.finish)
             rec.begin()
-            self._launches(st, cut=cut if self.world > 1 else None)
+            self._launches(st, cut=cut if self.ddp else None)
             rec.end()
             self._rec = rec
             rec.replay()                        # the capture itself executed nothing

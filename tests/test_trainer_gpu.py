@@ -1,0 +1,145 @@
+"""The fused training step (engine.HipTrainer: flat buffers, forked branches, hipGraph replay, self-counting
+optimizer) against the CPU oracle's training trajectory on identical seeded batches: per-step losses and the final
+parameters must match ("matched diffusion loss", north_star).  fp32 mode <= 1e-3 relative; bf16 mode follows the
+fp32 loss curve within 2 %.  Also: graph replay == eager launches bit-for-bit, regression task vs the oracle."""
+import argparse
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ref_cpu as R  # noqa: E402
+from oracle.fixture_inputs import det_state, ff_inputs, ff_labels  # noqa: E402
+
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+
+
+def load_det(module):
+    sd = module.state_dict()
+    new = det_state({k: tuple(v.shape) for k, v in sd.items()})
+    module.load_state_dict({k: v.to(sd[k].dtype) for k, v in new.items()})
+
+
+def batches(n, B, T, D, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return [(torch.randn(B, T, D, generator=g), torch.randint(0, 1000, (B,), generator=g), torch.randn(B, T, D, generator=g))
+            for _ in range(n)]
+
+
+def oracle_run(model, bs, hidden, opt, lr, steps):
+    p = {k: v.detach().cpu().double().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    st = {k: R.optim_init_state(opt, v.detach()) for k, v in p.items()}
+    tabs = R.schedule_tables()
+    losses = []
+    for i in range(steps):
+        x0, t, eps = bs[i % len(bs)]
+        for v in p.values():
+            v.grad = None
+        xt = R.q_sample(x0.double(), t, eps.double(), tabs)
+        loss = R.eps_mse(R.denoiser_mlp_forward(p, xt, t, hidden, temb_dim=model.temb_dim), eps.double())
+        loss.backward()
+        losses.append(float(loss))
+        with torch.no_grad():
+            for k, v in p.items():
+                v.copy_(R.optim_step(opt, v, v.grad, st[k], lr, i + 1))
+    return losses, {k: v.detach() for k, v in p.items()}
+
+
+@pytest.mark.parametrize("opt", ["rmsprop", "adam"])
+def test_fused_trainer_matches_oracle_trajectory_fp32(opt):
+    from inferbiomechanics_amd.engine import HipTrainer
+    from inferbiomechanics_amd.models.DiffusionDenoisers import DiffusionMLP
+    hidden, B, T, D, steps, lr = [64, 96], 8, 10, 44, 8, 1e-3
+    model = DiffusionMLP(D, hidden, temb_dim=32, temb_hidden=48, device=DEV)
+    load_det(model)
+    bs = batches(4, B, T, D)
+    ref_losses, ref_p = oracle_run(model, bs, hidden, opt, lr, steps)
+    tr = HipTrainer(model, "diffusion", opt, lr, use_graph=True)
+    got = []
+    for i in range(steps):                       # steps 0,1 eager, step 2 captured, 3.. replayed
+        x0, t, eps = bs[i % len(bs)]
+        tr.step((x0.to(DEV), t.to(DEV), eps.to(DEV)))
+        got.append(tr.loss_value())
+    assert tr._rec is not None, "the step was never captured into a hipGraph"
+    for a, e in zip(got, ref_losses):
+        assert abs(a - e) <= 1e-3 * abs(e), (got, ref_losses)
+    assert int(tr.step_dev.cpu()) == steps
+    for k, v in model.state_dict().items():
+        e = ref_p[k]
+        err = (v.detach().cpu().double() - e).abs().max().item()
+        assert err <= 2e-3 * max(e.abs().max().item(), 1e-6) + 2e-5, (k, err)
+
+
+def test_graph_replay_is_bitwise_equal_to_eager_launches():
+    from inferbiomechanics_amd.engine import HipTrainer
+    from inferbiomechanics_amd.models.DiffusionDenoisers import DiffusionMLP
+    bs = batches(3, 6, 10, 44, seed=3)
+    finals = []
+    for use_graph in (False, True):
+        model = DiffusionMLP(44, [64, 64], temb_dim=32, temb_hidden=48, device=DEV, compute_dtype=torch.bfloat16)
+        load_det(model)
+        tr = HipTrainer(model, "diffusion", "rmsprop", 1e-3, use_graph=use_graph)
+        for i in range(7):
+            x0, t, eps = bs[i % 3]
+            tr.step((x0.to(DEV, torch.bfloat16), t.to(DEV), eps.to(DEV, torch.bfloat16)))
+        torch.cuda.synchronize()
+        finals.append((tr.flat.clone(), tr.loss_value()))
+    assert torch.equal(finals[0][0], finals[1][0]) and finals[0][1] == finals[1][1]
+
+
+def test_bf16_trainer_tracks_fp32_loss_curve():
+    from inferbiomechanics_amd.engine import HipTrainer
+    from inferbiomechanics_amd.models.DiffusionDenoisers import DiffusionMLP
+    bs = batches(8, 32, 10, 44, seed=5)
+    curves = {}
+    for dt in (torch.float32, torch.bfloat16):
+        model = DiffusionMLP(44, [64, 64], temb_dim=32, temb_hidden=48, device=DEV, compute_dtype=dt)
+        load_det(model)
+        tr = HipTrainer(model, "diffusion", "rmsprop", 1e-3)
+        c = []
+        for i in range(24):
+            x0, t, eps = bs[i % 8]
+            tr.step((x0.to(DEV, dt), t.to(DEV), eps.to(DEV, dt)))
+            c.append(tr.loss_value())
+        curves[dt] = c
+    for a, b in zip(curves[torch.float32], curves[torch.bfloat16]):
+        assert abs(a - b) <= 0.02 * abs(a), (curves[torch.float32], curves[torch.bfloat16])
+    assert curves[torch.float32][-1] < curves[torch.float32][0]          # it learns
+
+
+def test_regression_trainer_matches_oracle():
+    from inferbiomechanics_amd.engine import HipTrainer
+    from inferbiomechanics_amd.models.FeedForwardRegressionBaseline import FeedForwardBaseline
+    args = argparse.Namespace(predict_grf_components=list(range(6)), predict_cop_components=list(range(6)),
+                              predict_moment_components=list(range(6)), predict_wrench_components=list(range(12)))
+    model = FeedForwardBaseline(23, 2, 50, "all_frames", "sigmoid", 5, 10, hidden_dims=[64, 48], device=DEV)
+    load_det(model)
+    inputs, labels = ff_inputs(6, 10, 23, 5), ff_labels(6, 10)
+    p = {k: v.detach().cpu().double().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    st = {k: R.optim_init_state("rmsprop", v.detach()) for k, v in p.items()}
+    ref = []
+    for i in range(5):
+        for v in p.values():
+            v.grad = None
+        layers = [(p[f"net.{2 * j}.weight"], p[f"net.{2 * j}.bias"]) for j in range(3)]
+        out = R.feedforward_forward(layers, {k: v.double() for k, v in inputs.items()}, "sigmoid", 10)
+        loss, _, _ = R.regression_loss(out, {k: v.double() for k, v in labels.items()}, range(6), range(6), range(6), range(12))
+        loss.backward()
+        ref.append(float(loss))
+        with torch.no_grad():
+            for k, v in p.items():
+                v.copy_(R.optim_step("rmsprop", v, v.grad, st[k], 1e-3, i + 1))
+    tr = HipTrainer(model, "regression", "rmsprop", 1e-3, args=args)
+    got = []
+    for i in range(5):
+        tr.step(({k: v.to(DEV) for k, v in inputs.items()}, {k: v.to(DEV) for k, v in labels.items()}))
+        got.append(tr.loss_value())
+    for a, e in zip(got, ref):
+        assert abs(a - e) <= 1e-3 * abs(e), (got, ref)
