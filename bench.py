@@ -229,6 +229,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ddim", action="store_true")
     ap.add_argument("--bucket-mb", type=float, default=4.0)
+    ap.add_argument("--overlap-comm", default="auto", choices=["auto", "on", "off"],
+                    help="data-parallel policy: all-reduce buckets during the backward (on) or once after it (off)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -255,7 +257,8 @@ def main():
     kind, T, D, B = WORKLOADS[a.workload]
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     model = build_model(kind, T, D, dtype, dev)
-    trainer = HipTrainer(model, "diffusion", a.opt_type, 1e-4, use_graph=not a.no_graph, bucket_mb=a.bucket_mb)
+    trainer = HipTrainer(model, "diffusion", a.opt_type, 1e-4, use_graph=not a.no_graph, bucket_mb=a.bucket_mb,
+                         overlap_comm={"auto": None, "on": True, "off": False}[a.overlap_comm])
     batches = make_batches(16, B, T, D, dtype, dev, seed=rank)
 
     def sync():
@@ -290,7 +293,8 @@ def main():
                        else f"{a.workload}_D{D}_B{B}_{a.dtype}",
                        "per_gpu_batch": B, "global_batch": B * world, "window": T, "feat": D,
                        "optimizer": a.opt_type, "hipgraph": not a.no_graph, "parallelism": f"dp{world}",
-                       "grad_buckets": len(trainer.buckets.ranges) if trainer.ddp else 0},
+                       "grad_buckets": len(trainer.buckets.ranges) if trainer.ddp else 0,
+                       "overlap_comm": bool(trainer.overlap_comm)},
             "final_loss": round(loss, 6),
             "train_tflops": round(value * train_flops_per_window(kind, T, D) / 1e12, 2),
         }

@@ -154,7 +154,7 @@ class HipTrainer:
     """
 
     def __init__(self, model: HipModule, task: str, opt_type: str = "rmsprop", lr: float = 1e-4, args=None,
-                 group=None, bucket_mb: float = 4.0, use_graph: bool = True):
+                 group=None, bucket_mb: float = 4.0, use_graph: bool = True, overlap_comm: Optional[bool] = None):
         if task not in ("diffusion", "regression"):
             raise ValueError(task)
         if opt_type not in hip.OPT:
@@ -170,7 +170,13 @@ class HipTrainer:
         dev = next(model.parameters()).device
         self.device = dev
         self.plan = self._plan_for(dev)
-        if self.ddp and hasattr(self.plan, "branches"):
+        # Data-parallel policy.  Small models (gradients < 16 MiB, e.g. the MLP denoiser's 4.7 MB): the step is
+        # latency-bound, the forked branches are worth more than comm/backward overlap -> branches stay ON and the
+        # whole flat gradient is all-reduced in ONE call after the backward.  Large models (transformer: 52 MB):
+        # buckets are all-reduced while the backward is still running (events on the main stream), branches OFF.
+        nparam_bytes = sum(p.numel() for p in model.parameters()) * 4
+        self.overlap_comm = self.ddp and (nparam_bytes >= (16 << 20) if overlap_comm is None else bool(overlap_comm))
+        if self.overlap_comm and hasattr(self.plan, "branches"):
             for br in self.plan.branches():
                 br.on = False               # gradient-bucket events are recorded on one stream only
         # ---- flat buffers in gradient-ready order
@@ -204,7 +210,8 @@ class HipTrainer:
         model._shadow_fresh = True          # from here on the optimizer kernel keeps the shadow current
         self._gviews = {k: params[k].grad for k in order}
         self._params = params
-        self.buckets = GradBuckets(self.grad, self.layout, int(bucket_mb * (1 << 20)), group, active=self.ddp)
+        self.buckets = GradBuckets(self.grad, self.layout,
+                                   int(bucket_mb * (1 << 20)) if self.overlap_comm else (1 << 62), group, active=self.ddp)
         self.result = torch.zeros(64, dtype=torch.float32, device=dev)
         self.comp_w = None
         if task == "regression":
@@ -215,7 +222,7 @@ class HipTrainer:
         # ordered after / before the caller's current stream by events
         self.stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         from .plans import Branch
-        self._br_loss = Branch(dev, enabled=not self.ddp, name="loss")
+        self._br_loss = Branch(dev, enabled=not self.overlap_comm, name="loss")
         self._static: Dict[str, torch.Tensor] = {}
         self._rec: Optional[_Recorder] = None
         self._sig = None
@@ -242,7 +249,7 @@ class HipTrainer:
         def ready(name: str):
             self._ready_seen.append(name)
             b = self.buckets.mark_ready(name)
-            if b is not None and self.ddp:
+            if b is not None and self.overlap_comm:
                 if cut is not None:
                     cut(b)
                 else:
@@ -294,8 +301,10 @@ class HipTrainer:
             plan.backward(G, P, accumulate=False)
         if self.ddp:
             if cut is not None:
-                cut(-1)
+                cut(-1 if self.overlap_comm else -2)
             else:
+                if not self.overlap_comm:
+                    self.buckets.launch(0)           # one bucket = the whole flat gradient, after all joins
                 self.buckets.finish()
         # self-counting optimizer launch: uses *step_dev + 1 and publishes it itself (no separate counter launch)
         hip.optim_step(self.opt_type, self.flat, self.grad, self.s1, self.s2, self.lr, step=0, step_dev=self.step_dev,
@@ -351,7 +360,12 @@ class HipTrainer:
             rec = _Recorder()
 
             def cut(b: int):
-                rec.cut((lambda: self.buckets.launch(b)) if b >= 0 else self.buckets.finish)
+                if b >= 0:
+                    rec.cut(lambda: self.buckets.launch(b))
+                elif b == -1:
+                    rec.cut(self.buckets.finish)
+                else:
+                    rec.cut(lambda: (self.buckets.launch(0), self.buckets.finish()))
             rec.begin()
             self._launches(st, cut=cut if self.ddp else None)
             rec.end()

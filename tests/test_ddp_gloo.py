@@ -59,16 +59,18 @@ def _worker(rank, world, port, q):
         hip.set_dry_run(True)
         torch.manual_seed(rank)             # different init per rank -> must be equalised by the broadcast
         m = DiffusionMLP(12, [16, 24], temb_dim=8, temb_hidden=16)
-        tr = HipTrainer(m, "diffusion", "adam", 1e-3, bucket_mb=0.001)
-        assert tr.world == 2 and len(tr.buckets.ranges) > 1
-        ref = tr.flat.clone()
-        dist.broadcast(ref, src=0)
-        assert torch.equal(ref, tr.flat)
-        for _ in range(3):
-            tr.grad.fill_(float(rank + 1))
-            tr.step((torch.randn(2, 5, 12), torch.tensor([1, 2]), torch.randn(2, 5, 12)))
-            assert tr.buckets._works == [] and all(v == 0 for v in tr.buckets._pending)
-            assert torch.all(tr.grad == 3.0)          # dry-run kernels write nothing: the SUM of the fills remains
+        for overlap in (True, False):      # large-model policy (bucket overlap) / small-model policy (one all-reduce)
+            tr = HipTrainer(m, "diffusion", "adam", 1e-3, bucket_mb=0.001, overlap_comm=overlap)
+            assert tr.world == 2 and tr.ddp and tr.overlap_comm == overlap
+            assert (len(tr.buckets.ranges) > 1) == overlap
+            ref = tr.flat.clone()
+            dist.broadcast(ref, src=0)
+            assert torch.equal(ref, tr.flat)
+            for _ in range(3):
+                tr.grad.fill_(float(rank + 1))
+                tr.step((torch.randn(2, 5, 12), torch.tensor([1, 2]), torch.randn(2, 5, 12)))
+                assert tr.buckets._works == [] and all(v == 0 for v in tr.buckets._pending)
+                assert torch.all(tr.grad == 3.0)      # dry-run kernels write nothing: the SUM of the fills remains
         hip.set_dry_run(False)
         dist.barrier()
         dist.destroy_process_group()
