@@ -132,8 +132,9 @@ int ib_mse_loss(const void* pred, const void* target, void* dpred, float* result
                 size_t workspace_bytes, int64_t n, int dtype, ib_stream_t stream);
 /* the same in two halves, so the scalar reduction can run off the critical path (a forked stream): the first
  * writes dpred and the per-block partial sums into `workspace`, the second reduces them into result[0]. */
-int ib_mse_loss_partial(const void* pred, const void* target, void* dpred, void* workspace, size_t workspace_bytes,
-                        int64_t n, int dtype, ib_stream_t stream);
+int ib_mse_loss_partial(const void* pred, int64_t ld_pred, const void* target, void* dpred, int64_t ld_dpred,
+                        void* workspace, size_t workspace_bytes, int64_t rows, int64_t cols, int dtype,
+                        ib_stream_t stream);   /* pred / dpred: [rows, cols] with leading dimensions; target contiguous */
 int ib_mse_loss_finalize(const void* workspace, size_t workspace_bytes, float* result, int64_t n, ib_stream_t stream);
 
 /* ---- optimizer step: torch.optim.{SGD,Adam,RMSprop,Adagrad,Adadelta,Adamax}(lr) defaults,
@@ -152,10 +153,11 @@ int ib_optim_step(int opt, float* p, const float* g, float* s1, float* s2, int64
  * cast once).  idx int64. */
 int ib_gather_rows(const float* table, const int64_t* idx, void* out, int64_t B, int64_t dim,
                    int64_t table_rows, int dtype_out, ib_stream_t stream);
-/* x_t[b,:] = sqrt_ab[t[b]] * x0[b,:] + sqrt_1mab[t[b]] * eps[b,:]; per = T*D elements per window */
+/* x_t[b,f,:] = sqrt_ab[t[b]] * x0[b,f,:] + sqrt_1mab[t[b]] * eps[b,f,:]; x0 / eps contiguous [B,T,D];
+ * x_t is [B*T, D] with leading dimension ld_xt >= D (a 16-byte-aligned row pitch for D = 300). */
 int ib_q_sample(const void* x0, const void* eps, const int64_t* t, const float* sqrt_ab,
-                const float* sqrt_1mab, void* x_t, int64_t B, int64_t per, int64_t table_rows,
-                int dtype, ib_stream_t stream);
+                const float* sqrt_1mab, void* x_t, int64_t ld_xt, int64_t B, int64_t T, int64_t D,
+                int64_t table_rows, int dtype, ib_stream_t stream);
 /* x <- coef[s][0] * x + coef[s][1] * eps with s = *step_dev (or `step` if step_dev NULL).
  * Also writes t_out[b] = timesteps[s+1] (the NEXT step's timestep, if t_out given) so a captured
  * single-step graph can be replayed; ib_counter_add advances the counter. */

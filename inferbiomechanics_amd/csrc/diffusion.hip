@@ -45,22 +45,37 @@ __device__ __forceinline__ void stv(T* p, const float (&v)[V]) {
   }
 }
 
+// rows = B*T tokens, cols = D features; 4 consecutive columns per thread (8 B bf16 / 16 B fp32).  x_t may have a
+// padded leading dimension (the trainer keeps D = 300 activations at ld = 304 so every row starts 16-byte aligned).
 template <typename T, int V>
 __global__ void q_sample_kernel(const T* __restrict__ x0, const T* __restrict__ eps, const int64_t* __restrict__ t,
                                 const float* __restrict__ sqrt_ab, const float* __restrict__ sqrt_1mab, T* __restrict__ xt,
-                                int64_t B, int64_t per, int64_t table_rows) {
-  const int64_t n = B * per / V;
+                                int64_t ld_xt, int64_t rows, int64_t rows_per_window, int64_t cols, int64_t table_rows) {
+  const int64_t cv = cols / V;
+  const int64_t n = rows * cv;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t b = (i * V) / per;
-    int64_t r = t[b];
-    r = r < 0 ? 0 : (r >= table_rows ? table_rows - 1 : r);
-    const float a = sqrt_ab[r], s = sqrt_1mab[r];
-    float x[V], e[V], o[V];
-    ldv<T, V>(x0 + i * V, x);
-    ldv<T, V>(eps + i * V, e);
+    const int64_t r = i / cv, c = (i % cv) * V;
+    int64_t k = t[r / rows_per_window];
+    k = k < 0 ? 0 : (k >= table_rows ? table_rows - 1 : k);
+    const float a = sqrt_ab[k], s = sqrt_1mab[k];
+    if constexpr (V == 4) {
+      float x[4], e[4];
+      if constexpr (sizeof(T) == 2) {
+        bf16x4_t tx = *reinterpret_cast<const bf16x4_t*>(x0 + r * cols + c), te = *reinterpret_cast<const bf16x4_t*>(eps + r * cols + c);
 #pragma unroll
-    for (int k = 0; k < V; ++k) o[k] = a * x[k] + s * e[k];
-    stv<T, V>(xt + i * V, o);
+        for (int j = 0; j < 4; ++j) { x[j] = (float)tx[j]; e[j] = (float)te[j]; }
+        bf16x4_t o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (bf16_t)(a * x[j] + s * e[j]);
+        *reinterpret_cast<bf16x4_t*>(xt + r * ld_xt + c) = o;
+      } else {
+        const float4 tx = *reinterpret_cast<const float4*>(x0 + r * cols + c), te = *reinterpret_cast<const float4*>(eps + r * cols + c);
+        *reinterpret_cast<float4*>(xt + r * ld_xt + c) =
+            make_float4(a * tx.x + s * te.x, a * tx.y + s * te.y, a * tx.z + s * te.z, a * tx.w + s * te.w);
+      }
+    } else {
+      xt[r * ld_xt + c] = ib_from_f32<T>(a * ib_to_f32(x0[r * cols + c]) + s * ib_to_f32(eps[r * cols + c]));
+    }
   }
 }
 
@@ -109,18 +124,22 @@ extern "C" int ib_gather_rows(const float* table, const int64_t* idx, void* out,
 }
 
 extern "C" int ib_q_sample(const void* x0, const void* eps, const int64_t* t, const float* sqrt_ab, const float* sqrt_1mab,
-                           void* x_t, int64_t B, int64_t per, int64_t table_rows, int dtype, ib_stream_t stream) {
-  if (!x0 || !eps || !t || !sqrt_ab || !sqrt_1mab || !x_t || B <= 0 || per <= 0 || table_rows <= 0) return IB_E_ARG;
-  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) % 16) == 0; };
-  const bool v8 = (per % 8 == 0) && al16(x0) && al16(eps) && al16(x_t);
-  const int grid = ib_grid_1d(B * per / (v8 ? 8 : 1), 256);
+                           void* x_t, int64_t ld_xt, int64_t B, int64_t T, int64_t D, int64_t table_rows, int dtype,
+                           ib_stream_t stream) {
+  if (!x0 || !eps || !t || !sqrt_ab || !sqrt_1mab || !x_t || B <= 0 || T <= 0 || D <= 0 || table_rows <= 0 || ld_xt < D)
+    return IB_E_ARG;
+  const int es = dtype == IB_BF16 ? 2 : 4;
+  auto al = [&](const void* q) { return (reinterpret_cast<uintptr_t>(q) % (4 * es)) == 0; };
+  const bool v4 = (D % 4 == 0) && (ld_xt % 4 == 0) && al(x0) && al(eps) && al(x_t);
+  const int64_t rows = B * T;
+  const int grid = ib_grid_1d(rows * D / (v4 ? 4 : 1), 256);
   hipStream_t s = ib_s(stream);
   if (dtype == IB_F32) {
-    if (v8) hipLaunchKernelGGL((q_sample_kernel<float, 8>), dim3(grid), dim3(256), 0, s, (const float*)x0, (const float*)eps, t, sqrt_ab, sqrt_1mab, (float*)x_t, B, per, table_rows);
-    else hipLaunchKernelGGL((q_sample_kernel<float, 1>), dim3(grid), dim3(256), 0, s, (const float*)x0, (const float*)eps, t, sqrt_ab, sqrt_1mab, (float*)x_t, B, per, table_rows);
+    if (v4) hipLaunchKernelGGL((q_sample_kernel<float, 4>), dim3(grid), dim3(256), 0, s, (const float*)x0, (const float*)eps, t, sqrt_ab, sqrt_1mab, (float*)x_t, ld_xt, rows, T, D, table_rows);
+    else hipLaunchKernelGGL((q_sample_kernel<float, 1>), dim3(grid), dim3(256), 0, s, (const float*)x0, (const float*)eps, t, sqrt_ab, sqrt_1mab, (float*)x_t, ld_xt, rows, T, D, table_rows);
   } else if (dtype == IB_BF16) {
-    if (v8) hipLaunchKernelGGL((q_sample_kernel<bf16_t, 8>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x0, (const bf16_t*)eps, t, sqrt_ab, sqrt_1mab, (bf16_t*)x_t, B, per, table_rows);
-    else hipLaunchKernelGGL((q_sample_kernel<bf16_t, 1>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x0, (const bf16_t*)eps, t, sqrt_ab, sqrt_1mab, (bf16_t*)x_t, B, per, table_rows);
+    if (v4) hipLaunchKernelGGL((q_sample_kernel<bf16_t, 4>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x0, (const bf16_t*)eps, t, sqrt_ab, sqrt_1mab, (bf16_t*)x_t, ld_xt, rows, T, D, table_rows);
+    else hipLaunchKernelGGL((q_sample_kernel<bf16_t, 1>), dim3(grid), dim3(256), 0, s, (const bf16_t*)x0, (const bf16_t*)eps, t, sqrt_ab, sqrt_1mab, (bf16_t*)x_t, ld_xt, rows, T, D, table_rows);
   } else return IB_E_DTYPE;
   IB_CHECK_LAUNCH();
   return IB_OK;

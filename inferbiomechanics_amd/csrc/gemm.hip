@@ -15,6 +15,7 @@
 // transposing read), everything else with ds_read_b128 / ds_read_b32.
 // The MFMA is issued "swapped" (a = B-tile rows, b = A-tile rows) so that each lane ends up with
 // 4 CONSECUTIVE output columns of one output row -> 8/16-byte epilogue stores and bias loads.
+#include <cstdlib>
 #include <type_traits>
 
 #include "ib_common.h"
@@ -567,10 +568,38 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmParams p) {
   }
 }
 
-// out[e] (+)= sum_s slab[s][e]   (fixed order -> bitwise reproducible)
-__global__ void slab_reduce_kernel(const float* __restrict__ slabs, int nslab, int64_t slab_stride, float* out,
-                                   int64_t ldo, int rows, int cols, int accumulate) {
+// out[e] (+)= sum_s slab[s][e]   (fixed order -> bitwise reproducible).  float4 per thread, 4 slabs in flight.
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, int nslab, int64_t slab_stride,
+                                                          float* __restrict__ out, int64_t ldo, int rows, int cols,
+                                                          int accumulate, int vec) {
   const int64_t n = (int64_t)rows * cols;
+  if (vec) {   // cols % 4 == 0, slab_stride % 4 == 0, ldo % 4 == 0, 16-byte aligned bases
+    const int64_t n4 = n >> 2;
+    for (int64_t e4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e4 < n4; e4 += (int64_t)gridDim.x * blockDim.x) {
+      const float4* p = reinterpret_cast<const float4*>(slabs) + e4;
+      const int64_t st4 = slab_stride >> 2;
+      float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+      int k = 0;
+      for (; k + 4 <= nslab; k += 4) {
+        const float4 a = p[(int64_t)k * st4], b = p[(int64_t)(k + 1) * st4], c = p[(int64_t)(k + 2) * st4],
+                     d = p[(int64_t)(k + 3) * st4];
+        s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+        s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
+        s.x += c.x; s.y += c.y; s.z += c.z; s.w += c.w;
+        s.x += d.x; s.y += d.y; s.z += d.z; s.w += d.w;
+      }
+      for (; k < nslab; ++k) {
+        const float4 a = p[(int64_t)k * st4];
+        s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+      }
+      const int64_t e = e4 << 2;
+      const int r = (int)(e / cols), c0 = (int)(e % cols);
+      float4* o = reinterpret_cast<float4*>(out + (int64_t)r * ldo + c0);
+      if (accumulate) { const float4 t = *o; s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w; }
+      *o = s;
+    }
+    return;
+  }
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
     float s = 0.f;
     for (int k = 0; k < nslab; ++k) s += slabs[(int64_t)k * slab_stride + e];
@@ -595,7 +624,8 @@ template <typename T> bool vec_store_ok(const void* p, int64_t ld) {
 int wgrad_split(int64_t M, int64_t N, int64_t K, int bk, int* chunk_out) {
   // reduction length is M; output tiles over [N, K]
   const int64_t tiles = ((N + BM - 1) / BM) * ((K + BN - 1) / BN);
-  int64_t want = (512 + tiles - 1) / tiles;  // ~2 workgroups per CU
+  static const int target = []() { const char* e = getenv("IB_WGRAD_TARGET"); return e ? atoi(e) : 512; }();
+  int64_t want = (target + tiles - 1) / tiles;  // ~2 workgroups per CU (IB_WGRAD_TARGET: tuning override)
   if (want < 1) want = 1;
   if (want > 32) want = 32;
   int64_t chunk = (M + want - 1) / want;
@@ -725,9 +755,10 @@ extern "C" int ib_linear_wgrad(const void* dz, int64_t lddz, const void* x, int6
   IB_CHECK_LAUNCH();
   if (split > 1) {
     const int64_t n = (int64_t)N * K;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(ib_grid_1d(n, 256)), dim3(256), 0, s,
+    const int rvec = (K % 4 == 0) && (lddw % 4 == 0) && aligned(workspace, 16) && aligned(dw, 16);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(ib_grid_1d(rvec ? n / 4 : n, 256)), dim3(256), 0, s,
                        reinterpret_cast<const float*>(workspace), split, (int64_t)N * K, dw, lddw, (int)N, (int)K,
-                       accumulate);
+                       accumulate, rvec);
     IB_CHECK_LAUNCH();
   }
   return IB_OK;

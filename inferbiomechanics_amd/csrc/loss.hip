@@ -134,46 +134,46 @@ __global__ void regression_loss_final_kernel(const float* __restrict__ partial, 
   }
 }
 
+// pred / dpred are [rows, cols] with leading dimensions (the trainer pads D = 300 rows to ld = 304); target is
+// contiguous.  4 consecutive columns per thread.
 template <typename T, int V>
-__global__ __launch_bounds__(256) void mse_partial_kernel(const T* __restrict__ pred, const T* __restrict__ target,
-                                                          T* __restrict__ dpred, float* __restrict__ partial, int64_t n,
-                                                          float gscale) {
+__global__ __launch_bounds__(256) void mse_partial_kernel(const T* __restrict__ pred, int64_t ld_pred,
+                                                          const T* __restrict__ target, T* __restrict__ dpred,
+                                                          int64_t ld_dpred, float* __restrict__ partial, int64_t rows,
+                                                          int64_t cols, float gscale) {
   __shared__ float red[4];
   float s = 0.f;
-  const int64_t nv = n / V;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (int64_t)gridDim.x * blockDim.x) {
+  const int64_t cv = cols / V;
+  const int64_t n = rows * cv;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / cv, c = (i % cv) * V;
     float a[V], b[V], d[V];
-    if constexpr (V == 8) {
+    if constexpr (V == 4) {
       if constexpr (sizeof(T) == 2) {
-        bf16x8_t ta = *reinterpret_cast<const bf16x8_t*>(pred + i * 8), tb = *reinterpret_cast<const bf16x8_t*>(target + i * 8);
+        const bf16x4_t ta = *reinterpret_cast<const bf16x4_t*>(pred + r * ld_pred + c), tb = *reinterpret_cast<const bf16x4_t*>(target + r * cols + c);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { a[e] = (float)ta[e]; b[e] = (float)tb[e]; }
+        for (int e = 0; e < 4; ++e) { a[e] = (float)ta[e]; b[e] = (float)tb[e]; }
       } else {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          float4 ta = *reinterpret_cast<const float4*>(pred + i * 8 + 4 * h), tb = *reinterpret_cast<const float4*>(target + i * 8 + 4 * h);
-          a[4 * h] = ta.x; a[4 * h + 1] = ta.y; a[4 * h + 2] = ta.z; a[4 * h + 3] = ta.w;
-          b[4 * h] = tb.x; b[4 * h + 1] = tb.y; b[4 * h + 2] = tb.z; b[4 * h + 3] = tb.w;
-        }
+        const float4 ta = *reinterpret_cast<const float4*>(pred + r * ld_pred + c), tb = *reinterpret_cast<const float4*>(target + r * cols + c);
+        a[0] = ta.x; a[1] = ta.y; a[2] = ta.z; a[3] = ta.w; b[0] = tb.x; b[1] = tb.y; b[2] = tb.z; b[3] = tb.w;
       }
     } else {
-      a[0] = ib_to_f32(pred[i]); b[0] = ib_to_f32(target[i]);
+      a[0] = ib_to_f32(pred[r * ld_pred + c]); b[0] = ib_to_f32(target[r * cols + c]);
     }
 #pragma unroll
     for (int e = 0; e < V; ++e) { d[e] = a[e] - b[e]; s += d[e] * d[e]; d[e] *= gscale; }
     if (dpred) {
-      if constexpr (V == 8) {
+      if constexpr (V == 4) {
         if constexpr (sizeof(T) == 2) {
-          bf16x8_t o;
+          bf16x4_t o;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) o[e] = (bf16_t)d[e];
-          *reinterpret_cast<bf16x8_t*>(dpred + i * 8) = o;
+          for (int e = 0; e < 4; ++e) o[e] = (bf16_t)d[e];
+          *reinterpret_cast<bf16x4_t*>(dpred + r * ld_dpred + c) = o;
         } else {
-          *reinterpret_cast<float4*>(dpred + i * 8) = make_float4(d[0], d[1], d[2], d[3]);
-          *reinterpret_cast<float4*>(dpred + i * 8 + 4) = make_float4(d[4], d[5], d[6], d[7]);
+          *reinterpret_cast<float4*>(dpred + r * ld_dpred + c) = make_float4(d[0], d[1], d[2], d[3]);
         }
       } else {
-        dpred[i] = ib_from_f32<T>(d[0]);
+        dpred[r * ld_dpred + c] = ib_from_f32<T>(d[0]);
       }
     }
   }
@@ -243,22 +243,25 @@ extern "C" int ib_regression_loss(const void* o_cop, const void* o_force, const 
 
 extern "C" size_t ib_mse_loss_workspace(int64_t n) { return (size_t)mse_parts(n) * sizeof(float); }
 
-extern "C" int ib_mse_loss_partial(const void* pred, const void* target, void* dpred, void* workspace,
-                                   size_t workspace_bytes, int64_t n, int dtype, ib_stream_t stream) {
-  if (!pred || !target || n <= 0) return IB_E_ARG;
+extern "C" int ib_mse_loss_partial(const void* pred, int64_t ld_pred, const void* target, void* dpred, int64_t ld_dpred,
+                                   void* workspace, size_t workspace_bytes, int64_t rows, int64_t cols, int dtype,
+                                   ib_stream_t stream) {
+  if (!pred || !target || rows <= 0 || cols <= 0 || ld_pred < cols || (dpred && ld_dpred < cols)) return IB_E_ARG;
+  const int64_t n = rows * cols;
   const int parts = mse_parts(n);
   if (!workspace || workspace_bytes < (size_t)parts * sizeof(float)) return IB_E_WORKSPACE;
   float* partial = reinterpret_cast<float*>(workspace);
   hipStream_t s = ib_s(stream);
   const float gscale = 2.f / (float)n;
-  auto al16 = [](const void* q) { return !q || (reinterpret_cast<uintptr_t>(q) % 16) == 0; };
-  const bool v8 = (n % 8 == 0) && al16(pred) && al16(target) && al16(dpred);
+  const int es = dtype == IB_BF16 ? 2 : 4;
+  auto al = [&](const void* q) { return !q || (reinterpret_cast<uintptr_t>(q) % (4 * es)) == 0; };
+  const bool v4 = (cols % 4 == 0) && (ld_pred % 4 == 0) && (!dpred || ld_dpred % 4 == 0) && al(pred) && al(target) && al(dpred);
   if (dtype == IB_F32) {
-    if (v8) hipLaunchKernelGGL((mse_partial_kernel<float, 8>), dim3(parts), dim3(256), 0, s, (const float*)pred, (const float*)target, (float*)dpred, partial, n, gscale);
-    else hipLaunchKernelGGL((mse_partial_kernel<float, 1>), dim3(parts), dim3(256), 0, s, (const float*)pred, (const float*)target, (float*)dpred, partial, n, gscale);
+    if (v4) hipLaunchKernelGGL((mse_partial_kernel<float, 4>), dim3(parts), dim3(256), 0, s, (const float*)pred, ld_pred, (const float*)target, (float*)dpred, ld_dpred, partial, rows, cols, gscale);
+    else hipLaunchKernelGGL((mse_partial_kernel<float, 1>), dim3(parts), dim3(256), 0, s, (const float*)pred, ld_pred, (const float*)target, (float*)dpred, ld_dpred, partial, rows, cols, gscale);
   } else if (dtype == IB_BF16) {
-    if (v8) hipLaunchKernelGGL((mse_partial_kernel<bf16_t, 8>), dim3(parts), dim3(256), 0, s, (const bf16_t*)pred, (const bf16_t*)target, (bf16_t*)dpred, partial, n, gscale);
-    else hipLaunchKernelGGL((mse_partial_kernel<bf16_t, 1>), dim3(parts), dim3(256), 0, s, (const bf16_t*)pred, (const bf16_t*)target, (bf16_t*)dpred, partial, n, gscale);
+    if (v4) hipLaunchKernelGGL((mse_partial_kernel<bf16_t, 4>), dim3(parts), dim3(256), 0, s, (const bf16_t*)pred, ld_pred, (const bf16_t*)target, (bf16_t*)dpred, ld_dpred, partial, rows, cols, gscale);
+    else hipLaunchKernelGGL((mse_partial_kernel<bf16_t, 1>), dim3(parts), dim3(256), 0, s, (const bf16_t*)pred, ld_pred, (const bf16_t*)target, (bf16_t*)dpred, ld_dpred, partial, rows, cols, gscale);
   } else
     return IB_E_DTYPE;
   IB_CHECK_LAUNCH();
@@ -279,7 +282,7 @@ extern "C" int ib_mse_loss_finalize(const void* workspace, size_t workspace_byte
 extern "C" int ib_mse_loss(const void* pred, const void* target, void* dpred, float* result, void* workspace,
                            size_t workspace_bytes, int64_t n, int dtype, ib_stream_t stream) {
   if (!result) return IB_E_ARG;
-  const int rc = ib_mse_loss_partial(pred, target, dpred, workspace, workspace_bytes, n, dtype, stream);
+  const int rc = ib_mse_loss_partial(pred, n, target, dpred, n, workspace, workspace_bytes, 1, n, dtype, stream);
   if (rc != IB_OK) return rc;
   return ib_mse_loss_finalize(workspace, workspace_bytes, result, n, stream);
 }

@@ -274,13 +274,19 @@ class HipTrainer:
         if self.task == "diffusion":
             x0, t, eps = st["x0"], st["t"], st["eps"]
             tabs = m.tables(self.device)
-            xt = plan.buf.get("tr.xt", x0.shape, dt)
+            B, T, D = x0.shape
+            M = B * T
+            # activations that are D (= 300) wide live in buffers with a 16-byte-aligned row pitch (304): the GEMM
+            # operand pieces are then aligned 16-byte loads (the unpadded rows were 8-byte aligned: +11 us per wgrad)
+            Dp = (D + 7) // 8 * 8
+            xt = plan.buf.get("tr.xt", (M, Dp), dt)[:, :D]
+            pred = plan.buf.get("tr.pred", (M, Dp), dt)[:, :D]
+            dpred = plan.buf.get("tr.dpred", (M, Dp), dt)[:, :D]
             hip.q_sample(x0, eps, t, tabs.sqrt_ab, tabs.sqrt_1mab, xt)
-            pred = plan.forward(xt, t, tabs.temb, P)
-            dpred = plan.buf.get("tr.dpred", pred.shape, dt)
-            ws = plan.buf.bytes("tr.mse", hip.mse_loss_workspace_bytes(pred.numel()))
+            plan.forward(xt, t, tabs.temb, P, out=pred, BT=(B, T))
+            ws = plan.buf.bytes("tr.mse", hip.mse_loss_workspace_bytes(M * D))
             hip.mse_loss_partial(pred, eps, ws, dpred=dpred)          # dL/dpred + per-block partial sums
-            n = pred.numel()
+            n = M * D
             self._br_loss.run(lambda: hip.mse_loss_finalize(ws, self.result, n))   # the scalar: off the chain
             plan.backward(dpred, P, accumulate=False)
             self._br_loss.join()

@@ -58,11 +58,11 @@ _SIGS = {
                                       _vp, _vp, _vp, _sz, _i64, _i64, _c.c_int, _vp]),
     "ib_mse_loss_workspace": (_sz, [_i64]),
     "ib_mse_loss": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _sz, _i64, _c.c_int, _vp]),
-    "ib_mse_loss_partial": (_c.c_int, [_vp, _vp, _vp, _vp, _sz, _i64, _c.c_int, _vp]),
+    "ib_mse_loss_partial": (_c.c_int, [_vp, _i64, _vp, _vp, _i64, _vp, _sz, _i64, _i64, _c.c_int, _vp]),
     "ib_mse_loss_finalize": (_c.c_int, [_vp, _sz, _vp, _i64, _vp]),
     "ib_optim_step": (_c.c_int, [_c.c_int, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _i32, _vp, _vp, _vp, _vp]),
     "ib_gather_rows": (_c.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _c.c_int, _vp]),
-    "ib_q_sample": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _c.c_int, _vp]),
+    "ib_q_sample": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _c.c_int, _vp]),
     "ib_ddim_step": (_c.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i64, _i64, _c.c_int, _vp]),
     "ib_counter_add": (_c.c_int, [_vp, _i32, _vp]),
     "ib_fill_i64": (_c.c_int, [_vp, _i64, _i64, _vp]),
@@ -629,19 +629,36 @@ def mse_loss(pred, target, result, workspace, dpred=None):
 
 
 def mse_loss_partial(pred, target, workspace, dpred=None):
+    """pred / dpred: contiguous, or row-padded 2-D [rows, cols] views; target: contiguous with rows*cols elements"""
     dt = pred.dtype
     _req(pred, "pred", dt)
     _req(target, "target", dt)
-    n = pred.numel()
-    if target.numel() != n or not pred.is_contiguous() or not target.is_contiguous():
-        raise HipError("mse_loss: pred/target must be contiguous with equal numel")
-    if dpred is not None and (dpred.dtype != dt or dpred.numel() != n or not dpred.is_contiguous()):
-        raise HipError("mse_loss: dpred mismatch")
+    if not target.is_contiguous():
+        raise HipError("mse_loss: target must be contiguous")
+    if pred.dim() == 2 and not pred.is_contiguous():
+        rows, cols, ldp = _mat(pred, "pred", dt)
+    else:
+        if not pred.is_contiguous():
+            raise HipError("mse_loss: pred must be contiguous or a 2-D row-padded view")
+        rows, cols, ldp = 1, pred.numel(), pred.numel()
+    if target.numel() != rows * cols:
+        raise HipError("mse_loss: pred/target size mismatch")
+    ldd = 0
+    if dpred is not None:
+        _req(dpred, "dpred", dt)
+        if dpred.dim() == 2 and not dpred.is_contiguous():
+            r2, c2, ldd = _mat(dpred, "dpred", dt)
+            if (r2, c2) != (rows, cols):
+                raise HipError("mse_loss: dpred shape mismatch")
+        else:
+            if not dpred.is_contiguous() or dpred.numel() != rows * cols:
+                raise HipError("mse_loss: dpred mismatch")
+            ldd = cols
     wsb = workspace.numel() * workspace.element_size()
-    if wsb < mse_loss_workspace_bytes(n):
+    if wsb < mse_loss_workspace_bytes(rows * cols):
         raise HipError("mse_loss: workspace too small")
-    _check(lib().ib_mse_loss_partial(_ptr(pred), _ptr(target), _ptr(dpred), _ptr(workspace), wsb, n, dtype_code(dt),
-                                     stream_ptr()), "ib_mse_loss_partial")
+    _check(lib().ib_mse_loss_partial(_ptr(pred), ldp, _ptr(target), _ptr(dpred), ldd, _ptr(workspace), wsb, rows, cols,
+                                     dtype_code(dt), stream_ptr()), "ib_mse_loss_partial")
 
 
 def mse_loss_finalize(workspace, result, n):
@@ -692,19 +709,29 @@ def gather_rows(table, idx, out):
 
 
 def q_sample(x0, eps, t, sqrt_ab, sqrt_1mab, x_t):
+    """x0 / eps: contiguous [B,T,D]; x_t: contiguous [B,T,D] or a row-padded 2-D [B*T, D] view"""
     dt = x0.dtype
-    for a, n in ((x0, "x0"), (eps, "eps"), (x_t, "x_t")):
-        _req(a, n, dt)
+    for a, n in ((x0, "x0"), (eps, "eps")):
+        _req(a, n, dt, 3)
         if a.shape != x0.shape or not a.is_contiguous():
-            raise HipError(f"{n}: contiguous tensors of one shape required")
+            raise HipError(f"{n}: contiguous [B,T,D] tensors of one shape required")
+    B, T, D = x0.shape
+    _req(x_t, "x_t", dt)
+    if x_t.dim() == 3:
+        if x_t.shape != x0.shape or not x_t.is_contiguous():
+            raise HipError("x_t: contiguous [B,T,D] or 2-D [B*T, D] required")
+        ld = D
+    else:
+        r, c, ld = _mat(x_t, "x_t", dt)
+        if (r, c) != (B * T, D):
+            raise HipError("x_t shape mismatch")
     _req(t, "t", torch.int64, 1)
-    B = x0.shape[0]
     if t.numel() != B:
         raise HipError("t must be int64 [B]")
     _req(sqrt_ab, "sqrt_ab", torch.float32, 1)
     _req(sqrt_1mab, "sqrt_1mab", torch.float32, 1)
-    _check(lib().ib_q_sample(_ptr(x0), _ptr(eps), _ptr(t), _ptr(sqrt_ab), _ptr(sqrt_1mab), _ptr(x_t), B,
-                             x0.numel() // B, sqrt_ab.numel(), dtype_code(dt), stream_ptr()), "ib_q_sample")
+    _check(lib().ib_q_sample(_ptr(x0), _ptr(eps), _ptr(t), _ptr(sqrt_ab), _ptr(sqrt_1mab), _ptr(x_t), ld, B, T, D,
+                             sqrt_ab.numel(), dtype_code(dt), stream_ptr()), "ib_q_sample")
     return x_t
 
 

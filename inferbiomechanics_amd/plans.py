@@ -494,9 +494,14 @@ class DenoiserTransformerPlan:
         return [lp.branch for lp in self.layers]
 
     def forward(self, x3: torch.Tensor, t: torch.Tensor, table: torch.Tensor, P: ParamSource,
-                out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        B, T, D = x3.shape
+                out: Optional[torch.Tensor] = None, BT: Optional[Tuple[int, int]] = None) -> torch.Tensor:
+        """x3 / out: contiguous [B,T,D], or (with BT=(B,T)) row-padded 2-D [B*T, D] views"""
+        if x3.dim() == 2:
+            (B, T), D = BT, x3.shape[1]
+        else:
+            B, T, D = x3.shape
         M = B * T
+        x2 = x3 if x3.dim() == 2 else x3.view(M, D)
         g, dt = self.buf.get, self.dtype
         e = self.time.forward(t, table, P)                                   # [B, d]
         w_in = P.w("in_proj.weight")                                         # [d, D + Pd]
@@ -504,14 +509,15 @@ class DenoiserTransformerPlan:
         posproj = g("dt.posproj", (T, self.d), dt)
         hip.linear_fwd(pos, w_in[:, D:], None, posproj)
         h0 = g("dt.h0", (B, T, self.d), dt)
-        hip.linear_fwd(x3.view(M, D), w_in[:, :D], P.v("in_proj.bias"), h0.view(M, self.d), add_div=e,
+        hip.linear_fwd(x2, w_in[:, :D], P.v("in_proj.bias"), h0.view(M, self.d), add_div=e,
                        add_mod=posproj, seg=T)
         h = h0
         for lp in self.layers:
             h = lp.forward(h, P)
         out = out if out is not None else g("dt.out", (B, T, D), dt)
-        hip.linear_fwd(h.view(M, self.d), P.w("out_proj.weight"), P.v("out_proj.bias"), out.view(M, D))
-        self.ctx = (x3.view(M, D), pos, h, B, T)
+        hip.linear_fwd(h.view(M, self.d), P.w("out_proj.weight"), P.v("out_proj.bias"),
+                       out if out.dim() == 2 else out.view(M, D))
+        self.ctx = (x2, pos, h, B, T)
         return out
 
     def ready_order(self) -> List[str]:
@@ -524,7 +530,7 @@ class DenoiserTransformerPlan:
         x, pos, hlast, B, T = self.ctx
         M, D = x.shape
         g, dt = self.buf.get, self.dtype
-        dout = dout3.view(M, D)
+        dout = dout3 if dout3.dim() == 2 else dout3.view(M, D)
         _wgrad(self.buf, dout, hlast.view(M, self.d), P.g("out_proj.weight"), accumulate)
         P.ready("out_proj.weight")
         _colsum(self.buf, "dt.bo", dout, P.g("out_proj.bias"), accumulate)
