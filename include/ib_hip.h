@@ -167,6 +167,32 @@ int ib_ddim_step(void* x, const void* eps, const float* coef, const int64_t* tim
 int ib_counter_add(int32_t* counter, int32_t delta, ib_stream_t stream);
 int ib_fill_i64(int64_t* dst, int64_t value, int64_t n, ib_stream_t stream);
 
+/* ---- fused training chain of the token-wise MLP denoiser (BASELINE.json configs[1]; bf16 only).
+ * Replaces, in ONE launch, what the per-op plan issues for SURVEY.md §8a rows "forward" + "loss" + the dgrad half of
+ * "backward" (the torch ops behind cli/train.py:240-281 for this model family): q_sample, every block
+ * (Linear + time embedding + SiLU + LayerNorm), the head, MSE loss with dL/dpred, and the backward chain through the
+ * head, LayerNorm/SiLU and the block weights.  Token rows never mix, so a workgroup owns <= 64 tokens and keeps their
+ * activations in LDS.  The weight gradients stay ib_linear_wgrad launches over the operands this leaves in HBM.
+ *   hidden width H in {128, 256, 512} for every block, L <= 4 blocks, D % 4 == 0 (see ib_mlp_chain_supported).
+ *   packed: the bf16 weights in MFMA-fragment order (ib_mlp_chain_pack; re-pack after every optimizer step).
+ *   bias[L+1], gamma[L], beta[L], u[L], h[L], dz[L], ln_partial[L]: HOST arrays of device pointers.
+ *   u_i = W_i h_{i-1} + b_i + e[window] (bf16), h_i = LN(silu(u_i)), dz_i = dL/du_i, all [M, H] contiguous.
+ *   ln_partial[i]: [2 * ib_mlp_chain_workgroups(M), H] fp32 - per-workgroup dgamma rows, then dbeta rows.
+ *   loss_partial: [workgroups] fp32 sums of squared error; loss = ib_sum_partials(.., 1 / (M * D)). */
+int ib_mlp_chain_supported(int64_t D, int64_t H, int L);
+size_t ib_mlp_chain_packed_elems(int64_t D, int64_t H, int L);
+int ib_mlp_chain_workgroups(int64_t M, int* rows_per_workgroup);
+int ib_mlp_chain_pack(const void* const* w, const int64_t* ldw, void* packed, int64_t D, int64_t H, int L,
+                      ib_stream_t stream);        /* w[L+1]: blocks.i.linear.weight (bf16), then head.weight */
+int ib_mlp_chain_train(const void* x0, const void* eps, const int64_t* t, const float* sqrt_ab,
+                       const float* sqrt_1mab, int64_t table_rows, const void* e, int64_t ld_e,
+                       const void* packed, const float* const* bias, const float* const* gamma,
+                       const float* const* beta, void* xt, int64_t ld_xt, void* const* u, void* const* h,
+                       void* const* dz, void* dpred, int64_t ld_dpred, float* const* ln_partial,
+                       float* loss_partial, int64_t M, int64_t T, int64_t D, int64_t H, int L, float ln_eps,
+                       ib_stream_t stream);
+int ib_sum_partials(const float* partial, int64_t parts, float scale, float* out, ib_stream_t stream);
+
 /* ---- hipGraph capture of a launch sequence (the captured denoise / train step) */
 int ib_graph_begin(ib_stream_t stream);
 int ib_graph_end(ib_stream_t stream, void** graph_exec_out);

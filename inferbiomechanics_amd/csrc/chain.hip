@@ -1,0 +1,590 @@
+// Fused training chain of the token-wise MLP denoiser (BASELINE.json configs[1]) for gfx950.
+//
+// One launch = q_sample + every forward block (GEMM + bias + time embedding + SiLU + LayerNorm) + head GEMM +
+// MSE loss / dL/dpred + the whole dgrad chain (head^T GEMM, LayerNorm/SiLU backward, block^T GEMMs).  The weight
+// gradients (reductions over ALL tokens) stay separate GEMMs; this kernel leaves their operands in HBM:
+//   xt, h_i (block outputs), dz_i (gradients w.r.t. the block pre-activations), dpred.
+//
+// Why a chain kernel: the network is token-local (rows never mix) and its weights are ~1 MB in bf16, so a workgroup
+// that owns a panel of <= 64 tokens can run the whole network with its activations resident in LDS and the weights
+// streamed from L2.  The unfused plan moved every [M,512] activation through HBM 2-4 times and paid ~25 launches.
+//
+// Geometry: 512 threads = 8 waves; the panel's activations are the MFMA "b" operand (64 rows = 4 m-tiles), each
+// wave owns a distinct slice of the layer's OUTPUT columns (NT n-tiles of 16) and therefore a distinct slice of the
+// weight matrix -> weights go global -> VGPR directly (no LDS round trip, no sharing to exploit), from a
+// fragment-major packed image (ib_mlp_chain_pack) so that every wave-instruction reads one contiguous 1 KiB block.
+// MFMA is issued "swapped" (a = weights, b = activations): a lane ends up with 4 consecutive output columns of one
+// row, so bias / embedding / gamma loads and every store are 8- or 16-byte pieces.
+// LayerNorm row statistics: 16-lane-group shuffles + one cross-wave exchange through LDS, fixed order (deterministic).
+#include "ib_common.h"
+
+namespace {
+
+constexpr int CH_ROWS = 64, CH_WAVES = 8, CH_THREADS = 512, CH_MAXL = 4;
+
+struct ChainParams {
+  const bf16_t* x0; const bf16_t* eps; const int64_t* t;
+  const float* sqrt_ab; const float* sqrt_1mab; int table_rows;
+  const bf16_t* e; int64_t ld_e;
+  int M, T, D, L, P;             // P = tokens per workgroup (<= 64)
+  const bf16_t* wf[CH_MAXL + 1];   // packed forward weights: blocks 0..L-1, then the head
+  const bf16_t* wb[CH_MAXL + 1];   // packed TRANSPOSED weights: wb[i] = blocks.i.linear^T (1..L-1), wb[L] = head^T
+  const float* bias[CH_MAXL + 1];
+  const float* gamma[CH_MAXL]; const float* beta[CH_MAXL];
+  bf16_t* xt; int64_t ld_xt;
+  bf16_t* u[CH_MAXL]; bf16_t* h[CH_MAXL]; bf16_t* dz[CH_MAXL];
+  bf16_t* dpred; int64_t ld_dpred;
+  float* ln_partial[CH_MAXL];      // [2 * gridDim.x, H]: per-workgroup dgamma rows, then dbeta rows
+  float* loss_partial;             // [gridDim.x]
+  float gscale, ln_eps;
+};
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+// sum over the 16 lanes of a DPP row (= the 16 token rows a lane group holds); every lane gets the total
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v);   // row_half_mirror
+  v += dpp_mov<0x140>(v);   // row_mirror
+  return v;
+}
+
+__device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.f + __expf(-x)); }
+
+__device__ __forceinline__ bf16x4_t pack4(float a, float b, float c, float d) {
+  bf16x4_t o;
+  o[0] = (bf16_t)a; o[1] = (bf16_t)b; o[2] = (bf16_t)c; o[3] = (bf16_t)d;
+  return o;
+}
+
+// acc[mt][u] += W_eff[16*(nt0+u) .. +15][:] . A[16*mt .. +15][:]^T over KB k-blocks of 32.
+// Packed weights: block (nt, kb) is 1 KiB at ((nt * KB + kb) * 64 + lane) * 16 bytes.
+// Prefetch ring of 3 k-blocks (2 in flight while one is consumed); the loop is fully unrolled so ring slots are
+// static registers.
+template <int NT, int KB>
+__device__ __forceinline__ void chain_gemm(const bf16_t* __restrict__ wp, int nt0, const unsigned char* abuf, int rs,
+                                           int lane, f32x4_t (&acc)[4][NT]) {
+  constexpr int RING = 3, PD = 2;
+  const bf16x8_t* wl = reinterpret_cast<const bf16x8_t*>(wp) + ((int64_t)nt0 * KB) * 64 + lane;
+  const unsigned char* arow = abuf + (lane & 15) * rs + 16 * (lane >> 4);
+  bf16x8_t wr[RING][NT];
+#pragma unroll
+  for (int s = 0; s < PD && s < KB; ++s)
+#pragma unroll
+    for (int u = 0; u < NT; ++u) wr[s][u] = wl[(u * KB + s) * 64];
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) {
+    if (kb + PD < KB) {
+#pragma unroll
+      for (int u = 0; u < NT; ++u) wr[(kb + PD) % RING][u] = wl[(u * KB + kb + PD) * 64];
+    }
+    bf16x8_t fa[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) fa[mt] = *reinterpret_cast<const bf16x8_t*>(arow + 16 * mt * rs + 64 * kb);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int u = 0; u < NT; ++u)
+        acc[mt][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[kb % RING][u], fa[mt], acc[mt][u], 0, 0, 0);
+  }
+}
+
+template <int NT>
+__device__ __forceinline__ void zero_acc(f32x4_t (&acc)[4][NT]) {
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int u = 0; u < NT; ++u) acc[mt][u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+}
+
+// Cross-wave row reduction: each lane holds partial sums for NM of its rows (m-tiles mt0 .. mt0+NM-1) over this
+// wave's columns.  red: [64 rows][8 waves] floats.  Returns the full-row totals (fixed summation order).
+template <int NM>
+__device__ __forceinline__ void row_reduce(float (&v)[NM], float* red, int lane, int wave, int mt0) {
+#pragma unroll
+  for (int m = 0; m < NM; ++m) {
+    v[m] += __shfl_xor(v[m], 16, 64);
+    v[m] += __shfl_xor(v[m], 32, 64);
+  }
+  if (lane < 16) {
+#pragma unroll
+    for (int m = 0; m < NM; ++m) red[(16 * (mt0 + m) + lane) * CH_WAVES + wave] = v[m];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int m = 0; m < NM; ++m) {
+    const float4* r4 = reinterpret_cast<const float4*>(red + (16 * (mt0 + m) + (lane & 15)) * CH_WAVES);
+    const float4 a = r4[0], b = r4[1];
+    v[m] = ((((((a.x + a.y) + a.z) + a.w) + b.x) + b.y) + b.z) + b.w;
+  }
+}
+
+// NTH: n-tiles per wave for the hidden width (H = 128 * NTH);  NTD / KBD: n-tiles per wave and k-blocks for the
+// feature width (D <= 128 * NTD, D <= 32 * KBD).
+template <int NTH, int NTD, int KBD>
+struct ChainCfg {
+  static constexpr int H = 128 * NTH, KBH = 4 * NTH, DP = 32 * KBD, DN = 128 * NTD;
+  static constexpr int WMAX = (H > DP ? (H > DN ? H : DN) : (DP > DN ? DP : DN));
+  static constexpr int RS = WMAX * 2 + 16;                 // LDS row stride (bytes): +16 -> conflict-free b128 reads
+  static constexpr int BUF = CH_ROWS * RS;
+  static constexpr int RED = CH_ROWS * CH_WAVES * 4;       // one cross-wave exchange array
+  static constexpr int STATS = CH_MAXL * CH_ROWS * 2 * 4;
+  static constexpr int LDS = 2 * BUF + 3 * RED + STATS + 64;
+};
+
+template <int NTH, int NTD, int KBD>
+__global__ __launch_bounds__(CH_THREADS) void mlp_chain_kernel(ChainParams p) {
+  using C = ChainCfg<NTH, NTD, KBD>;
+  constexpr int H = C::H, RS = C::RS;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[C::LDS];
+  unsigned char* buf0 = smem;
+  unsigned char* buf1 = smem + C::BUF;
+  float* red0 = reinterpret_cast<float*>(smem + 2 * C::BUF);
+  float* red1 = red0 + CH_ROWS * CH_WAVES;
+  float* red2 = red1 + CH_ROWS * CH_WAVES;
+  float* stats = red2 + CH_ROWS * CH_WAVES;                // [L][64][2] mean, rstd
+  float* lossred = stats + CH_MAXL * CH_ROWS * 2;          // [8]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, l16 = lane & 15;
+  const int r0 = blockIdx.x * p.P;
+  const int D = p.D, M = p.M;
+  const float invH = 1.f / (float)H;
+
+  int rowg[4]; bool valid[4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const int lr = 16 * mt + l16;
+    valid[mt] = (lr < p.P) && (r0 + lr < M);
+    rowg[mt] = min(r0 + lr, M - 1);
+  }
+
+  // ---- q_sample: xt = sqrt_ab[t] x0 + sqrt_1mab[t] eps -> LDS image (zero-padded to DP columns / 64 rows) + HBM
+  {
+    constexpr int PC = C::DP / 4;
+    const int d4 = D >> 2;
+    for (int idx = tid; idx < CH_ROWS * PC; idx += CH_THREADS) {
+      const int lr = idx / PC, c = (idx % PC) * 4;
+      const int row = r0 + lr;
+      bf16x4_t o = pack4(0.f, 0.f, 0.f, 0.f);
+      if (lr < p.P && row < M && c < 4 * d4) {
+        int64_t k = p.t[row / p.T];
+        k = k < 0 ? 0 : (k >= p.table_rows ? p.table_rows - 1 : k);
+        const float a = p.sqrt_ab[k], s = p.sqrt_1mab[k];
+        const bf16x4_t xv = *reinterpret_cast<const bf16x4_t*>(p.x0 + (int64_t)row * D + c);
+        const bf16x4_t ev = *reinterpret_cast<const bf16x4_t*>(p.eps + (int64_t)row * D + c);
+        o = pack4(a * (float)xv[0] + s * (float)ev[0], a * (float)xv[1] + s * (float)ev[1],
+                  a * (float)xv[2] + s * (float)ev[2], a * (float)xv[3] + s * (float)ev[3]);
+        *reinterpret_cast<bf16x4_t*>(p.xt + (int64_t)row * p.ld_xt + c) = o;
+      }
+      *reinterpret_cast<bf16x4_t*>(buf0 + lr * RS + c * 2) = o;
+    }
+  }
+  __syncthreads();
+
+  unsigned char* cur = buf0;
+  unsigned char* nxt = buf1;
+
+  // ---- forward blocks
+  for (int i = 0; i < p.L; ++i) {
+    f32x4_t acc[4][NTH];
+    zero_acc<NTH>(acc);
+    if (i == 0) chain_gemm<NTH, KBD>(p.wf[0], wave * NTH, cur, RS, lane, acc);
+    else chain_gemm<NTH, C::KBH>(p.wf[i], wave * NTH, cur, RS, lane, acc);
+    const int colb = wave * 16 * NTH + 4 * g;
+    // u = z + bias + e (bf16) ; v = silu(u)
+    float s1[4] = {0.f, 0.f, 0.f, 0.f};
+    float4 b4[NTH];
+#pragma unroll
+    for (int u = 0; u < NTH; ++u) b4[u] = *reinterpret_cast<const float4*>(p.bias[i] + colb + 16 * u);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const bf16_t* erow = p.e + (int64_t)(rowg[mt] / p.T) * p.ld_e + (int64_t)i * H;
+      bf16_t* urow = p.u[i] + (int64_t)rowg[mt] * H;
+#pragma unroll
+      for (int u = 0; u < NTH; ++u) {
+        const int col = colb + 16 * u;
+        const bf16x4_t e4 = *reinterpret_cast<const bf16x4_t*>(erow + col);
+        const float bb[4] = {b4[u].x, b4[u].y, b4[u].z, b4[u].w};
+        bf16x4_t ub;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ub[r] = (bf16_t)(acc[mt][u][r] + bb[r] + (float)e4[r]);
+        if (valid[mt]) *reinterpret_cast<bf16x4_t*>(urow + col) = ub;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float x = (float)ub[r];
+          const float v = x * fast_sigmoid(x);
+          acc[mt][u][r] = v;
+          s1[mt] += v;
+        }
+      }
+    }
+    row_reduce<4>(s1, red0, lane, wave, 0);
+    float mean[4], s2[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      mean[mt] = s1[mt] * invH;
+      float q = 0.f;
+#pragma unroll
+      for (int u = 0; u < NTH; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float d = acc[mt][u][r] - mean[mt]; q += d * d; }
+      s2[mt] = q;
+    }
+    row_reduce<4>(s2, red1, lane, wave, 0);
+    float rstd[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) rstd[mt] = 1.f / sqrtf(s2[mt] * invH + p.ln_eps);
+    if (wave == 0 && lane < 16) {
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        stats[(i * CH_ROWS + 16 * mt + lane) * 2 + 0] = mean[mt];
+        stats[(i * CH_ROWS + 16 * mt + lane) * 2 + 1] = rstd[mt];
+      }
+    }
+    // h = gamma * xhat + beta -> next A image + HBM
+#pragma unroll
+    for (int u = 0; u < NTH; ++u) {
+      const int col = colb + 16 * u;
+      const float4 g4 = *reinterpret_cast<const float4*>(p.gamma[i] + col);
+      const float4 be4 = *reinterpret_cast<const float4*>(p.beta[i] + col);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const float m = mean[mt], rsd = rstd[mt];
+        bf16x4_t hb = pack4((acc[mt][u][0] - m) * rsd * g4.x + be4.x, (acc[mt][u][1] - m) * rsd * g4.y + be4.y,
+                            (acc[mt][u][2] - m) * rsd * g4.z + be4.z, (acc[mt][u][3] - m) * rsd * g4.w + be4.w);
+        if (!valid[mt]) hb = pack4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<bf16x4_t*>(nxt + (16 * mt + l16) * RS + col * 2) = hb;
+        if (valid[mt]) *reinterpret_cast<bf16x4_t*>(p.h[i] + (int64_t)rowg[mt] * H + col) = hb;
+      }
+    }
+    __syncthreads();
+    unsigned char* t = cur; cur = nxt; nxt = t;
+  }
+
+  // ---- head + loss + dL/dpred  (columns >= D come out as exact zeros: the packed head rows there are zero)
+  {
+    f32x4_t acc[4][NTD];
+    zero_acc<NTD>(acc);
+    chain_gemm<NTD, C::KBH>(p.wf[p.L], wave * NTD, cur, RS, lane, acc);
+    const int colb = wave * 16 * NTD + 4 * g;
+    float lsum = 0.f;
+#pragma unroll
+    for (int u = 0; u < NTD; ++u) {
+      const int col = colb + 16 * u;
+      const bool cin = col < D;
+      float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (cin) b4 = *reinterpret_cast<const float4*>(p.bias[p.L] + col);
+      const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        bf16x4_t dp = pack4(0.f, 0.f, 0.f, 0.f);
+        if (cin && valid[mt]) {
+          const bf16x4_t e4 = *reinterpret_cast<const bf16x4_t*>(p.eps + (int64_t)rowg[mt] * D + col);
+          float d[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float pr = (float)(bf16_t)(acc[mt][u][r] + bb[r]);
+            d[r] = pr - (float)e4[r];
+            lsum += d[r] * d[r];
+          }
+          dp = pack4(d[0] * p.gscale, d[1] * p.gscale, d[2] * p.gscale, d[3] * p.gscale);
+          *reinterpret_cast<bf16x4_t*>(p.dpred + (int64_t)rowg[mt] * p.ld_dpred + col) = dp;
+        }
+        *reinterpret_cast<bf16x4_t*>(nxt + (16 * mt + l16) * RS + col * 2) = dp;
+      }
+    }
+    lsum = ib_wave_sum(lsum);
+    if (lane == 0) lossred[wave] = lsum;
+    __syncthreads();
+    if (tid == 0) {
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < CH_WAVES; ++w) s += lossred[w];
+      p.loss_partial[blockIdx.x] = s;
+    }
+    unsigned char* t = cur; cur = nxt; nxt = t;
+  }
+
+  // ---- backward: dh_i = d(out of block i) ; through LayerNorm and SiLU -> dz_i ; dh_{i-1} = dz_i W_i
+  for (int i = p.L - 1; i >= 0; --i) {
+    f32x4_t acc[4][NTH];
+    zero_acc<NTH>(acc);
+    if (i == p.L - 1) chain_gemm<NTH, KBD>(p.wb[p.L], wave * NTH, cur, RS, lane, acc);
+    else chain_gemm<NTH, C::KBH>(p.wb[i + 1], wave * NTH, cur, RS, lane, acc);
+    const int colb = wave * 16 * NTH + 4 * g;
+    float mean[4], rstd[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const float2 st = *reinterpret_cast<const float2*>(stats + (i * CH_ROWS + 16 * mt + l16) * 2);
+      mean[mt] = st.x; rstd[mt] = st.y;
+    }
+    // Two m-tile halves (rows are independent; halving keeps xhat / silu' for only 32 elements per lane live):
+    //   pass 1: xhat, silu'(u); dgamma / dbeta partials; row sums of dxhat and dxhat * xhat
+    //   pass 2: dv = rstd (dxhat - mean(dxhat) - xhat mean(dxhat xhat)) ; dz = dv * silu'(u)
+    float dg[NTH][4], db[NTH][4];
+#pragma unroll
+    for (int u = 0; u < NTH; ++u)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { dg[u][r] = 0.f; db[u][r] = 0.f; }
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      float xh[2][NTH][4];
+      bf16x4_t dsl[2][NTH];            // silu'(u), bf16
+      float sa[2] = {0.f, 0.f}, sb[2] = {0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < NTH; ++u) {
+        const int col = colb + 16 * u;
+        const float4 g4 = *reinterpret_cast<const float4*>(p.gamma[i] + col);
+        const float gg[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+        for (int m2 = 0; m2 < 2; ++m2) {
+          const int mt = 2 * hf + m2;
+          const bf16x4_t ub = *reinterpret_cast<const bf16x4_t*>(p.u[i] + (int64_t)rowg[mt] * H + col);
+          float ds[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float x = valid[mt] ? (float)ub[r] : 0.f;
+            const float sg = fast_sigmoid(x);
+            const float v = x * sg;
+            ds[r] = sg * (1.f + x * (1.f - sg));
+            const float xhat = (v - mean[mt]) * rstd[mt];
+            const float dh = valid[mt] ? acc[mt][u][r] : 0.f;
+            dg[u][r] += dh * xhat;
+            db[u][r] += dh;
+            const float dxh = dh * gg[r];
+            acc[mt][u][r] = dxh;
+            xh[m2][u][r] = xhat;
+            sa[m2] += dxh;
+            sb[m2] += dxh * xhat;
+          }
+          dsl[m2][u] = pack4(ds[0], ds[1], ds[2], ds[3]);
+        }
+      }
+      row_reduce<2>(sa, red2, lane, wave, 2 * hf);
+      row_reduce<2>(sb, red0, lane, wave, 2 * hf);
+#pragma unroll
+      for (int m2 = 0; m2 < 2; ++m2) {
+        const int mt = 2 * hf + m2;
+        const float ma = sa[m2] * invH, mb = sb[m2] * invH, rsd = rstd[mt];
+#pragma unroll
+        for (int u = 0; u < NTH; ++u) {
+          const int col = colb + 16 * u;
+          float dzv[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            dzv[r] = rsd * (acc[mt][u][r] - ma - xh[m2][u][r] * mb) * (float)dsl[m2][u][r];
+          bf16x4_t o = pack4(dzv[0], dzv[1], dzv[2], dzv[3]);
+          if (!valid[mt]) o = pack4(0.f, 0.f, 0.f, 0.f);
+          if (i > 0) *reinterpret_cast<bf16x4_t*>(nxt + (16 * mt + l16) * RS + col * 2) = o;
+          if (valid[mt]) *reinterpret_cast<bf16x4_t*>(p.dz[i] + (int64_t)rowg[mt] * H + col) = o;
+        }
+      }
+    }
+    {
+      float* pg = p.ln_partial[i] + (int64_t)blockIdx.x * H;
+      float* pb = p.ln_partial[i] + ((int64_t)gridDim.x + blockIdx.x) * H;
+#pragma unroll
+      for (int u = 0; u < NTH; ++u) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { dg[u][r] = row16_sum(dg[u][r]); db[u][r] = row16_sum(db[u][r]); }
+        if (l16 == 0) {
+          *reinterpret_cast<float4*>(pg + colb + 16 * u) = make_float4(dg[u][0], dg[u][1], dg[u][2], dg[u][3]);
+          *reinterpret_cast<float4*>(pb + colb + 16 * u) = make_float4(db[u][0], db[u][1], db[u][2], db[u][3]);
+        }
+      }
+    }
+    __syncthreads();
+    unsigned char* t = cur; cur = nxt; nxt = t;
+  }
+}
+
+// ---- weight packing: bf16 row-major [N_out, K_in] -> fragment-major blocks, zero padded
+struct PackDesc {
+  const bf16_t* src; int64_t ld;
+  int N, K;            // logical W_eff dims (rows n, reduction k)
+  int transpose;       // W_eff[n][k] = src[k * ld + n] instead of src[n * ld + k]
+  int n_tiles, KB;
+  int64_t dst_off;     // in elements
+  int block0;
+};
+struct PackParams { PackDesc d[2 * CH_MAXL + 1]; int count; int total_blocks; bf16_t* dst; };
+
+__global__ __launch_bounds__(256) void mlp_chain_pack_kernel(PackParams p) {
+  const int lane = threadIdx.x & 63;
+  for (int blk = blockIdx.x * 4 + (threadIdx.x >> 6); blk < p.total_blocks; blk += gridDim.x * 4) {
+    int di = 0;
+    for (int j = 1; j < p.count; ++j)
+      if (blk >= p.d[j].block0) di = j;
+    const PackDesc& d = p.d[di];
+    const int local = blk - d.block0;
+    const int nt = local / d.KB, kb = local % d.KB;
+    const int n = 16 * nt + (lane & 15), k0 = 32 * kb + 8 * (lane >> 4);
+    bf16x8_t v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = k0 + j;
+      bf16_t x = (bf16_t)0.f;
+      if (n < d.N && k < d.K) x = d.transpose ? d.src[(int64_t)k * d.ld + n] : d.src[(int64_t)n * d.ld + k];
+      v[j] = x;
+    }
+    reinterpret_cast<bf16x8_t*>(p.dst + d.dst_off)[(int64_t)local * 64 + lane] = v;
+  }
+}
+
+struct ChainShape { int nth, ntd, kbd; };
+bool chain_shape(int64_t D, int64_t H, ChainShape* s) {
+  if (H != 128 && H != 256 && H != 512) return false;
+  if (D <= 0 || D % 4 != 0) return false;
+  s->nth = (int)(H / 128);
+  if (D <= 64) { s->ntd = 1; s->kbd = 2; }
+  else if (D <= 128) { s->ntd = 1; s->kbd = 4; }
+  else if (D > 256 && D <= 320) { s->ntd = 3; s->kbd = 10; }
+  else return false;
+  // the instantiated set (below)
+  if (s->ntd == 3) return H == 512 || H == 256;
+  return H == 128;
+}
+
+// packed image layout (elements): forward blocks 0..L-1, head, then transposed blocks 1..L-1, head^T
+struct PackLayout { int64_t off_f[CH_MAXL + 1]; int64_t off_b[CH_MAXL + 1]; int64_t total; };
+void chain_layout(int64_t D, int64_t H, int L, const ChainShape& s, PackLayout* o) {
+  const int64_t kbh = H / 32, nth8 = H / 16, ntd8 = 8 * s.ntd;
+  int64_t off = 0;
+  for (int i = 0; i < L; ++i) { o->off_f[i] = off; off += nth8 * (i == 0 ? s.kbd : kbh) * 512; }
+  o->off_f[L] = off; off += ntd8 * kbh * 512;
+  o->off_b[0] = -1;
+  for (int i = 1; i < L; ++i) { o->off_b[i] = off; off += nth8 * kbh * 512; }
+  o->off_b[L] = off; off += nth8 * s.kbd * 512;
+  o->total = off;
+}
+
+}  // namespace
+
+extern "C" int ib_mlp_chain_supported(int64_t D, int64_t H, int L) {
+  ChainShape s;
+  return (L >= 1 && L <= CH_MAXL && chain_shape(D, H, &s)) ? 1 : 0;
+}
+
+extern "C" size_t ib_mlp_chain_packed_elems(int64_t D, int64_t H, int L) {
+  ChainShape s;
+  if (L < 1 || L > CH_MAXL || !chain_shape(D, H, &s)) return 0;
+  PackLayout lo;
+  chain_layout(D, H, L, s, &lo);
+  return (size_t)lo.total;
+}
+
+extern "C" int ib_mlp_chain_workgroups(int64_t M, int* rows_per_wg) {
+  // one workgroup per CU when the token count allows it (256 CUs), never more than 64 tokens per workgroup
+  int64_t P = (M + 255) / 256;
+  if (P > CH_ROWS) P = CH_ROWS;
+  if (P < 16) P = M < 16 ? M : 16;
+  if (rows_per_wg) *rows_per_wg = (int)P;
+  return (int)((M + P - 1) / P);
+}
+
+extern "C" int ib_mlp_chain_pack(const void* const* w, const int64_t* ldw, void* packed, int64_t D, int64_t H, int L,
+                                 ib_stream_t stream) {
+  ChainShape s;
+  if (!w || !ldw || !packed || L < 1 || L > CH_MAXL || !chain_shape(D, H, &s)) return IB_E_ARG;
+  PackLayout lo;
+  chain_layout(D, H, L, s, &lo);
+  PackParams pp{};
+  pp.dst = reinterpret_cast<bf16_t*>(packed);
+  int blocks = 0, c = 0;
+  auto add = [&](const void* src, int64_t ld, int N, int K, int tr, int n_tiles, int KB, int64_t off) {
+    PackDesc& d = pp.d[c++];
+    d.src = reinterpret_cast<const bf16_t*>(src); d.ld = ld; d.N = N; d.K = K; d.transpose = tr;
+    d.n_tiles = n_tiles; d.KB = KB; d.dst_off = off; d.block0 = blocks;
+    blocks += n_tiles * KB;
+  };
+  const int kbh = (int)(H / 32), nth8 = (int)(H / 16), ntd8 = 8 * s.ntd;
+  for (int i = 0; i <= L; ++i)
+    if (!w[i]) return IB_E_ARG;
+  for (int i = 0; i < L; ++i) add(w[i], ldw[i], (int)H, i == 0 ? (int)D : (int)H, 0, nth8, i == 0 ? s.kbd : kbh, lo.off_f[i]);
+  add(w[L], ldw[L], (int)D, (int)H, 0, ntd8, kbh, lo.off_f[L]);
+  for (int i = 1; i < L; ++i) add(w[i], ldw[i], (int)H, (int)H, 1, nth8, kbh, lo.off_b[i]);
+  add(w[L], ldw[L], (int)H, (int)D, 1, nth8, s.kbd, lo.off_b[L]);
+  pp.count = c; pp.total_blocks = blocks;
+  hipLaunchKernelGGL(mlp_chain_pack_kernel, dim3(ib_grid_1d(blocks, 4)), dim3(256), 0, ib_s(stream), pp);
+  IB_CHECK_LAUNCH();
+  return IB_OK;
+}
+
+extern "C" int ib_mlp_chain_train(const void* x0, const void* eps, const int64_t* t, const float* sqrt_ab,
+                                  const float* sqrt_1mab, int64_t table_rows, const void* e, int64_t ld_e,
+                                  const void* packed, const float* const* bias, const float* const* gamma,
+                                  const float* const* beta, void* xt, int64_t ld_xt, void* const* u, void* const* h,
+                                  void* const* dz, void* dpred, int64_t ld_dpred, float* const* ln_partial,
+                                  float* loss_partial, int64_t M, int64_t T, int64_t D, int64_t H, int L, float ln_eps,
+                                  ib_stream_t stream) {
+  ChainShape s;
+  if (L < 1 || L > CH_MAXL || !chain_shape(D, H, &s)) return IB_E_UNSUPPORTED;
+  if (!x0 || !eps || !t || !sqrt_ab || !sqrt_1mab || !e || !packed || !bias || !gamma || !beta || !xt || !u || !h ||
+      !dz || !dpred || !ln_partial || !loss_partial || M <= 0 || T <= 0 || table_rows <= 0)
+    return IB_E_ARG;
+  if (ld_e < (int64_t)L * H || ld_e % 4 != 0 || ld_xt < D || ld_xt % 4 != 0 || ld_dpred < D || ld_dpred % 4 != 0) return IB_E_ARG;
+  auto al8 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) % 8) == 0; };
+  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) % 16) == 0; };
+  if (!al8(x0) || !al8(eps) || !al8(e) || !al8(xt) || !al8(dpred) || !al16(packed)) return IB_E_ARG;
+  PackLayout lo;
+  chain_layout(D, H, L, s, &lo);
+  ChainParams p{};
+  p.x0 = (const bf16_t*)x0; p.eps = (const bf16_t*)eps; p.t = t; p.sqrt_ab = sqrt_ab; p.sqrt_1mab = sqrt_1mab;
+  p.table_rows = (int)table_rows; p.e = (const bf16_t*)e; p.ld_e = ld_e;
+  p.M = (int)M; p.T = (int)T; p.D = (int)D; p.L = L;
+  int P;
+  const int nwg = ib_mlp_chain_workgroups(M, &P);
+  p.P = P;
+  const bf16_t* pk = (const bf16_t*)packed;
+  for (int i = 0; i <= L; ++i) {
+    p.wf[i] = pk + lo.off_f[i];
+    p.wb[i] = lo.off_b[i] >= 0 ? pk + lo.off_b[i] : nullptr;
+    if (!bias[i] || !al16(bias[i])) return IB_E_ARG;
+    p.bias[i] = bias[i];
+  }
+  for (int i = 0; i < L; ++i) {
+    if (!gamma[i] || !beta[i] || !u[i] || !h[i] || !dz[i] || !ln_partial[i]) return IB_E_ARG;
+    if (!al16(gamma[i]) || !al16(beta[i]) || !al8(u[i]) || !al8(h[i]) || !al8(dz[i]) || !al16(ln_partial[i])) return IB_E_ARG;
+    p.gamma[i] = gamma[i]; p.beta[i] = beta[i];
+    p.u[i] = (bf16_t*)u[i]; p.h[i] = (bf16_t*)h[i]; p.dz[i] = (bf16_t*)dz[i]; p.ln_partial[i] = ln_partial[i];
+  }
+  p.xt = (bf16_t*)xt; p.ld_xt = ld_xt; p.dpred = (bf16_t*)dpred; p.ld_dpred = ld_dpred;
+  p.loss_partial = loss_partial;
+  p.gscale = 2.f / ((float)M * (float)D); p.ln_eps = ln_eps;
+  hipStream_t st = ib_s(stream);
+#define IB_CHAIN_LAUNCH(NTH, NTD, KBD) \
+  hipLaunchKernelGGL((mlp_chain_kernel<NTH, NTD, KBD>), dim3(nwg), dim3(CH_THREADS), 0, st, p)
+  if (s.nth == 4 && s.ntd == 3 && s.kbd == 10) IB_CHAIN_LAUNCH(4, 3, 10);
+  else if (s.nth == 2 && s.ntd == 3 && s.kbd == 10) IB_CHAIN_LAUNCH(2, 3, 10);
+  else if (s.nth == 1 && s.ntd == 1 && s.kbd == 2) IB_CHAIN_LAUNCH(1, 1, 2);
+  else if (s.nth == 1 && s.ntd == 1 && s.kbd == 4) IB_CHAIN_LAUNCH(1, 1, 4);
+  else return IB_E_UNSUPPORTED;
+#undef IB_CHAIN_LAUNCH
+  IB_CHECK_LAUNCH();
+  return IB_OK;
+}
+
+// out = scale * sum(partial[0..parts))   (fixed order; the chain kernel's per-workgroup loss sums)
+namespace {
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ partial, int parts, float scale,
+                                                           float* __restrict__ out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < parts; i += 256) s += partial[i];
+  s = ib_wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) *out = (((red[0] + red[1]) + red[2]) + red[3]) * scale;
+}
+}  // namespace
+
+extern "C" int ib_sum_partials(const float* partial, int64_t parts, float scale, float* out, ib_stream_t stream) {
+  if (!partial || !out || parts <= 0) return IB_E_ARG;
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, ib_s(stream), partial, (int)parts, scale, out);
+  IB_CHECK_LAUNCH();
+  return IB_OK;
+}

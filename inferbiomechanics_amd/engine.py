@@ -21,6 +21,7 @@ at construction (DDP ctor), optimizer arithmetic = torch.optim defaults with onl
 """
 from __future__ import annotations
 
+import os
 from collections import OrderedDict
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
@@ -276,9 +277,14 @@ class HipTrainer:
             tabs = m.tables(self.device)
             B, T, D = x0.shape
             M = B * T
+            if hasattr(plan, "chain_ok") and plan.chain_ok(D):
+                # MLP denoiser, bf16: q_sample + forward + loss + the dgrad chain are ONE launch (csrc/chain.hip)
+                plan.chain_step(x0, eps, t, tabs, P, self.result, br_loss=self._br_loss)
+                self._br_loss.join()
+                return self._finish_step(cut)
             # activations that are D (= 300) wide live in buffers with a 16-byte-aligned row pitch (304): the GEMM
             # operand pieces are then aligned 16-byte loads (the unpadded rows were 8-byte aligned: +11 us per wgrad)
-            Dp = (D + 7) // 8 * 8
+            Dp = D if os.environ.get("IB_NO_PAD") else (D + 7) // 8 * 8
             xt = plan.buf.get("tr.xt", (M, Dp), dt)[:, :D]
             pred = plan.buf.get("tr.pred", (M, Dp), dt)[:, :D]
             dpred = plan.buf.get("tr.dpred", (M, Dp), dt)[:, :D]
@@ -305,6 +311,10 @@ class HipTrainer:
             ws = plan.buf.bytes("tr.rl", hip.regression_loss_workspace_bytes(B, F))
             hip.regression_loss(outs, labs, self.comp_w, self.result, ws, grads=grads, threshold=10.0)
             plan.backward(G, P, accumulate=False)
+        self._finish_step(cut)
+
+    def _finish_step(self, cut):
+        m, dt = self.model, self.model.compute_dtype
         if self.ddp:
             if cut is not None:
                 cut(-1 if self.overlap_comm else -2)

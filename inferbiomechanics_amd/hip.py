@@ -62,6 +62,13 @@ _SIGS = {
     "ib_mse_loss_finalize": (_c.c_int, [_vp, _sz, _vp, _i64, _vp]),
     "ib_optim_step": (_c.c_int, [_c.c_int, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _i32, _vp, _vp, _vp, _vp]),
     "ib_gather_rows": (_c.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _c.c_int, _vp]),
+    "ib_mlp_chain_supported": (_c.c_int, [_i64, _i64, _c.c_int]),
+    "ib_mlp_chain_packed_elems": (_sz, [_i64, _i64, _c.c_int]),
+    "ib_mlp_chain_workgroups": (_c.c_int, [_i64, _vp]),
+    "ib_mlp_chain_pack": (_c.c_int, [_vp, _vp, _vp, _i64, _i64, _c.c_int, _vp]),
+    "ib_mlp_chain_train": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp,
+                                      _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _c.c_int, _f32, _vp]),
+    "ib_sum_partials": (_c.c_int, [_vp, _i64, _f32, _vp, _vp]),
     "ib_q_sample": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _c.c_int, _vp]),
     "ib_ddim_step": (_c.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i64, _i64, _c.c_int, _vp]),
     "ib_counter_add": (_c.c_int, [_vp, _i32, _vp]),
@@ -86,6 +93,9 @@ def declared_symbols() -> List[str]:
     return sorted(set(re.findall(r"\b(ib_[a-z0-9_]+)\s*\(", src)))
 
 
+_HOST_ONLY = ("_workspace", "_supported", "_workgroups", "_packed_elems")   # pure host queries: no launch, no stream
+
+
 class _DryRunLib:
     """TEST-ONLY stand-in (tests/test_plumbing_cpu.py): marshals every argument through the real ctypes
     signature (so arity / type errors surface) and returns IB_OK without launching anything.  It computes
@@ -98,7 +108,7 @@ class _DryRunLib:
     def __getattr__(self, name):
         res, args = _SIGS[name]
         real = getattr(self._real, name)
-        if name.endswith("_workspace") or name in ("ib_version", "ib_error_string"):
+        if name.endswith(_HOST_ONLY) or name in ("ib_version", "ib_error_string"):
             return real
 
         def call(*a):
@@ -122,7 +132,7 @@ class _TimingLib:
 
     def __getattr__(self, name):
         real = getattr(self._real, name)
-        if not name.startswith("ib_") or name.startswith(("ib_event", "ib_graph")) or name.endswith("_workspace") \
+        if not name.startswith("ib_") or name.startswith(("ib_event", "ib_graph")) or name.endswith(_HOST_ONLY) \
                 or name in ("ib_version", "ib_error_string"):
             return real
 
@@ -155,7 +165,7 @@ class _RecordingLib:
 
     def __getattr__(self, name):
         real = getattr(self._real, name)
-        if not name.startswith("ib_") or name.startswith(("ib_event", "ib_graph")) or name.endswith("_workspace") \
+        if not name.startswith("ib_") or name.startswith(("ib_event", "ib_graph")) or name.endswith(_HOST_ONLY) \
                 or name in ("ib_version", "ib_error_string"):
             return real
 
@@ -733,6 +743,100 @@ def q_sample(x0, eps, t, sqrt_ab, sqrt_1mab, x_t):
     _check(lib().ib_q_sample(_ptr(x0), _ptr(eps), _ptr(t), _ptr(sqrt_ab), _ptr(sqrt_1mab), _ptr(x_t), ld, B, T, D,
                              sqrt_ab.numel(), dtype_code(dt), stream_ptr()), "ib_q_sample")
     return x_t
+
+
+def _ptr_array(tensors):
+    arr = (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    return arr, ctypes.cast(arr, ctypes.c_void_p)
+
+
+def mlp_chain_supported(D: int, H: int, L: int) -> bool:
+    return bool(lib().ib_mlp_chain_supported(D, H, L))
+
+
+def mlp_chain_workgroups(M: int) -> int:
+    return int(lib().ib_mlp_chain_workgroups(M, None))
+
+
+def mlp_chain_packed_elems(D: int, H: int, L: int) -> int:
+    return int(lib().ib_mlp_chain_packed_elems(D, H, L))
+
+
+def mlp_chain_pack(weights, packed, D: int, H: int):
+    """weights: bf16 [H,D], [H,H] x (L-1), [D,H] (blocks then head; row-major, last dim contiguous)"""
+    L = len(weights) - 1
+    for w in weights:
+        _mat(w, "chain weight", torch.bfloat16)
+    _req(packed, "packed", torch.bfloat16, 1)
+    if packed.numel() < mlp_chain_packed_elems(D, H, L):
+        raise HipError("mlp_chain_pack: packed buffer too small")
+    keep, wp = _ptr_array(weights)
+    ld = (ctypes.c_int64 * len(weights))(*[w.stride(0) for w in weights])
+    _check(lib().ib_mlp_chain_pack(wp, ctypes.cast(ld, ctypes.c_void_p), _ptr(packed), D, H, L, stream_ptr()),
+           "ib_mlp_chain_pack")
+    return packed
+
+
+def mlp_chain_train(x0, eps, t, sqrt_ab, sqrt_1mab, e, packed, bias, gamma, beta, xt, u, h, dz, dpred, ln_partial,
+                    loss_partial, T: int, ln_eps: float = 1e-5):
+    """x0 / eps: contiguous bf16 [B,T,D]; e: bf16 [B, L*H]; xt / dpred: bf16 2-D [B*T, D] (row pitch % 4 == 0);
+    u / h / dz: L contiguous bf16 [B*T, H]; bias: L+1 fp32 vectors; gamma / beta: L fp32 vectors;
+    ln_partial: L fp32 [2 * workgroups, H]; loss_partial: fp32 [workgroups]"""
+    bt = torch.bfloat16
+    _req(x0, "x0", bt, 3); _req(eps, "eps", bt, 3)
+    if x0.shape != eps.shape or not x0.is_contiguous() or not eps.is_contiguous():
+        raise HipError("mlp_chain_train: x0 / eps must be contiguous and of one shape")
+    B, T_, D = x0.shape
+    if T_ != T:
+        raise HipError("mlp_chain_train: T mismatch")
+    M, L = B * T, len(u)
+    H = u[0].shape[1]
+    _req(t, "t", torch.int64, 1); _req(sqrt_ab, "sqrt_ab", torch.float32, 1); _req(sqrt_1mab, "sqrt_1mab", torch.float32, 1)
+    er, ec, lde = _mat(e, "e", bt)
+    if (er, ec) != (B, L * H) or t.numel() != B:
+        raise HipError("mlp_chain_train: e must be [B, L*H], t [B]")
+    for name, a in (("xt", xt), ("dpred", dpred)):
+        r, c, _ = _mat(a, name, bt)
+        if (r, c) != (M, D):
+            raise HipError(f"mlp_chain_train: {name} must be [B*T, D]")
+    for name, lst, shape, dt in (("u", u, (M, H), bt), ("h", h, (M, H), bt), ("dz", dz, (M, H), bt),
+                                 ("gamma", gamma, (H,), torch.float32), ("beta", beta, (H,), torch.float32)):
+        if len(lst) != L:
+            raise HipError(f"mlp_chain_train: {name} needs {L} entries")
+        for a in lst:
+            _req(a, name, dt)
+            if tuple(a.shape) != shape or not a.is_contiguous():
+                raise HipError(f"mlp_chain_train: {name} must be contiguous {shape}")
+    if len(bias) != L + 1:
+        raise HipError("mlp_chain_train: bias needs L+1 entries")
+    for i, a in enumerate(bias):
+        _req(a, "bias", torch.float32, 1)
+        if a.numel() != (H if i < L else D):
+            raise HipError("mlp_chain_train: bias size mismatch")
+    nwg = mlp_chain_workgroups(M)
+    for a in ln_partial:
+        _req(a, "ln_partial", torch.float32)
+        if a.numel() < 2 * nwg * H or not a.is_contiguous():
+            raise HipError("mlp_chain_train: ln_partial must hold [2 * workgroups, H]")
+    _req(loss_partial, "loss_partial", torch.float32, 1)
+    if loss_partial.numel() < nwg or packed.numel() < mlp_chain_packed_elems(D, H, L):
+        raise HipError("mlp_chain_train: loss_partial / packed too small")
+    _req(packed, "packed", bt, 1)
+    k1, pb = _ptr_array(bias); k2, pg = _ptr_array(gamma); k3, pbe = _ptr_array(beta)
+    k4, pu = _ptr_array(u); k5, ph = _ptr_array(h); k6, pdz = _ptr_array(dz); k7, pln = _ptr_array(ln_partial)
+    _check(lib().ib_mlp_chain_train(_ptr(x0), _ptr(eps), _ptr(t), _ptr(sqrt_ab), _ptr(sqrt_1mab), sqrt_ab.numel(),
+                                    _ptr(e), lde, _ptr(packed), pb, pg, pbe, _ptr(xt), xt.stride(0), pu, ph, pdz,
+                                    _ptr(dpred), dpred.stride(0), pln, _ptr(loss_partial), M, T, D, H, L,
+                                    float(ln_eps), stream_ptr()), "ib_mlp_chain_train")
+    return nwg
+
+
+def sum_partials(partial, parts: int, scale: float, out):
+    _req(partial, "partial", torch.float32); _req(out, "out", torch.float32)
+    if partial.numel() < parts:
+        raise HipError("sum_partials: partial too small")
+    _check(lib().ib_sum_partials(_ptr(partial), parts, float(scale), _ptr(out), stream_ptr()), "ib_sum_partials")
+    return out
 
 
 def ddim_step(x, eps, coef, timesteps, step=0, step_dev=None, t_out=None):

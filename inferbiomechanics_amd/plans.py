@@ -15,6 +15,7 @@ Reference arithmetic implemented here (file:line relative to the reference root)
 """
 from __future__ import annotations
 
+import os
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -469,6 +470,79 @@ class DenoiserMLPPlan:
             else:
                 # de32 is complete: the two halves of the time-MLP backward fork off as siblings; block 0's own
                 # gradients stay on the main stream
+                self.br_tout.run(lambda: self.time.backward_out_layer(de32, de_lp, P, accumulate))
+                self.branch.run(lambda: self.time.backward_hidden(de32, de_lp, P, accumulate))
+                blk_grads()
+        for b in self.branches():
+            b.join()
+
+
+    # ---- fused chain: q_sample + forward + loss + dgrad chain in ONE launch (csrc/chain.hip) ------------------
+    def chain_ok(self, D: int) -> bool:
+        if os.environ.get("IB_NO_CHAIN") or self.dtype != torch.bfloat16 or not self.hidden:
+            return False
+        H = self.hidden[0]
+        return all(h == H for h in self.hidden) and hip.mlp_chain_supported(D, H, len(self.hidden))
+
+    def chain_step(self, x0: torch.Tensor, eps: torch.Tensor, t: torch.Tensor, tabs, P: ParamSource,
+                   result: torch.Tensor, br_loss: Optional[Branch] = None, accumulate=False):
+        """the whole diffusion training step up to the gradients (HipTrainer's diffusion path for this model)"""
+        B, T, D = x0.shape
+        M, L, H = B * T, len(self.hidden), self.hidden[0]
+        g, dt = self.buf.get, self.dtype
+        names = [f"blocks.{i}.linear.weight" for i in range(L)] + ["head.weight"]
+        packed = g("ch.packed", (hip.mlp_chain_packed_elems(D, H, L),), dt)
+        hip.mlp_chain_pack([P.w(n) for n in names], packed, D, H)
+        e = self.time.forward(t, tabs.temb, P)                               # [B, L*H]
+        Dp = (D + 7) // 8 * 8
+        xt = g("ch.xt", (M, Dp), dt)[:, :D]
+        dpred = g("ch.dpred", (M, Dp), dt)[:, :D]
+        u = [g(f"ch.u{i}", (M, H), dt) for i in range(L)]
+        h = [g(f"ch.h{i}", (M, H), dt) for i in range(L)]
+        dz = [g(f"ch.dz{i}", (M, H), dt) for i in range(L)]
+        nwg = hip.mlp_chain_workgroups(M)
+        lnp = [g(f"ch.lnp{i}", (2 * nwg, H), torch.float32) for i in range(L)]
+        lossp = g("ch.lossp", (nwg,), torch.float32)
+        hip.mlp_chain_train(x0, eps, t, tabs.sqrt_ab, tabs.sqrt_1mab, e, packed,
+                            [P.v(f"blocks.{i}.linear.bias") for i in range(L)] + [P.v("head.bias")],
+                            [P.v(f"blocks.{i}.norm.weight") for i in range(L)],
+                            [P.v(f"blocks.{i}.norm.bias") for i in range(L)], xt, u, h, dz, dpred, lnp, lossp, T)
+        if br_loss is not None:
+            br_loss.run(lambda: hip.sum_partials(lossp, nwg, 1.0 / (M * D), result))
+        else:
+            hip.sum_partials(lossp, nwg, 1.0 / (M * D), result)
+
+        # every gradient operand now sits in HBM: the rest is independent side work (weight-gradient GEMMs, sums)
+        def head_grads():
+            _wgrad(self.buf, dpred, h[L - 1], P.g("head.weight"), accumulate, ws_tag="dm.wsH")
+            P.ready("head.weight")
+            _colsum(self.buf, "dm.bh", dpred, P.g("head.bias"), accumulate)
+            P.ready("head.bias")
+        self.br_head.run(head_grads)
+        Hs = L * H
+        de32 = g("dm.de32", (B, Hs), torch.float32)
+        de_lp = g("dm.de_lp", (B, Hs), torch.bfloat16)
+        for i in range(L - 1, -1, -1):
+            off = i * H
+            sl = de32[:, off:off + H]
+            hin = h[i - 1] if i > 0 else xt
+
+            def blk_grads(i=i, sl=sl, hin=hin):
+                hip.segment_colsum(lnp[i][:nwg], P.g(f"blocks.{i}.norm.weight").view(1, H), seg=nwg, mode=0,
+                                   accumulate=accumulate)
+                P.ready(f"blocks.{i}.norm.weight")
+                hip.segment_colsum(lnp[i][nwg:], P.g(f"blocks.{i}.norm.bias").view(1, H), seg=nwg, mode=0,
+                                   accumulate=accumulate)
+                P.ready(f"blocks.{i}.norm.bias")
+                _wgrad(self.buf, dz[i], hin, P.g(f"blocks.{i}.linear.weight"), accumulate, ws_tag=f"dm.ws{i}")
+                P.ready(f"blocks.{i}.linear.weight")
+                _colsum(self.buf, f"dm.b{i}", sl, P.g(f"blocks.{i}.linear.bias"), accumulate)
+                P.ready(f"blocks.{i}.linear.bias")
+
+            hip.segment_colsum(dz[i], sl, seg=T, mode=0, out_bf16=de_lp[:, off:off + H])
+            if i > 0:
+                self.br_blk[i].run(blk_grads)
+            else:
                 self.br_tout.run(lambda: self.time.backward_out_layer(de32, de_lp, P, accumulate))
                 self.branch.run(lambda: self.time.backward_hidden(de32, de_lp, P, accumulate))
                 blk_grads()

@@ -1,0 +1,169 @@
+"""Fused MLP-denoiser chain kernel (csrc/chain.hip) against a float64 restatement of the same math with the kernel's
+bf16 storage points (weights, x_t, u, h, pred, dz are bf16 tensors).  Tolerance: 3e-2 of each tensor's max magnitude
+(bf16 has 8 significant bits; the chain accumulates a few roundings per layer).  GPU only."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ref_cpu as R  # noqa: E402
+
+DEV = "cuda"
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def hip():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from inferbiomechanics_amd import hip as h
+    h.lib()
+    return h
+
+
+def rnd(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g, dtype=torch.float64) * scale
+
+
+def close(actual, expected, rtol, what):
+    a = actual.detach().to("cpu", torch.float64)
+    e = expected.detach().to("cpu", torch.float64)
+    assert a.shape == e.shape, (what, a.shape, e.shape)
+    assert torch.isfinite(a).all(), f"{what}: non-finite values"
+    err = (a - e).abs().max().item()
+    ref = max(e.abs().max().item(), 1e-30)
+    assert err <= rtol * ref, f"{what}: max err {err:.3e} > {rtol:.1e} * {ref:.3e}"
+
+
+def bf(x):
+    return x.to(BF).to(torch.float64)
+
+
+CASES = [(256, 50, 300, 512, 2),     # BASELINE configs[1]: 12800 tokens -> 256 workgroups of 50
+         (7, 50, 300, 512, 2),       # 350 tokens: ragged last workgroup
+         (300, 50, 300, 512, 3),     # 15000 tokens: 64-token panels, three blocks
+         (5, 13, 48, 128, 1),        # small widths, one block
+         (3, 50, 100, 128, 2),
+         (9, 20, 300, 256, 2)]
+
+
+@pytest.mark.parametrize("B,T,D,H,L", CASES)
+def test_chain_matches_float64_restatement(hip, B, T, D, H, L):
+    assert hip.mlp_chain_supported(D, H, L)
+    M = B * T
+    x0 = rnd((B, T, D), 1).to(BF)
+    eps = rnd((B, T, D), 2).to(BF)
+    t = torch.randint(0, 1000, (B,), generator=torch.Generator().manual_seed(3))
+    t[0] = 0
+    t[-1] = 999
+    tabs = R.schedule_tables()
+    sab, s1m = tabs["sqrt_ab"].to(torch.float32), tabs["sqrt_1mab"].to(torch.float32)
+    e = rnd((B, L * H), 4, 0.5).to(BF)
+    dims = [D] + [H] * L
+    W = [rnd((dims[i + 1], dims[i]), 10 + i, dims[i] ** -0.5).to(BF) for i in range(L)] + [rnd((D, H), 30, H ** -0.5).to(BF)]
+    bias = [rnd((H,), 40 + i, 0.1).to(torch.float32) for i in range(L)] + [rnd((D,), 49, 0.1).to(torch.float32)]
+    gamma = [(1.0 + rnd((H,), 50 + i, 0.2)).to(torch.float32) for i in range(L)]
+    beta = [rnd((H,), 60 + i, 0.1).to(torch.float32) for i in range(L)]
+
+    # ---- float64 restatement (autograd) with the kernel's storage points
+    a = sab.to(torch.float64)[t][:, None, None]
+    s = s1m.to(torch.float64)[t][:, None, None]
+    xt_ref = bf(a * x0.to(torch.float64) + s * eps.to(torch.float64)).reshape(M, D)
+    hcur = xt_ref.clone().requires_grad_(True)
+    us, hs = [], []
+    g64 = [g.to(torch.float64).requires_grad_(True) for g in gamma]
+    b64 = [b.to(torch.float64).requires_grad_(True) for b in beta]
+    for i in range(L):
+        z = hcur @ W[i].to(torch.float64).T + bias[i].to(torch.float64) \
+            + e.to(torch.float64)[:, i * H:(i + 1) * H].repeat_interleave(T, dim=0)
+        # value rounded to bf16, gradient passes straight through
+        u = z + (bf(z) - z).detach()
+        u.retain_grad()
+        v = u * torch.sigmoid(u)
+        mu = v.mean(-1, keepdim=True)
+        var = ((v - mu) ** 2).mean(-1, keepdim=True)
+        hh = (v - mu) / torch.sqrt(var + 1e-5) * g64[i] + b64[i]
+        hh = hh + (bf(hh) - hh).detach()
+        us.append(u)
+        hs.append(hh)
+        hcur = hh
+    pred = hcur @ W[L].to(torch.float64).T + bias[L].to(torch.float64)
+    pred = pred + (bf(pred) - pred).detach()
+    pred.retain_grad()
+    loss = ((pred - eps.to(torch.float64).reshape(M, D)) ** 2).mean()
+    loss.backward()
+
+    # ---- kernel
+    d = lambda x: x.to(DEV)
+    packed = torch.zeros(hip.mlp_chain_packed_elems(D, H, L), dtype=BF, device=DEV)
+    hip.mlp_chain_pack([d(w) for w in W], packed, D, H)
+    Dp = (D + 7) // 8 * 8
+    xt = torch.zeros(M, Dp, dtype=BF, device=DEV)[:, :D]
+    dpred = torch.zeros(M, Dp, dtype=BF, device=DEV)[:, :D]
+    u_k = [torch.zeros(M, H, dtype=BF, device=DEV) for _ in range(L)]
+    h_k = [torch.zeros(M, H, dtype=BF, device=DEV) for _ in range(L)]
+    dz_k = [torch.zeros(M, H, dtype=BF, device=DEV) for _ in range(L)]
+    nwg = hip.mlp_chain_workgroups(M)
+    lnp = [torch.zeros(2 * nwg, H, dtype=torch.float32, device=DEV) for _ in range(L)]
+    lossp = torch.zeros(nwg, dtype=torch.float32, device=DEV)
+    out = torch.zeros(1, dtype=torch.float32, device=DEV)
+    hip.mlp_chain_train(d(x0), d(eps), d(t), d(sab), d(s1m), d(e), packed, [d(b) for b in bias], [d(g) for g in gamma],
+                        [d(b) for b in beta], xt, u_k, h_k, dz_k, dpred, lnp, lossp, T)
+    hip.sum_partials(lossp, nwg, 1.0 / (M * D), out)
+    torch.cuda.synchronize()
+
+    tol = 3e-2
+    close(xt, xt_ref, 1e-2, "x_t")
+    for i in range(L):
+        close(u_k[i], us[i], tol, f"u{i}")
+        close(h_k[i], hs[i], tol, f"h{i}")
+    assert abs(out.item() - loss.item()) <= 1e-2 * abs(loss.item()), (out.item(), loss.item())
+    close(dpred, pred.grad, tol, "dpred")
+    for i in range(L - 1, -1, -1):
+        close(dz_k[i], us[i].grad, tol, f"dz{i}")
+        close(lnp[i][:nwg].sum(0), g64[i].grad, tol, f"dgamma{i}")
+        close(lnp[i][nwg:].sum(0), b64[i].grad, tol, f"dbeta{i}")
+
+
+def test_chain_trainer_tracks_per_op_trainer():
+    """HipTrainer with the chain kernel vs the per-op launch plan (IB_NO_CHAIN=1): same model, same batches; the two
+    bf16 trajectories may differ by rounding only."""
+    import os
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from inferbiomechanics_amd.engine import HipTrainer
+    from inferbiomechanics_amd.models.DiffusionDenoisers import DiffusionMLP
+
+    def run(no_chain):
+        if no_chain:
+            os.environ["IB_NO_CHAIN"] = "1"
+        else:
+            os.environ.pop("IB_NO_CHAIN", None)
+        try:
+            torch.manual_seed(0)
+            m = DiffusionMLP(300, [512, 512], compute_dtype=BF).to(DEV)
+            sd = R.det_params(R.denoiser_mlp_param_shapes(300, [512, 512]), seed0=5.0)
+            m.load_state_dict({k: v.to(torch.float32) for k, v in sd.items()})
+            p0 = {k: v.detach().float().cpu().clone() for k, v in m.state_dict().items()}
+            tr = HipTrainer(m, "diffusion", "sgd", 5e-2, use_graph=not no_chain)
+            losses = []
+            for s in range(12):
+                g = torch.Generator().manual_seed(100 + s)
+                x0 = torch.randn(32, 50, 300, generator=g).to(DEV)
+                eps = torch.randn(32, 50, 300, generator=g).to(DEV)
+                t = torch.randint(0, 1000, (32,), generator=g).to(DEV)
+                tr.step((x0, t, eps))
+                losses.append(tr.loss_value())
+            return losses, {k: v.detach().float().cpu() - p0[k] for k, v in m.state_dict().items()}
+        finally:
+            os.environ.pop("IB_NO_CHAIN", None)
+
+    la, pa = run(False)
+    lb, pb = run(True)
+    assert la[-1] < la[0]
+    for x, y in zip(la, lb):
+        assert abs(x - y) <= 2e-2 * abs(y), (la, lb)
+    for k in pa:                       # pa / pb: parameter MOVEMENT over the 12 SGD steps
+        dlt = (pa[k] - pb[k]).abs().max().item()
+        assert dlt <= 0.1 * max(pb[k].abs().max().item(), 1e-6), (k, dlt, pb[k].abs().max().item())
