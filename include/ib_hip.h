@@ -64,6 +64,16 @@ size_t ib_linear_wgrad_workspace(int64_t M, int64_t N, int64_t K);
 int ib_linear_wgrad(const void* dz, int64_t lddz, const void* x, int64_t ldx, float* dw, int64_t lddw,
                     int accumulate, void* workspace, size_t workspace_bytes,
                     int64_t M, int64_t N, int64_t K, int dtype, ib_stream_t stream);
+/* Deferred form for a step that computes several weight gradients: ib_linear_wgrad_slabs writes only the split-M
+ * partial slabs ([*nslab_out][N][K] fp32, workspace of ib_linear_wgrad_slabs_workspace bytes); ONE
+ * ib_slab_reduce_multi launch (n <= 8 gradients, K % 4 == 0, host arrays) then sums every slab set into its dw. */
+size_t ib_linear_wgrad_slabs_workspace(int64_t M, int64_t N, int64_t K);
+int ib_linear_wgrad_slabs(const void* dz, int64_t lddz, const void* x, int64_t ldx, void* workspace,
+                          size_t workspace_bytes, int* nslab_out, int64_t M, int64_t N, int64_t K, int dtype,
+                          ib_stream_t stream);
+int ib_slab_reduce_multi(int n, const void* const* slabs, const int32_t* nslab, float* const* dw,
+                         const int64_t* lddw, const int32_t* N, const int32_t* K, int accumulate,
+                         ib_stream_t stream);
 
 /* out[s, n] (fp32) = sum over rows m of segment s of x[m, n]; mode 0: s = m / seg (M/seg segments,
  * bias grads / per-window time-embedding grads), mode 1: s = m % seg (seg segments, per-frame
@@ -175,22 +185,33 @@ int ib_fill_i64(int64_t* dst, int64_t value, int64_t n, ib_stream_t stream);
  * activations in LDS.  The weight gradients stay ib_linear_wgrad launches over the operands this leaves in HBM.
  *   hidden width H in {128, 256, 512} for every block, L <= 4 blocks, D % 4 == 0 (see ib_mlp_chain_supported).
  *   packed: the bf16 weights in MFMA-fragment order (ib_mlp_chain_pack; re-pack after every optimizer step).
- *   bias[L+1], gamma[L], beta[L], u[L], h[L], dz[L], ln_partial[L]: HOST arrays of device pointers.
+ *   bias[L+1], gamma[L], beta[L], u[L], h[L], dz[L]: HOST arrays of device pointers.
  *   u_i = W_i h_{i-1} + b_i + e[window] (bf16), h_i = LN(silu(u_i)), dz_i = dL/du_i, all [M, H] contiguous.
- *   ln_partial[i]: [2 * ib_mlp_chain_workgroups(M), H] fp32 - per-workgroup dgamma rows, then dbeta rows.
- *   loss_partial: [workgroups] fp32 sums of squared error; loss = ib_sum_partials(.., 1 / (M * D)). */
+ *   partial: [ib_mlp_chain_workgroups(M), ld_part >= ib_mlp_chain_partial_width()] fp32 per-workgroup column sums:
+ *     block i at columns 3iH: dgamma_i | dbeta_i | dbias_i (H each); head-bias sums at 3LH; the squared-error sum
+ *     at width - 4.  ib_colsum_segments() turns them into the parameter gradients and the loss in one launch.
+ *   de_lp: optional bf16 [B, >= L*H]: when each workgroup's panel is exactly one window (rows_per_workgroup == T)
+ *     the dbias sums are also that window's time-embedding gradient row; NULL otherwise (use ib_segment_colsum). */
 int ib_mlp_chain_supported(int64_t D, int64_t H, int L);
 size_t ib_mlp_chain_packed_elems(int64_t D, int64_t H, int L);
 int ib_mlp_chain_workgroups(int64_t M, int* rows_per_workgroup);
 int ib_mlp_chain_pack(const void* const* w, const int64_t* ldw, void* packed, int64_t D, int64_t H, int L,
                       ib_stream_t stream);        /* w[L+1]: blocks.i.linear.weight (bf16), then head.weight */
+int64_t ib_mlp_chain_partial_width(int64_t D, int64_t H, int L);
 int ib_mlp_chain_train(const void* x0, const void* eps, const int64_t* t, const float* sqrt_ab,
                        const float* sqrt_1mab, int64_t table_rows, const void* e, int64_t ld_e,
                        const void* packed, const float* const* bias, const float* const* gamma,
                        const float* const* beta, void* xt, int64_t ld_xt, void* const* u, void* const* h,
-                       void* const* dz, void* dpred, int64_t ld_dpred, float* const* ln_partial,
-                       float* loss_partial, int64_t M, int64_t T, int64_t D, int64_t H, int L, float ln_eps,
+                       void* const* dz, void* dpred, int64_t ld_dpred, float* partial, int64_t ld_part,
+                       void* de_lp, int64_t ld_de, int64_t M, int64_t T, int64_t D, int64_t H, int L, float ln_eps,
                        ib_stream_t stream);
+/* dst_s[c] (+)= scale_s * sum_r part[r][col0_s + c], c < ncols_s, for nseg <= 24 segments in ONE launch (fixed
+ * summation order); dst2 (array or NULL; entries may be NULL) receives a second copy.  Host arrays. */
+int ib_colsum_segments(const float* part, int64_t ld, int64_t rows, int nseg, const int32_t* col0,
+                       const int32_t* ncols, float* const* dst, float* const* dst2, const float* scale,
+                       int accumulate, ib_stream_t stream);
+int ib_debug_stamp(void* slot, ib_stream_t stream);   /* timing-only: *slot = 100 MHz wall clock when the stream gets here */
+int ib_debug_set_chain_prof(void* stamps);   /* timing-only: [workgroups][16] int64 wall-clock stamps, NULL = off */
 int ib_sum_partials(const float* partial, int64_t parts, float scale, float* out, ib_stream_t stream);
 
 /* ---- hipGraph capture of a launch sequence (the captured denoise / train step) */

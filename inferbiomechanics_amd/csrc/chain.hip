@@ -21,6 +21,8 @@
 namespace {
 
 constexpr int CH_ROWS = 64, CH_WAVES = 8, CH_THREADS = 512, CH_MAXL = 4;
+long long* g_chain_prof = nullptr;
+#define CH_STAMP(k) do { if (p.prof && tid == 0) p.prof[blockIdx.x * 16 + (k)] = wall_clock64(); } while (0)
 
 struct ChainParams {
   const bf16_t* x0; const bf16_t* eps; const int64_t* t;
@@ -34,9 +36,11 @@ struct ChainParams {
   bf16_t* xt; int64_t ld_xt;
   bf16_t* u[CH_MAXL]; bf16_t* h[CH_MAXL]; bf16_t* dz[CH_MAXL];
   bf16_t* dpred; int64_t ld_dpred;
-  float* ln_partial[CH_MAXL];      // [2 * gridDim.x, H]: per-workgroup dgamma rows, then dbeta rows
-  float* loss_partial;             // [gridDim.x]
+  float* partial; int64_t ld_part; // [gridDim.x, W] per-workgroup column sums: per block dgamma | dbeta | dbias (3H each
+                                   // block), then the head-bias sums (128*NTD columns), then the squared-error sum
+  bf16_t* de_lp; int64_t ld_de;    // optional (panel == window): bf16 [B, L*H] time-embedding gradient rows
   float gscale, ln_eps;
+  long long* prof;                 // TIMING-ONLY (tools/chain_prof.py): [gridDim.x][16] wall-clock stamps, else NULL
 };
 
 template <int CTRL>
@@ -135,10 +139,70 @@ struct ChainCfg {
   static constexpr int LDS = 2 * BUF + 3 * RED + STATS + 64;
 };
 
+// ---- coalesced row movers between HBM and an LDS image (row stride rs bytes).  Per-lane epilogue accesses are
+// 16 rows x 32 B per wave-instruction (store-issue-bound: ~9k cycles per 16 of them); whole rows move as 16-byte pieces.
+__device__ __forceinline__ void copy_out16(const unsigned char* img, int rs, bf16_t* g, int64_t ldg, int nrows, int ppr,
+                                           int tid) {
+  const int total = nrows * ppr;
+  for (int idx = tid; idx < total; idx += CH_THREADS) {
+    const int row = idx / ppr, pc = idx - row * ppr;
+    const uint4 v = *reinterpret_cast<const uint4*>(img + row * rs + pc * 16);
+    *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(g + (int64_t)row * ldg) + pc * 16) = v;
+  }
+}
+__device__ __forceinline__ void copy_out8(const unsigned char* img, int rs, bf16_t* g, int64_t ldg, int nrows, int ppr,
+                                          int tid) {
+  const int total = nrows * ppr;
+  for (int idx = tid; idx < total; idx += CH_THREADS) {
+    const int row = idx / ppr, pc = idx - row * ppr;
+    const uint2 v = *reinterpret_cast<const uint2*>(img + row * rs + pc * 8);
+    *reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(g + (int64_t)row * ldg) + pc * 8) = v;
+  }
+}
+// rows -> registers (issued before a GEMM), registers -> image (after it); rows >= nrows become zeros
+template <int NP>
+__device__ __forceinline__ void load_rows16(const bf16_t* g, int64_t ldg, int nrows, int ppr, int tid, uint4 (&r)[NP]) {
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
+    const int idx = tid + j * CH_THREADS;
+    const int row = idx / ppr, pc = idx - row * ppr;
+    r[j] = make_uint4(0u, 0u, 0u, 0u);
+    if (row < nrows) r[j] = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(g + (int64_t)row * ldg) + pc * 16);
+  }
+}
+template <int NP>
+__device__ __forceinline__ void store_rows16(unsigned char* img, int rs, int ppr, int tid, const uint4 (&r)[NP]) {
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
+    const int idx = tid + j * CH_THREADS;
+    const int row = idx / ppr, pc = idx - row * ppr;
+    if (row < CH_ROWS) *reinterpret_cast<uint4*>(img + row * rs + pc * 16) = r[j];
+  }
+}
+template <int NP>
+__device__ __forceinline__ void load_rows8(const bf16_t* g, int64_t ldg, int nrows, int ppr, int tid, uint2 (&r)[NP]) {
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
+    const int idx = tid + j * CH_THREADS;
+    const int row = idx / ppr, pc = idx - row * ppr;
+    r[j] = make_uint2(0u, 0u);
+    if (row < nrows) r[j] = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned char*>(g + (int64_t)row * ldg) + pc * 8);
+  }
+}
+template <int NP>
+__device__ __forceinline__ void store_rows8(unsigned char* img, int rs, int ppr, int tid, const uint2 (&r)[NP]) {
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
+    const int idx = tid + j * CH_THREADS;
+    const int row = idx / ppr, pc = idx - row * ppr;
+    if (row < CH_ROWS) *reinterpret_cast<uint2*>(img + row * rs + pc * 8) = r[j];
+  }
+}
+
 template <int NTH, int NTD, int KBD>
 __global__ __launch_bounds__(CH_THREADS) void mlp_chain_kernel(ChainParams p) {
   using C = ChainCfg<NTH, NTD, KBD>;
-  constexpr int H = C::H, RS = C::RS;
+  constexpr int H = C::H, RS = C::RS, PPR = H / 8;
   __shared__ __attribute__((aligned(16))) unsigned char smem[C::LDS];
   unsigned char* buf0 = smem;
   unsigned char* buf1 = smem + C::BUF;
@@ -152,48 +216,71 @@ __global__ __launch_bounds__(CH_THREADS) void mlp_chain_kernel(ChainParams p) {
   const int g = lane >> 4, l16 = lane & 15;
   const int r0 = blockIdx.x * p.P;
   const int D = p.D, M = p.M;
+  const int nrows = min(p.P, M - r0);                      // valid token rows of this panel
   const float invH = 1.f / (float)H;
+  int stamp = 0;
+  CH_STAMP(stamp++);
 
   int rowg[4]; bool valid[4];
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) {
     const int lr = 16 * mt + l16;
-    valid[mt] = (lr < p.P) && (r0 + lr < M);
+    valid[mt] = lr < nrows;
     rowg[mt] = min(r0 + lr, M - 1);
   }
 
-  // ---- q_sample: xt = sqrt_ab[t] x0 + sqrt_1mab[t] eps -> LDS image (zero-padded to DP columns / 64 rows) + HBM
+  // ---- q_sample: xt = sqrt_ab[t] x0 + sqrt_1mab[t] eps -> LDS image (zero-padded to DP columns / 64 rows) + HBM.
+  // The per-row coefficients (two dependent loads) and the x0 / eps rows are fetched concurrently.
   {
-    constexpr int PC = C::DP / 4;
-    const int d4 = D >> 2;
-    for (int idx = tid; idx < CH_ROWS * PC; idx += CH_THREADS) {
-      const int lr = idx / PC, c = (idx % PC) * 4;
-      const int row = r0 + lr;
-      bf16x4_t o = pack4(0.f, 0.f, 0.f, 0.f);
-      if (lr < p.P && row < M && c < 4 * d4) {
-        int64_t k = p.t[row / p.T];
+    const int ppr = D >> 2;                                // 8-byte pieces per row
+    uint2 rx[KBD], re[KBD];
+    load_rows8<KBD>(p.x0 + (int64_t)r0 * D, D, nrows, ppr, tid, rx);
+    load_rows8<KBD>(p.eps + (int64_t)r0 * D, D, nrows, ppr, tid, re);
+    float2* coef = reinterpret_cast<float2*>(red0);
+    if (tid < CH_ROWS) {
+      float2 c = make_float2(0.f, 0.f);
+      if (tid < nrows) {
+        int64_t k = p.t[(r0 + tid) / p.T];
         k = k < 0 ? 0 : (k >= p.table_rows ? p.table_rows - 1 : k);
-        const float a = p.sqrt_ab[k], s = p.sqrt_1mab[k];
-        const bf16x4_t xv = *reinterpret_cast<const bf16x4_t*>(p.x0 + (int64_t)row * D + c);
-        const bf16x4_t ev = *reinterpret_cast<const bf16x4_t*>(p.eps + (int64_t)row * D + c);
-        o = pack4(a * (float)xv[0] + s * (float)ev[0], a * (float)xv[1] + s * (float)ev[1],
-                  a * (float)xv[2] + s * (float)ev[2], a * (float)xv[3] + s * (float)ev[3]);
-        *reinterpret_cast<bf16x4_t*>(p.xt + (int64_t)row * p.ld_xt + c) = o;
+        c = make_float2(p.sqrt_ab[k], p.sqrt_1mab[k]);
       }
-      *reinterpret_cast<bf16x4_t*>(buf0 + lr * RS + c * 2) = o;
+      coef[tid] = c;
+    }
+    // zero the whole image first (pad columns / rows), then the computed pieces overwrite their slots
+    for (int idx = tid; idx < CH_ROWS * (C::DP / 8); idx += CH_THREADS) {
+      const int row = idx / (C::DP / 8), pc = idx % (C::DP / 8);
+      *reinterpret_cast<uint4*>(buf0 + row * RS + pc * 16) = make_uint4(0u, 0u, 0u, 0u);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < KBD; ++j) {
+      const int idx = tid + j * CH_THREADS;
+      const int row = idx / ppr, pc = idx - row * ppr;
+      if (row < nrows) {
+        const float2 c = coef[row];
+        const bf16x4_t xv = __builtin_bit_cast(bf16x4_t, rx[j]), ev = __builtin_bit_cast(bf16x4_t, re[j]);
+        const bf16x4_t o = pack4(c.x * (float)xv[0] + c.y * (float)ev[0], c.x * (float)xv[1] + c.y * (float)ev[1],
+                                 c.x * (float)xv[2] + c.y * (float)ev[2], c.x * (float)xv[3] + c.y * (float)ev[3]);
+        *reinterpret_cast<bf16x4_t*>(p.xt + (int64_t)(r0 + row) * p.ld_xt + pc * 4) = o;
+        *reinterpret_cast<bf16x4_t*>(buf0 + row * RS + pc * 8) = o;
+      }
     }
   }
   __syncthreads();
+  CH_STAMP(stamp++);
 
   unsigned char* cur = buf0;
   unsigned char* nxt = buf1;
 
   // ---- forward blocks
   for (int i = 0; i < p.L; ++i) {
+    if (i > 0) copy_out16(cur, RS, p.h[i - 1] + (int64_t)r0 * H, H, nrows, PPR, tid);   // previous block's output rows
     f32x4_t acc[4][NTH];
     zero_acc<NTH>(acc);
     if (i == 0) chain_gemm<NTH, KBD>(p.wf[0], wave * NTH, cur, RS, lane, acc);
     else chain_gemm<NTH, C::KBH>(p.wf[i], wave * NTH, cur, RS, lane, acc);
+    CH_STAMP(stamp++);
+    __syncthreads();                       // every wave is done reading `cur`: it becomes the u image
     const int colb = wave * 16 * NTH + 4 * g;
     // u = z + bias + e (bf16) ; v = silu(u)
     float s1[4] = {0.f, 0.f, 0.f, 0.f};
@@ -203,7 +290,6 @@ __global__ __launch_bounds__(CH_THREADS) void mlp_chain_kernel(ChainParams p) {
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
       const bf16_t* erow = p.e + (int64_t)(rowg[mt] / p.T) * p.ld_e + (int64_t)i * H;
-      bf16_t* urow = p.u[i] + (int64_t)rowg[mt] * H;
 #pragma unroll
       for (int u = 0; u < NTH; ++u) {
         const int col = colb + 16 * u;
@@ -212,7 +298,7 @@ __global__ __launch_bounds__(CH_THREADS) void mlp_chain_kernel(ChainParams p) {
         bf16x4_t ub;
 #pragma unroll
         for (int r = 0; r < 4; ++r) ub[r] = (bf16_t)(acc[mt][u][r] + bb[r] + (float)e4[r]);
-        if (valid[mt]) *reinterpret_cast<bf16x4_t*>(urow + col) = ub;
+        *reinterpret_cast<bf16x4_t*>(cur + (16 * mt + l16) * RS + col * 2) = ub;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float x = (float)ub[r];
@@ -223,6 +309,7 @@ __global__ __launch_bounds__(CH_THREADS) void mlp_chain_kernel(ChainParams p) {
       }
     }
     row_reduce<4>(s1, red0, lane, wave, 0);
+    copy_out16(cur, RS, p.u[i] + (int64_t)r0 * H, H, nrows, PPR, tid);      // u image complete after the barrier inside
     float mean[4], s2[4];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
@@ -245,7 +332,7 @@ __global__ __launch_bounds__(CH_THREADS) void mlp_chain_kernel(ChainParams p) {
         stats[(i * CH_ROWS + 16 * mt + lane) * 2 + 1] = rstd[mt];
       }
     }
-    // h = gamma * xhat + beta -> next A image + HBM
+    // h = gamma * xhat + beta -> next A image (rows beyond the panel stay zero)
 #pragma unroll
     for (int u = 0; u < NTH; ++u) {
       const int col = colb + 16 * u;
@@ -258,20 +345,28 @@ __global__ __launch_bounds__(CH_THREADS) void mlp_chain_kernel(ChainParams p) {
                             (acc[mt][u][2] - m) * rsd * g4.z + be4.z, (acc[mt][u][3] - m) * rsd * g4.w + be4.w);
         if (!valid[mt]) hb = pack4(0.f, 0.f, 0.f, 0.f);
         *reinterpret_cast<bf16x4_t*>(nxt + (16 * mt + l16) * RS + col * 2) = hb;
-        if (valid[mt]) *reinterpret_cast<bf16x4_t*>(p.h[i] + (int64_t)rowg[mt] * H + col) = hb;
       }
     }
     __syncthreads();
+    CH_STAMP(stamp++);
     unsigned char* t = cur; cur = nxt; nxt = t;
   }
 
   // ---- head + loss + dL/dpred  (columns >= D come out as exact zeros: the packed head rows there are zero)
   {
+    copy_out16(cur, RS, p.h[p.L - 1] + (int64_t)r0 * H, H, nrows, PPR, tid);
+    const int ppr = D >> 2;
+    uint2 re[KBD];
+    load_rows8<KBD>(p.eps + (int64_t)r0 * D, D, nrows, ppr, tid, re);
     f32x4_t acc[4][NTD];
     zero_acc<NTD>(acc);
     chain_gemm<NTD, C::KBH>(p.wf[p.L], wave * NTD, cur, RS, lane, acc);
+    CH_STAMP(stamp++);
+    store_rows8<KBD>(nxt, RS, ppr, tid, re);             // eps image; dpred overwrites it in place
+    __syncthreads();
     const int colb = wave * 16 * NTD + 4 * g;
     float lsum = 0.f;
+    float* prow = p.partial + (int64_t)blockIdx.x * p.ld_part;
 #pragma unroll
     for (int u = 0; u < NTD; ++u) {
       const int col = colb + 16 * u;
@@ -279,11 +374,13 @@ __global__ __launch_bounds__(CH_THREADS) void mlp_chain_kernel(ChainParams p) {
       float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
       if (cin) b4 = *reinterpret_cast<const float4*>(p.bias[p.L] + col);
       const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+      float cs[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
+        bf16x4_t* slot = reinterpret_cast<bf16x4_t*>(nxt + (16 * mt + l16) * RS + col * 2);
         bf16x4_t dp = pack4(0.f, 0.f, 0.f, 0.f);
         if (cin && valid[mt]) {
-          const bf16x4_t e4 = *reinterpret_cast<const bf16x4_t*>(p.eps + (int64_t)rowg[mt] * D + col);
+          const bf16x4_t e4 = *slot;
           float d[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -292,10 +389,14 @@ __global__ __launch_bounds__(CH_THREADS) void mlp_chain_kernel(ChainParams p) {
             lsum += d[r] * d[r];
           }
           dp = pack4(d[0] * p.gscale, d[1] * p.gscale, d[2] * p.gscale, d[3] * p.gscale);
-          *reinterpret_cast<bf16x4_t*>(p.dpred + (int64_t)rowg[mt] * p.ld_dpred + col) = dp;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) cs[r] += (float)dp[r];
         }
-        *reinterpret_cast<bf16x4_t*>(nxt + (16 * mt + l16) * RS + col * 2) = dp;
+        *slot = dp;
       }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cs[r] = row16_sum(cs[r]);          // head-bias gradient: this panel's column sums
+      if (l16 == 0) *reinterpret_cast<float4*>(prow + 3 * p.L * H + col) = make_float4(cs[0], cs[1], cs[2], cs[3]);
     }
     lsum = ib_wave_sum(lsum);
     if (lane == 0) lossred[wave] = lsum;
@@ -304,17 +405,29 @@ __global__ __launch_bounds__(CH_THREADS) void mlp_chain_kernel(ChainParams p) {
       float s = 0.f;
 #pragma unroll
       for (int w = 0; w < CH_WAVES; ++w) s += lossred[w];
-      p.loss_partial[blockIdx.x] = s;
+      prow[3 * p.L * H + C::DN] = s;
     }
+    bf16_t* dpg = p.dpred + (int64_t)r0 * p.ld_dpred;
+    if ((p.ld_dpred & 7) == 0 && (reinterpret_cast<uintptr_t>(p.dpred) & 15) == 0)
+      copy_out16(nxt, RS, dpg, p.ld_dpred, nrows, (D + 7) >> 3, tid);     // pad columns receive the image's zeros
+    else
+      copy_out8(nxt, RS, dpg, p.ld_dpred, nrows, D >> 2, tid);
+    CH_STAMP(stamp++);
     unsigned char* t = cur; cur = nxt; nxt = t;
   }
 
-  // ---- backward: dh_i = d(out of block i) ; through LayerNorm and SiLU -> dz_i ; dh_{i-1} = dz_i W_i
+  // ---- backward: dh_i = d(out of block i) ; through LayerNorm and SiLU -> dz_i ; dh_{i-1} = dz_i W_i.
+  // `cur` = the GEMM input image (dpred, then dz_{i+1}); after the GEMM it receives dz_i.  `nxt` = the u_i image.
   for (int i = p.L - 1; i >= 0; --i) {
+    uint4 ru[2 * NTH];
+    load_rows16<2 * NTH>(p.u[i] + (int64_t)r0 * H, H, nrows, PPR, tid, ru);
     f32x4_t acc[4][NTH];
     zero_acc<NTH>(acc);
     if (i == p.L - 1) chain_gemm<NTH, KBD>(p.wb[p.L], wave * NTH, cur, RS, lane, acc);
     else chain_gemm<NTH, C::KBH>(p.wb[i + 1], wave * NTH, cur, RS, lane, acc);
+    CH_STAMP(stamp++);
+    store_rows16<2 * NTH>(nxt, RS, PPR, tid, ru);
+    __syncthreads();
     const int colb = wave * 16 * NTH + 4 * g;
     float mean[4], rstd[4];
 #pragma unroll
@@ -325,11 +438,11 @@ __global__ __launch_bounds__(CH_THREADS) void mlp_chain_kernel(ChainParams p) {
     // Two m-tile halves (rows are independent; halving keeps xhat / silu' for only 32 elements per lane live):
     //   pass 1: xhat, silu'(u); dgamma / dbeta partials; row sums of dxhat and dxhat * xhat
     //   pass 2: dv = rstd (dxhat - mean(dxhat) - xhat mean(dxhat xhat)) ; dz = dv * silu'(u)
-    float dg[NTH][4], db[NTH][4];
+    float dg[NTH][4], db[NTH][4], dzs[NTH][4];
 #pragma unroll
     for (int u = 0; u < NTH; ++u)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { dg[u][r] = 0.f; db[u][r] = 0.f; }
+      for (int r = 0; r < 4; ++r) { dg[u][r] = 0.f; db[u][r] = 0.f; dzs[u][r] = 0.f; }
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
       float xh[2][NTH][4];
@@ -343,11 +456,11 @@ __global__ __launch_bounds__(CH_THREADS) void mlp_chain_kernel(ChainParams p) {
 #pragma unroll
         for (int m2 = 0; m2 < 2; ++m2) {
           const int mt = 2 * hf + m2;
-          const bf16x4_t ub = *reinterpret_cast<const bf16x4_t*>(p.u[i] + (int64_t)rowg[mt] * H + col);
+          const bf16x4_t ub = *reinterpret_cast<const bf16x4_t*>(nxt + (16 * mt + l16) * RS + col * 2);
           float ds[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float x = valid[mt] ? (float)ub[r] : 0.f;
+            const float x = (float)ub[r];                  // rows beyond the panel hold zeros
             const float sg = fast_sigmoid(x);
             const float v = x * sg;
             ds[r] = sg * (1.f + x * (1.f - sg));
@@ -379,26 +492,36 @@ __global__ __launch_bounds__(CH_THREADS) void mlp_chain_kernel(ChainParams p) {
             dzv[r] = rsd * (acc[mt][u][r] - ma - xh[m2][u][r] * mb) * (float)dsl[m2][u][r];
           bf16x4_t o = pack4(dzv[0], dzv[1], dzv[2], dzv[3]);
           if (!valid[mt]) o = pack4(0.f, 0.f, 0.f, 0.f);
-          if (i > 0) *reinterpret_cast<bf16x4_t*>(nxt + (16 * mt + l16) * RS + col * 2) = o;
-          if (valid[mt]) *reinterpret_cast<bf16x4_t*>(p.dz[i] + (int64_t)rowg[mt] * H + col) = o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dzs[u][r] += (float)o[r];
+          *reinterpret_cast<bf16x4_t*>(cur + (16 * mt + l16) * RS + col * 2) = o;
         }
       }
     }
     {
-      float* pg = p.ln_partial[i] + (int64_t)blockIdx.x * H;
-      float* pb = p.ln_partial[i] + ((int64_t)gridDim.x + blockIdx.x) * H;
+      // per-workgroup column sums: dgamma | dbeta | dbias (= sum of dz over the panel's tokens)
+      float* pg = p.partial + (int64_t)blockIdx.x * p.ld_part + 3 * i * H;
 #pragma unroll
       for (int u = 0; u < NTH; ++u) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { dg[u][r] = row16_sum(dg[u][r]); db[u][r] = row16_sum(db[u][r]); }
+        for (int r = 0; r < 4; ++r) {
+          dg[u][r] = row16_sum(dg[u][r]); db[u][r] = row16_sum(db[u][r]); dzs[u][r] = row16_sum(dzs[u][r]);
+        }
         if (l16 == 0) {
-          *reinterpret_cast<float4*>(pg + colb + 16 * u) = make_float4(dg[u][0], dg[u][1], dg[u][2], dg[u][3]);
-          *reinterpret_cast<float4*>(pb + colb + 16 * u) = make_float4(db[u][0], db[u][1], db[u][2], db[u][3]);
+          const int col = colb + 16 * u;
+          *reinterpret_cast<float4*>(pg + col) = make_float4(dg[u][0], dg[u][1], dg[u][2], dg[u][3]);
+          *reinterpret_cast<float4*>(pg + H + col) = make_float4(db[u][0], db[u][1], db[u][2], db[u][3]);
+          *reinterpret_cast<float4*>(pg + 2 * H + col) = make_float4(dzs[u][0], dzs[u][1], dzs[u][2], dzs[u][3]);
+          // panel == one window: the column sums of dz ARE the time-embedding gradient row of that window
+          if (p.de_lp)
+            *reinterpret_cast<bf16x4_t*>(p.de_lp + (int64_t)blockIdx.x * p.ld_de + i * H + col) =
+                pack4(dzs[u][0], dzs[u][1], dzs[u][2], dzs[u][3]);
         }
       }
     }
     __syncthreads();
-    unsigned char* t = cur; cur = nxt; nxt = t;
+    copy_out16(cur, RS, p.dz[i] + (int64_t)r0 * H, H, nrows, PPR, tid);
+    CH_STAMP(stamp++);
   }
 }
 
@@ -464,6 +587,9 @@ void chain_layout(int64_t D, int64_t H, int L, const ChainShape& s, PackLayout* 
 
 }  // namespace
 
+// TIMING-ONLY: device buffer of [workgroups][16] int64 stamps filled by the next chain launches (NULL = off)
+extern "C" int ib_debug_set_chain_prof(void* buf) { g_chain_prof = reinterpret_cast<long long*>(buf); return IB_OK; }
+
 extern "C" int ib_mlp_chain_supported(int64_t D, int64_t H, int L) {
   ChainShape s;
   return (L >= 1 && L <= CH_MAXL && chain_shape(D, H, &s)) ? 1 : 0;
@@ -514,22 +640,29 @@ extern "C" int ib_mlp_chain_pack(const void* const* w, const int64_t* ldw, void*
   return IB_OK;
 }
 
+extern "C" int64_t ib_mlp_chain_partial_width(int64_t D, int64_t H, int L) {
+  ChainShape s;
+  if (L < 1 || L > CH_MAXL || !chain_shape(D, H, &s)) return 0;
+  return 3 * (int64_t)L * H + 128 * s.ntd + 4;
+}
+
 extern "C" int ib_mlp_chain_train(const void* x0, const void* eps, const int64_t* t, const float* sqrt_ab,
                                   const float* sqrt_1mab, int64_t table_rows, const void* e, int64_t ld_e,
                                   const void* packed, const float* const* bias, const float* const* gamma,
                                   const float* const* beta, void* xt, int64_t ld_xt, void* const* u, void* const* h,
-                                  void* const* dz, void* dpred, int64_t ld_dpred, float* const* ln_partial,
-                                  float* loss_partial, int64_t M, int64_t T, int64_t D, int64_t H, int L, float ln_eps,
-                                  ib_stream_t stream) {
+                                  void* const* dz, void* dpred, int64_t ld_dpred, float* partial, int64_t ld_part,
+                                  void* de_lp, int64_t ld_de, int64_t M, int64_t T, int64_t D, int64_t H, int L,
+                                  float ln_eps, ib_stream_t stream) {
   ChainShape s;
   if (L < 1 || L > CH_MAXL || !chain_shape(D, H, &s)) return IB_E_UNSUPPORTED;
   if (!x0 || !eps || !t || !sqrt_ab || !sqrt_1mab || !e || !packed || !bias || !gamma || !beta || !xt || !u || !h ||
-      !dz || !dpred || !ln_partial || !loss_partial || M <= 0 || T <= 0 || table_rows <= 0)
+      !dz || !dpred || !partial || M <= 0 || T <= 0 || table_rows <= 0)
     return IB_E_ARG;
   if (ld_e < (int64_t)L * H || ld_e % 4 != 0 || ld_xt < D || ld_xt % 4 != 0 || ld_dpred < D || ld_dpred % 4 != 0) return IB_E_ARG;
   auto al8 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) % 8) == 0; };
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) % 16) == 0; };
-  if (!al8(x0) || !al8(eps) || !al8(e) || !al8(xt) || !al8(dpred) || !al16(packed)) return IB_E_ARG;
+  if (!al8(x0) || !al8(eps) || !al8(e) || !al8(xt) || !al8(dpred) || !al16(packed) || !al16(partial)) return IB_E_ARG;
+  if (ld_part < ib_mlp_chain_partial_width(D, H, L) || ld_part % 4 != 0) return IB_E_ARG;
   PackLayout lo;
   chain_layout(D, H, L, s, &lo);
   ChainParams p{};
@@ -539,6 +672,10 @@ extern "C" int ib_mlp_chain_train(const void* x0, const void* eps, const int64_t
   int P;
   const int nwg = ib_mlp_chain_workgroups(M, &P);
   p.P = P;
+  if (de_lp) {   // only meaningful when every workgroup's panel is exactly one window
+    if (P != T || M % T != 0 || ld_de < (int64_t)L * H || ld_de % 4 != 0 || !al8(de_lp)) return IB_E_ARG;
+  }
+  p.de_lp = (bf16_t*)de_lp; p.ld_de = ld_de;
   const bf16_t* pk = (const bf16_t*)packed;
   for (int i = 0; i <= L; ++i) {
     p.wf[i] = pk + lo.off_f[i];
@@ -547,14 +684,15 @@ extern "C" int ib_mlp_chain_train(const void* x0, const void* eps, const int64_t
     p.bias[i] = bias[i];
   }
   for (int i = 0; i < L; ++i) {
-    if (!gamma[i] || !beta[i] || !u[i] || !h[i] || !dz[i] || !ln_partial[i]) return IB_E_ARG;
-    if (!al16(gamma[i]) || !al16(beta[i]) || !al8(u[i]) || !al8(h[i]) || !al8(dz[i]) || !al16(ln_partial[i])) return IB_E_ARG;
+    if (!gamma[i] || !beta[i] || !u[i] || !h[i] || !dz[i]) return IB_E_ARG;
+    if (!al16(gamma[i]) || !al16(beta[i]) || !al16(u[i]) || !al16(h[i]) || !al16(dz[i])) return IB_E_ARG;
     p.gamma[i] = gamma[i]; p.beta[i] = beta[i];
-    p.u[i] = (bf16_t*)u[i]; p.h[i] = (bf16_t*)h[i]; p.dz[i] = (bf16_t*)dz[i]; p.ln_partial[i] = ln_partial[i];
+    p.u[i] = (bf16_t*)u[i]; p.h[i] = (bf16_t*)h[i]; p.dz[i] = (bf16_t*)dz[i];
   }
   p.xt = (bf16_t*)xt; p.ld_xt = ld_xt; p.dpred = (bf16_t*)dpred; p.ld_dpred = ld_dpred;
-  p.loss_partial = loss_partial;
+  p.partial = partial; p.ld_part = ld_part;
   p.gscale = 2.f / ((float)M * (float)D); p.ln_eps = ln_eps;
+  p.prof = g_chain_prof;
   hipStream_t st = ib_s(stream);
 #define IB_CHAIN_LAUNCH(NTH, NTD, KBD) \
   hipLaunchKernelGGL((mlp_chain_kernel<NTH, NTD, KBD>), dim3(nwg), dim3(CH_THREADS), 0, st, p)
@@ -564,6 +702,83 @@ extern "C" int ib_mlp_chain_train(const void* x0, const void* eps, const int64_t
   else if (s.nth == 1 && s.ntd == 1 && s.kbd == 4) IB_CHAIN_LAUNCH(1, 1, 4);
   else return IB_E_UNSUPPORTED;
 #undef IB_CHAIN_LAUNCH
+  IB_CHECK_LAUNCH();
+  return IB_OK;
+}
+
+// ---- multi-segment column sums: out_s[c] (+)= scale_s * sum_r part[r][col0_s + c]   (fixed order, one launch for
+// every small parameter gradient of a step: LayerNorm gains / biases, linear biases, the loss scalar)
+namespace {
+constexpr int CS_MAXSEG = 24;
+struct ColsumSegs {
+  const float* part; int64_t ld; int rows; int nseg; int accumulate;
+  int col0[CS_MAXSEG], ncols[CS_MAXSEG];
+  float* dst[CS_MAXSEG]; float* dst2[CS_MAXSEG];
+  float scale[CS_MAXSEG];
+  int blk0[CS_MAXSEG + 1];       // first block of each segment (64 columns per block)
+};
+__global__ __launch_bounds__(256) void colsum_segments_kernel(ColsumSegs p) {
+  __shared__ float4 red[16][16];
+  int sgi = 0;
+  for (int j = 1; j < p.nseg; ++j)
+    if ((int)blockIdx.x >= p.blk0[j]) sgi = j;
+  const int c4 = threadIdx.x & 15, rg = threadIdx.x >> 4;      // 16 float4 columns x 16 row groups
+  const int c = ((int)blockIdx.x - p.blk0[sgi]) * 64 + 4 * c4;
+  const int nc = p.ncols[sgi];
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c < nc) {
+    const float* base = p.part + p.col0[sgi] + c;
+    if (c + 4 <= nc) {
+      for (int r = rg; r < p.rows; r += 16) {
+        const float4 v = *reinterpret_cast<const float4*>(base + (int64_t)r * p.ld);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+    } else {
+      for (int r = rg; r < p.rows; r += 16) {
+        const float* q = base + (int64_t)r * p.ld;
+        s.x += q[0];
+        if (c + 1 < nc) s.y += q[1];
+        if (c + 2 < nc) s.z += q[2];
+      }
+    }
+  }
+  red[rg][c4] = s;
+  __syncthreads();
+  if (rg == 0 && c < nc) {
+    float4 t = red[0][c4];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) { const float4 v = red[k][c4]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+    const float sc = p.scale[sgi];
+    const float o[4] = {t.x * sc, t.y * sc, t.z * sc, t.w * sc};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (c + k < nc) {
+        float* d = p.dst[sgi] + c + k;
+        *d = p.accumulate ? *d + o[k] : o[k];
+        if (p.dst2[sgi]) { float* d2 = p.dst2[sgi] + c + k; *d2 = p.accumulate ? *d2 + o[k] : o[k]; }
+      }
+    }
+  }
+}
+}  // namespace
+
+extern "C" int ib_colsum_segments(const float* part, int64_t ld, int64_t rows, int nseg, const int32_t* col0,
+                                  const int32_t* ncols, float* const* dst, float* const* dst2, const float* scale,
+                                  int accumulate, ib_stream_t stream) {
+  if (!part || rows <= 0 || nseg <= 0 || nseg > CS_MAXSEG || !col0 || !ncols || !dst || ld % 4 != 0) return IB_E_ARG;
+  if ((reinterpret_cast<uintptr_t>(part) % 16) != 0) return IB_E_ARG;
+  ColsumSegs p{};
+  p.part = part; p.ld = ld; p.rows = (int)rows; p.nseg = nseg; p.accumulate = accumulate;
+  int blocks = 0;
+  for (int j = 0; j < nseg; ++j) {
+    if (!dst[j] || ncols[j] <= 0 || col0[j] < 0 || col0[j] % 4 != 0 || col0[j] + ncols[j] > ld) return IB_E_ARG;
+    p.col0[j] = col0[j]; p.ncols[j] = ncols[j]; p.dst[j] = dst[j]; p.dst2[j] = dst2 ? dst2[j] : nullptr;
+    p.scale[j] = scale ? scale[j] : 1.f;
+    p.blk0[j] = blocks;
+    blocks += (ncols[j] + 63) / 64;
+  }
+  p.blk0[nseg] = blocks;
+  hipLaunchKernelGGL(colsum_segments_kernel, dim3(blocks), dim3(256), 0, ib_s(stream), p);
   IB_CHECK_LAUNCH();
   return IB_OK;
 }

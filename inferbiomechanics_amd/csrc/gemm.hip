@@ -717,14 +717,19 @@ extern "C" size_t ib_linear_wgrad_workspace(int64_t M, int64_t N, int64_t K) {
   return split > 1 ? (size_t)split * (size_t)N * (size_t)K * sizeof(float) : 0;
 }
 
-extern "C" int ib_linear_wgrad(const void* dz, int64_t lddz, const void* x, int64_t ldx, float* dw,
-                               int64_t lddw, int accumulate, void* workspace, size_t workspace_bytes,
-                               int64_t M, int64_t N, int64_t K, int dtype, ib_stream_t stream) {
-  if (!dz || !x || !dw || M <= 0 || N <= 0 || K <= 0 || lddz < N || ldx < K || lddw < K) return IB_E_ARG;
+namespace {
+// the split-M weight-gradient GEMM.  slabs_only: always write fp32 partial slabs [split][N][K] into the workspace
+// (even for split == 1) and leave the reduction to ib_slab_reduce_multi (one launch for several gradients).
+int wgrad_gemm(const void* dz, int64_t lddz, const void* x, int64_t ldx, float* dw, int64_t lddw, int accumulate,
+               void* workspace, size_t workspace_bytes, int64_t M, int64_t N, int64_t K, int dtype, hipStream_t s,
+               bool slabs_only, int* split_out) {
+  if (!dz || !x || M <= 0 || N <= 0 || K <= 0 || lddz < N || ldx < K) return IB_E_ARG;
+  if (!slabs_only && (!dw || lddw < K)) return IB_E_ARG;
   if (dtype != IB_F32 && dtype != IB_BF16) return IB_E_DTYPE;
   int chunk;
   const int split = wgrad_split(M, N, K, 64, &chunk);
-  const size_t need = split > 1 ? (size_t)split * (size_t)N * (size_t)K * sizeof(float) : 0;
+  const bool to_ws = slabs_only || split > 1;
+  const size_t need = to_ws ? (size_t)split * (size_t)N * (size_t)K * sizeof(float) : 0;
   if (need > 0 && (!workspace || workspace_bytes < need)) return IB_E_WORKSPACE;
   // C[N,K] = sum_m dz[m][n] * x[m][k]: A(i=n, kk=m) = dz[m*lddz + n], B(j=k, kk=m) = x[m*ldx + k]
   GemmParams p{};
@@ -737,8 +742,7 @@ extern "C" int ib_linear_wgrad(const void* dz, int64_t lddz, const void* x, int6
   // L2 (measured: [12800,512,300] 42 -> 36 us grouped, but [12800,1536,512] 48 -> 63 us: 5.2 MB per chunk thrashes)
   p.xcd_group = ((int64_t)chunk * (N + K) * (dtype == IB_BF16 ? 2 : 4) <= (2 << 20)) ? 1 : 0;
   const int tiles = p.tiles_m * p.tiles_n;
-  hipStream_t s = ib_s(stream);
-  if (split > 1) {
+  if (to_ws) {
     p.C = workspace; p.ldc = K; p.slab_stride = (int64_t)N * K; p.accumulate = 0;
   } else {
     p.C = dw; p.ldc = lddw; p.slab_stride = 0;
@@ -753,7 +757,8 @@ extern "C" int ib_linear_wgrad(const void* dz, int64_t lddz, const void* x, int6
     hipLaunchKernelGGL((gemm_kernel<bf16_t, false, false, EPI_WGRAD>), dim3(tiles * split), dim3(NTHREADS), 0, s, p);
   }
   IB_CHECK_LAUNCH();
-  if (split > 1) {
+  if (split_out) *split_out = split;
+  if (!slabs_only && split > 1) {
     const int64_t n = (int64_t)N * K;
     const int rvec = (K % 4 == 0) && (lddw % 4 == 0) && aligned(workspace, 16) && aligned(dw, 16);
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(ib_grid_1d(rvec ? n / 4 : n, 256)), dim3(256), 0, s,
@@ -761,5 +766,87 @@ extern "C" int ib_linear_wgrad(const void* dz, int64_t lddz, const void* x, int6
                        accumulate, rvec);
     IB_CHECK_LAUNCH();
   }
+  return IB_OK;
+}
+
+constexpr int SR_MAX = 8;
+struct SlabMulti {
+  const float* slabs[SR_MAX]; float* dw[SR_MAX]; int64_t lddw[SR_MAX];
+  int nslab[SR_MAX], rows[SR_MAX], cols[SR_MAX], blk0[SR_MAX + 1];
+  int n, accumulate;
+};
+// several wgrad slab sets -> their gradients in ONE launch (float4 path only: cols % 4 == 0, aligned)
+__global__ __launch_bounds__(256) void slab_reduce_multi_kernel(SlabMulti p) {
+  int e = 0;
+  for (int j = 1; j < p.n; ++j)
+    if ((int)blockIdx.x >= p.blk0[j]) e = j;
+  const int nb = p.blk0[e + 1] - p.blk0[e];
+  const int cols = p.cols[e], nslab = p.nslab[e];
+  const int64_t n4 = ((int64_t)p.rows[e] * cols) >> 2, st4 = n4;
+  const float4* base = reinterpret_cast<const float4*>(p.slabs[e]);
+  for (int64_t e4 = (int64_t)((int)blockIdx.x - p.blk0[e]) * 256 + threadIdx.x; e4 < n4; e4 += (int64_t)nb * 256) {
+    const float4* q = base + e4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    int k = 0;
+    for (; k + 4 <= nslab; k += 4) {
+      const float4 a = q[(int64_t)k * st4], b = q[(int64_t)(k + 1) * st4], c = q[(int64_t)(k + 2) * st4],
+                   d = q[(int64_t)(k + 3) * st4];
+      s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+      s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
+      s.x += c.x; s.y += c.y; s.z += c.z; s.w += c.w;
+      s.x += d.x; s.y += d.y; s.z += d.z; s.w += d.w;
+    }
+    for (; k < nslab; ++k) {
+      const float4 a = q[(int64_t)k * st4];
+      s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+    }
+    const int64_t el = e4 << 2;
+    const int r = (int)(el / cols), c0 = (int)(el % cols);
+    float4* o = reinterpret_cast<float4*>(p.dw[e] + (int64_t)r * p.lddw[e] + c0);
+    if (p.accumulate) { const float4 t = *o; s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w; }
+    *o = s;
+  }
+}
+}  // namespace
+
+extern "C" int ib_linear_wgrad(const void* dz, int64_t lddz, const void* x, int64_t ldx, float* dw,
+                               int64_t lddw, int accumulate, void* workspace, size_t workspace_bytes,
+                               int64_t M, int64_t N, int64_t K, int dtype, ib_stream_t stream) {
+  return wgrad_gemm(dz, lddz, x, ldx, dw, lddw, accumulate, workspace, workspace_bytes, M, N, K, dtype, ib_s(stream),
+                    false, nullptr);
+}
+
+extern "C" size_t ib_linear_wgrad_slabs_workspace(int64_t M, int64_t N, int64_t K) {
+  int chunk;
+  const int split = wgrad_split(M, N, K, 64, &chunk);
+  return (size_t)split * (size_t)N * (size_t)K * sizeof(float);
+}
+
+extern "C" int ib_linear_wgrad_slabs(const void* dz, int64_t lddz, const void* x, int64_t ldx, void* workspace,
+                                     size_t workspace_bytes, int* nslab_out, int64_t M, int64_t N, int64_t K,
+                                     int dtype, ib_stream_t stream) {
+  if (!nslab_out) return IB_E_ARG;
+  return wgrad_gemm(dz, lddz, x, ldx, nullptr, 0, 0, workspace, workspace_bytes, M, N, K, dtype, ib_s(stream), true,
+                    nslab_out);
+}
+
+extern "C" int ib_slab_reduce_multi(int n, const void* const* slabs, const int32_t* nslab, float* const* dw,
+                                    const int64_t* lddw, const int32_t* N, const int32_t* K, int accumulate,
+                                    ib_stream_t stream) {
+  if (n <= 0 || n > SR_MAX || !slabs || !nslab || !dw || !lddw || !N || !K) return IB_E_ARG;
+  SlabMulti p{};
+  p.n = n; p.accumulate = accumulate;
+  int blocks = 0;
+  for (int j = 0; j < n; ++j) {
+    if (!slabs[j] || !dw[j] || nslab[j] <= 0 || N[j] <= 0 || K[j] <= 0 || lddw[j] < K[j]) return IB_E_ARG;
+    if (K[j] % 4 != 0 || lddw[j] % 4 != 0 || !aligned(slabs[j], 16) || !aligned(dw[j], 16)) return IB_E_UNSUPPORTED;
+    p.slabs[j] = reinterpret_cast<const float*>(slabs[j]); p.dw[j] = dw[j]; p.lddw[j] = lddw[j];
+    p.nslab[j] = nslab[j]; p.rows[j] = N[j]; p.cols[j] = K[j];
+    p.blk0[j] = blocks;
+    blocks += ib_grid_1d((int64_t)N[j] * K[j] / 4, 256, 1024);
+  }
+  p.blk0[n] = blocks;
+  hipLaunchKernelGGL(slab_reduce_multi_kernel, dim3(blocks), dim3(256), 0, ib_s(stream), p);
+  IB_CHECK_LAUNCH();
   return IB_OK;
 }

@@ -86,3 +86,14 @@ extern "C" int ib_selftest_tr16(const void* in_bf16_64x16, void* out_bf16_64x4, 
   IB_CHECK_LAUNCH();
   return IB_OK;
 }
+
+// TIMING-ONLY (tools/timeline.py): one thread writes the 100 MHz wall clock into *slot when the stream reaches it
+namespace {
+__global__ void stamp_kernel(long long* slot) { *slot = wall_clock64(); }
+}  // namespace
+extern "C" int ib_debug_stamp(void* slot, ib_stream_t stream) {
+  if (!slot) return IB_E_ARG;
+  hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, ib_s(stream), reinterpret_cast<long long*>(slot));
+  IB_CHECK_LAUNCH();
+  return IB_OK;
+}

@@ -279,8 +279,7 @@ class HipTrainer:
             M = B * T
             if hasattr(plan, "chain_ok") and plan.chain_ok(D):
                 # MLP denoiser, bf16: q_sample + forward + loss + the dgrad chain are ONE launch (csrc/chain.hip)
-                plan.chain_step(x0, eps, t, tabs, P, self.result, br_loss=self._br_loss)
-                self._br_loss.join()
+                plan.chain_step(x0, eps, t, tabs, P, self.result)
                 return self._finish_step(cut)
             # activations that are D (= 300) wide live in buffers with a 16-byte-aligned row pitch (304): the GEMM
             # operand pieces are then aligned 16-byte loads (the unpadded rows were 8-byte aligned: +11 us per wgrad)

@@ -41,6 +41,9 @@ _SIGS = {
                                    _c.c_int, _vp]),
     "ib_linear_wgrad_workspace": (_sz, [_i64, _i64, _i64]),
     "ib_linear_wgrad": (_c.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _c.c_int, _vp, _sz, _i64, _i64, _i64, _c.c_int, _vp]),
+    "ib_linear_wgrad_slabs_workspace": (_sz, [_i64, _i64, _i64]),
+    "ib_linear_wgrad_slabs": (_c.c_int, [_vp, _i64, _vp, _i64, _vp, _sz, _vp, _i64, _i64, _i64, _c.c_int, _vp]),
+    "ib_slab_reduce_multi": (_c.c_int, [_c.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _c.c_int, _vp]),
     "ib_segment_colsum": (_c.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _c.c_int, _c.c_int, _c.c_int, _vp]),
     "ib_layernorm_bwd_reduce": (_c.c_int, [_vp, _sz, _vp, _vp, _c.c_int, _i64, _i64, _vp]),
     "ib_layernorm_fwd": (_c.c_int, [_vp, _vp, _c.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _f32,
@@ -66,8 +69,13 @@ _SIGS = {
     "ib_mlp_chain_packed_elems": (_sz, [_i64, _i64, _c.c_int]),
     "ib_mlp_chain_workgroups": (_c.c_int, [_i64, _vp]),
     "ib_mlp_chain_pack": (_c.c_int, [_vp, _vp, _vp, _i64, _i64, _c.c_int, _vp]),
+    "ib_mlp_chain_partial_width": (_i64, [_i64, _i64, _c.c_int]),
     "ib_mlp_chain_train": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp,
-                                      _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _c.c_int, _f32, _vp]),
+                                      _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _i64, _c.c_int,
+                                      _f32, _vp]),
+    "ib_colsum_segments": (_c.c_int, [_vp, _i64, _i64, _c.c_int, _vp, _vp, _vp, _vp, _vp, _c.c_int, _vp]),
+    "ib_debug_set_chain_prof": (_c.c_int, [_vp]),
+    "ib_debug_stamp": (_c.c_int, [_vp, _vp]),
     "ib_sum_partials": (_c.c_int, [_vp, _i64, _f32, _vp, _vp]),
     "ib_q_sample": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _c.c_int, _vp]),
     "ib_ddim_step": (_c.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i64, _i64, _c.c_int, _vp]),
@@ -93,7 +101,7 @@ def declared_symbols() -> List[str]:
     return sorted(set(re.findall(r"\b(ib_[a-z0-9_]+)\s*\(", src)))
 
 
-_HOST_ONLY = ("_workspace", "_supported", "_workgroups", "_packed_elems")   # pure host queries: no launch, no stream
+_HOST_ONLY = ("_workspace", "_supported", "_workgroups", "_packed_elems", "_partial_width")   # pure host queries: no launch, no stream
 
 
 class _DryRunLib:
@@ -173,6 +181,62 @@ class _RecordingLib:
             self.calls.append((name, a))
             return real(*a)
         return call
+
+
+class _StampLib:
+    """TIMING-ONLY (tools/timeline.py): brackets every C-ABI launch with two one-thread kernels that write the
+    device wall clock, on the launch's own stream -- under hipGraph capture they become graph nodes, so a replay
+    yields the device-side timeline of the step (which launches overlap, where the gaps are)."""
+
+    def __init__(self, real, slots: int = 4096, only=None):
+        self._real = real
+        self.buf = torch.zeros(slots, dtype=torch.int64, device="cuda")
+        self.calls = []      # (name, int args)
+        self.only = only     # None = every launch; else the entry-point names to bracket (less perturbation)
+
+    def __getattr__(self, name):
+        real = getattr(self._real, name)
+        if not name.startswith("ib_") or name.startswith(("ib_event", "ib_graph", "ib_debug")) \
+                or name.endswith(_HOST_ONLY) or name in ("ib_version", "ib_error_string") \
+                or (self.only is not None and name not in self.only):
+            return real
+
+        def call(*a):
+            k = len(self.calls)
+            base = self.buf.data_ptr() + 16 * k
+            self._real.ib_debug_stamp(ctypes.c_void_p(base), a[-1])
+            rc = real(*a)
+            self._real.ib_debug_stamp(ctypes.c_void_p(base + 8), a[-1])
+            self.calls.append((name, tuple(v for v in a if isinstance(v, int) and not isinstance(v, bool) and 0 <= v < (1 << 31)),
+                               a[-1].value if hasattr(a[-1], "value") else a[-1]))
+            return rc
+        return call
+
+    def timeline(self):
+        """[(name, ints, stream, start_us, end_us)] relative to the first stamp (synchronises)"""
+        torch.cuda.synchronize()
+        t = self.buf.cpu().tolist()
+        n = len(self.calls)
+        t0 = min(t[2 * k] for k in range(n))
+        return [(self.calls[k][0], self.calls[k][1], self.calls[k][2], (t[2 * k] - t0) * 0.01, (t[2 * k + 1] - t0) * 0.01)
+                for k in range(n)]
+
+
+class stamp_launches:
+    def __init__(self, only=None):
+        self.only = only
+
+    def __enter__(self):
+        global _lib
+        self._saved = lib()
+        self.lib = _StampLib(self._saved, only=self.only)
+        _lib = self.lib
+        return self.lib
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self._saved
+        return False
 
 
 class record_launches:
@@ -377,6 +441,41 @@ def linear_wgrad(dz, x, dw, workspace, accumulate=False):
     _check(lib().ib_linear_wgrad(_ptr(dz), lddz, _ptr(x), ldx, _ptr(dw), lddw, int(accumulate), _ptr(workspace), wsb,
                                  M, N, K, dtype_code(dt), stream_ptr()), "ib_linear_wgrad")
     return dw
+
+
+def linear_wgrad_slabs(dz, x, workspace) -> int:
+    """split-M partial slabs of dw = dz^T x into `workspace`; returns the slab count (see slab_reduce_multi)"""
+    dt = dz.dtype
+    M, N, lddz = _mat(dz, "dz", dt)
+    Mx, K, ldx = _mat(x, "x", dt)
+    if Mx != M:
+        raise HipError("linear_wgrad_slabs: dz / x row counts differ")
+    need = int(lib().ib_linear_wgrad_slabs_workspace(M, N, K))
+    wsb = workspace.numel() * workspace.element_size()
+    if need > wsb:
+        raise HipError(f"linear_wgrad_slabs: workspace of {need} bytes required, got {wsb}")
+    n = ctypes.c_int(0)
+    _check(lib().ib_linear_wgrad_slabs(_ptr(dz), lddz, _ptr(x), ldx, _ptr(workspace), wsb,
+                                       ctypes.cast(ctypes.pointer(n), ctypes.c_void_p), M, N, K, dtype_code(dt),
+                                       stream_ptr()), "ib_linear_wgrad_slabs")
+    return n.value if not _dry_run else 1
+
+
+def slab_reduce_multi(items, accumulate=False):
+    """items: [(workspace, nslab, dw)] with dw fp32 2-D [N, K] (row pitch % 4 == 0): dw (+)= sum of its slabs"""
+    n = len(items)
+    for ws, ns, dw in items:
+        _req(ws, "workspace")
+        _mat(dw, "dw", torch.float32)
+    cv = lambda a: ctypes.cast(a, ctypes.c_void_p)
+    slabs = (ctypes.c_void_p * n)(*[it[0].data_ptr() for it in items])
+    nslab = (ctypes.c_int32 * n)(*[int(it[1]) for it in items])
+    dws = (ctypes.c_void_p * n)(*[it[2].data_ptr() for it in items])
+    ldd = (ctypes.c_int64 * n)(*[it[2].stride(0) for it in items])
+    Ns = (ctypes.c_int32 * n)(*[it[2].shape[0] for it in items])
+    Ks = (ctypes.c_int32 * n)(*[it[2].shape[1] for it in items])
+    _check(lib().ib_slab_reduce_multi(n, cv(slabs), cv(nslab), cv(dws), cv(ldd), cv(Ns), cv(Ks), int(accumulate),
+                                      stream_ptr()), "ib_slab_reduce_multi")
 
 
 def segment_colsum(x, out, seg, mode=0, accumulate=False, out_bf16=None):
@@ -777,11 +876,22 @@ def mlp_chain_pack(weights, packed, D: int, H: int):
     return packed
 
 
-def mlp_chain_train(x0, eps, t, sqrt_ab, sqrt_1mab, e, packed, bias, gamma, beta, xt, u, h, dz, dpred, ln_partial,
-                    loss_partial, T: int, ln_eps: float = 1e-5):
+def mlp_chain_partial_width(D: int, H: int, L: int) -> int:
+    return int(lib().ib_mlp_chain_partial_width(D, H, L))
+
+
+def mlp_chain_rows_per_workgroup(M: int) -> int:
+    p = ctypes.c_int(0)
+    lib().ib_mlp_chain_workgroups(M, ctypes.cast(ctypes.pointer(p), ctypes.c_void_p))
+    return p.value
+
+
+def mlp_chain_train(x0, eps, t, sqrt_ab, sqrt_1mab, e, packed, bias, gamma, beta, xt, u, h, dz, dpred, partial,
+                    T: int, de_lp=None, ln_eps: float = 1e-5):
     """x0 / eps: contiguous bf16 [B,T,D]; e: bf16 [B, L*H]; xt / dpred: bf16 2-D [B*T, D] (row pitch % 4 == 0);
     u / h / dz: L contiguous bf16 [B*T, H]; bias: L+1 fp32 vectors; gamma / beta: L fp32 vectors;
-    ln_partial: L fp32 [2 * workgroups, H]; loss_partial: fp32 [workgroups]"""
+    partial: fp32 [workgroups, >= mlp_chain_partial_width] (column layout: include/ib_hip.h);
+    de_lp: optional bf16 [B, L*H], legal only when mlp_chain_rows_per_workgroup(B*T) == T"""
     bt = torch.bfloat16
     _req(x0, "x0", bt, 3); _req(eps, "eps", bt, 3)
     if x0.shape != eps.shape or not x0.is_contiguous() or not eps.is_contiguous():
@@ -814,21 +924,48 @@ def mlp_chain_train(x0, eps, t, sqrt_ab, sqrt_1mab, e, packed, bias, gamma, beta
         if a.numel() != (H if i < L else D):
             raise HipError("mlp_chain_train: bias size mismatch")
     nwg = mlp_chain_workgroups(M)
-    for a in ln_partial:
-        _req(a, "ln_partial", torch.float32)
-        if a.numel() < 2 * nwg * H or not a.is_contiguous():
-            raise HipError("mlp_chain_train: ln_partial must hold [2 * workgroups, H]")
-    _req(loss_partial, "loss_partial", torch.float32, 1)
-    if loss_partial.numel() < nwg or packed.numel() < mlp_chain_packed_elems(D, H, L):
-        raise HipError("mlp_chain_train: loss_partial / packed too small")
+    pr, pc, ldp = _mat(partial, "partial", torch.float32)
+    if pr < nwg or pc < mlp_chain_partial_width(D, H, L):
+        raise HipError("mlp_chain_train: partial must be [workgroups, >= partial_width]")
+    ldd = 0
+    if de_lp is not None:
+        dr, dc, ldd = _mat(de_lp, "de_lp", bt)
+        if dr < B or dc < L * H or mlp_chain_rows_per_workgroup(M) != T:
+            raise HipError("mlp_chain_train: de_lp needs [B, L*H] and panels of exactly one window")
     _req(packed, "packed", bt, 1)
+    if packed.numel() < mlp_chain_packed_elems(D, H, L):
+        raise HipError("mlp_chain_train: packed too small")
     k1, pb = _ptr_array(bias); k2, pg = _ptr_array(gamma); k3, pbe = _ptr_array(beta)
-    k4, pu = _ptr_array(u); k5, ph = _ptr_array(h); k6, pdz = _ptr_array(dz); k7, pln = _ptr_array(ln_partial)
+    k4, pu = _ptr_array(u); k5, ph = _ptr_array(h); k6, pdz = _ptr_array(dz)
     _check(lib().ib_mlp_chain_train(_ptr(x0), _ptr(eps), _ptr(t), _ptr(sqrt_ab), _ptr(sqrt_1mab), sqrt_ab.numel(),
                                     _ptr(e), lde, _ptr(packed), pb, pg, pbe, _ptr(xt), xt.stride(0), pu, ph, pdz,
-                                    _ptr(dpred), dpred.stride(0), pln, _ptr(loss_partial), M, T, D, H, L,
+                                    _ptr(dpred), dpred.stride(0), _ptr(partial), ldp, _ptr(de_lp), ldd, M, T, D, H, L,
                                     float(ln_eps), stream_ptr()), "ib_mlp_chain_train")
     return nwg
+
+
+def colsum_segments(part, rows: int, segs, accumulate=False):
+    """segs: [(col0, ncols, dst, dst2_or_None, scale)]; dst[c] (+)= scale * sum_{r < rows} part[r, col0 + c]"""
+    pr, pc, ld = _mat(part, "part", torch.float32)
+    if rows > pr:
+        raise HipError("colsum_segments: rows exceed the partial array")
+    n = len(segs)
+    for c0, nc, d, d2, sc in segs:
+        _req(d, "dst", torch.float32)
+        if d.numel() < nc or not d.is_contiguous() or c0 + nc > pc:
+            raise HipError("colsum_segments: segment does not fit")
+        if d2 is not None:
+            _req(d2, "dst2", torch.float32)
+            if d2.numel() < nc or not d2.is_contiguous():
+                raise HipError("colsum_segments: dst2 too small")
+    col0 = (ctypes.c_int32 * n)(*[s[0] for s in segs])
+    ncols = (ctypes.c_int32 * n)(*[s[1] for s in segs])
+    dst = (ctypes.c_void_p * n)(*[s[2].data_ptr() for s in segs])
+    dst2 = (ctypes.c_void_p * n)(*[(s[3].data_ptr() if s[3] is not None else None) for s in segs])
+    scale = (ctypes.c_float * n)(*[float(s[4]) for s in segs])
+    cv = lambda a: ctypes.cast(a, ctypes.c_void_p)
+    _check(lib().ib_colsum_segments(_ptr(part), ld, rows, n, cv(col0), cv(ncols), cv(dst), cv(dst2), cv(scale),
+                                    int(accumulate), stream_ptr()), "ib_colsum_segments")
 
 
 def sum_partials(partial, parts: int, scale: float, out):

@@ -114,10 +114,17 @@ def _colsum(buf: Buffers, tag: str, x2d: torch.Tensor, out_vec: torch.Tensor, ac
         hip.segment_colsum(part, out_vec.view(1, N), seg=part.shape[0], mode=0, accumulate=accumulate)
 
 
-def _wgrad(buf: Buffers, dz: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, accumulate: bool, ws_tag: str = "wgrad.ws"):
-    """`ws_tag`: launches that may run concurrently (different branches) must not share a slab workspace"""
+def _wgrad(buf: Buffers, dz: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, accumulate: bool, ws_tag: str = "wgrad.ws",
+           defer: Optional[list] = None):
+    """`ws_tag`: launches that may run concurrently (different branches) must not share a slab workspace.
+    `defer`: only write the split-M slabs now and append (workspace, nslab, dw) -- the caller sums every deferred
+    gradient with ONE hip.slab_reduce_multi launch (each kernel boundary of a captured step costs ~4.5 us)."""
     M, N = dz.shape
     K = x.shape[1]
+    if defer is not None and K % 4 == 0 and dw.stride(0) % 4 == 0:
+        ws = buf.bytes(ws_tag, int(hip.lib().ib_linear_wgrad_slabs_workspace(M, N, K)))
+        defer.append((ws, hip.linear_wgrad_slabs(dz, x, ws), dw))
+        return
     ws = buf.bytes(ws_tag, hip.linear_wgrad_workspace_bytes(M, N, K))
     hip.linear_wgrad(dz, x, dw, ws, accumulate=accumulate)
 
@@ -325,24 +332,30 @@ class TimeMLPPlan:
             return de32
         return de_lp if de_lp is not None else _as_dtype(self.buf, self.tag + ".de", de32, self.dtype)
 
-    def backward_out_layer(self, de32, de_lp, P: ParamSource, accumulate=False):
-        """gradients of the output layer (time_mlp.2): independent of the dgrad chain below"""
+    def backward_out_layer(self, de32, de_lp, P: ParamSource, accumulate=False, defer=None, ready=True):
+        """gradients of the output layer (time_mlp.2): independent of the dgrad chain below.
+        de32 None: the caller produces the bias gradient itself (chain path: one multi-segment reduction)."""
         s, u, zu = self.ctx
         tg = self.tag
-        _wgrad(self.buf, self._de(de32, de_lp), u, P.g("time_mlp.2.weight"), accumulate, ws_tag=tg + ".ws2")
-        P.ready("time_mlp.2.weight")
-        _colsum(self.buf, tg + ".b2", de32, P.g("time_mlp.2.bias"), accumulate)
-        P.ready("time_mlp.2.bias")
+        _wgrad(self.buf, self._de(de32, de_lp), u, P.g("time_mlp.2.weight"), accumulate, ws_tag=tg + ".ws2", defer=defer)
+        if ready:
+            P.ready("time_mlp.2.weight")
+        if de32 is not None:
+            _colsum(self.buf, tg + ".b2", de32, P.g("time_mlp.2.bias"), accumulate)
+            if ready:
+                P.ready("time_mlp.2.bias")
 
-    def backward_hidden(self, de32, de_lp, P: ParamSource, accumulate=False):
+    def backward_hidden(self, de32, de_lp, P: ParamSource, accumulate=False, defer=None, ready=True):
         s, u, zu = self.ctx
         tg = self.tag
         du = self.buf.get(tg + ".du", u.shape, self.dtype)
         hip.linear_dgrad(self._de(de32, de_lp), P.w("time_mlp.2.weight"), du, act_below="silu", aux=zu)
-        _wgrad(self.buf, du, s, P.g("time_mlp.0.weight"), accumulate, ws_tag=tg + ".ws0")
-        P.ready("time_mlp.0.weight")
+        _wgrad(self.buf, du, s, P.g("time_mlp.0.weight"), accumulate, ws_tag=tg + ".ws0", defer=defer)
+        if ready:
+            P.ready("time_mlp.0.weight")
         _colsum(self.buf, tg + ".b1", du, P.g("time_mlp.0.bias"), accumulate)
-        P.ready("time_mlp.0.bias")
+        if ready:
+            P.ready("time_mlp.0.bias")
 
     def backward(self, de32: torch.Tensor, P: ParamSource, accumulate=False, de_lp: Optional[torch.Tensor] = None):
         """both halves on the current stream (callers that want them concurrent fork the halves as SIBLING
@@ -371,9 +384,10 @@ class DenoiserMLPPlan:
         self.branch = Branch(device, name="time_bwd")   # time-MLP backward: hidden-layer chain
         self.br_tout = Branch(device, name="time_out")  # time-MLP backward: output-layer gradients
         self.br_tfwd = Branch(device, name="time_fwd")  # time-MLP forward (beside q_sample + the first block's GEMM)
+        self.br_pack = Branch(device, name="pack")      # chain path: weight packing beside the time-MLP forward
 
     def branches(self) -> List[Branch]:
-        return [self.br_head, self.branch, self.br_tout, self.br_tfwd] + self.br_blk
+        return [self.br_head, self.branch, self.br_tout, self.br_tfwd, self.br_pack] + self.br_blk
 
     def forward(self, x, t: torch.Tensor, table: torch.Tensor, P: ParamSource,
                 out: Optional[torch.Tensor] = None, BT: Optional[Tuple[int, int]] = None) -> torch.Tensor:
@@ -485,15 +499,18 @@ class DenoiserMLPPlan:
         return all(h == H for h in self.hidden) and hip.mlp_chain_supported(D, H, len(self.hidden))
 
     def chain_step(self, x0: torch.Tensor, eps: torch.Tensor, t: torch.Tensor, tabs, P: ParamSource,
-                   result: torch.Tensor, br_loss: Optional[Branch] = None, accumulate=False):
-        """the whole diffusion training step up to the gradients (HipTrainer's diffusion path for this model)"""
+                   result: torch.Tensor, accumulate=False):
+        """the whole diffusion training step up to the gradients (HipTrainer's diffusion path for this model):
+        [weight pack || time-MLP forward] -> chain kernel -> {weight-gradient GEMMs (slabs only), one multi-segment
+        reduction for every small gradient + the loss, time-MLP backward} -> one slab reduction for all GEMMs."""
         B, T, D = x0.shape
         M, L, H = B * T, len(self.hidden), self.hidden[0]
         g, dt = self.buf.get, self.dtype
         names = [f"blocks.{i}.linear.weight" for i in range(L)] + ["head.weight"]
         packed = g("ch.packed", (hip.mlp_chain_packed_elems(D, H, L),), dt)
-        hip.mlp_chain_pack([P.w(n) for n in names], packed, D, H)
+        self.br_pack.run(lambda: hip.mlp_chain_pack([P.w(n) for n in names], packed, D, H))
         e = self.time.forward(t, tabs.temb, P)                               # [B, L*H]
+        self.br_pack.join()
         Dp = (D + 7) // 8 * 8
         xt = g("ch.xt", (M, Dp), dt)[:, :D]
         dpred = g("ch.dpred", (M, Dp), dt)[:, :D]
@@ -501,53 +518,52 @@ class DenoiserMLPPlan:
         h = [g(f"ch.h{i}", (M, H), dt) for i in range(L)]
         dz = [g(f"ch.dz{i}", (M, H), dt) for i in range(L)]
         nwg = hip.mlp_chain_workgroups(M)
-        lnp = [g(f"ch.lnp{i}", (2 * nwg, H), torch.float32) for i in range(L)]
-        lossp = g("ch.lossp", (nwg,), torch.float32)
+        W = hip.mlp_chain_partial_width(D, H, L)
+        part = g("ch.part", (nwg, W), torch.float32)
+        Hs = L * H
+        de_lp = g("dm.de_lp", (B, Hs), torch.bfloat16)
+        window_panels = hip.mlp_chain_rows_per_workgroup(M) == T and nwg == B   # panel == window: de comes for free
         hip.mlp_chain_train(x0, eps, t, tabs.sqrt_ab, tabs.sqrt_1mab, e, packed,
                             [P.v(f"blocks.{i}.linear.bias") for i in range(L)] + [P.v("head.bias")],
                             [P.v(f"blocks.{i}.norm.weight") for i in range(L)],
-                            [P.v(f"blocks.{i}.norm.bias") for i in range(L)], xt, u, h, dz, dpred, lnp, lossp, T)
-        if br_loss is not None:
-            br_loss.run(lambda: hip.sum_partials(lossp, nwg, 1.0 / (M * D), result))
-        else:
-            hip.sum_partials(lossp, nwg, 1.0 / (M * D), result)
+                            [P.v(f"blocks.{i}.norm.bias") for i in range(L)], xt, u, h, dz, dpred, part, T,
+                            de_lp=de_lp if window_panels else None)
 
-        # every gradient operand now sits in HBM: the rest is independent side work (weight-gradient GEMMs, sums)
-        def head_grads():
-            _wgrad(self.buf, dpred, h[L - 1], P.g("head.weight"), accumulate, ws_tag="dm.wsH")
-            P.ready("head.weight")
-            _colsum(self.buf, "dm.bh", dpred, P.g("head.bias"), accumulate)
-            P.ready("head.bias")
-        self.br_head.run(head_grads)
-        Hs = L * H
-        de32 = g("dm.de32", (B, Hs), torch.float32)
-        de_lp = g("dm.de_lp", (B, Hs), torch.bfloat16)
+        # every gradient operand now sits in HBM.  The large weight-gradient GEMMs go first, one branch each.
+        defer: list = []
+        self.br_head.run(lambda: _wgrad(self.buf, dpred, h[L - 1], P.g("head.weight"), accumulate, ws_tag="dm.wsH",
+                                        defer=defer))
         for i in range(L - 1, -1, -1):
-            off = i * H
-            sl = de32[:, off:off + H]
             hin = h[i - 1] if i > 0 else xt
-
-            def blk_grads(i=i, sl=sl, hin=hin):
-                hip.segment_colsum(lnp[i][:nwg], P.g(f"blocks.{i}.norm.weight").view(1, H), seg=nwg, mode=0,
-                                   accumulate=accumulate)
-                P.ready(f"blocks.{i}.norm.weight")
-                hip.segment_colsum(lnp[i][nwg:], P.g(f"blocks.{i}.norm.bias").view(1, H), seg=nwg, mode=0,
-                                   accumulate=accumulate)
-                P.ready(f"blocks.{i}.norm.bias")
-                _wgrad(self.buf, dz[i], hin, P.g(f"blocks.{i}.linear.weight"), accumulate, ws_tag=f"dm.ws{i}")
-                P.ready(f"blocks.{i}.linear.weight")
-                _colsum(self.buf, f"dm.b{i}", sl, P.g(f"blocks.{i}.linear.bias"), accumulate)
-                P.ready(f"blocks.{i}.linear.bias")
-
-            hip.segment_colsum(dz[i], sl, seg=T, mode=0, out_bf16=de_lp[:, off:off + H])
-            if i > 0:
-                self.br_blk[i].run(blk_grads)
-            else:
-                self.br_tout.run(lambda: self.time.backward_out_layer(de32, de_lp, P, accumulate))
-                self.branch.run(lambda: self.time.backward_hidden(de32, de_lp, P, accumulate))
-                blk_grads()
+            self.br_blk[i].run(lambda i=i, hin=hin: _wgrad(self.buf, dz[i], hin, P.g(f"blocks.{i}.linear.weight"),
+                                                           accumulate, ws_tag=f"dm.ws{i}", defer=defer))
+        # main stream: every small gradient (LayerNorm gains / biases, linear biases, head bias, time_mlp.2.bias) and
+        # the loss in one launch, then the time-MLP backward
+        tb2 = P.g("time_mlp.2.bias")
+        segs = []
+        for i in range(L):
+            segs += [(3 * i * H, H, P.g(f"blocks.{i}.norm.weight"), None, 1.0),
+                     (3 * i * H + H, H, P.g(f"blocks.{i}.norm.bias"), None, 1.0),
+                     (3 * i * H + 2 * H, H, P.g(f"blocks.{i}.linear.bias"), tb2[i * H:(i + 1) * H], 1.0)]
+        segs += [(3 * L * H, D, P.g("head.bias"), None, 1.0), (W - 4, 1, result, None, 1.0 / (M * D))]
+        if accumulate:     # the loss scalar is never accumulated
+            hip.colsum_segments(part, nwg, segs[:-1], accumulate=True)
+            hip.colsum_segments(part, nwg, segs[-1:], accumulate=False)
+        else:
+            hip.colsum_segments(part, nwg, segs, accumulate=False)
+        de32 = None
+        if not window_panels:
+            de32 = g("dm.de32", (B, Hs), torch.float32)
+            for i in range(L):
+                hip.segment_colsum(dz[i], de32[:, i * H:(i + 1) * H], seg=T, mode=0, out_bf16=de_lp[:, i * H:(i + 1) * H])
+        self.br_tout.run(lambda: self.time.backward_out_layer(None, de_lp, P, accumulate, defer=defer, ready=False))
+        self.time.backward_hidden(de32, de_lp, P, accumulate, defer=defer, ready=False)
         for b in self.branches():
             b.join()
+        if defer:
+            hip.slab_reduce_multi(defer, accumulate=accumulate)
+        for n in self.ready_order():
+            P.ready(n)
 
 
 class DenoiserTransformerPlan:

@@ -105,12 +105,25 @@ def test_chain_matches_float64_restatement(hip, B, T, D, H, L):
     h_k = [torch.zeros(M, H, dtype=BF, device=DEV) for _ in range(L)]
     dz_k = [torch.zeros(M, H, dtype=BF, device=DEV) for _ in range(L)]
     nwg = hip.mlp_chain_workgroups(M)
-    lnp = [torch.zeros(2 * nwg, H, dtype=torch.float32, device=DEV) for _ in range(L)]
-    lossp = torch.zeros(nwg, dtype=torch.float32, device=DEV)
-    out = torch.zeros(1, dtype=torch.float32, device=DEV)
+    Wd = hip.mlp_chain_partial_width(D, H, L)
+    part = torch.zeros(nwg, Wd, dtype=torch.float32, device=DEV)
+    window_panels = hip.mlp_chain_rows_per_workgroup(M) == T and nwg == B
+    de_lp = torch.zeros(B, L * H, dtype=BF, device=DEV) if window_panels else None
     hip.mlp_chain_train(d(x0), d(eps), d(t), d(sab), d(s1m), d(e), packed, [d(b) for b in bias], [d(g) for g in gamma],
-                        [d(b) for b in beta], xt, u_k, h_k, dz_k, dpred, lnp, lossp, T)
-    hip.sum_partials(lossp, nwg, 1.0 / (M * D), out)
+                        [d(b) for b in beta], xt, u_k, h_k, dz_k, dpred, part, T, de_lp=de_lp)
+    # every small gradient + the loss in one multi-segment reduction
+    out = torch.zeros(1, dtype=torch.float32, device=DEV)
+    dg_k = [torch.zeros(H, device=DEV) for _ in range(L)]
+    db_k = [torch.zeros(H, device=DEV) for _ in range(L)]
+    dbl_k = [torch.zeros(H, device=DEV) for _ in range(L)]
+    dbl2 = torch.zeros(L * H, device=DEV)
+    dbh_k = torch.zeros(D, device=DEV)
+    segs = []
+    for i in range(L):
+        segs += [(3 * i * H, H, dg_k[i], None, 1.0), (3 * i * H + H, H, db_k[i], None, 1.0),
+                 (3 * i * H + 2 * H, H, dbl_k[i], dbl2[i * H:(i + 1) * H], 1.0)]
+    segs += [(3 * L * H, D, dbh_k, None, 1.0), (Wd - 4, 1, out, None, 1.0 / (M * D))]
+    hip.colsum_segments(part, nwg, segs)
     torch.cuda.synchronize()
 
     tol = 3e-2
@@ -122,8 +135,53 @@ def test_chain_matches_float64_restatement(hip, B, T, D, H, L):
     close(dpred, pred.grad, tol, "dpred")
     for i in range(L - 1, -1, -1):
         close(dz_k[i], us[i].grad, tol, f"dz{i}")
-        close(lnp[i][:nwg].sum(0), g64[i].grad, tol, f"dgamma{i}")
-        close(lnp[i][nwg:].sum(0), b64[i].grad, tol, f"dbeta{i}")
+        close(dg_k[i], g64[i].grad, tol, f"dgamma{i}")
+        close(db_k[i], b64[i].grad, tol, f"dbeta{i}")
+        close(dbl_k[i], us[i].grad.sum(0), tol, f"dbias{i}")
+        close(dbl2[i * H:(i + 1) * H], us[i].grad.sum(0), tol, f"dbias{i} (second destination)")
+        if de_lp is not None:
+            close(de_lp[:, i * H:(i + 1) * H], us[i].grad.reshape(B, T, H).sum(1), tol, f"de{i}")
+    close(dbh_k, pred.grad.sum(0), tol, "dbias head")
+
+
+def test_deferred_wgrad_slabs_match_fused_wgrad(hip):
+    """ib_linear_wgrad_slabs + ONE ib_slab_reduce_multi == ib_linear_wgrad, bitwise (same slabs, same order)"""
+    shapes = [(12800, 512, 300), (12800, 300, 512), (256, 1024, 512), (256, 512, 128), (100, 64, 32)]
+    items, refs = [], []
+    for j, (M, N, K) in enumerate(shapes):
+        dz = rnd((M, N), 70 + j).to(BF).to(DEV)
+        x = rnd((M, K), 80 + j).to(BF).to(DEV)
+        ws = torch.zeros(max(hip.linear_wgrad_workspace_bytes(M, N, K), 4), dtype=torch.uint8, device=DEV)
+        ref = torch.zeros(N, K, device=DEV)
+        hip.linear_wgrad(dz, x, ref, ws)
+        ws2 = torch.zeros(int(hip.lib().ib_linear_wgrad_slabs_workspace(M, N, K)), dtype=torch.uint8, device=DEV)
+        n = hip.linear_wgrad_slabs(dz, x, ws2)
+        items.append((ws2, n, torch.full((N, K), 7.0, device=DEV)))
+        refs.append(ref)
+    hip.slab_reduce_multi(items)
+    torch.cuda.synchronize()
+    for (ws2, n, dw), ref in zip(items, refs):
+        assert torch.equal(dw, ref)
+    hip.slab_reduce_multi(items, accumulate=True)
+    torch.cuda.synchronize()
+    for (ws2, n, dw), ref in zip(items, refs):
+        assert torch.equal(dw, ref + ref)
+
+
+def test_colsum_segments_ragged(hip):
+    part = rnd((37, 132), 90).to(torch.float32).to(DEV)
+    a, b, c = torch.zeros(70, device=DEV), torch.ones(3, device=DEV), torch.zeros(1, device=DEV)
+    a2 = torch.zeros(70, device=DEV)
+    hip.colsum_segments(part, 37, [(0, 70, a, a2, 1.0), (72, 3, b, None, 2.0), (128, 1, c, None, 0.5)])
+    torch.cuda.synchronize()
+    p64 = part.double().cpu()
+    close(a, p64[:, :70].sum(0), 1e-5, "seg0")
+    close(a2, p64[:, :70].sum(0), 1e-5, "seg0 copy")
+    close(b, 2.0 * p64[:, 72:75].sum(0), 1e-5, "seg1")
+    close(c, 0.5 * p64[:, 128:129].sum(0), 1e-5, "seg2")
+    hip.colsum_segments(part, 37, [(72, 3, b, None, 2.0)], accumulate=True)
+    torch.cuda.synchronize()
+    close(b, 4.0 * p64[:, 72:75].sum(0), 1e-5, "seg1 accumulated")
 
 
 def test_chain_trainer_tracks_per_op_trainer():

@@ -1,0 +1,73 @@
+"""Per-phase timing of the fused MLP chain kernel (csrc/chain.hip): workgroup thread 0 stamps s_memrealtime
+(100 MHz) at every phase boundary into a debug buffer; prints the mean / max per phase over all workgroups.
+Usage (GPU box): python tools/chain_prof.py [B T D H L]"""
+import sys
+
+import torch
+
+sys.path.insert(0, ".")
+from inferbiomechanics_amd import hip  # noqa: E402
+import ctypes  # noqa: E402
+
+
+def main():
+    B, T, D, H, L = [int(v) for v in sys.argv[1:6]] if len(sys.argv) >= 6 else (256, 50, 300, 512, 2)
+    dev, bf = "cuda", torch.bfloat16
+    M = B * T
+    g = torch.Generator().manual_seed(0)
+    x0 = torch.randn(B, T, D, generator=g).to(dev, bf)
+    eps = torch.randn(B, T, D, generator=g).to(dev, bf)
+    t = torch.randint(0, 1000, (B,), generator=g).to(dev)
+    sab = torch.rand(1000, generator=g).to(dev)
+    s1m = torch.rand(1000, generator=g).to(dev)
+    e = (torch.randn(B, L * H, generator=g) * 0.5).to(dev, bf)
+    dims = [D] + [H] * L
+    W = [(torch.randn(dims[i + 1], dims[i], generator=g) * dims[i] ** -0.5).to(dev, bf) for i in range(L)]
+    W.append((torch.randn(D, H, generator=g) * H ** -0.5).to(dev, bf))
+    bias = [torch.zeros(H, device=dev) for _ in range(L)] + [torch.zeros(D, device=dev)]
+    gamma = [torch.ones(H, device=dev) for _ in range(L)]
+    beta = [torch.zeros(H, device=dev) for _ in range(L)]
+    packed = torch.zeros(hip.mlp_chain_packed_elems(D, H, L), dtype=bf, device=dev)
+    hip.mlp_chain_pack(W, packed, D, H)
+    Dp = (D + 7) // 8 * 8
+    xt = torch.zeros(M, Dp, dtype=bf, device=dev)[:, :D]
+    dpred = torch.zeros(M, Dp, dtype=bf, device=dev)[:, :D]
+    u = [torch.zeros(M, H, dtype=bf, device=dev) for _ in range(L)]
+    h = [torch.zeros(M, H, dtype=bf, device=dev) for _ in range(L)]
+    dz = [torch.zeros(M, H, dtype=bf, device=dev) for _ in range(L)]
+    nwg = hip.mlp_chain_workgroups(M)
+    part = torch.zeros(nwg, hip.mlp_chain_partial_width(D, H, L), device=dev)
+    stamps = torch.zeros(nwg, 16, dtype=torch.int64, device=dev)
+
+    def launch():
+        hip.mlp_chain_train(x0, eps, t, sab, s1m, e, packed, bias, gamma, beta, xt, u, h, dz, dpred, part, T)
+    for _ in range(5):
+        launch()
+    torch.cuda.synchronize()
+    hip.lib().ib_debug_set_chain_prof(ctypes.c_void_p(stamps.data_ptr()))
+    acc = None
+    reps = 20
+    for _ in range(reps):
+        launch()
+        torch.cuda.synchronize()
+        s = stamps.cpu().double()
+        d = (s[:, 1:] - s[:, :-1]) * 0.01            # us (100 MHz)
+        tot = (s[:, 4 * L + 3] - s[:, 0]) * 0.01
+        span = (s[:, 4 * L + 3].max() - s[:, 0].min()) * 0.01
+        row = torch.cat([d[:, :4 * L + 3].mean(0), tot.mean().view(1), tot.max().view(1), span.view(1)])
+        acc = row if acc is None else acc + row
+    hip.lib().ib_debug_set_chain_prof(None)
+    acc /= reps
+    names = ["q_sample"]
+    for i in range(L):
+        names += [f"fwd{i}.gemm", f"fwd{i}.epi"]
+    names += ["head.gemm", "head.epi"]
+    for i in range(L - 1, -1, -1):
+        names += [f"bwd{i}.gemm", f"bwd{i}.epi"]
+    for n, v in zip(names, acc[:len(names)].tolist()):
+        print(f"{n:12s} {v:7.2f} us")
+    print(f"per-WG total mean {acc[-3]:.2f} us, max {acc[-2]:.2f} us, first-start -> last-end {acc[-1]:.2f} us  ({nwg} workgroups)")
+
+
+if __name__ == "__main__":
+    main()
