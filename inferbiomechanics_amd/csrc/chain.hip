@@ -22,7 +22,7 @@ namespace {
 
 constexpr int CH_ROWS = 64, CH_WAVES = 8, CH_THREADS = 512, CH_MAXL = 4;
 long long* g_chain_prof = nullptr;
-#define CH_STAMP(k) do { if (p.prof && tid == 0) p.prof[blockIdx.x * 16 + (k)] = wall_clock64(); } while (0)
+#define CH_STAMP(k) do { if (p.prof && tid == 0) p.prof[blockIdx.x * 64 + (k)] = wall_clock64(); } while (0)
 
 struct ChainParams {
   const bf16_t* x0; const bf16_t* eps; const int64_t* t;
@@ -40,7 +40,7 @@ struct ChainParams {
                                    // block), then the head-bias sums (128*NTD columns), then the squared-error sum
   bf16_t* de_lp; int64_t ld_de;    // optional (panel == window): bf16 [B, L*H] time-embedding gradient rows
   float gscale, ln_eps;
-  long long* prof;                 // TIMING-ONLY (tools/chain_prof.py): [gridDim.x][16] wall-clock stamps, else NULL
+  long long* prof;                 // TIMING-ONLY (tools/chain_prof.py): [gridDim.x][64] wall-clock stamps, else NULL
 };
 
 template <int CTRL>
@@ -56,7 +56,18 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
-__device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.f + __expf(-x)); }
+// keeps per-phase index arithmetic (divisions by runtime row widths) from being computed once and spilled across phases
+__device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+// lane id recomputed at every use (2 VALU): a cached copy of threadIdx.x was spilled and its reload -- a VMEM
+// operation, retired in order -- stalled on the weight prefetch issued just before it
+__device__ __forceinline__ int lane_id_now() {
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
+
+// v_exp_f32 + v_rcp_f32 (1 ulp each; __frcp_rn / 1.f/x expand to the 10-instruction IEEE division sequence)
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 
 __device__ __forceinline__ bf16x4_t pack4(float a, float b, float c, float d) {
   bf16x4_t o;
@@ -67,10 +78,14 @@ __device__ __forceinline__ bf16x4_t pack4(float a, float b, float c, float d) {
 // acc[mt][u] += W_eff[16*(nt0+u) .. +15][:] . A[16*mt .. +15][:]^T over KB k-blocks of 32.
 // Packed weights: block (nt, kb) is 1 KiB at ((nt * KB + kb) * 64 + lane) * 16 bytes.
 // Prefetch ring of 3 k-blocks (2 in flight while one is consumed); the loop is fully unrolled so ring slots are
-// static registers.
-template <int NT, int KB>
+// static registers.  `side(kb)` is called once per k-block: the row copies of the neighbouring phases (stores of the
+// previous output image, loads of the next epilogue's operands) are issued a piece per k-block BEHIND the first weight
+// loads -- vmcnt retires in order, so a burst of stores issued ahead of the weight stream delayed every GEMM phase by
+// the stores' round trip (+5 us per phase).
+template <int V> struct IntC { static constexpr int value = V; };
+template <int NT, int KB, class Side>
 __device__ __forceinline__ void chain_gemm(const bf16_t* __restrict__ wp, int nt0, const unsigned char* abuf, int rs,
-                                           int lane, f32x4_t (&acc)[4][NT]) {
+                                           int lane, f32x4_t (&acc)[4][NT], Side&& side) {
   constexpr int RING = 3, PD = 2;
   const bf16x8_t* wl = reinterpret_cast<const bf16x8_t*>(wp) + ((int64_t)nt0 * KB) * 64 + lane;
   const unsigned char* arow = abuf + (lane & 15) * rs + 16 * (lane >> 4);
@@ -85,6 +100,10 @@ __device__ __forceinline__ void chain_gemm(const bf16_t* __restrict__ wp, int nt
 #pragma unroll
       for (int u = 0; u < NT; ++u) wr[(kb + PD) % RING][u] = wl[(u * KB + kb + PD) * 64];
     }
+    side(kb, IntC<KB>{});      // piece j of a side job runs at k-block j % KB
+    // pin the issue point of this k-block's prefetch: at the register limit hipcc otherwise sinks every weight load
+    // to just before its first MFMA (prefetch distance 0: a full L2 round trip per k-block)
+    __builtin_amdgcn_sched_barrier(0);
     bf16x8_t fa[4];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) fa[mt] = *reinterpret_cast<const bf16x8_t*>(arow + 16 * mt * rs + 64 * kb);
@@ -104,71 +123,71 @@ __device__ __forceinline__ void zero_acc(f32x4_t (&acc)[4][NT]) {
     for (int u = 0; u < NT; ++u) acc[mt][u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 }
 
-// Cross-wave row reduction: each lane holds partial sums for NM of its rows (m-tiles mt0 .. mt0+NM-1) over this
-// wave's columns.  red: [64 rows][8 waves] floats.  Returns the full-row totals (fixed summation order).
+// Cross-wave row reduction of TWO quantities in one exchange: each lane holds partial sums for NM of its rows (m-tiles
+// mt0 .. mt0+NM-1) over this wave's columns.  red: [64 rows][8 waves] float2.  Returns the full-row totals (fixed order).
 template <int NM>
-__device__ __forceinline__ void row_reduce(float (&v)[NM], float* red, int lane, int wave, int mt0) {
+__device__ __forceinline__ void row_reduce2(float (&a)[NM], float (&b)[NM], float2* red, int lane, int wave, int mt0) {
 #pragma unroll
   for (int m = 0; m < NM; ++m) {
-    v[m] += __shfl_xor(v[m], 16, 64);
-    v[m] += __shfl_xor(v[m], 32, 64);
+    a[m] += __shfl_xor(a[m], 16, 64); b[m] += __shfl_xor(b[m], 16, 64);
+    a[m] += __shfl_xor(a[m], 32, 64); b[m] += __shfl_xor(b[m], 32, 64);
   }
   if (lane < 16) {
 #pragma unroll
-    for (int m = 0; m < NM; ++m) red[(16 * (mt0 + m) + lane) * CH_WAVES + wave] = v[m];
+    for (int m = 0; m < NM; ++m) red[(16 * (mt0 + m) + lane) * CH_WAVES + wave] = make_float2(a[m], b[m]);
   }
   __syncthreads();
 #pragma unroll
   for (int m = 0; m < NM; ++m) {
     const float4* r4 = reinterpret_cast<const float4*>(red + (16 * (mt0 + m) + (lane & 15)) * CH_WAVES);
-    const float4 a = r4[0], b = r4[1];
-    v[m] = ((((((a.x + a.y) + a.z) + a.w) + b.x) + b.y) + b.z) + b.w;
+    const float4 p0 = r4[0], p1 = r4[1], p2 = r4[2], p3 = r4[3];
+    a[m] = ((((((p0.x + p0.z) + p1.x) + p1.z) + p2.x) + p2.z) + p3.x) + p3.z;
+    b[m] = ((((((p0.y + p0.w) + p1.y) + p1.w) + p2.y) + p2.w) + p3.y) + p3.w;
   }
 }
 
 // NTH: n-tiles per wave for the hidden width (H = 128 * NTH);  NTD / KBD: n-tiles per wave and k-blocks for the
 // feature width (D <= 128 * NTD, D <= 32 * KBD).
+constexpr int CH_NWIN = 8;                                 // windows whose time embedding is staged per panel
 template <int NTH, int NTD, int KBD>
 struct ChainCfg {
   static constexpr int H = 128 * NTH, KBH = 4 * NTH, DP = 32 * KBD, DN = 128 * NTD;
   static constexpr int WMAX = (H > DP ? (H > DN ? H : DN) : (DP > DN ? DP : DN));
   static constexpr int RS = WMAX * 2 + 16;                 // LDS row stride (bytes): +16 -> conflict-free b128 reads
   static constexpr int BUF = CH_ROWS * RS;
-  static constexpr int RED = CH_ROWS * CH_WAVES * 4;       // one cross-wave exchange array
+  static constexpr int RED = CH_ROWS * CH_WAVES * 8;       // one cross-wave exchange array (float2)
   static constexpr int STATS = CH_MAXL * CH_ROWS * 2 * 4;
-  static constexpr int LDS = 2 * BUF + 3 * RED + STATS + 64;
+  static constexpr int EIMG = CH_NWIN * H * 2;
+  static constexpr int LDS = 2 * BUF + 2 * RED + STATS + EIMG + 64;
+  static constexpr int CSS = 16 * NTH + 4;                 // column-sum scratch row stride (floats)
+  static_assert(CH_WAVES * 16 * CSS * 4 <= BUF, "column-sum scratch must fit one image buffer");
 };
 
 // ---- coalesced row movers between HBM and an LDS image (row stride rs bytes).  Per-lane epilogue accesses are
-// 16 rows x 32 B per wave-instruction (store-issue-bound: ~9k cycles per 16 of them); whole rows move as 16-byte pieces.
-__device__ __forceinline__ void copy_out16(const unsigned char* img, int rs, bf16_t* g, int64_t ldg, int nrows, int ppr,
-                                           int tid) {
-  const int total = nrows * ppr;
-  for (int idx = tid; idx < total; idx += CH_THREADS) {
-    const int row = idx / ppr, pc = idx - row * ppr;
-    const uint4 v = *reinterpret_cast<const uint4*>(img + row * rs + pc * 16);
-    *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(g + (int64_t)row * ldg) + pc * 16) = v;
-  }
+// 16 rows x 32 B per wave-instruction (store-issue-bound: ~9k cycles per 16 of them); whole rows move as 16-byte pieces,
+// one piece per thread per call (piece j of thread tid is element tid + 512 j of the row-major piece grid).
+// Branch-free: rows beyond the panel are CLAMPED to its last row (a duplicate store of identical bytes / a finite
+// duplicate load whose consumers are masked).  A divergent branch around a load or store inside the GEMM loop makes
+// hipcc fall back to s_waitcnt vmcnt(0) at the join, which drains the weight prefetch ring every k-block.
+__device__ __forceinline__ void out_piece16(const unsigned char* img, int rs, bf16_t* g, int64_t ldg, int nrows, int ppr,
+                                            int idx) {
+  const int row = min(idx / ppr, nrows - 1), pc = idx % ppr;
+  const uint4 v = *reinterpret_cast<const uint4*>(img + row * rs + pc * 16);
+  *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(g + (int64_t)row * ldg) + pc * 16) = v;
 }
-__device__ __forceinline__ void copy_out8(const unsigned char* img, int rs, bf16_t* g, int64_t ldg, int nrows, int ppr,
-                                          int tid) {
-  const int total = nrows * ppr;
-  for (int idx = tid; idx < total; idx += CH_THREADS) {
-    const int row = idx / ppr, pc = idx - row * ppr;
-    const uint2 v = *reinterpret_cast<const uint2*>(img + row * rs + pc * 8);
-    *reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(g + (int64_t)row * ldg) + pc * 8) = v;
-  }
+__device__ __forceinline__ void out_piece8(const unsigned char* img, int rs, bf16_t* g, int64_t ldg, int nrows, int ppr,
+                                           int idx) {
+  const int row = min(idx / ppr, nrows - 1), pc = idx % ppr;
+  const uint2 v = *reinterpret_cast<const uint2*>(img + row * rs + pc * 8);
+  *reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(g + (int64_t)row * ldg) + pc * 8) = v;
 }
-// rows -> registers (issued before a GEMM), registers -> image (after it); rows >= nrows become zeros
-template <int NP>
-__device__ __forceinline__ void load_rows16(const bf16_t* g, int64_t ldg, int nrows, int ppr, int tid, uint4 (&r)[NP]) {
-#pragma unroll
-  for (int j = 0; j < NP; ++j) {
-    const int idx = tid + j * CH_THREADS;
-    const int row = idx / ppr, pc = idx - row * ppr;
-    r[j] = make_uint4(0u, 0u, 0u, 0u);
-    if (row < nrows) r[j] = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(g + (int64_t)row * ldg) + pc * 16);
-  }
+__device__ __forceinline__ uint4 in_piece16(const bf16_t* g, int64_t ldg, int nrows, int ppr, int idx) {
+  const int row = min(idx / ppr, nrows - 1), pc = idx % ppr;
+  return *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(g + (int64_t)row * ldg) + pc * 16);
+}
+__device__ __forceinline__ uint2 in_piece8(const bf16_t* g, int64_t ldg, int nrows, int ppr, int idx) {
+  const int row = min(idx / ppr, nrows - 1), pc = idx % ppr;
+  return *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned char*>(g + (int64_t)row * ldg) + pc * 8);
 }
 template <int NP>
 __device__ __forceinline__ void store_rows16(unsigned char* img, int rs, int ppr, int tid, const uint4 (&r)[NP]) {
@@ -177,16 +196,6 @@ __device__ __forceinline__ void store_rows16(unsigned char* img, int rs, int ppr
     const int idx = tid + j * CH_THREADS;
     const int row = idx / ppr, pc = idx - row * ppr;
     if (row < CH_ROWS) *reinterpret_cast<uint4*>(img + row * rs + pc * 16) = r[j];
-  }
-}
-template <int NP>
-__device__ __forceinline__ void load_rows8(const bf16_t* g, int64_t ldg, int nrows, int ppr, int tid, uint2 (&r)[NP]) {
-#pragma unroll
-  for (int j = 0; j < NP; ++j) {
-    const int idx = tid + j * CH_THREADS;
-    const int row = idx / ppr, pc = idx - row * ppr;
-    r[j] = make_uint2(0u, 0u);
-    if (row < nrows) r[j] = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned char*>(g + (int64_t)row * ldg) + pc * 8);
   }
 }
 template <int NP>
@@ -199,27 +208,54 @@ __device__ __forceinline__ void store_rows8(unsigned char* img, int rs, int ppr,
   }
 }
 
+// column sums over the panel's 64 rows of a per-lane quantity q[u][r] (already summed over the lane's 4 m-tiles):
+// through a wave-private LDS scratch [16 rows][16*NT columns] -- 4 float4 writes + 16 reads per lane instead of 64
+// DPP steps.  Lane j < 16*NT returns the total of column (16*NT*wave + j); other lanes return 0.
+// Lanes exchange data through LDS WITHOUT a workgroup barrier here (the scratch is wave-private and a wave's LDS
+// operations execute in order), so the compiler must be told not to move the accesses across the exchange points.
+__device__ __forceinline__ void wave_sync_lds() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+template <int NT>
+__device__ __forceinline__ float wave_colsum(const float (&q)[NT][4], float* scr, int css, int lane) {
+  const int l16 = lane & 15, g = lane >> 4;
+  wave_sync_lds();                 // earlier reads of the scratch (previous quantity) are done
+#pragma unroll
+  for (int u = 0; u < NT; ++u)
+    *reinterpret_cast<float4*>(scr + l16 * css + 16 * u + 4 * g) = make_float4(q[u][0], q[u][1], q[u][2], q[u][3]);
+  wave_sync_lds();
+  float s = 0.f;
+  if (lane < 16 * NT) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += scr[r * css + lane];
+  }
+  return s;
+}
+
 template <int NTH, int NTD, int KBD>
 __global__ __launch_bounds__(CH_THREADS) void mlp_chain_kernel(ChainParams p) {
   using C = ChainCfg<NTH, NTD, KBD>;
-  constexpr int H = C::H, RS = C::RS, PPR = H / 8;
+  constexpr int H = C::H, RS = C::RS, PPR = H / 8, NPH = 2 * NTH;   // NPH: 16-byte pieces per thread of a [64, H] image
   __shared__ __attribute__((aligned(16))) unsigned char smem[C::LDS];
   unsigned char* buf0 = smem;
   unsigned char* buf1 = smem + C::BUF;
-  float* red0 = reinterpret_cast<float*>(smem + 2 * C::BUF);
-  float* red1 = red0 + CH_ROWS * CH_WAVES;
-  float* red2 = red1 + CH_ROWS * CH_WAVES;
-  float* stats = red2 + CH_ROWS * CH_WAVES;                // [L][64][2] mean, rstd
-  float* lossred = stats + CH_MAXL * CH_ROWS * 2;          // [8]
+  float2* redA = reinterpret_cast<float2*>(smem + 2 * C::BUF);
+  float2* redB = redA + CH_ROWS * CH_WAVES;
+  float* stats = reinterpret_cast<float*>(redB + CH_ROWS * CH_WAVES);   // [L][64][2] mean, rstd
+  unsigned char* eimg = reinterpret_cast<unsigned char*>(stats + CH_MAXL * CH_ROWS * 2);   // [CH_NWIN][H] bf16
+  float* lossred = reinterpret_cast<float*>(eimg + C::EIMG);            // [8]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);     // scalar copy: thread ids for the row movers are rebuilt
+#define TIDV ((wave_s << 6) | lane_id_now())                    // from it, never kept in a (spillable) VGPR
   const int g = lane >> 4, l16 = lane & 15;
   const int r0 = blockIdx.x * p.P;
   const int D = p.D, M = p.M;
   const int nrows = min(p.P, M - r0);                      // valid token rows of this panel
   const float invH = 1.f / (float)H;
-  int stamp = 0;
-  CH_STAMP(stamp++);
+  CH_STAMP(0);
 
   int rowg[4]; bool valid[4];
 #pragma unroll
@@ -228,15 +264,26 @@ __global__ __launch_bounds__(CH_THREADS) void mlp_chain_kernel(ChainParams p) {
     valid[mt] = lr < nrows;
     rowg[mt] = min(r0 + lr, M - 1);
   }
+  // time-embedding rows of the panel's windows are staged in LDS (a panel of <= 64 tokens spans few windows; all 16
+  // rows a lane group touches usually share ONE row of e: per-lane global loads of it were 16 x (16 rows x 32 B))
+  const int w0 = r0 / p.T;
+  const int nwin = (r0 + nrows - 1) / p.T - w0 + 1;
+  const bool estage = nwin <= CH_NWIN;
+  int ewl[4];                                              // local window of the lane's 4 rows
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) ewl[mt] = min(rowg[mt] / p.T - w0, CH_NWIN - 1);
 
   // ---- q_sample: xt = sqrt_ab[t] x0 + sqrt_1mab[t] eps -> LDS image (zero-padded to DP columns / 64 rows) + HBM.
   // The per-row coefficients (two dependent loads) and the x0 / eps rows are fetched concurrently.
   {
     const int ppr = D >> 2;                                // 8-byte pieces per row
     uint2 rx[KBD], re[KBD];
-    load_rows8<KBD>(p.x0 + (int64_t)r0 * D, D, nrows, ppr, tid, rx);
-    load_rows8<KBD>(p.eps + (int64_t)r0 * D, D, nrows, ppr, tid, re);
-    float2* coef = reinterpret_cast<float2*>(red0);
+#pragma unroll
+    for (int j = 0; j < KBD; ++j) {
+      rx[j] = in_piece8(p.x0 + (int64_t)r0 * D, D, nrows, ppr, TIDV + j * CH_THREADS);
+      re[j] = in_piece8(p.eps + (int64_t)r0 * D, D, nrows, ppr, TIDV + j * CH_THREADS);
+    }
+    float2* coef = redA;
     if (tid < CH_ROWS) {
       float2 c = make_float2(0.f, 0.f);
       if (tid < nrows) {
@@ -267,64 +314,86 @@ __global__ __launch_bounds__(CH_THREADS) void mlp_chain_kernel(ChainParams p) {
     }
   }
   __syncthreads();
-  CH_STAMP(stamp++);
+  CH_STAMP(1);
 
   unsigned char* cur = buf0;
   unsigned char* nxt = buf1;
 
   // ---- forward blocks
   for (int i = 0; i < p.L; ++i) {
-    if (i > 0) copy_out16(cur, RS, p.h[i - 1] + (int64_t)r0 * H, H, nrows, PPR, tid);   // previous block's output rows
     f32x4_t acc[4][NTH];
     zero_acc<NTH>(acc);
-    if (i == 0) chain_gemm<NTH, KBD>(p.wf[0], wave * NTH, cur, RS, lane, acc);
-    else chain_gemm<NTH, C::KBH>(p.wf[i], wave * NTH, cur, RS, lane, acc);
-    CH_STAMP(stamp++);
-    __syncthreads();                       // every wave is done reading `cur`: it becomes the u image
+    // side jobs of the GEMM phase: the previous block's output rows go out (the `cur` image), this block's slice of
+    // the time embedding comes in
+    uint4 er = make_uint4(0u, 0u, 0u, 0u);
+    const bf16_t* esrc = p.e + (int64_t)w0 * p.ld_e + (int64_t)i * H;
+    if (i == 0) {
+      auto side = [&](int kb, auto) {
+        if (kb == 0) er = in_piece16(esrc, p.ld_e, min(nwin, CH_NWIN), PPR, TIDV);
+      };
+      chain_gemm<NTH, KBD>(p.wf[0], wave * NTH, cur, RS, lane, acc, side);
+    } else {
+      bf16_t* hprev = p.h[i - 1] + (int64_t)r0 * H;
+      auto side = [&](int kb, auto kbc) {
+        constexpr int KB = decltype(kbc)::value;
+        if (kb == 0) er = in_piece16(esrc, p.ld_e, min(nwin, CH_NWIN), PPR, TIDV);
+#pragma unroll
+        for (int j = 0; j < NPH; ++j)
+          if (j % KB == kb) out_piece16(cur, RS, hprev, H, nrows, PPR, TIDV + j * CH_THREADS);
+      };
+      chain_gemm<NTH, C::KBH>(p.wf[i], wave * NTH, cur, RS, lane, acc, side);
+    }
+    if (tid < CH_NWIN * PPR) *reinterpret_cast<uint4*>(eimg + tid * 16) = er;
+    CH_STAMP(2 + 4 * i);
+    __syncthreads();                       // every wave is done reading `cur`: it becomes the u image; e image complete
     const int colb = wave * 16 * NTH + 4 * g;
-    // u = z + bias + e (bf16) ; v = silu(u)
-    float s1[4] = {0.f, 0.f, 0.f, 0.f};
+    // u = z + bias + e (bf16) ; v = silu(u) ; one-pass row statistics (sum, sum of squares)
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
     float4 b4[NTH];
 #pragma unroll
     for (int u = 0; u < NTH; ++u) b4[u] = *reinterpret_cast<const float4*>(p.bias[i] + colb + 16 * u);
+    auto pass_u = [&](auto stagedc) {
+      constexpr bool STAGED = decltype(stagedc)::value != 0;
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-      const bf16_t* erow = p.e + (int64_t)(rowg[mt] / p.T) * p.ld_e + (int64_t)i * H;
+      for (int mt = 0; mt < 4; ++mt) {
+        const bf16_t* erow = p.e + (int64_t)(rowg[mt] / p.T) * p.ld_e + (int64_t)i * H;
+        const unsigned char* el = eimg + ewl[mt] * (H * 2);
 #pragma unroll
-      for (int u = 0; u < NTH; ++u) {
-        const int col = colb + 16 * u;
-        const bf16x4_t e4 = *reinterpret_cast<const bf16x4_t*>(erow + col);
-        const float bb[4] = {b4[u].x, b4[u].y, b4[u].z, b4[u].w};
-        bf16x4_t ub;
+        for (int u = 0; u < NTH; ++u) {
+          const int col = colb + 16 * u;
+          bf16x4_t e4;
+          if constexpr (STAGED) e4 = *reinterpret_cast<const bf16x4_t*>(el + col * 2);
+          else e4 = *reinterpret_cast<const bf16x4_t*>(erow + col);
+          const float bb[4] = {b4[u].x, b4[u].y, b4[u].z, b4[u].w};
+          bf16x4_t ub;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) ub[r] = (bf16_t)(acc[mt][u][r] + bb[r] + (float)e4[r]);
-        *reinterpret_cast<bf16x4_t*>(cur + (16 * mt + l16) * RS + col * 2) = ub;
+          for (int r = 0; r < 4; ++r) ub[r] = (bf16_t)(acc[mt][u][r] + bb[r] + (float)e4[r]);
+          *reinterpret_cast<bf16x4_t*>(cur + (16 * mt + l16) * RS + col * 2) = ub;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float x = (float)ub[r];
-          const float v = x * fast_sigmoid(x);
-          acc[mt][u][r] = v;
-          s1[mt] += v;
+          for (int r = 0; r < 4; ++r) {
+            const float x = (float)ub[r];
+            const float v = x * fast_sigmoid(x);
+            acc[mt][u][r] = v;
+            s1[mt] += v;
+            s2[mt] += v * v;
+          }
         }
       }
-    }
-    row_reduce<4>(s1, red0, lane, wave, 0);
-    copy_out16(cur, RS, p.u[i] + (int64_t)r0 * H, H, nrows, PPR, tid);      // u image complete after the barrier inside
-    float mean[4], s2[4];
+    };
+    if (estage) pass_u(IntC<1>{});
+    else pass_u(IntC<0>{});
+    CH_STAMP(3 + 4 * i);
+    row_reduce2<4>(s1, s2, (i & 1) ? redB : redA, lane, wave, 0);
+    CH_STAMP(4 + 4 * i);
+#pragma unroll
+    for (int j = 0; j < NPH; ++j)          // u image complete after the barrier inside the reduction
+      out_piece16(cur, RS, p.u[i] + (int64_t)r0 * H, H, nrows, PPR, TIDV + j * CH_THREADS);
+    float mean[4], rstd[4];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
       mean[mt] = s1[mt] * invH;
-      float q = 0.f;
-#pragma unroll
-      for (int u = 0; u < NTH; ++u)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { const float d = acc[mt][u][r] - mean[mt]; q += d * d; }
-      s2[mt] = q;
+      rstd[mt] = __builtin_amdgcn_rsqf(fmaxf(s2[mt] * invH - mean[mt] * mean[mt], 0.f) + p.ln_eps);
     }
-    row_reduce<4>(s2, red1, lane, wave, 0);
-    float rstd[4];
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) rstd[mt] = 1.f / sqrtf(s2[mt] * invH + p.ln_eps);
     if (wave == 0 && lane < 16) {
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
@@ -348,21 +417,30 @@ __global__ __launch_bounds__(CH_THREADS) void mlp_chain_kernel(ChainParams p) {
       }
     }
     __syncthreads();
-    CH_STAMP(stamp++);
+    CH_STAMP(5 + 4 * i);
     unsigned char* t = cur; cur = nxt; nxt = t;
   }
 
   // ---- head + loss + dL/dpred  (columns >= D come out as exact zeros: the packed head rows there are zero)
   {
-    copy_out16(cur, RS, p.h[p.L - 1] + (int64_t)r0 * H, H, nrows, PPR, tid);
     const int ppr = D >> 2;
     uint2 re[KBD];
-    load_rows8<KBD>(p.eps + (int64_t)r0 * D, D, nrows, ppr, tid, re);
     f32x4_t acc[4][NTD];
     zero_acc<NTD>(acc);
-    chain_gemm<NTD, C::KBH>(p.wf[p.L], wave * NTD, cur, RS, lane, acc);
-    CH_STAMP(stamp++);
-    store_rows8<KBD>(nxt, RS, ppr, tid, re);             // eps image; dpred overwrites it in place
+    bf16_t* hlast = p.h[p.L - 1] + (int64_t)r0 * H;
+    const bf16_t* epsg = p.eps + (int64_t)r0 * D;
+    auto side = [&](int kb, auto kbc) {
+      constexpr int KB = decltype(kbc)::value;
+#pragma unroll
+      for (int j = 0; j < NPH; ++j)
+        if (j % KB == kb) out_piece16(cur, RS, hlast, H, nrows, PPR, TIDV + j * CH_THREADS);
+#pragma unroll
+      for (int j = 0; j < KBD; ++j)
+        if (j % KB == kb) re[j] = in_piece8(epsg, D, nrows, ppr, TIDV + j * CH_THREADS);
+    };
+    chain_gemm<NTD, C::KBH>(p.wf[p.L], wave * NTD, cur, RS, lane, acc, side);
+    CH_STAMP(2 + 4 * p.L);
+    store_rows8<KBD>(nxt, RS, ppr, TIDV, re);     // eps image; dpred overwrites it in place
     __syncthreads();
     const int colb = wave * 16 * NTD + 4 * g;
     float lsum = 0.f;
@@ -407,27 +485,73 @@ __global__ __launch_bounds__(CH_THREADS) void mlp_chain_kernel(ChainParams p) {
       for (int w = 0; w < CH_WAVES; ++w) s += lossred[w];
       prow[3 * p.L * H + C::DN] = s;
     }
-    bf16_t* dpg = p.dpred + (int64_t)r0 * p.ld_dpred;
-    if ((p.ld_dpred & 7) == 0 && (reinterpret_cast<uintptr_t>(p.dpred) & 15) == 0)
-      copy_out16(nxt, RS, dpg, p.ld_dpred, nrows, (D + 7) >> 3, tid);     // pad columns receive the image's zeros
-    else
-      copy_out8(nxt, RS, dpg, p.ld_dpred, nrows, D >> 2, tid);
-    CH_STAMP(stamp++);
+    CH_STAMP(3 + 4 * p.L);
     unsigned char* t = cur; cur = nxt; nxt = t;
   }
 
   // ---- backward: dh_i = d(out of block i) ; through LayerNorm and SiLU -> dz_i ; dh_{i-1} = dz_i W_i.
   // `cur` = the GEMM input image (dpred, then dz_{i+1}); after the GEMM it receives dz_i.  `nxt` = the u_i image.
+  const bool dp16 = (p.ld_dpred & 7) == 0 && (reinterpret_cast<uintptr_t>(p.dpred) & 15) == 0;
   for (int i = p.L - 1; i >= 0; --i) {
-    uint4 ru[2 * NTH];
-    load_rows16<2 * NTH>(p.u[i] + (int64_t)r0 * H, H, nrows, PPR, tid, ru);
+    uint4 ru[NPH];
     f32x4_t acc[4][NTH];
     zero_acc<NTH>(acc);
-    if (i == p.L - 1) chain_gemm<NTH, KBD>(p.wb[p.L], wave * NTH, cur, RS, lane, acc);
-    else chain_gemm<NTH, C::KBH>(p.wb[i + 1], wave * NTH, cur, RS, lane, acc);
-    CH_STAMP(stamp++);
-    store_rows16<2 * NTH>(nxt, RS, PPR, tid, ru);
+    const bf16_t* usrc = p.u[i] + (int64_t)r0 * H;
+    if (i == p.L - 1) {
+      bf16_t* dpg = p.dpred + (int64_t)r0 * p.ld_dpred;
+      const int ppd = dp16 ? (D + 7) >> 3 : D >> 2;      // 16-byte pieces (pad columns receive the image's zeros) or 8
+      // [64, DP] image: DP/8 16-byte (or DP/4 8-byte) pieces per row cover every ld_dpred <= DP; piece columns beyond
+      // the row pitch are clamped onto the row's last piece
+      if (dp16) {
+        auto side = [&](int kb, auto kbc) {
+          constexpr int KB = decltype(kbc)::value;
+#pragma unroll
+          for (int j = 0; j < NPH; ++j)
+            if (j % KB == kb) ru[j] = in_piece16(usrc, H, nrows, PPR, TIDV + j * CH_THREADS);
+#pragma unroll
+          for (int j = 0; j < (C::DP / 8 * CH_ROWS + CH_THREADS - 1) / CH_THREADS; ++j)
+            if (j % KB == kb) {
+              const int idx = TIDV + j * CH_THREADS;
+              const int row = min(idx / (C::DP / 8), nrows - 1), pc = min(idx % (C::DP / 8), ppd - 1);
+              const uint4 v = *reinterpret_cast<const uint4*>(cur + row * RS + pc * 16);
+              *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(dpg + (int64_t)row * p.ld_dpred) + pc * 16) = v;
+            }
+        };
+        chain_gemm<NTH, KBD>(p.wb[p.L], wave * NTH, cur, RS, lane, acc, side);
+      } else {
+        auto side = [&](int kb, auto kbc) {
+          constexpr int KB = decltype(kbc)::value;
+#pragma unroll
+          for (int j = 0; j < NPH; ++j)
+            if (j % KB == kb) ru[j] = in_piece16(usrc, H, nrows, PPR, TIDV + j * CH_THREADS);
+#pragma unroll
+          for (int j = 0; j < (C::DP / 4 * CH_ROWS + CH_THREADS - 1) / CH_THREADS; ++j)
+            if (j % KB == kb) {
+              const int idx = TIDV + j * CH_THREADS;
+              const int row = min(idx / (C::DP / 4), nrows - 1), pc = min(idx % (C::DP / 4), ppd - 1);
+              const uint2 v = *reinterpret_cast<const uint2*>(cur + row * RS + pc * 8);
+              *reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(dpg + (int64_t)row * p.ld_dpred) + pc * 8) = v;
+            }
+        };
+        chain_gemm<NTH, KBD>(p.wb[p.L], wave * NTH, cur, RS, lane, acc, side);
+      }
+    } else {
+      bf16_t* dzg = p.dz[i + 1] + (int64_t)r0 * H;
+      auto side = [&](int kb, auto kbc) {
+        constexpr int KB = decltype(kbc)::value;
+#pragma unroll
+        for (int j = 0; j < NPH; ++j)
+          if (j % KB == kb) {
+            ru[j] = in_piece16(usrc, H, nrows, PPR, TIDV + j * CH_THREADS);
+            out_piece16(cur, RS, dzg, H, nrows, PPR, TIDV + j * CH_THREADS);
+          }
+      };
+      chain_gemm<NTH, C::KBH>(p.wb[i + 1], wave * NTH, cur, RS, lane, acc, side);
+    }
+    CH_STAMP(4 + 4 * p.L + 9 * (p.L - 1 - i));
+    store_rows16<NPH>(nxt, RS, PPR, TIDV, ru);
     __syncthreads();
+    CH_STAMP(5 + 4 * p.L + 9 * (p.L - 1 - i));
     const int colb = wave * 16 * NTH + 4 * g;
     float mean[4], rstd[4];
 #pragma unroll
@@ -438,14 +562,14 @@ __global__ __launch_bounds__(CH_THREADS) void mlp_chain_kernel(ChainParams p) {
     // Two m-tile halves (rows are independent; halving keeps xhat / silu' for only 32 elements per lane live):
     //   pass 1: xhat, silu'(u); dgamma / dbeta partials; row sums of dxhat and dxhat * xhat
     //   pass 2: dv = rstd (dxhat - mean(dxhat) - xhat mean(dxhat xhat)) ; dz = dv * silu'(u)
-    float dg[NTH][4], db[NTH][4], dzs[NTH][4];
+    float dg[NTH][4], db[NTH][4];
 #pragma unroll
     for (int u = 0; u < NTH; ++u)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { dg[u][r] = 0.f; db[u][r] = 0.f; dzs[u][r] = 0.f; }
+      for (int r = 0; r < 4; ++r) { dg[u][r] = 0.f; db[u][r] = 0.f; }
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
-      float xh[2][NTH][4];
+      bf16x4_t xh[2][NTH];             // xhat, bf16 (its only later use multiplies it into the bf16 dz)
       bf16x4_t dsl[2][NTH];            // silu'(u), bf16
       float sa[2] = {0.f, 0.f}, sb[2] = {0.f, 0.f};
 #pragma unroll
@@ -457,10 +581,10 @@ __global__ __launch_bounds__(CH_THREADS) void mlp_chain_kernel(ChainParams p) {
         for (int m2 = 0; m2 < 2; ++m2) {
           const int mt = 2 * hf + m2;
           const bf16x4_t ub = *reinterpret_cast<const bf16x4_t*>(nxt + (16 * mt + l16) * RS + col * 2);
-          float ds[4];
+          float ds[4], xq[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float x = (float)ub[r];                  // rows beyond the panel hold zeros
+            const float x = (float)ub[r];                  // rows beyond the panel hold a finite duplicate row
             const float sg = fast_sigmoid(x);
             const float v = x * sg;
             ds[r] = sg * (1.f + x * (1.f - sg));
@@ -470,15 +594,18 @@ __global__ __launch_bounds__(CH_THREADS) void mlp_chain_kernel(ChainParams p) {
             db[u][r] += dh;
             const float dxh = dh * gg[r];
             acc[mt][u][r] = dxh;
-            xh[m2][u][r] = xhat;
+            xq[r] = xhat;
             sa[m2] += dxh;
             sb[m2] += dxh * xhat;
           }
           dsl[m2][u] = pack4(ds[0], ds[1], ds[2], ds[3]);
+          xh[m2][u] = pack4(xq[0], xq[1], xq[2], xq[3]);
         }
       }
-      row_reduce<2>(sa, red2, lane, wave, 2 * hf);
-      row_reduce<2>(sb, red0, lane, wave, 2 * hf);
+      __builtin_amdgcn_sched_barrier(0);    // keep the dgamma / dbeta FMAs inside their pass (hipcc deferred them with their operands spilled)
+      CH_STAMP(6 + 4 * p.L + 9 * (p.L - 1 - i) + 2 * hf);
+      row_reduce2<2>(sa, sb, hf ? redA : redB, lane, wave, 2 * hf);
+      CH_STAMP(7 + 4 * p.L + 9 * (p.L - 1 - i) + 2 * hf);
 #pragma unroll
       for (int m2 = 0; m2 < 2; ++m2) {
         const int mt = 2 * hf + m2;
@@ -489,41 +616,51 @@ __global__ __launch_bounds__(CH_THREADS) void mlp_chain_kernel(ChainParams p) {
           float dzv[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            dzv[r] = rsd * (acc[mt][u][r] - ma - xh[m2][u][r] * mb) * (float)dsl[m2][u][r];
+            dzv[r] = rsd * (acc[mt][u][r] - ma - (float)xh[m2][u][r] * mb) * (float)dsl[m2][u][r];
           bf16x4_t o = pack4(dzv[0], dzv[1], dzv[2], dzv[3]);
           if (!valid[mt]) o = pack4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) dzs[u][r] += (float)o[r];
           *reinterpret_cast<bf16x4_t*>(cur + (16 * mt + l16) * RS + col * 2) = o;
         }
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
+    CH_STAMP(10 + 4 * p.L + 9 * (p.L - 1 - i));
     {
-      // per-workgroup column sums: dgamma | dbeta | dbias (= sum of dz over the panel's tokens)
+      // per-workgroup column sums dgamma | dbeta.  Scratch = the u image (`nxt`): every wave finished reading it before
+      // the barrier inside the second reduction above.
+      float* scr = reinterpret_cast<float*>(nxt) + wave * 16 * C::CSS;
       float* pg = p.partial + (int64_t)blockIdx.x * p.ld_part + 3 * i * H;
-#pragma unroll
-      for (int u = 0; u < NTH; ++u) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          dg[u][r] = row16_sum(dg[u][r]); db[u][r] = row16_sum(db[u][r]); dzs[u][r] = row16_sum(dzs[u][r]);
-        }
-        if (l16 == 0) {
-          const int col = colb + 16 * u;
-          *reinterpret_cast<float4*>(pg + col) = make_float4(dg[u][0], dg[u][1], dg[u][2], dg[u][3]);
-          *reinterpret_cast<float4*>(pg + H + col) = make_float4(db[u][0], db[u][1], db[u][2], db[u][3]);
-          *reinterpret_cast<float4*>(pg + 2 * H + col) = make_float4(dzs[u][0], dzs[u][1], dzs[u][2], dzs[u][3]);
-          // panel == one window: the column sums of dz ARE the time-embedding gradient row of that window
-          if (p.de_lp)
-            *reinterpret_cast<bf16x4_t*>(p.de_lp + (int64_t)blockIdx.x * p.ld_de + i * H + col) =
-                pack4(dzs[u][0], dzs[u][1], dzs[u][2], dzs[u][3]);
-        }
+      const int col = wave * 16 * NTH + lane;
+      const float sg_ = wave_colsum<NTH>(dg, scr, C::CSS, lane);
+      const float sb_ = wave_colsum<NTH>(db, scr, C::CSS, lane);
+      if (lane < 16 * NTH) {
+        pg[col] = sg_;
+        pg[H + col] = sb_;
       }
     }
+    CH_STAMP(11 + 4 * p.L + 9 * (p.L - 1 - i));
     __syncthreads();
-    copy_out16(cur, RS, p.dz[i] + (int64_t)r0 * H, H, nrows, PPR, tid);
-    CH_STAMP(stamp++);
+    {
+      // dbias = column sums of the bf16 dz image (rows beyond the panel are zero), one column per thread, fixed order.
+      // panel == one window: they ARE the time-embedding gradient row of that window.
+      if (tid < H) {
+        const unsigned char* cp = cur + tid * 2;
+        float sz = 0.f;
+#pragma unroll 16
+        for (int r = 0; r < CH_ROWS; ++r) sz += (float)*reinterpret_cast<const bf16_t*>(cp + r * RS);
+        p.partial[(int64_t)blockIdx.x * p.ld_part + 3 * i * H + 2 * H + tid] = sz;
+        if (p.de_lp) p.de_lp[(int64_t)blockIdx.x * p.ld_de + i * H + tid] = (bf16_t)sz;
+      }
+    }
+    if (i == 0) {
+#pragma unroll
+      for (int j = 0; j < NPH; ++j) out_piece16(cur, RS, p.dz[0] + (int64_t)r0 * H, H, nrows, PPR, TIDV + j * CH_THREADS);
+    }
+    CH_STAMP(12 + 4 * p.L + 9 * (p.L - 1 - i));
   }
 }
+
+#undef TIDV
 
 // ---- weight packing: bf16 row-major [N_out, K_in] -> fragment-major blocks, zero padded
 struct PackDesc {

@@ -37,7 +37,7 @@ def main():
     dz = [torch.zeros(M, H, dtype=bf, device=dev) for _ in range(L)]
     nwg = hip.mlp_chain_workgroups(M)
     part = torch.zeros(nwg, hip.mlp_chain_partial_width(D, H, L), device=dev)
-    stamps = torch.zeros(nwg, 16, dtype=torch.int64, device=dev)
+    stamps = torch.zeros(nwg, 64, dtype=torch.int64, device=dev)
 
     def launch():
         hip.mlp_chain_train(x0, eps, t, sab, s1m, e, packed, bias, gamma, beta, xt, u, h, dz, dpred, part, T)
@@ -45,27 +45,30 @@ def main():
         launch()
     torch.cuda.synchronize()
     hip.lib().ib_debug_set_chain_prof(ctypes.c_void_p(stamps.data_ptr()))
+    names = ["q_sample"]
+    for i in range(L):
+        names += [f"fwd{i}.gemm", f"fwd{i}.epi.sync+u+silu", f"fwd{i}.epi.reduce", f"fwd{i}.epi.copy_u+h+sync"]
+    names += ["head.gemm", "head.epi"]
+    for i in range(L - 1, -1, -1):
+        names += [f"bwd{i}.gemm", f"bwd{i}.u_image+sync", f"bwd{i}.pass1a", f"bwd{i}.reduce_a", f"bwd{i}.pass2a+pass1b",
+                  f"bwd{i}.reduce_b", f"bwd{i}.pass2b", f"bwd{i}.colsums", f"bwd{i}.sync(+copy_dz0)"]
+    n = len(names)
     acc = None
-    reps = 20
+    reps = 8
     for _ in range(reps):
-        launch()
+        for _ in range(40):                 # back-to-back launches: warm clocks, steady state; the last one is read
+            launch()
         torch.cuda.synchronize()
         s = stamps.cpu().double()
-        d = (s[:, 1:] - s[:, :-1]) * 0.01            # us (100 MHz)
-        tot = (s[:, 4 * L + 3] - s[:, 0]) * 0.01
-        span = (s[:, 4 * L + 3].max() - s[:, 0].min()) * 0.01
-        row = torch.cat([d[:, :4 * L + 3].mean(0), tot.mean().view(1), tot.max().view(1), span.view(1)])
+        d = (s[:, 1:n + 1] - s[:, :n]) * 0.01            # us (100 MHz)
+        tot = (s[:, n] - s[:, 0]) * 0.01
+        span = (s[:, n].max() - s[:, 0].min()) * 0.01
+        row = torch.cat([d.mean(0), tot.mean().view(1), tot.max().view(1), span.view(1)])
         acc = row if acc is None else acc + row
     hip.lib().ib_debug_set_chain_prof(None)
     acc /= reps
-    names = ["q_sample"]
-    for i in range(L):
-        names += [f"fwd{i}.gemm", f"fwd{i}.epi"]
-    names += ["head.gemm", "head.epi"]
-    for i in range(L - 1, -1, -1):
-        names += [f"bwd{i}.gemm", f"bwd{i}.epi"]
-    for n, v in zip(names, acc[:len(names)].tolist()):
-        print(f"{n:12s} {v:7.2f} us")
+    for nm, v in zip(names, acc[:n].tolist()):
+        print(f"{nm:24s} {v:7.2f} us")
     print(f"per-WG total mean {acc[-3]:.2f} us, max {acc[-2]:.2f} us, first-start -> last-end {acc[-1]:.2f} us  ({nwg} workgroups)")
 
 
