@@ -210,7 +210,16 @@ int ib_mlp_chain_train(const void* x0, const void* eps, const int64_t* t, const 
 int ib_colsum_segments(const float* part, int64_t ld, int64_t rows, int nseg, const int32_t* col0,
                        const int32_t* ncols, float* const* dst, float* const* dst2, const float* scale,
                        int accumulate, ib_stream_t stream);
+/* fused forward of the time-embedding MLP (models: time_mlp.0 / time_mlp.2; bf16): e = W2 silu(W1 sinus(t) + b1) + b2.
+ * table: fp32 [table_rows, temb] sinusoid rows; w1 [hidden, temb], w2 [out, hidden] row-major bf16 (as stored).
+ * Also writes what the backward needs: s [B, temb] (gathered rows), zu [B, hidden] (pre-activation), u = silu(zu). */
+int ib_time_mlp_fwd_supported(int64_t temb, int64_t hidden, int64_t out);
+int ib_time_mlp_fwd(const float* table, int64_t table_rows, const int64_t* t, const void* w1, int64_t ldw1,
+                    const float* b1, const void* w2, int64_t ldw2, const float* b2, void* s, void* zu, void* u,
+                    void* e, int64_t ld_e, int64_t B, int64_t temb, int64_t hidden, int64_t out,
+                    ib_stream_t stream);
 int ib_debug_stamp(void* slot, ib_stream_t stream);   /* timing-only: *slot = 100 MHz wall clock when the stream gets here */
+int ib_debug_set_gemm_prof(void* stamps);    /* timing-only: [workgroups][8] stamps of the ring GEMM kernel, NULL = off */
 int ib_debug_set_chain_prof(void* stamps);   /* timing-only: [workgroups][16] int64 wall-clock stamps, NULL = off */
 int ib_sum_partials(const float* partial, int64_t parts, float scale, float* out, ib_stream_t stream);
 

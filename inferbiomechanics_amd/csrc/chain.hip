@@ -920,6 +920,155 @@ extern "C" int ib_colsum_segments(const float* part, int64_t ld, int64_t rows, i
   return IB_OK;
 }
 
+// ---- fused time-embedding MLP forward: e = W2 silu(W1 sinus(t) + b1) + b2 for B windows in ONE launch (the per-op
+// plan needs a gather and two M = B GEMMs whose 8-16 workgroups are pure latency: ~28 us of kernels + 3 boundaries on
+// the step's critical path).  Workgroup = 64 windows x one group of 128 output columns; every column group recomputes
+// the (tiny) hidden layer for its rows, so there is no inter-workgroup dependency.  Weights are read as they are
+// (row-major bf16, fragment-shaped 16-byte loads): nothing to pack, so this runs beside the chain's weight packing.
+namespace {
+// all KB x NT weight fragments of a wave's slice, issued at once (they depend on nothing: one L2 round trip for the
+// whole slice instead of one per k-block) ...
+template <int NT, int KB>
+__device__ __forceinline__ void rowmajor_load(const bf16_t* __restrict__ w, int64_t ldw, int n0, int lane,
+                                              bf16x8_t (&wr)[KB][NT]) {
+  const bf16_t* wl = w + (int64_t)(n0 + (lane & 15)) * ldw + 8 * (lane >> 4);
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+    for (int u = 0; u < NT; ++u) wr[kb][u] = *reinterpret_cast<const bf16x8_t*>(wl + (int64_t)16 * u * ldw + 32 * kb);
+}
+// ... and consumed later
+template <int NT, int KB>
+__device__ __forceinline__ void reg_gemm(const bf16x8_t (&wr)[KB][NT], const unsigned char* abuf, int rs, int lane,
+                                         f32x4_t (&acc)[4][NT]) {
+  const unsigned char* arow = abuf + (lane & 15) * rs + 16 * (lane >> 4);
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) {
+    bf16x8_t fa[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) fa[mt] = *reinterpret_cast<const bf16x8_t*>(arow + 16 * mt * rs + 64 * kb);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int u = 0; u < NT; ++u)
+        acc[mt][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[kb][u], fa[mt], acc[mt][u], 0, 0, 0);
+  }
+}
+
+struct TimeFwdParams {
+  const float* table; int64_t table_rows; const int64_t* t;
+  const bf16_t* w1; int64_t ldw1; const float* b1;
+  const bf16_t* w2; int64_t ldw2; const float* b2;
+  bf16_t* s; bf16_t* zu; bf16_t* u; bf16_t* e; int64_t ld_e;
+  int B, out;
+};
+
+// NT1 = hidden / 128, KB1 = temb / 32 ; hidden = 128 * NT1 = 32 * KB2 ; output columns: 128 per workgroup (16 per wave)
+template <int NT1, int KB1>
+__global__ __launch_bounds__(CH_THREADS) void time_mlp_fwd_kernel(TimeFwdParams p) {
+  constexpr int HID = 128 * NT1, KB2 = 4 * NT1, TE = 32 * KB1;
+  constexpr int RS1 = TE * 2 + 16, RS2 = HID * 2 + 16;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[CH_ROWS * RS1 + CH_ROWS * RS2];
+  unsigned char* simg = smem;
+  unsigned char* uimg = smem + CH_ROWS * RS1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l16 = lane & 15;
+  const int r0 = blockIdx.y * CH_ROWS, cg = blockIdx.x;
+  const int nrows = min(CH_ROWS, p.B - r0);
+  bf16x8_t wr1[KB1][NT1], wr2[KB2][1];
+  rowmajor_load<NT1, KB1>(p.w1, p.ldw1, wave * 16 * NT1, lane, wr1);
+  rowmajor_load<1, KB2>(p.w2, p.ldw2, cg * 128 + wave * 16, lane, wr2);
+  // gather: sinusoid rows (fp32 table) -> bf16 image; the first column group also writes them out (wgrad operand)
+  for (int idx = tid; idx < CH_ROWS * (TE / 4); idx += CH_THREADS) {
+    const int row = idx / (TE / 4), c = (idx % (TE / 4)) * 4;
+    bf16x4_t o = pack4(0.f, 0.f, 0.f, 0.f);
+    if (row < nrows) {
+      int64_t k = p.t[r0 + row];
+      k = k < 0 ? 0 : (k >= p.table_rows ? p.table_rows - 1 : k);
+      const float4 v = *reinterpret_cast<const float4*>(p.table + k * TE + c);
+      o = pack4(v.x, v.y, v.z, v.w);
+      if (cg == 0) *reinterpret_cast<bf16x4_t*>(p.s + (int64_t)(r0 + row) * TE + c) = o;
+    }
+    *reinterpret_cast<bf16x4_t*>(simg + row * RS1 + c * 2) = o;
+  }
+  __syncthreads();
+  {
+    f32x4_t acc[4][NT1];
+    zero_acc<NT1>(acc);
+    reg_gemm<NT1, KB1>(wr1, simg, RS1, lane, acc);
+    const int colb = wave * 16 * NT1 + 4 * g;
+#pragma unroll
+    for (int u = 0; u < NT1; ++u) {
+      const int col = colb + 16 * u;
+      const float4 b4 = *reinterpret_cast<const float4*>(p.b1 + col);
+      const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const int lr = 16 * mt + l16;
+        bf16x4_t zb, ub;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          zb[r] = (bf16_t)(acc[mt][u][r] + bb[r]);
+          const float x = (float)zb[r];
+          ub[r] = (bf16_t)(x * fast_sigmoid(x));
+        }
+        if (lr >= nrows) ub = pack4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<bf16x4_t*>(uimg + lr * RS2 + col * 2) = ub;
+        if (cg == 0 && lr < nrows) {
+          *reinterpret_cast<bf16x4_t*>(p.zu + (int64_t)(r0 + lr) * HID + col) = zb;
+          *reinterpret_cast<bf16x4_t*>(p.u + (int64_t)(r0 + lr) * HID + col) = ub;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  {
+    f32x4_t acc[4][1];
+    zero_acc<1>(acc);
+    const int n0 = cg * 128 + wave * 16;
+    reg_gemm<1, KB2>(wr2, uimg, RS2, lane, acc);
+    const int col = n0 + 4 * g;
+    const float4 b4 = *reinterpret_cast<const float4*>(p.b2 + col);
+    const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const int lr = 16 * mt + l16;
+      if (lr < nrows)
+        *reinterpret_cast<bf16x4_t*>(p.e + (int64_t)(r0 + lr) * p.ld_e + col) =
+            pack4(acc[mt][0][0] + bb[0], acc[mt][0][1] + bb[1], acc[mt][0][2] + bb[2], acc[mt][0][3] + bb[3]);
+    }
+  }
+}
+}  // namespace
+
+extern "C" int ib_time_mlp_fwd_supported(int64_t temb, int64_t hidden, int64_t out) {
+  const bool shape = (temb == 128 && hidden == 512) || (temb == 32 && hidden == 128);
+  return (shape && out > 0 && out % 128 == 0) ? 1 : 0;
+}
+
+extern "C" int ib_time_mlp_fwd(const float* table, int64_t table_rows, const int64_t* t, const void* w1, int64_t ldw1,
+                               const float* b1, const void* w2, int64_t ldw2, const float* b2, void* s, void* zu,
+                               void* u, void* e, int64_t ld_e, int64_t B, int64_t temb, int64_t hidden, int64_t out,
+                               ib_stream_t stream) {
+  if (!ib_time_mlp_fwd_supported(temb, hidden, out)) return IB_E_UNSUPPORTED;
+  if (!table || !t || !w1 || !b1 || !w2 || !b2 || !s || !zu || !u || !e || B <= 0 || table_rows <= 0) return IB_E_ARG;
+  if (ldw1 < temb || ldw2 < hidden || ld_e < out || ldw1 % 8 != 0 || ldw2 % 8 != 0 || ld_e % 4 != 0) return IB_E_ARG;
+  auto al = [](const void* q, uintptr_t a) { return (reinterpret_cast<uintptr_t>(q) % a) == 0; };
+  if (!al(table, 16) || !al(w1, 16) || !al(w2, 16) || !al(b1, 16) || !al(b2, 16) || !al(s, 8) || !al(zu, 8) ||
+      !al(u, 8) || !al(e, 8))
+    return IB_E_ARG;
+  TimeFwdParams p{};
+  p.table = table; p.table_rows = table_rows; p.t = t;
+  p.w1 = (const bf16_t*)w1; p.ldw1 = ldw1; p.b1 = b1; p.w2 = (const bf16_t*)w2; p.ldw2 = ldw2; p.b2 = b2;
+  p.s = (bf16_t*)s; p.zu = (bf16_t*)zu; p.u = (bf16_t*)u; p.e = (bf16_t*)e; p.ld_e = ld_e;
+  p.B = (int)B; p.out = (int)out;
+  const dim3 grid((unsigned)(out / 128), (unsigned)((B + CH_ROWS - 1) / CH_ROWS));
+  hipStream_t st = ib_s(stream);
+  if (temb == 128 && hidden == 512) hipLaunchKernelGGL((time_mlp_fwd_kernel<4, 4>), grid, dim3(CH_THREADS), 0, st, p);
+  else hipLaunchKernelGGL((time_mlp_fwd_kernel<1, 1>), grid, dim3(CH_THREADS), 0, st, p);
+  IB_CHECK_LAUNCH();
+  return IB_OK;
+}
+
 // out = scale * sum(partial[0..parts))   (fixed order; the chain kernel's per-workgroup loss sums)
 namespace {
 __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ partial, int parts, float scale,

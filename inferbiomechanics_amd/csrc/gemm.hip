@@ -38,6 +38,7 @@ enum { EPI_FWD = 0, EPI_DGRAD = 1, EPI_WGRAD = 2 };
 // TIMING-ONLY ablation switch (tools/kbench.py --ablate): bit0 skip steady-state global loads, bit1 skip LDS
 // stores, bit2 skip MFMAs, bit3 skip the epilogue stores.  Results are wrong when non-zero; never set by product code.
 int g_ablate = 0;
+long long* g_gemm_prof = nullptr;   // TIMING-ONLY (tools/gemm_prof.py): [workgroups][8] wall-clock stamps of the ring kernel
 
 struct GemmParams {
   const void* A; const void* B; int64_t lda, ldb;
@@ -60,6 +61,7 @@ struct GemmParams {
   int64_t slab_stride;         // wgrad: elements between partial slabs (0 when not split)
   int accumulate;
   int ablate;
+  long long* prof;
 };
 
 template <typename T>
@@ -205,10 +207,10 @@ __device__ __forceinline__ void glds_issue(const bf16_t* base, const int64_t (&o
 typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
 
 // bf16 fragment: 8 consecutive k of tile row (rbase + lane%16), k = kbase + 8*(lane/16) + j
-template <bool KC>
+template <bool KC, int KCS = Tile<bf16_t>::KC_STRIDE>
 __device__ __forceinline__ bf16x8_t read_frag_bf16(const unsigned char* tile, int rbase, int kbase, int lane) {
   if (KC) {
-    const int off = ((rbase + (lane & 15)) * Tile<bf16_t>::KC_STRIDE + kbase + 8 * (lane >> 4)) * 2;
+    const int off = ((rbase + (lane & 15)) * KCS + kbase + 8 * (lane >> 4)) * 2;
     return *reinterpret_cast<const bf16x8_t*>(tile + off);
   } else {
     // [k][row] image; transposing read: lane 4q+p of a 16-lane group addresses row (k) q,
@@ -568,6 +570,170 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmParams p) {
   }
 }
 
+// ---- ring-pipelined variant (bf16, every operand piece 16-byte aligned, reduction a multiple of 32) -------------
+// The kernel above stages ONE K step ahead and its __syncthreads() drains the in-flight loads (vmcnt(0)): every K
+// step exposes a full L2/HBM round trip, ~1.2 us per 64-deep step at these sizes.  Here the operands go HBM/L2 -> LDS
+// by global_load_lds only, into a ring of four 32-deep stages: three stages (2 x 54 KiB per CU at 2 workgroups/CU) are
+// in flight while one is consumed, each wave waits for ITS OWN pieces of the stage with a counted s_waitcnt vmcnt(N),
+// and the workgroup barrier is the raw s_barrier (no vmcnt(0) drain).  One barrier per K step:
+//   wait(stage kt landed, mine) ; barrier (everyone's landed; everyone is done reading stage kt-1)
+//   issue stage kt+3 into the slot stage kt-1 occupied ; MFMAs on stage kt.
+// Out-of-range tile rows/columns are CLAMPED onto valid memory (they only feed outputs that are never stored); the
+// reduction range itself must be exact (no zero fill with LDS-DMA), so ragged reductions use the kernel above.
+namespace ring {
+constexpr int BK = 32, NS = 4, KCS = 40;                   // KC image: 128 rows x (32 + 8 pad) bf16 = 10 chunks of 1 KiB
+constexpr int KC_BYTES = 128 * KCS * 2, KS_BYTES = BK * Tile<bf16_t>::KS_STRIDE * 2;   // 10240 / 9216
+template <bool KC> constexpr int chunks() { return (KC ? KC_BYTES : KS_BYTES) / 1024; }
+
+// per-lane global element offsets of the (up to 3) chunks wave `w` stages for one operand tile
+template <bool KC>
+__device__ __forceinline__ void offsets(int64_t ld, int row0, int rows_total, int wave, int lane, int64_t (&off)[3]) {
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int chunk = wave + 4 * j;
+    const int o = (chunk < chunks<KC>() ? chunk : 0) * 1024 + lane * 16;
+    if (KC) {
+      const int row = o / (KCS * 2), c = min((o % (KCS * 2)) / 16, 3);
+      off[j] = (int64_t)min(row0 + row, rows_total - 1) * ld + 8 * c;
+    } else {
+      const int kk = o / 288, c = min((o % 288) / 16, 15);
+      off[j] = (int64_t)kk * ld + min((int64_t)row0 + 8 * c, ld - 8);
+    }
+  }
+}
+template <bool KC>
+__device__ __forceinline__ void issue(const bf16_t* base, const int64_t (&off)[3], int64_t koff, unsigned char* tile, int wave) {
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int chunk = wave + 4 * j;
+    if (chunk < chunks<KC>())
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(base + off[j] + koff), (lds_void_t*)(tile + chunk * 1024), 16, 0, 0);
+  }
+}
+template <bool KC> __device__ __forceinline__ int per_wave(int wave) { return (chunks<KC>() - wave + 3) / 4; }
+
+// LDS fragment reads as inline asm: hipcc orders every LDS read it can see behind ALL outstanding LDS-DMA writes
+// (s_waitcnt vmcnt(0) before the first ds_read of the K step), which would drain the ring; reads it cannot see are
+// ordered by hand -- the counted vmcnt + barrier above them, one lgkmcnt(0) (frags_ready) below them.
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
+}
+template <bool KC>
+__device__ __forceinline__ bf16x8_t read_frag_asm(const unsigned char* tile, int rbase, int lane) {
+  if (KC) {
+    const unsigned a = lds_addr(tile) + ((rbase + (lane & 15)) * KCS + 8 * (lane >> 4)) * 2;
+    u32x4_t v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(a));
+    return __builtin_bit_cast(bf16x8_t, v);
+  } else {
+    const int q = (lane & 15) >> 2, pp = lane & 3;
+    const int kr = 8 * (lane >> 4) + q;
+    const unsigned a = lds_addr(tile) + (kr * Tile<bf16_t>::KS_STRIDE + rbase + 4 * pp) * 2;
+    u32x2_t lo, hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(a), "n"(4 * Tile<bf16_t>::KS_STRIDE * 2));
+    u32x4_t v;
+    v[0] = lo[0]; v[1] = lo[1]; v[2] = hi[0]; v[3] = hi[1];
+    return __builtin_bit_cast(bf16x8_t, v);
+  }
+}
+// the fragments are the asm's in/out operands, so no consumer can be scheduled above the wait
+__device__ __forceinline__ void frags_ready(bf16x8_t (&fa)[4], bf16x8_t (&fb)[4]) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]), "+v"(fb[3]));
+}
+
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void wait_vmcnt(int n) {      // n is wave-uniform, one of {0, 4, 5, 6, 8, 10, 12}
+  switch (n) {
+    case 0: wait_vm<0>(); break;
+    case 4: wait_vm<4>(); break;
+    case 5: wait_vm<5>(); break;
+    case 6: wait_vm<6>(); break;
+    case 8: wait_vm<8>(); break;
+    case 10: wait_vm<10>(); break;
+    default: wait_vm<12>(); break;
+  }
+}
+}  // namespace ring
+
+template <bool A_KC, bool B_KC, int EPI>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_ring_kernel(GemmParams p) {
+  using namespace ring;
+  constexpr int A_BYTES = A_KC ? KC_BYTES : KS_BYTES, B_BYTES = B_KC ? KC_BYTES : KS_BYTES, STAGE = A_BYTES + B_BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NS * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wi = wave >> 1, wj = wave & 1;
+  const int bid = p.xcd_group ? ib_xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int tiles_total = p.tiles_m * p.tiles_n;
+  const int split_id = bid / tiles_total, tile_id = bid % tiles_total;
+  const int ti = tile_id / p.tiles_n, tj = tile_id % p.tiles_n;
+  const int i0 = ti * BM, j0 = tj * BN;
+  const int kb = split_id * p.k_chunk;
+  const int ke = min(p.K, kb + p.k_chunk);
+  const int nk = (ke - kb) / BK;                            // exact by the launch conditions
+  const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A);
+  const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B);
+
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc[t][u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+#define RING_STAMP(k) do { if (p.prof && tid == 0) p.prof[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
+  RING_STAMP(0);
+  int64_t oa[3], ob[3];
+  offsets<A_KC>(p.lda, i0, p.M, wave, lane, oa);
+  offsets<B_KC>(p.ldb, j0, p.N, wave, lane, ob);
+  const int per = per_wave<A_KC>(wave) + per_wave<B_KC>(wave);   // this wave's LDS-DMA instructions per stage
+  auto stage = [&](int kt) {
+    unsigned char* tA = smem + (kt % NS) * STAGE;
+    const int k0 = kb + kt * BK;
+    issue<A_KC>(A, oa, A_KC ? (int64_t)k0 : (int64_t)k0 * p.lda, tA, wave);
+    issue<B_KC>(B, ob, B_KC ? (int64_t)k0 : (int64_t)k0 * p.ldb, tA + A_BYTES, wave);
+  };
+  for (int s = 0; s < NS - 1 && s < nk; ++s) stage(s);
+  RING_STAMP(1);
+  for (int kt = 0; kt < nk; ++kt) {
+    wait_vmcnt(min(nk - 1 - kt, NS - 2) * per);             // my pieces of stage kt have landed
+    __builtin_amdgcn_s_barrier();                            // everyone's have; everyone finished reading stage kt-1
+    if (kt == 0) RING_STAMP(2);
+    if (kt + NS - 1 < nk) stage(kt + NS - 1);
+    const unsigned char* tA = smem + (kt % NS) * STAGE;
+    const unsigned char* tB = tA + A_BYTES;
+    bf16x8_t fa[4], fb[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) fa[t] = read_frag_asm<A_KC>(tA, wi * 64 + 16 * t, lane);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) fb[u] = read_frag_asm<B_KC>(tB, wj * 64 + 16 * u, lane);
+    frags_ready(fa, fb);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[u], fa[t], acc[t][u], 0, 0, 0);
+  }
+  RING_STAMP(3);
+  if constexpr (EPI == EPI_WGRAD) {
+    epilogue<bf16_t, EPI, IB_ACT_NONE>(p, acc, i0, j0, wi, wj, lane, split_id);
+    RING_STAMP(4);
+    return;
+  }
+  switch (p.act) {
+    case IB_ACT_RELU: epilogue<bf16_t, EPI, IB_ACT_RELU>(p, acc, i0, j0, wi, wj, lane, split_id); break;
+    case IB_ACT_TANH: epilogue<bf16_t, EPI, IB_ACT_TANH>(p, acc, i0, j0, wi, wj, lane, split_id); break;
+    case IB_ACT_SIGMOID: epilogue<bf16_t, EPI, IB_ACT_SIGMOID>(p, acc, i0, j0, wi, wj, lane, split_id); break;
+    case IB_ACT_SILU: epilogue<bf16_t, EPI, IB_ACT_SILU>(p, acc, i0, j0, wi, wj, lane, split_id); break;
+    default: epilogue<bf16_t, EPI, IB_ACT_NONE>(p, acc, i0, j0, wi, wj, lane, split_id); break;
+  }
+  RING_STAMP(4);
+#undef RING_STAMP
+}
+
 // out[e] (+)= sum_s slab[s][e]   (fixed order -> bitwise reproducible).  float4 per thread, 4 slabs in flight.
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, int nslab, int64_t slab_stride,
                                                           float* __restrict__ out, int64_t ldo, int rows, int cols,
@@ -624,8 +790,10 @@ template <typename T> bool vec_store_ok(const void* p, int64_t ld) {
 int wgrad_split(int64_t M, int64_t N, int64_t K, int bk, int* chunk_out) {
   // reduction length is M; output tiles over [N, K]
   const int64_t tiles = ((N + BM - 1) / BM) * ((K + BN - 1) / BN);
-  static const int target = []() { const char* e = getenv("IB_WGRAD_TARGET"); return e ? atoi(e) : 512; }();
-  int64_t want = (target + tiles - 1) / tiles;  // ~2 workgroups per CU (IB_WGRAD_TARGET: tuning override)
+  static const int target = []() { const char* e = getenv("IB_WGRAD_TARGET"); return e ? atoi(e) : 256; }();
+  // ~1 workgroup per CU: with the ring-pipelined main loop fewer, longer slices win (half the slab traffic; measured
+  // step 0.310 -> 0.305 ms against 2 per CU).  IB_WGRAD_TARGET: tuning override.
+  int64_t want = (target + tiles - 1) / tiles;
   if (want < 1) want = 1;
   if (want > 32) want = 32;
   int64_t chunk = (M + want - 1) / want;
@@ -637,9 +805,16 @@ int wgrad_split(int64_t M, int64_t N, int64_t K, int bk, int* chunk_out) {
   return (int)split;
 }
 
+// ring kernel: bf16, every staged piece 16-byte aligned, exact reduction tiling, >= 2 K steps of 32
+bool ring_ok(const GemmParams& p, int dtype, int red_len, int red_chunk) {
+  static const int off = []() { const char* e = getenv("IB_NO_RING"); return e ? atoi(e) : 0; }();
+  return !off && dtype == IB_BF16 && p.gldsA && p.gldsB && red_len % 32 == 0 && red_chunk % 32 == 0 && red_len >= 64 &&
+         p.lda >= 8 && p.ldb >= 8;
+}
+
 template <typename T>
 int launch_fwd(GemmParams& p, hipStream_t s) {
-  p.ablate = g_ablate;
+  p.ablate = g_ablate; p.prof = g_gemm_prof;
   p.vecA = vec_load_ok<T>(p.A, p.lda);
   p.vecB = vec_load_ok<T>(p.B, p.ldb);
   p.gldsA = glds_ok<T>(p.A, p.lda); p.gldsB = glds_ok<T>(p.B, p.ldb);
@@ -650,6 +825,11 @@ int launch_fwd(GemmParams& p, hipStream_t s) {
   p.tiles_n = (p.N + BN - 1) / BN; p.tiles_m = (p.M + BM - 1) / BM;
   p.k_chunk = p.K; p.slab_stride = 0; p.xcd_group = 1;
   const int tiles = p.tiles_m * p.tiles_n;
+  if (sizeof(T) == 2 && ring_ok(p, IB_BF16, p.K, p.K)) {
+    hipLaunchKernelGGL((gemm_ring_kernel<true, true, EPI_FWD>), dim3(tiles, 1), dim3(NTHREADS), 0, s, p);
+    IB_CHECK_LAUNCH();
+    return IB_OK;
+  }
   hipLaunchKernelGGL((gemm_kernel<T, true, true, EPI_FWD>), dim3(tiles, 1), dim3(NTHREADS), 0, s, p);
   IB_CHECK_LAUNCH();
   return IB_OK;
@@ -657,7 +837,7 @@ int launch_fwd(GemmParams& p, hipStream_t s) {
 
 template <typename T>
 int launch_dgrad(GemmParams& p, hipStream_t s) {
-  p.ablate = g_ablate;
+  p.ablate = g_ablate; p.prof = g_gemm_prof;
   p.vecA = vec_load_ok<T>(p.A, p.lda);
   p.vecB = vec_load_ok<T>(p.B, p.ldb);
   p.gldsA = glds_ok<T>(p.A, p.lda); p.gldsB = glds_ok<T>(p.B, p.ldb);
@@ -667,6 +847,11 @@ int launch_dgrad(GemmParams& p, hipStream_t s) {
   p.tiles_n = (p.N + BN - 1) / BN; p.tiles_m = (p.M + BM - 1) / BM;
   p.k_chunk = p.K; p.slab_stride = 0; p.xcd_group = 1;
   const int tiles = p.tiles_m * p.tiles_n;
+  if (sizeof(T) == 2 && ring_ok(p, IB_BF16, p.K, p.K)) {
+    hipLaunchKernelGGL((gemm_ring_kernel<true, false, EPI_DGRAD>), dim3(tiles, 1), dim3(NTHREADS), 0, s, p);
+    IB_CHECK_LAUNCH();
+    return IB_OK;
+  }
   hipLaunchKernelGGL((gemm_kernel<T, true, false, EPI_DGRAD>), dim3(tiles, 1), dim3(NTHREADS), 0, s, p);
   IB_CHECK_LAUNCH();
   return IB_OK;
@@ -675,6 +860,7 @@ int launch_dgrad(GemmParams& p, hipStream_t s) {
 }  // namespace
 
 extern "C" int ib_debug_set_ablate(int mask) { g_ablate = mask; return IB_OK; }
+extern "C" int ib_debug_set_gemm_prof(void* buf) { g_gemm_prof = reinterpret_cast<long long*>(buf); return IB_OK; }
 
 extern "C" int ib_linear_fwd(const void* x, int64_t ldx, const void* w, int64_t ldw, const float* bias,
                              const void* add_div, int64_t ld_add_div, const void* add_mod,
@@ -735,7 +921,7 @@ int wgrad_gemm(const void* dz, int64_t lddz, const void* x, int64_t ldx, float* 
   GemmParams p{};
   p.A = dz; p.lda = lddz; p.B = x; p.ldb = ldx; p.M = (int)N; p.N = (int)K; p.K = (int)M;
   p.seg = 1; p.act = IB_ACT_NONE; p.accumulate = accumulate;
-  p.ablate = g_ablate;
+  p.ablate = g_ablate; p.prof = g_gemm_prof;
   p.tiles_n = (p.N + BN - 1) / BN; p.tiles_m = (p.M + BM - 1) / BM;
   p.k_chunk = chunk;
   // all tiles of one M-chunk on one XCD only while that chunk's dz + x slices fit comfortably in the XCD's 4 MiB
@@ -754,7 +940,10 @@ int wgrad_gemm(const void* dz, int64_t lddz, const void* x, int64_t ldx, float* 
   } else {
     p.vecA = vec_load_ok<bf16_t>(p.A, p.lda); p.vecB = vec_load_ok<bf16_t>(p.B, p.ldb);
     p.gldsA = glds_ok<bf16_t>(p.A, p.lda); p.gldsB = glds_ok<bf16_t>(p.B, p.ldb);
-    hipLaunchKernelGGL((gemm_kernel<bf16_t, false, false, EPI_WGRAD>), dim3(tiles * split), dim3(NTHREADS), 0, s, p);
+    if (ring_ok(p, IB_BF16, p.K, chunk))
+      hipLaunchKernelGGL((gemm_ring_kernel<false, false, EPI_WGRAD>), dim3(tiles * split), dim3(NTHREADS), 0, s, p);
+    else
+      hipLaunchKernelGGL((gemm_kernel<bf16_t, false, false, EPI_WGRAD>), dim3(tiles * split), dim3(NTHREADS), 0, s, p);
   }
   IB_CHECK_LAUNCH();
   if (split_out) *split_out = split;

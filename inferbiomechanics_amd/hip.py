@@ -75,7 +75,11 @@ _SIGS = {
                                       _f32, _vp]),
     "ib_colsum_segments": (_c.c_int, [_vp, _i64, _i64, _c.c_int, _vp, _vp, _vp, _vp, _vp, _c.c_int, _vp]),
     "ib_debug_set_chain_prof": (_c.c_int, [_vp]),
+    "ib_debug_set_gemm_prof": (_c.c_int, [_vp]),
     "ib_debug_stamp": (_c.c_int, [_vp, _vp]),
+    "ib_time_mlp_fwd_supported": (_c.c_int, [_i64, _i64, _i64]),
+    "ib_time_mlp_fwd": (_c.c_int, [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64,
+                                   _i64, _i64, _vp]),
     "ib_sum_partials": (_c.c_int, [_vp, _i64, _f32, _vp, _vp]),
     "ib_q_sample": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _c.c_int, _vp]),
     "ib_ddim_step": (_c.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i64, _i64, _c.c_int, _vp]),
@@ -842,6 +846,36 @@ def q_sample(x0, eps, t, sqrt_ab, sqrt_1mab, x_t):
     _check(lib().ib_q_sample(_ptr(x0), _ptr(eps), _ptr(t), _ptr(sqrt_ab), _ptr(sqrt_1mab), _ptr(x_t), ld, B, T, D,
                              sqrt_ab.numel(), dtype_code(dt), stream_ptr()), "ib_q_sample")
     return x_t
+
+
+def time_mlp_fwd_supported(temb: int, hidden: int, out: int) -> bool:
+    return bool(lib().ib_time_mlp_fwd_supported(temb, hidden, out))
+
+
+def time_mlp_fwd(table, t, w1, b1, w2, b2, s, zu, u, e):
+    """fused time-embedding MLP forward (bf16 weights as stored); fills s, zu, u (backward operands) and e"""
+    bt = torch.bfloat16
+    rows, temb, _ = _mat(table, "table", torch.float32)
+    hid, k1, ldw1 = _mat(w1, "w1", bt)
+    out, k2, ldw2 = _mat(w2, "w2", bt)
+    _req(t, "t", torch.int64, 1)
+    B = t.numel()
+    if k1 != temb or k2 != hid or not table.is_contiguous():
+        raise HipError("time_mlp_fwd: weight / table shapes do not chain")
+    for name, a, shape in (("s", s, (B, temb)), ("zu", zu, (B, hid)), ("u", u, (B, hid))):
+        _req(a, name, bt)
+        if tuple(a.shape) != shape or not a.is_contiguous():
+            raise HipError(f"time_mlp_fwd: {name} must be contiguous {shape}")
+    er, ec, lde = _mat(e, "e", bt)
+    if (er, ec) != (B, out):
+        raise HipError("time_mlp_fwd: e must be [B, out]")
+    _req(b1, "b1", torch.float32, 1); _req(b2, "b2", torch.float32, 1)
+    if b1.numel() != hid or b2.numel() != out:
+        raise HipError("time_mlp_fwd: bias sizes")
+    _check(lib().ib_time_mlp_fwd(_ptr(table), rows, _ptr(t), _ptr(w1), ldw1, _ptr(b1), _ptr(w2), ldw2, _ptr(b2),
+                                 _ptr(s), _ptr(zu), _ptr(u), _ptr(e), lde, B, temb, hid, out, stream_ptr()),
+           "ib_time_mlp_fwd")
+    return e
 
 
 def _ptr_array(tensors):

@@ -314,11 +314,17 @@ class TimeMLPPlan:
         g, dt, tg = self.buf.get, self.dtype, self.tag
         w1, w2 = P.w("time_mlp.0.weight"), P.w("time_mlp.2.weight")
         s = g(tg + ".s", (B, table.shape[1]), dt)
-        hip.gather_rows(table, t, s)
         u = g(tg + ".u", (B, w1.shape[0]), dt)
         zu = g(tg + ".zu", (B, w1.shape[0]), dt)
-        hip.linear_fwd(s, w1, P.v("time_mlp.0.bias"), u, act="silu", z=zu)
         e = g(tg + ".e", (B, w2.shape[0]), dt)
+        if dt == torch.bfloat16 and not os.environ.get("IB_NO_TIME_FUSE") \
+                and hip.time_mlp_fwd_supported(table.shape[1], w1.shape[0], w2.shape[0]):
+            # one launch instead of gather + two M = B GEMMs (three latency-bound launches on the critical path)
+            hip.time_mlp_fwd(table, t, w1, P.v("time_mlp.0.bias"), w2, P.v("time_mlp.2.bias"), s, zu, u, e)
+            self.ctx = (s, u, zu)
+            return e
+        hip.gather_rows(table, t, s)
+        hip.linear_fwd(s, w1, P.v("time_mlp.0.bias"), u, act="silu", z=zu)
         hip.linear_fwd(u, w2, P.v("time_mlp.2.bias"), e)
         self.ctx = (s, u, zu)
         return e
@@ -529,16 +535,35 @@ class DenoiserMLPPlan:
                             [P.v(f"blocks.{i}.norm.bias") for i in range(L)], xt, u, h, dz, dpred, part, T,
                             de_lp=de_lp if window_panels else None)
 
-        # every gradient operand now sits in HBM.  The large weight-gradient GEMMs go first, one branch each.
+        # every gradient operand now sits in HBM.  Issue order = the order the graph's ready nodes get the machine:
+        # the time-MLP backward first (a dependent chain of small launches; started late it becomes the step's tail),
+        # then the large weight-gradient GEMMs, one branch each; the main stream does the small reductions.
         defer: list = []
-        self.br_head.run(lambda: _wgrad(self.buf, dpred, h[L - 1], P.g("head.weight"), accumulate, ws_tag="dm.wsH",
-                                        defer=defer))
-        for i in range(L - 1, -1, -1):
+        de32 = None
+        if not window_panels:
+            de32 = g("dm.de32", (B, Hs), torch.float32)
+            for i in range(L):
+                hip.segment_colsum(dz[i], de32[:, i * H:(i + 1) * H], seg=T, mode=0, out_bf16=de_lp[:, i * H:(i + 1) * H])
+        # at most FOUR concurrent streams (a fifth branch of the captured graph was observed to start only after
+        # another finished): main + 3 branches, large GEMMs spread one per stream
+        def wg(i):
             hin = h[i - 1] if i > 0 else xt
-            self.br_blk[i].run(lambda i=i, hin=hin: _wgrad(self.buf, dz[i], hin, P.g(f"blocks.{i}.linear.weight"),
-                                                           accumulate, ws_tag=f"dm.ws{i}", defer=defer))
+            _wgrad(self.buf, dz[i], hin, P.g(f"blocks.{i}.linear.weight"), accumulate, ws_tag=f"dm.ws{i}", defer=defer)
+
+        self.branch.run(lambda: self.time.backward_hidden(de32, de_lp, P, accumulate, defer=defer, ready=False))
+
+        def head_side():
+            _wgrad(self.buf, dpred, h[L - 1], P.g("head.weight"), accumulate, ws_tag="dm.wsH", defer=defer)
+            self.time.backward_out_layer(None, de_lp, P, accumulate, defer=defer, ready=False)
+        self.br_head.run(head_side)
+
+        def blocks_side():
+            for i in range(L - 1, 0, -1):
+                wg(i)
+        if L > 1:
+            self.br_blk[1].run(blocks_side)
         # main stream: every small gradient (LayerNorm gains / biases, linear biases, head bias, time_mlp.2.bias) and
-        # the loss in one launch, then the time-MLP backward
+        # the loss in one launch
         tb2 = P.g("time_mlp.2.bias")
         segs = []
         for i in range(L):
@@ -551,13 +576,7 @@ class DenoiserMLPPlan:
             hip.colsum_segments(part, nwg, segs[-1:], accumulate=False)
         else:
             hip.colsum_segments(part, nwg, segs, accumulate=False)
-        de32 = None
-        if not window_panels:
-            de32 = g("dm.de32", (B, Hs), torch.float32)
-            for i in range(L):
-                hip.segment_colsum(dz[i], de32[:, i * H:(i + 1) * H], seg=T, mode=0, out_bf16=de_lp[:, i * H:(i + 1) * H])
-        self.br_tout.run(lambda: self.time.backward_out_layer(None, de_lp, P, accumulate, defer=defer, ready=False))
-        self.time.backward_hidden(de32, de_lp, P, accumulate, defer=defer, ready=False)
+        wg(0)
         for b in self.branches():
             b.join()
         if defer:

@@ -144,6 +144,33 @@ def test_chain_matches_float64_restatement(hip, B, T, D, H, L):
     close(dbh_k, pred.grad.sum(0), tol, "dbias head")
 
 
+@pytest.mark.parametrize("B,temb,hid,out", [(256, 128, 512, 1024), (70, 32, 128, 256), (3, 128, 512, 512)])
+def test_time_mlp_fwd_matches_float64(hip, B, temb, hid, out):
+    assert hip.time_mlp_fwd_supported(temb, hid, out)
+    table = R.timestep_embedding(torch.arange(1000), temb).to(torch.float32)
+    t = torch.randint(0, 1000, (B,), generator=torch.Generator().manual_seed(1))
+    t[0], t[-1] = 0, 999
+    w1 = rnd((hid, temb), 2, temb ** -0.5).to(BF)
+    w2 = rnd((out, hid), 3, hid ** -0.5).to(BF)
+    b1 = rnd((hid,), 4, 0.1).to(torch.float32)
+    b2 = rnd((out,), 5, 0.1).to(torch.float32)
+    d = lambda x: x.to(DEV)
+    s = torch.zeros(B, temb, dtype=BF, device=DEV)
+    zu = torch.zeros(B, hid, dtype=BF, device=DEV)
+    u = torch.zeros(B, hid, dtype=BF, device=DEV)
+    e = torch.zeros(B, out, dtype=BF, device=DEV)
+    hip.time_mlp_fwd(d(table), d(t), d(w1), d(b1), d(w2), d(b2), s, zu, u, e)
+    torch.cuda.synchronize()
+    s_ref = table[t].to(BF)
+    assert torch.equal(s.cpu(), s_ref)                       # a gather + one rounding: bit-exact
+    z_ref = bf(s_ref.to(torch.float64) @ w1.to(torch.float64).T + b1.to(torch.float64))
+    u_ref = bf(z_ref * torch.sigmoid(z_ref))
+    e_ref = u_ref @ w2.to(torch.float64).T + b2.to(torch.float64)
+    close(zu, z_ref, 1e-2, "zu")
+    close(u, u_ref, 1e-2, "u")
+    close(e, e_ref, 1e-2, "e")
+
+
 def test_deferred_wgrad_slabs_match_fused_wgrad(hip):
     """ib_linear_wgrad_slabs + ONE ib_slab_reduce_multi == ib_linear_wgrad, bitwise (same slabs, same order)"""
     shapes = [(12800, 512, 300), (12800, 300, 512), (256, 1024, 512), (256, 512, 128), (100, 64, 32)]
