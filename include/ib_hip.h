@@ -218,6 +218,12 @@ int ib_time_mlp_fwd(const float* table, int64_t table_rows, const int64_t* t, co
                     const float* b1, const void* w2, int64_t ldw2, const float* b2, void* s, void* zu, void* u,
                     void* e, int64_t ld_e, int64_t B, int64_t temb, int64_t hidden, int64_t out,
                     ib_stream_t stream);
+/* ib_time_mlp_fwd + ib_mlp_chain_pack as ONE launch (both are independent and tiny; saves a kernel boundary) */
+int ib_mlp_chain_prep(const float* table, int64_t table_rows, const int64_t* t, const void* w1, int64_t ldw1,
+                      const float* b1, const void* w2, int64_t ldw2, const float* b2, void* s, void* zu, void* u,
+                      void* e, int64_t ld_e, int64_t B, int64_t temb, int64_t hidden, int64_t out,
+                      const void* const* w, const int64_t* ldw, void* packed, int64_t D, int64_t H, int L,
+                      ib_stream_t stream);
 int ib_debug_stamp(void* slot, ib_stream_t stream);   /* timing-only: *slot = 100 MHz wall clock when the stream gets here */
 int ib_debug_set_gemm_prof(void* stamps);    /* timing-only: [workgroups][8] stamps of the ring GEMM kernel, NULL = off */
 int ib_debug_set_chain_prof(void* stamps);   /* timing-only: [workgroups][16] int64 wall-clock stamps, NULL = off */

@@ -673,9 +673,9 @@ struct PackDesc {
 };
 struct PackParams { PackDesc d[2 * CH_MAXL + 1]; int count; int total_blocks; bf16_t* dst; };
 
-__global__ __launch_bounds__(256) void mlp_chain_pack_kernel(PackParams p) {
-  const int lane = threadIdx.x & 63;
-  for (int blk = blockIdx.x * 4 + (threadIdx.x >> 6); blk < p.total_blocks; blk += gridDim.x * 4) {
+// pack blocks first, first + stride, ... (one wave per 1-KiB block)
+__device__ __forceinline__ void pack_blocks(const PackParams& p, int first, int stride, int lane) {
+  for (int blk = first; blk < p.total_blocks; blk += stride) {
     int di = 0;
     for (int j = 1; j < p.count; ++j)
       if (blk >= p.d[j].block0) di = j;
@@ -693,6 +693,9 @@ __global__ __launch_bounds__(256) void mlp_chain_pack_kernel(PackParams p) {
     }
     reinterpret_cast<bf16x8_t*>(p.dst + d.dst_off)[(int64_t)local * 64 + lane] = v;
   }
+}
+__global__ __launch_bounds__(256) void mlp_chain_pack_kernel(PackParams p) {
+  pack_blocks(p, blockIdx.x * 4 + (threadIdx.x >> 6), gridDim.x * 4, threadIdx.x & 63);
 }
 
 struct ChainShape { int nth, ntd, kbd; };
@@ -749,13 +752,13 @@ extern "C" int ib_mlp_chain_workgroups(int64_t M, int* rows_per_wg) {
   return (int)((M + P - 1) / P);
 }
 
-extern "C" int ib_mlp_chain_pack(const void* const* w, const int64_t* ldw, void* packed, int64_t D, int64_t H, int L,
-                                 ib_stream_t stream) {
+namespace {
+int build_pack(const void* const* w, const int64_t* ldw, void* packed, int64_t D, int64_t H, int L, PackParams& pp) {
   ChainShape s;
   if (!w || !ldw || !packed || L < 1 || L > CH_MAXL || !chain_shape(D, H, &s)) return IB_E_ARG;
   PackLayout lo;
   chain_layout(D, H, L, s, &lo);
-  PackParams pp{};
+  pp = PackParams{};
   pp.dst = reinterpret_cast<bf16_t*>(packed);
   int blocks = 0, c = 0;
   auto add = [&](const void* src, int64_t ld, int N, int K, int tr, int n_tiles, int KB, int64_t off) {
@@ -772,7 +775,16 @@ extern "C" int ib_mlp_chain_pack(const void* const* w, const int64_t* ldw, void*
   for (int i = 1; i < L; ++i) add(w[i], ldw[i], (int)H, (int)H, 1, nth8, kbh, lo.off_b[i]);
   add(w[L], ldw[L], (int)H, (int)D, 1, nth8, s.kbd, lo.off_b[L]);
   pp.count = c; pp.total_blocks = blocks;
-  hipLaunchKernelGGL(mlp_chain_pack_kernel, dim3(ib_grid_1d(blocks, 4)), dim3(256), 0, ib_s(stream), pp);
+  return IB_OK;
+}
+}  // namespace
+
+extern "C" int ib_mlp_chain_pack(const void* const* w, const int64_t* ldw, void* packed, int64_t D, int64_t H, int L,
+                                 ib_stream_t stream) {
+  PackParams pp;
+  const int rc = build_pack(w, ldw, packed, D, H, L, pp);
+  if (rc != IB_OK) return rc;
+  hipLaunchKernelGGL(mlp_chain_pack_kernel, dim3(ib_grid_1d(pp.total_blocks, 4)), dim3(256), 0, ib_s(stream), pp);
   IB_CHECK_LAUNCH();
   return IB_OK;
 }
@@ -960,37 +972,61 @@ struct TimeFwdParams {
   const bf16_t* w1; int64_t ldw1; const float* b1;
   const bf16_t* w2; int64_t ldw2; const float* b2;
   bf16_t* s; bf16_t* zu; bf16_t* u; bf16_t* e; int64_t ld_e;
-  int B, out;
+  int B, out, ncg, time_blocks;
+  long long* prof;      // TIMING-ONLY: [time_blocks][8] stamps (ib_debug_set_chain_prof), else NULL
 };
 
 // NT1 = hidden / 128, KB1 = temb / 32 ; hidden = 128 * NT1 = 32 * KB2 ; output columns: 128 per workgroup (16 per wave)
+// Blocks >= p.time_blocks of the same launch pack the chain kernel's weights (ib_mlp_chain_prep): the two jobs are
+// independent and each far too small to fill the chip; one launch saves a kernel boundary (~4.5 us in a captured step).
 template <int NT1, int KB1>
-__global__ __launch_bounds__(CH_THREADS) void time_mlp_fwd_kernel(TimeFwdParams p) {
+__global__ __launch_bounds__(CH_THREADS) void time_mlp_fwd_kernel(TimeFwdParams p, PackParams pp) {
   constexpr int HID = 128 * NT1, KB2 = 4 * NT1, TE = 32 * KB1;
   constexpr int RS1 = TE * 2 + 16, RS2 = HID * 2 + 16;
   __shared__ __attribute__((aligned(16))) unsigned char smem[CH_ROWS * RS1 + CH_ROWS * RS2];
   unsigned char* simg = smem;
   unsigned char* uimg = smem + CH_ROWS * RS1;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l16 = lane & 15;
-  const int r0 = blockIdx.y * CH_ROWS, cg = blockIdx.x;
+  if ((int)blockIdx.x >= p.time_blocks) {
+    pack_blocks(pp, ((int)blockIdx.x - p.time_blocks) * CH_WAVES + wave, ((int)gridDim.x - p.time_blocks) * CH_WAVES, lane);
+    return;
+  }
+  const int r0 = ((int)blockIdx.x / p.ncg) * CH_ROWS, cg = (int)blockIdx.x % p.ncg;
   const int nrows = min(CH_ROWS, p.B - r0);
+#define T_STAMP(k) do { if (p.prof && tid == 0) p.prof[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
+  T_STAMP(0);
   bf16x8_t wr1[KB1][NT1], wr2[KB2][1];
-  rowmajor_load<NT1, KB1>(p.w1, p.ldw1, wave * 16 * NT1, lane, wr1);
-  rowmajor_load<1, KB2>(p.w2, p.ldw2, cg * 128 + wave * 16, lane, wr2);
-  // gather: sinusoid rows (fp32 table) -> bf16 image; the first column group also writes them out (wgrad operand)
-  for (int idx = tid; idx < CH_ROWS * (TE / 4); idx += CH_THREADS) {
-    const int row = idx / (TE / 4), c = (idx % (TE / 4)) * 4;
-    bf16x4_t o = pack4(0.f, 0.f, 0.f, 0.f);
-    if (row < nrows) {
-      int64_t k = p.t[r0 + row];
-      k = k < 0 ? 0 : (k >= p.table_rows ? p.table_rows - 1 : k);
-      const float4 v = *reinterpret_cast<const float4*>(p.table + k * TE + c);
-      o = pack4(v.x, v.y, v.z, v.w);
-      if (cg == 0) *reinterpret_cast<bf16x4_t*>(p.s + (int64_t)(r0 + row) * TE + c) = o;
+  // gather: sinusoid rows (fp32 table) -> bf16 image; the first column group also writes them out (wgrad operand).
+  // Thread (row group tid / (TE/4), column piece tid % (TE/4)) handles NG rows: all timestep loads first, then all
+  // table loads, then the stores (a per-row load -> load -> store loop serialised NG dependent round trips)
+  {
+    constexpr int PPR = TE / 4, RPI = CH_THREADS / PPR, NG = CH_ROWS / RPI;
+    const int c = (tid % PPR) * 4, rb = tid / PPR;
+    int64_t kk[NG];
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+      const int row = rb + j * RPI;
+      int64_t k = p.t[r0 + min(row, nrows - 1)];
+      kk[j] = k < 0 ? 0 : (k >= p.table_rows ? p.table_rows - 1 : k);
     }
-    *reinterpret_cast<bf16x4_t*>(simg + row * RS1 + c * 2) = o;
+    float4 v[NG];
+#pragma unroll
+    for (int j = 0; j < NG; ++j) v[j] = *reinterpret_cast<const float4*>(p.table + kk[j] * TE + c);
+    // the weight slices are requested BEHIND the gather's two dependent loads (vmcnt retires in order: issued first,
+    // the 32 KiB per wave of weights delayed the gather by their whole transfer)
+    rowmajor_load<NT1, KB1>(p.w1, p.ldw1, wave * 16 * NT1, lane, wr1);
+    rowmajor_load<1, KB2>(p.w2, p.ldw2, cg * 128 + wave * 16, lane, wr2);
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+      const int row = rb + j * RPI;
+      bf16x4_t o = pack4(v[j].x, v[j].y, v[j].z, v[j].w);
+      if (row >= nrows) o = pack4(0.f, 0.f, 0.f, 0.f);
+      else if (cg == 0) *reinterpret_cast<bf16x4_t*>(p.s + (int64_t)(r0 + row) * TE + c) = o;
+      *reinterpret_cast<bf16x4_t*>(simg + row * RS1 + c * 2) = o;
+    }
   }
   __syncthreads();
+  T_STAMP(1);
   {
     f32x4_t acc[4][NT1];
     zero_acc<NT1>(acc);
@@ -1021,11 +1057,13 @@ __global__ __launch_bounds__(CH_THREADS) void time_mlp_fwd_kernel(TimeFwdParams 
     }
   }
   __syncthreads();
+  T_STAMP(2);
   {
     f32x4_t acc[4][1];
     zero_acc<1>(acc);
     const int n0 = cg * 128 + wave * 16;
     reg_gemm<1, KB2>(wr2, uimg, RS2, lane, acc);
+    T_STAMP(3);
     const int col = n0 + 4 * g;
     const float4 b4 = *reinterpret_cast<const float4*>(p.b2 + col);
     const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
@@ -1037,6 +1075,8 @@ __global__ __launch_bounds__(CH_THREADS) void time_mlp_fwd_kernel(TimeFwdParams 
             pack4(acc[mt][0][0] + bb[0], acc[mt][0][1] + bb[1], acc[mt][0][2] + bb[2], acc[mt][0][3] + bb[3]);
     }
   }
+  T_STAMP(4);
+#undef T_STAMP
 }
 }  // namespace
 
@@ -1045,10 +1085,11 @@ extern "C" int ib_time_mlp_fwd_supported(int64_t temb, int64_t hidden, int64_t o
   return (shape && out > 0 && out % 128 == 0) ? 1 : 0;
 }
 
-extern "C" int ib_time_mlp_fwd(const float* table, int64_t table_rows, const int64_t* t, const void* w1, int64_t ldw1,
-                               const float* b1, const void* w2, int64_t ldw2, const float* b2, void* s, void* zu,
-                               void* u, void* e, int64_t ld_e, int64_t B, int64_t temb, int64_t hidden, int64_t out,
-                               ib_stream_t stream) {
+namespace {
+int time_fwd_launch(const float* table, int64_t table_rows, const int64_t* t, const void* w1, int64_t ldw1,
+                    const float* b1, const void* w2, int64_t ldw2, const float* b2, void* s, void* zu, void* u, void* e,
+                    int64_t ld_e, int64_t B, int64_t temb, int64_t hidden, int64_t out, const PackParams& pp,
+                    hipStream_t st) {
   if (!ib_time_mlp_fwd_supported(temb, hidden, out)) return IB_E_UNSUPPORTED;
   if (!table || !t || !w1 || !b1 || !w2 || !b2 || !s || !zu || !u || !e || B <= 0 || table_rows <= 0) return IB_E_ARG;
   if (ldw1 < temb || ldw2 < hidden || ld_e < out || ldw1 % 8 != 0 || ldw2 % 8 != 0 || ld_e % 4 != 0) return IB_E_ARG;
@@ -1061,12 +1102,38 @@ extern "C" int ib_time_mlp_fwd(const float* table, int64_t table_rows, const int
   p.w1 = (const bf16_t*)w1; p.ldw1 = ldw1; p.b1 = b1; p.w2 = (const bf16_t*)w2; p.ldw2 = ldw2; p.b2 = b2;
   p.s = (bf16_t*)s; p.zu = (bf16_t*)zu; p.u = (bf16_t*)u; p.e = (bf16_t*)e; p.ld_e = ld_e;
   p.B = (int)B; p.out = (int)out;
-  const dim3 grid((unsigned)(out / 128), (unsigned)((B + CH_ROWS - 1) / CH_ROWS));
-  hipStream_t st = ib_s(stream);
-  if (temb == 128 && hidden == 512) hipLaunchKernelGGL((time_mlp_fwd_kernel<4, 4>), grid, dim3(CH_THREADS), 0, st, p);
-  else hipLaunchKernelGGL((time_mlp_fwd_kernel<1, 1>), grid, dim3(CH_THREADS), 0, st, p);
+  p.ncg = (int)(out / 128);
+  p.time_blocks = p.ncg * (int)((B + CH_ROWS - 1) / CH_ROWS);
+  p.prof = g_chain_prof;
+  const int pack_wgs = pp.total_blocks > 0 ? ib_grid_1d(pp.total_blocks, CH_WAVES, 224) : 0;
+  const dim3 grid((unsigned)(p.time_blocks + pack_wgs));
+  if (temb == 128 && hidden == 512) hipLaunchKernelGGL((time_mlp_fwd_kernel<4, 4>), grid, dim3(CH_THREADS), 0, st, p, pp);
+  else hipLaunchKernelGGL((time_mlp_fwd_kernel<1, 1>), grid, dim3(CH_THREADS), 0, st, p, pp);
   IB_CHECK_LAUNCH();
   return IB_OK;
+}
+}  // namespace
+
+extern "C" int ib_time_mlp_fwd(const float* table, int64_t table_rows, const int64_t* t, const void* w1, int64_t ldw1,
+                               const float* b1, const void* w2, int64_t ldw2, const float* b2, void* s, void* zu,
+                               void* u, void* e, int64_t ld_e, int64_t B, int64_t temb, int64_t hidden, int64_t out,
+                               ib_stream_t stream) {
+  PackParams pp{};
+  return time_fwd_launch(table, table_rows, t, w1, ldw1, b1, w2, ldw2, b2, s, zu, u, e, ld_e, B, temb, hidden, out, pp,
+                         ib_s(stream));
+}
+
+// one launch for everything the chain kernel waits on: the time-embedding MLP forward AND the weight packing
+extern "C" int ib_mlp_chain_prep(const float* table, int64_t table_rows, const int64_t* t, const void* w1, int64_t ldw1,
+                                 const float* b1, const void* w2, int64_t ldw2, const float* b2, void* s, void* zu,
+                                 void* u, void* e, int64_t ld_e, int64_t B, int64_t temb, int64_t hidden, int64_t out,
+                                 const void* const* w, const int64_t* ldw, void* packed, int64_t D, int64_t H, int L,
+                                 ib_stream_t stream) {
+  PackParams pp;
+  const int rc = build_pack(w, ldw, packed, D, H, L, pp);
+  if (rc != IB_OK) return rc;
+  return time_fwd_launch(table, table_rows, t, w1, ldw1, b1, w2, ldw2, b2, s, zu, u, e, ld_e, B, temb, hidden, out, pp,
+                         ib_s(stream));
 }
 
 // out = scale * sum(partial[0..parts))   (fixed order; the chain kernel's per-workgroup loss sums)

@@ -78,6 +78,8 @@ _SIGS = {
     "ib_debug_set_gemm_prof": (_c.c_int, [_vp]),
     "ib_debug_stamp": (_c.c_int, [_vp, _vp]),
     "ib_time_mlp_fwd_supported": (_c.c_int, [_i64, _i64, _i64]),
+    "ib_mlp_chain_prep": (_c.c_int, [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64,
+                                     _i64, _i64, _vp, _vp, _vp, _i64, _i64, _c.c_int, _vp]),
     "ib_time_mlp_fwd": (_c.c_int, [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64,
                                    _i64, _i64, _vp]),
     "ib_sum_partials": (_c.c_int, [_vp, _i64, _f32, _vp, _vp]),
@@ -852,8 +854,9 @@ def time_mlp_fwd_supported(temb: int, hidden: int, out: int) -> bool:
     return bool(lib().ib_time_mlp_fwd_supported(temb, hidden, out))
 
 
-def time_mlp_fwd(table, t, w1, b1, w2, b2, s, zu, u, e):
-    """fused time-embedding MLP forward (bf16 weights as stored); fills s, zu, u (backward operands) and e"""
+def time_mlp_fwd(table, t, w1, b1, w2, b2, s, zu, u, e, pack=None):
+    """fused time-embedding MLP forward (bf16 weights as stored); fills s, zu, u (backward operands) and e.
+    pack=(weights, packed, D, H): the same launch also packs the chain kernel's weights (ib_mlp_chain_prep)"""
     bt = torch.bfloat16
     rows, temb, _ = _mat(table, "table", torch.float32)
     hid, k1, ldw1 = _mat(w1, "w1", bt)
@@ -872,6 +875,21 @@ def time_mlp_fwd(table, t, w1, b1, w2, b2, s, zu, u, e):
     _req(b1, "b1", torch.float32, 1); _req(b2, "b2", torch.float32, 1)
     if b1.numel() != hid or b2.numel() != out:
         raise HipError("time_mlp_fwd: bias sizes")
+    if pack is not None:
+        weights, packed, D, H = pack
+        L = len(weights) - 1
+        for w in weights:
+            _mat(w, "chain weight", bt)
+        _req(packed, "packed", bt, 1)
+        if packed.numel() < mlp_chain_packed_elems(D, H, L):
+            raise HipError("mlp_chain_prep: packed buffer too small")
+        keep, wp = _ptr_array(weights)
+        ld = (ctypes.c_int64 * len(weights))(*[w.stride(0) for w in weights])
+        _check(lib().ib_mlp_chain_prep(_ptr(table), rows, _ptr(t), _ptr(w1), ldw1, _ptr(b1), _ptr(w2), ldw2, _ptr(b2),
+                                       _ptr(s), _ptr(zu), _ptr(u), _ptr(e), lde, B, temb, hid, out, wp,
+                                       ctypes.cast(ld, ctypes.c_void_p), _ptr(packed), D, H, L, stream_ptr()),
+               "ib_mlp_chain_prep")
+        return e
     _check(lib().ib_time_mlp_fwd(_ptr(table), rows, _ptr(t), _ptr(w1), ldw1, _ptr(b1), _ptr(w2), ldw2, _ptr(b2),
                                  _ptr(s), _ptr(zu), _ptr(u), _ptr(e), lde, B, temb, hid, out, stream_ptr()),
            "ib_time_mlp_fwd")

@@ -309,7 +309,14 @@ class TimeMLPPlan:
         self.dtype, self.buf, self.tag = dtype, buf, tag
         self.ctx = None
 
-    def forward(self, t: torch.Tensor, table: torch.Tensor, P: ParamSource) -> torch.Tensor:
+    def fused_ok(self, table: torch.Tensor, P: ParamSource) -> bool:
+        w1, w2 = P.w("time_mlp.0.weight"), P.w("time_mlp.2.weight")
+        return self.dtype == torch.bfloat16 and not os.environ.get("IB_NO_TIME_FUSE") \
+            and hip.time_mlp_fwd_supported(table.shape[1], w1.shape[0], w2.shape[0])
+
+    def forward(self, t: torch.Tensor, table: torch.Tensor, P: ParamSource, pack=None) -> torch.Tensor:
+        """pack: (weights, packed, D, H) of the chain kernel -- packed by the same launch when the fused kernel runs
+        (the caller checks fused_ok() first)"""
         B = t.shape[0]
         g, dt, tg = self.buf.get, self.dtype, self.tag
         w1, w2 = P.w("time_mlp.0.weight"), P.w("time_mlp.2.weight")
@@ -317,10 +324,9 @@ class TimeMLPPlan:
         u = g(tg + ".u", (B, w1.shape[0]), dt)
         zu = g(tg + ".zu", (B, w1.shape[0]), dt)
         e = g(tg + ".e", (B, w2.shape[0]), dt)
-        if dt == torch.bfloat16 and not os.environ.get("IB_NO_TIME_FUSE") \
-                and hip.time_mlp_fwd_supported(table.shape[1], w1.shape[0], w2.shape[0]):
+        if self.fused_ok(table, P):
             # one launch instead of gather + two M = B GEMMs (three latency-bound launches on the critical path)
-            hip.time_mlp_fwd(table, t, w1, P.v("time_mlp.0.bias"), w2, P.v("time_mlp.2.bias"), s, zu, u, e)
+            hip.time_mlp_fwd(table, t, w1, P.v("time_mlp.0.bias"), w2, P.v("time_mlp.2.bias"), s, zu, u, e, pack=pack)
             self.ctx = (s, u, zu)
             return e
         hip.gather_rows(table, t, s)
@@ -514,9 +520,14 @@ class DenoiserMLPPlan:
         g, dt = self.buf.get, self.dtype
         names = [f"blocks.{i}.linear.weight" for i in range(L)] + ["head.weight"]
         packed = g("ch.packed", (hip.mlp_chain_packed_elems(D, H, L),), dt)
-        self.br_pack.run(lambda: hip.mlp_chain_pack([P.w(n) for n in names], packed, D, H))
-        e = self.time.forward(t, tabs.temb, P)                               # [B, L*H]
-        self.br_pack.join()
+        # the weight packing rides in the time-MLP forward's launch (every fork / join of the captured graph costs
+        # tens of microseconds here: they are independent, but NOT worth a branch)
+        weights = [P.w(n) for n in names]
+        if self.time.fused_ok(tabs.temb, P):
+            e = self.time.forward(t, tabs.temb, P, pack=(weights, packed, D, H))   # [B, L*H]
+        else:
+            hip.mlp_chain_pack(weights, packed, D, H)
+            e = self.time.forward(t, tabs.temb, P)
         Dp = (D + 7) // 8 * 8
         xt = g("ch.xt", (M, Dp), dt)[:, :D]
         dpred = g("ch.dpred", (M, Dp), dt)[:, :D]
@@ -538,7 +549,7 @@ class DenoiserMLPPlan:
         # every gradient operand now sits in HBM.  Issue order = the order the graph's ready nodes get the machine:
         # the time-MLP backward first (a dependent chain of small launches; started late it becomes the step's tail),
         # then the large weight-gradient GEMMs, one branch each; the main stream does the small reductions.
-        defer: list = []
+        defer = None if os.environ.get("IB_NO_DEFER") else []
         de32 = None
         if not window_panels:
             de32 = g("dm.de32", (B, Hs), torch.float32)
@@ -550,18 +561,16 @@ class DenoiserMLPPlan:
             hin = h[i - 1] if i > 0 else xt
             _wgrad(self.buf, dz[i], hin, P.g(f"blocks.{i}.linear.weight"), accumulate, ws_tag=f"dm.ws{i}", defer=defer)
 
+        # measured on one box, same process set: main + time-MLP branch + block branch 0.282 ms; a third branch for the
+        # head 0.308; everything inline 0.320 -- forks are expensive, the dependent time-MLP chain still needs its own
         self.branch.run(lambda: self.time.backward_hidden(de32, de_lp, P, accumulate, defer=defer, ready=False))
-
-        def head_side():
-            _wgrad(self.buf, dpred, h[L - 1], P.g("head.weight"), accumulate, ws_tag="dm.wsH", defer=defer)
-            self.time.backward_out_layer(None, de_lp, P, accumulate, defer=defer, ready=False)
-        self.br_head.run(head_side)
 
         def blocks_side():
             for i in range(L - 1, 0, -1):
                 wg(i)
         if L > 1:
             self.br_blk[1].run(blocks_side)
+        _wgrad(self.buf, dpred, h[L - 1], P.g("head.weight"), accumulate, ws_tag="dm.wsH", defer=defer)
         # main stream: every small gradient (LayerNorm gains / biases, linear biases, head bias, time_mlp.2.bias) and
         # the loss in one launch
         tb2 = P.g("time_mlp.2.bias")
@@ -576,6 +585,7 @@ class DenoiserMLPPlan:
             hip.colsum_segments(part, nwg, segs[-1:], accumulate=False)
         else:
             hip.colsum_segments(part, nwg, segs, accumulate=False)
+        self.time.backward_out_layer(None, de_lp, P, accumulate, defer=defer, ready=False)
         wg(0)
         for b in self.branches():
             b.join()
