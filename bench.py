@@ -112,6 +112,9 @@ def cpu_baseline(kind, T, D, B, budget_s=15.0):
 
 
 KERNEL_OF = {   # C-ABI entry -> device kernel it launches (names as rocprofv3 --kernel-trace reports them)
+    "ib_mlp_chain_train": "mlp_chain_kernel<4, 3, 10>", "ib_mlp_chain_prep": "time_mlp_fwd_kernel<4, 4> (+ weight packing blocks)",
+    "ib_linear_wgrad_slabs": "gemm_ring_kernel<false, false, EPI_WGRAD>", "ib_slab_reduce_multi": "slab_reduce_multi_kernel",
+    "ib_colsum_segments": "colsum_segments_kernel",
     "ib_linear_fwd": "gemm_kernel<T, true, true, EPI_FWD>", "ib_linear_dgrad": "gemm_kernel<T, true, false, EPI_DGRAD>",
     "ib_linear_wgrad": "gemm_kernel<T, false, false, EPI_WGRAD> (+ slab_reduce_kernel)",
     "ib_layernorm_fwd": "layernorm_fwd_kernel", "ib_layernorm_bwd": "layernorm_bwd_kernel (+ segment_colsum_kernel)",
@@ -157,6 +160,18 @@ def roofline_leg(trainer, batches, dtype_name):
         """(algorithmic flops, algorithmic bytes) of ONE launch; dims = the call's small-integer arguments, which
         for every entry point end with (..., M, N, K, dtype) or (..., M, N, dtype)"""
         d, e = r["dims"], r["entry"]
+        if e == "ib_mlp_chain_train":
+            # dims end with (M, T, D, H, L).  FLOPs: the forward GEMMs (D->H, (L-1) x H->H, H->D) and the dgrad chain
+            # (D->H transposed head, (L-1) x H->H).  Bytes: what the step needs in HBM given that the weight gradients
+            # are separate GEMMs -- x0, eps in; x_t, dpred, h_i, dz_i out; the packed weights once per workgroup wave
+            # from L2 are not HBM traffic (2 x the weight bytes counted once).  u_i (written, re-read) is overhead.
+            M, T_, D_, H_, L_ = d[-5], d[-4], d[-3], d[-2], d[-1]
+            fw = D_ * H_ + (L_ - 1) * H_ * H_ + H_ * D_
+            bw = D_ * H_ + (L_ - 1) * H_ * H_
+            return 2 * M * (fw + bw), 4 * M * D_ * es + 2 * L_ * M * H_ * es + (fw + bw) * es
+        if e == "ib_linear_wgrad_slabs":
+            M, N, K = d[-4], d[-3], d[-2]
+            return 2 * M * N * K, (M * K + M * N) * es + N * K * 4
         if e in ("ib_linear_fwd", "ib_linear_dgrad", "ib_linear_wgrad"):
             M, N, K = d[-4], d[-3], d[-2]
             return 2 * M * N * K, (M * K + N * K) * es + M * N * (4 if e.endswith("wgrad") else es)
@@ -220,8 +235,8 @@ def ddim_leg(dev, dtype, B=16, T=200, D=300, steps=100):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--workload", default="mlp_denoiser_T50", choices=list(WORKLOADS))
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--opt-type", default="rmsprop")

@@ -106,3 +106,22 @@ def test_checkpoint_loader_accepts_ddp_prefix_and_orders_files(dry, tmp_path):
     epoch, batch = AbstractCommand().load_latest_checkpoint(m, checkpoint_dir=d)
     assert (epoch, batch) == (1, 5) and float(m.state_dict()['net.0.bias'][0]) == 2.0
     assert AbstractCommand().load_latest_checkpoint(m, checkpoint_dir=os.path.join(d, 'nope')) == (-1, 0)
+
+
+def test_chain_step_plumbing(dry):
+    """the fused chain path of HipTrainer (prep -> chain -> deferred weight-gradient slabs -> one slab reduction), every
+    call marshalled through the real ctypes signatures with the kernels in dry-run"""
+    from inferbiomechanics_amd.engine import HipTrainer
+    from inferbiomechanics_amd.models.DiffusionDenoisers import DiffusionMLP
+    for T in (13, 16):                                   # ragged panels / panel == window
+        m = DiffusionMLP(48, [128, 128], temb_dim=32, temb_hidden=128, compute_dtype=torch.bfloat16)
+        tr = HipTrainer(m, "diffusion", "adam", 1e-3, use_graph=False)
+        assert tr.plan.chain_ok(48)
+        x0, eps = torch.randn(5, T, 48), torch.randn(5, T, 48)
+        t = torch.randint(0, 1000, (5,))
+        dry.lib().calls.clear()
+        tr.step((x0, t, eps))
+        names = dry.lib().calls
+        assert "ib_mlp_chain_train" in names and "ib_mlp_chain_prep" in names and "ib_slab_reduce_multi" in names
+        assert "ib_q_sample" not in names and "ib_layernorm_fwd" not in names
+        assert names[-1] == "ib_optim_step"

@@ -17,7 +17,11 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ENTRY_OF = [("gemm_kernel", "Lb1ELb1ELi0", "ib_linear_fwd"), ("gemm_kernel", "Lb1ELb0ELi1", "ib_linear_dgrad"),
+ENTRY_OF = [("mlp_chain_kernel", "", "ib_mlp_chain_train"), ("time_mlp_fwd_kernel", "", "ib_mlp_chain_prep"),
+            ("gemm_ring_kernel", "Lb0ELb0ELi2", "ib_linear_wgrad_slabs"), ("gemm_ring_kernel", "Lb1ELb1ELi0", "ib_linear_fwd"),
+            ("gemm_ring_kernel", "Lb1ELb0ELi1", "ib_linear_dgrad"), ("slab_reduce_multi_kernel", "", "ib_slab_reduce_multi"),
+            ("colsum_segments_kernel", "", "ib_colsum_segments"),
+            ("gemm_kernel", "Lb1ELb1ELi0", "ib_linear_fwd"), ("gemm_kernel", "Lb1ELb0ELi1", "ib_linear_dgrad"),
             ("gemm_kernel", "Lb0ELb0ELi2", "ib_linear_wgrad"), ("layernorm_fwd_kernel", "", "ib_layernorm_fwd"),
             ("layernorm_bwd_kernel", "", "ib_layernorm_bwd"), ("attn_fwd_mfma", "", "ib_attention_fwd"),
             ("attn_bwd_mfma", "", "ib_attention_bwd")]
@@ -28,6 +32,10 @@ def entry_of(name):
         if a in name and b in name:
             return e
     # demangled form of the template kernels
+    if "gemm_ring_kernel" in name:
+        if "false, false" in name:
+            return "ib_linear_wgrad_slabs"
+        return "ib_linear_fwd" if "true, true" in name else "ib_linear_dgrad"
     if "gemm_kernel" in name:
         if "true, true" in name or ", true, 0>" in name:
             return "ib_linear_fwd"
@@ -79,7 +87,8 @@ def main():
                 "tools/kbench.py / bench.py's roofline leg time launches back-to-back inside a hipGraph.\n\n"
                 "| kernel | grid (threads) | dispatches | avg us | total ms | FETCH KiB | WRITE KiB | hbm MB/launch |\n|---|---|---|---|---|---|---|---|\n")
         for r in rows[:40]:
-            name = r["kernel"].split("(")[0][-70:]
+            name = r["kernel"].replace("void ", "").replace("(anonymous namespace)::", "")
+            name = name.split("(")[0][-70:] or r["kernel"][:70]
             f.write(f"| `{name}` | {r['grid_threads']} | {r['dispatches']} | {r['avg_us']:.1f} | {r['total_ms']:.2f} | "
                     f"{'' if r['FETCH_SIZE_KiB'] is None else round(r['FETCH_SIZE_KiB'])} | "
                     f"{'' if r['WRITE_SIZE_KiB'] is None else round(r['WRITE_SIZE_KiB'])} | "
