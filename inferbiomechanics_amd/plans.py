@@ -565,11 +565,10 @@ class DenoiserMLPPlan:
         # head 0.308; everything inline 0.320 -- forks are expensive, the dependent time-MLP chain still needs its own
         self.branch.run(lambda: self.time.backward_hidden(de32, de_lp, P, accumulate, defer=defer, ready=False))
 
-        def blocks_side():
-            for i in range(L - 1, 0, -1):
+        def blocks_side():           # every block's weight gradient, back to back on one branch
+            for i in range(L - 1, -1, -1):
                 wg(i)
-        if L > 1:
-            self.br_blk[1].run(blocks_side)
+        self.br_blk[0].run(blocks_side)
         _wgrad(self.buf, dpred, h[L - 1], P.g("head.weight"), accumulate, ws_tag="dm.wsH", defer=defer)
         # main stream: every small gradient (LayerNorm gains / biases, linear biases, head bias, time_mlp.2.bias) and
         # the loss in one launch
@@ -586,7 +585,6 @@ class DenoiserMLPPlan:
         else:
             hip.colsum_segments(part, nwg, segs, accumulate=False)
         self.time.backward_out_layer(None, de_lp, P, accumulate, defer=defer, ready=False)
-        wg(0)
         for b in self.branches():
             b.join()
         if defer:
