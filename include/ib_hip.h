@@ -224,6 +224,11 @@ int ib_mlp_chain_prep(const float* table, int64_t table_rows, const int64_t* t, 
                       void* e, int64_t ld_e, int64_t B, int64_t temb, int64_t hidden, int64_t out,
                       const void* const* w, const int64_t* ldw, void* packed, int64_t D, int64_t H, int L,
                       ib_stream_t stream);
+/* ib_slab_reduce_multi + ib_colsum_segments in ONE launch (the reductions that finish a training step's gradients) */
+int ib_step_reduce(int n, const void* const* slabs, const int32_t* nslab, float* const* dw, const int64_t* lddw,
+                   const int32_t* N, const int32_t* K, const float* part, int64_t ld, int64_t rows, int nseg,
+                   const int32_t* col0, const int32_t* ncols, float* const* dst, float* const* dst2,
+                   const float* scale, int accumulate, ib_stream_t stream);
 int ib_debug_stamp(void* slot, ib_stream_t stream);   /* timing-only: *slot = 100 MHz wall clock when the stream gets here */
 int ib_debug_set_gemm_prof(void* stamps);    /* timing-only: [workgroups][8] stamps of the ring GEMM kernel, NULL = off */
 int ib_debug_set_chain_prof(void* stamps);   /* timing-only: [workgroups][16] int64 wall-clock stamps, NULL = off */

@@ -855,83 +855,6 @@ extern "C" int ib_mlp_chain_train(const void* x0, const void* eps, const int64_t
   return IB_OK;
 }
 
-// ---- multi-segment column sums: out_s[c] (+)= scale_s * sum_r part[r][col0_s + c]   (fixed order, one launch for
-// every small parameter gradient of a step: LayerNorm gains / biases, linear biases, the loss scalar)
-namespace {
-constexpr int CS_MAXSEG = 24;
-struct ColsumSegs {
-  const float* part; int64_t ld; int rows; int nseg; int accumulate;
-  int col0[CS_MAXSEG], ncols[CS_MAXSEG];
-  float* dst[CS_MAXSEG]; float* dst2[CS_MAXSEG];
-  float scale[CS_MAXSEG];
-  int blk0[CS_MAXSEG + 1];       // first block of each segment (64 columns per block)
-};
-__global__ __launch_bounds__(256) void colsum_segments_kernel(ColsumSegs p) {
-  __shared__ float4 red[16][16];
-  int sgi = 0;
-  for (int j = 1; j < p.nseg; ++j)
-    if ((int)blockIdx.x >= p.blk0[j]) sgi = j;
-  const int c4 = threadIdx.x & 15, rg = threadIdx.x >> 4;      // 16 float4 columns x 16 row groups
-  const int c = ((int)blockIdx.x - p.blk0[sgi]) * 64 + 4 * c4;
-  const int nc = p.ncols[sgi];
-  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (c < nc) {
-    const float* base = p.part + p.col0[sgi] + c;
-    if (c + 4 <= nc) {
-      for (int r = rg; r < p.rows; r += 16) {
-        const float4 v = *reinterpret_cast<const float4*>(base + (int64_t)r * p.ld);
-        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-      }
-    } else {
-      for (int r = rg; r < p.rows; r += 16) {
-        const float* q = base + (int64_t)r * p.ld;
-        s.x += q[0];
-        if (c + 1 < nc) s.y += q[1];
-        if (c + 2 < nc) s.z += q[2];
-      }
-    }
-  }
-  red[rg][c4] = s;
-  __syncthreads();
-  if (rg == 0 && c < nc) {
-    float4 t = red[0][c4];
-#pragma unroll
-    for (int k = 1; k < 16; ++k) { const float4 v = red[k][c4]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
-    const float sc = p.scale[sgi];
-    const float o[4] = {t.x * sc, t.y * sc, t.z * sc, t.w * sc};
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      if (c + k < nc) {
-        float* d = p.dst[sgi] + c + k;
-        *d = p.accumulate ? *d + o[k] : o[k];
-        if (p.dst2[sgi]) { float* d2 = p.dst2[sgi] + c + k; *d2 = p.accumulate ? *d2 + o[k] : o[k]; }
-      }
-    }
-  }
-}
-}  // namespace
-
-extern "C" int ib_colsum_segments(const float* part, int64_t ld, int64_t rows, int nseg, const int32_t* col0,
-                                  const int32_t* ncols, float* const* dst, float* const* dst2, const float* scale,
-                                  int accumulate, ib_stream_t stream) {
-  if (!part || rows <= 0 || nseg <= 0 || nseg > CS_MAXSEG || !col0 || !ncols || !dst || ld % 4 != 0) return IB_E_ARG;
-  if ((reinterpret_cast<uintptr_t>(part) % 16) != 0) return IB_E_ARG;
-  ColsumSegs p{};
-  p.part = part; p.ld = ld; p.rows = (int)rows; p.nseg = nseg; p.accumulate = accumulate;
-  int blocks = 0;
-  for (int j = 0; j < nseg; ++j) {
-    if (!dst[j] || ncols[j] <= 0 || col0[j] < 0 || col0[j] % 4 != 0 || col0[j] + ncols[j] > ld) return IB_E_ARG;
-    p.col0[j] = col0[j]; p.ncols[j] = ncols[j]; p.dst[j] = dst[j]; p.dst2[j] = dst2 ? dst2[j] : nullptr;
-    p.scale[j] = scale ? scale[j] : 1.f;
-    p.blk0[j] = blocks;
-    blocks += (ncols[j] + 63) / 64;
-  }
-  p.blk0[nseg] = blocks;
-  hipLaunchKernelGGL(colsum_segments_kernel, dim3(blocks), dim3(256), 0, ib_s(stream), p);
-  IB_CHECK_LAUNCH();
-  return IB_OK;
-}
-
 // ---- fused time-embedding MLP forward: e = W2 silu(W1 sinus(t) + b1) + b2 for B windows in ONE launch (the per-op
 // plan needs a gather and two M = B GEMMs whose 8-16 workgroups are pure latency: ~28 us of kernels + 3 boundaries on
 // the step's critical path).  Workgroup = 64 windows x one group of 128 output columns; every column group recomputes

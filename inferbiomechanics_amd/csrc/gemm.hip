@@ -958,44 +958,6 @@ int wgrad_gemm(const void* dz, int64_t lddz, const void* x, int64_t ldx, float* 
   return IB_OK;
 }
 
-constexpr int SR_MAX = 8;
-struct SlabMulti {
-  const float* slabs[SR_MAX]; float* dw[SR_MAX]; int64_t lddw[SR_MAX];
-  int nslab[SR_MAX], rows[SR_MAX], cols[SR_MAX], blk0[SR_MAX + 1];
-  int n, accumulate;
-};
-// several wgrad slab sets -> their gradients in ONE launch (float4 path only: cols % 4 == 0, aligned)
-__global__ __launch_bounds__(256) void slab_reduce_multi_kernel(SlabMulti p) {
-  int e = 0;
-  for (int j = 1; j < p.n; ++j)
-    if ((int)blockIdx.x >= p.blk0[j]) e = j;
-  const int nb = p.blk0[e + 1] - p.blk0[e];
-  const int cols = p.cols[e], nslab = p.nslab[e];
-  const int64_t n4 = ((int64_t)p.rows[e] * cols) >> 2, st4 = n4;
-  const float4* base = reinterpret_cast<const float4*>(p.slabs[e]);
-  for (int64_t e4 = (int64_t)((int)blockIdx.x - p.blk0[e]) * 256 + threadIdx.x; e4 < n4; e4 += (int64_t)nb * 256) {
-    const float4* q = base + e4;
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    int k = 0;
-    for (; k + 4 <= nslab; k += 4) {
-      const float4 a = q[(int64_t)k * st4], b = q[(int64_t)(k + 1) * st4], c = q[(int64_t)(k + 2) * st4],
-                   d = q[(int64_t)(k + 3) * st4];
-      s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
-      s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
-      s.x += c.x; s.y += c.y; s.z += c.z; s.w += c.w;
-      s.x += d.x; s.y += d.y; s.z += d.z; s.w += d.w;
-    }
-    for (; k < nslab; ++k) {
-      const float4 a = q[(int64_t)k * st4];
-      s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
-    }
-    const int64_t el = e4 << 2;
-    const int r = (int)(el / cols), c0 = (int)(el % cols);
-    float4* o = reinterpret_cast<float4*>(p.dw[e] + (int64_t)r * p.lddw[e] + c0);
-    if (p.accumulate) { const float4 t = *o; s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w; }
-    *o = s;
-  }
-}
 }  // namespace
 
 extern "C" int ib_linear_wgrad(const void* dz, int64_t lddz, const void* x, int64_t ldx, float* dw,
@@ -1017,25 +979,4 @@ extern "C" int ib_linear_wgrad_slabs(const void* dz, int64_t lddz, const void* x
   if (!nslab_out) return IB_E_ARG;
   return wgrad_gemm(dz, lddz, x, ldx, nullptr, 0, 0, workspace, workspace_bytes, M, N, K, dtype, ib_s(stream), true,
                     nslab_out);
-}
-
-extern "C" int ib_slab_reduce_multi(int n, const void* const* slabs, const int32_t* nslab, float* const* dw,
-                                    const int64_t* lddw, const int32_t* N, const int32_t* K, int accumulate,
-                                    ib_stream_t stream) {
-  if (n <= 0 || n > SR_MAX || !slabs || !nslab || !dw || !lddw || !N || !K) return IB_E_ARG;
-  SlabMulti p{};
-  p.n = n; p.accumulate = accumulate;
-  int blocks = 0;
-  for (int j = 0; j < n; ++j) {
-    if (!slabs[j] || !dw[j] || nslab[j] <= 0 || N[j] <= 0 || K[j] <= 0 || lddw[j] < K[j]) return IB_E_ARG;
-    if (K[j] % 4 != 0 || lddw[j] % 4 != 0 || !aligned(slabs[j], 16) || !aligned(dw[j], 16)) return IB_E_UNSUPPORTED;
-    p.slabs[j] = reinterpret_cast<const float*>(slabs[j]); p.dw[j] = dw[j]; p.lddw[j] = lddw[j];
-    p.nslab[j] = nslab[j]; p.rows[j] = N[j]; p.cols[j] = K[j];
-    p.blk0[j] = blocks;
-    blocks += ib_grid_1d((int64_t)N[j] * K[j] / 4, 256, 1024);
-  }
-  p.blk0[n] = blocks;
-  hipLaunchKernelGGL(slab_reduce_multi_kernel, dim3(blocks), dim3(256), 0, ib_s(stream), p);
-  IB_CHECK_LAUNCH();
-  return IB_OK;
 }

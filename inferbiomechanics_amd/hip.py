@@ -44,6 +44,8 @@ _SIGS = {
     "ib_linear_wgrad_slabs_workspace": (_sz, [_i64, _i64, _i64]),
     "ib_linear_wgrad_slabs": (_c.c_int, [_vp, _i64, _vp, _i64, _vp, _sz, _vp, _i64, _i64, _i64, _c.c_int, _vp]),
     "ib_slab_reduce_multi": (_c.c_int, [_c.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _c.c_int, _vp]),
+    "ib_step_reduce": (_c.c_int, [_c.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _c.c_int, _vp, _vp, _vp, _vp, _vp,
+                                  _c.c_int, _vp]),
     "ib_segment_colsum": (_c.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _c.c_int, _c.c_int, _c.c_int, _vp]),
     "ib_layernorm_bwd_reduce": (_c.c_int, [_vp, _sz, _vp, _vp, _c.c_int, _i64, _i64, _vp]),
     "ib_layernorm_fwd": (_c.c_int, [_vp, _vp, _c.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _f32,
@@ -482,6 +484,37 @@ def slab_reduce_multi(items, accumulate=False):
     Ks = (ctypes.c_int32 * n)(*[it[2].shape[1] for it in items])
     _check(lib().ib_slab_reduce_multi(n, cv(slabs), cv(nslab), cv(dws), cv(ldd), cv(Ns), cv(Ks), int(accumulate),
                                       stream_ptr()), "ib_slab_reduce_multi")
+
+
+def step_reduce(items, part, rows: int, segs, accumulate=False):
+    """slab_reduce_multi(items) + colsum_segments(part, rows, segs) as ONE launch"""
+    n = len(items)
+    for ws, ns, dw in items:
+        _req(ws, "workspace")
+        _mat(dw, "dw", torch.float32)
+    pr, pc, ld = _mat(part, "part", torch.float32)
+    if rows > pr:
+        raise HipError("step_reduce: rows exceed the partial array")
+    for c0, nc, d, d2, sc in segs:
+        _req(d, "dst", torch.float32)
+        if d.numel() < nc or not d.is_contiguous() or c0 + nc > pc:
+            raise HipError("step_reduce: segment does not fit")
+    cv = lambda a: ctypes.cast(a, ctypes.c_void_p)
+    slabs = (ctypes.c_void_p * n)(*[it[0].data_ptr() for it in items])
+    nslab = (ctypes.c_int32 * n)(*[int(it[1]) for it in items])
+    dws = (ctypes.c_void_p * n)(*[it[2].data_ptr() for it in items])
+    ldd = (ctypes.c_int64 * n)(*[it[2].stride(0) for it in items])
+    Ns = (ctypes.c_int32 * n)(*[it[2].shape[0] for it in items])
+    Ks = (ctypes.c_int32 * n)(*[it[2].shape[1] for it in items])
+    m = len(segs)
+    col0 = (ctypes.c_int32 * m)(*[s[0] for s in segs])
+    ncols = (ctypes.c_int32 * m)(*[s[1] for s in segs])
+    dst = (ctypes.c_void_p * m)(*[s[2].data_ptr() for s in segs])
+    dst2 = (ctypes.c_void_p * m)(*[(s[3].data_ptr() if s[3] is not None else None) for s in segs])
+    scale = (ctypes.c_float * m)(*[float(s[4]) for s in segs])
+    _check(lib().ib_step_reduce(n, cv(slabs), cv(nslab), cv(dws), cv(ldd), cv(Ns), cv(Ks), _ptr(part), ld, rows, m,
+                                cv(col0), cv(ncols), cv(dst), cv(dst2), cv(scale), int(accumulate), stream_ptr()),
+           "ib_step_reduce")
 
 
 def segment_colsum(x, out, seg, mode=0, accumulate=False, out_bf16=None):

@@ -579,15 +579,19 @@ class DenoiserMLPPlan:
                      (3 * i * H + H, H, P.g(f"blocks.{i}.norm.bias"), None, 1.0),
                      (3 * i * H + 2 * H, H, P.g(f"blocks.{i}.linear.bias"), tb2[i * H:(i + 1) * H], 1.0)]
         segs += [(3 * L * H, D, P.g("head.bias"), None, 1.0), (W - 4, 1, result, None, 1.0 / (M * D))]
-        if accumulate:     # the loss scalar is never accumulated
-            hip.colsum_segments(part, nwg, segs[:-1], accumulate=True)
-            hip.colsum_segments(part, nwg, segs[-1:], accumulate=False)
-        else:
-            hip.colsum_segments(part, nwg, segs, accumulate=False)
+        merged = bool(defer) and not accumulate and len(defer) <= 8
+        if not merged:
+            if accumulate:     # the loss scalar is never accumulated
+                hip.colsum_segments(part, nwg, segs[:-1], accumulate=True)
+                hip.colsum_segments(part, nwg, segs[-1:], accumulate=False)
+            else:
+                hip.colsum_segments(part, nwg, segs, accumulate=False)
         self.time.backward_out_layer(None, de_lp, P, accumulate, defer=defer, ready=False)
         for b in self.branches():
             b.join()
-        if defer:
+        if merged:               # every slab set + every small gradient + the loss: one launch
+            hip.step_reduce(defer, part, nwg, segs)
+        elif defer:
             hip.slab_reduce_multi(defer, accumulate=accumulate)
         for n in self.ready_order():
             P.ready(n)
