@@ -71,6 +71,12 @@ size_t ib_linear_wgrad_slabs_workspace(int64_t M, int64_t N, int64_t K);
 int ib_linear_wgrad_slabs(const void* dz, int64_t lddz, const void* x, int64_t ldx, void* workspace,
                           size_t workspace_bytes, int* nslab_out, int64_t M, int64_t N, int64_t K, int dtype,
                           ib_stream_t stream);
+/* n <= 6 independent weight-gradient problems in ONE launch (bf16 ring kernel only: IB_E_UNSUPPORTED otherwise, the
+ * caller then issues them one by one); host arrays */
+int ib_linear_wgrad_slabs_multi(int n, const void* const* dz, const int64_t* lddz, const void* const* x,
+                                const int64_t* ldx, void* const* workspace, const size_t* workspace_bytes,
+                                int32_t* nslab_out, const int64_t* M, const int64_t* N, const int64_t* K, int dtype,
+                                ib_stream_t stream);
 int ib_slab_reduce_multi(int n, const void* const* slabs, const int32_t* nslab, float* const* dw,
                          const int64_t* lddw, const int32_t* N, const int32_t* K, int accumulate,
                          ib_stream_t stream);

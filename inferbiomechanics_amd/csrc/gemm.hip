@@ -659,15 +659,19 @@ __device__ __forceinline__ void wait_vmcnt(int n) {      // n is wave-uniform, o
 }
 }  // namespace ring
 
+template <bool A_KC, bool B_KC>
+constexpr int ring_lds_bytes() {
+  return ring::NS * ((A_KC ? ring::KC_BYTES : ring::KS_BYTES) + (B_KC ? ring::KC_BYTES : ring::KS_BYTES));
+}
+// blk / nblk: this problem's block id and block count (== blockIdx.x / gridDim.x unless several problems share a launch)
 template <bool A_KC, bool B_KC, int EPI>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_ring_kernel(GemmParams p) {
+__device__ __forceinline__ void gemm_ring_body(const GemmParams& p, unsigned char* smem, int blk, int nblk) {
   using namespace ring;
   constexpr int A_BYTES = A_KC ? KC_BYTES : KS_BYTES, B_BYTES = B_KC ? KC_BYTES : KS_BYTES, STAGE = A_BYTES + B_BYTES;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[NS * STAGE];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wi = wave >> 1, wj = wave & 1;
-  const int bid = p.xcd_group ? ib_xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int bid = p.xcd_group ? ib_xcd_remap(blk, nblk) : blk;
   const int tiles_total = p.tiles_m * p.tiles_n;
   const int split_id = bid / tiles_total, tile_id = bid % tiles_total;
   const int ti = tile_id / p.tiles_n, tj = tile_id % p.tiles_n;
@@ -732,6 +736,24 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_ring_kernel(GemmParams p) {
   }
   RING_STAMP(4);
 #undef RING_STAMP
+}
+
+template <bool A_KC, bool B_KC, int EPI>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_ring_kernel(GemmParams p) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[ring_lds_bytes<A_KC, B_KC>()];
+  gemm_ring_body<A_KC, B_KC, EPI>(p, smem, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// several weight-gradient problems in ONE launch (a training step's dW GEMMs are independent and each is short: one
+// launch saves their kernel boundaries and the streams / joins that ran them side by side)
+constexpr int WG_MAX = 6;
+struct WgradMulti { GemmParams p[WG_MAX]; int blk0[WG_MAX + 1]; int n; };
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_ring_wgrad_multi_kernel(WgradMulti m) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[ring_lds_bytes<false, false>()];
+  int e = 0;
+  for (int j = 1; j < m.n; ++j)
+    if ((int)blockIdx.x >= m.blk0[j]) e = j;
+  gemm_ring_body<false, false, EPI_WGRAD>(m.p[e], smem, (int)blockIdx.x - m.blk0[e], m.blk0[e + 1] - m.blk0[e]);
 }
 
 // out[e] (+)= sum_s slab[s][e]   (fixed order -> bitwise reproducible).  float4 per thread, 4 slabs in flight.
@@ -906,9 +928,10 @@ extern "C" size_t ib_linear_wgrad_workspace(int64_t M, int64_t N, int64_t K) {
 namespace {
 // the split-M weight-gradient GEMM.  slabs_only: always write fp32 partial slabs [split][N][K] into the workspace
 // (even for split == 1) and leave the reduction to ib_slab_reduce_multi (one launch for several gradients).
-int wgrad_gemm(const void* dz, int64_t lddz, const void* x, int64_t ldx, float* dw, int64_t lddw, int accumulate,
-               void* workspace, size_t workspace_bytes, int64_t M, int64_t N, int64_t K, int dtype, hipStream_t s,
-               bool slabs_only, int* split_out) {
+// fills the GemmParams of dW = dz^T x (split over M); returns the error code, *split_out / *tiles_out on success
+int wgrad_params(const void* dz, int64_t lddz, const void* x, int64_t ldx, float* dw, int64_t lddw, int accumulate,
+                 void* workspace, size_t workspace_bytes, int64_t M, int64_t N, int64_t K, int dtype, bool slabs_only,
+                 GemmParams& p, int* split_out, int* tiles_out, int* chunk_out) {
   if (!dz || !x || M <= 0 || N <= 0 || K <= 0 || lddz < N || ldx < K) return IB_E_ARG;
   if (!slabs_only && (!dw || lddw < K)) return IB_E_ARG;
   if (dtype != IB_F32 && dtype != IB_BF16) return IB_E_DTYPE;
@@ -918,7 +941,7 @@ int wgrad_gemm(const void* dz, int64_t lddz, const void* x, int64_t ldx, float* 
   const size_t need = to_ws ? (size_t)split * (size_t)N * (size_t)K * sizeof(float) : 0;
   if (need > 0 && (!workspace || workspace_bytes < need)) return IB_E_WORKSPACE;
   // C[N,K] = sum_m dz[m][n] * x[m][k]: A(i=n, kk=m) = dz[m*lddz + n], B(j=k, kk=m) = x[m*ldx + k]
-  GemmParams p{};
+  p = GemmParams{};
   p.A = dz; p.lda = lddz; p.B = x; p.ldb = ldx; p.M = (int)N; p.N = (int)K; p.K = (int)M;
   p.seg = 1; p.act = IB_ACT_NONE; p.accumulate = accumulate;
   p.ablate = g_ablate; p.prof = g_gemm_prof;
@@ -927,7 +950,6 @@ int wgrad_gemm(const void* dz, int64_t lddz, const void* x, int64_t ldx, float* 
   // all tiles of one M-chunk on one XCD only while that chunk's dz + x slices fit comfortably in the XCD's 4 MiB
   // L2 (measured: [12800,512,300] 42 -> 36 us grouped, but [12800,1536,512] 48 -> 63 us: 5.2 MB per chunk thrashes)
   p.xcd_group = ((int64_t)chunk * (N + K) * (dtype == IB_BF16 ? 2 : 4) <= (2 << 20)) ? 1 : 0;
-  const int tiles = p.tiles_m * p.tiles_n;
   if (to_ws) {
     p.C = workspace; p.ldc = K; p.slab_stride = (int64_t)N * K; p.accumulate = 0;
   } else {
@@ -936,10 +958,27 @@ int wgrad_gemm(const void* dz, int64_t lddz, const void* x, int64_t ldx, float* 
   p.vecC = aligned(p.C, 16) && (p.ldc % 4 == 0) && (p.slab_stride % 4 == 0);
   if (dtype == IB_F32) {
     p.vecA = vec_load_ok<float>(p.A, p.lda); p.vecB = vec_load_ok<float>(p.B, p.ldb);
-    hipLaunchKernelGGL((gemm_kernel<float, false, false, EPI_WGRAD>), dim3(tiles * split), dim3(NTHREADS), 0, s, p);
   } else {
     p.vecA = vec_load_ok<bf16_t>(p.A, p.lda); p.vecB = vec_load_ok<bf16_t>(p.B, p.ldb);
     p.gldsA = glds_ok<bf16_t>(p.A, p.lda); p.gldsB = glds_ok<bf16_t>(p.B, p.ldb);
+  }
+  *split_out = split; *tiles_out = p.tiles_m * p.tiles_n; *chunk_out = chunk;
+  return IB_OK;
+}
+
+// the split-M weight-gradient GEMM.  slabs_only: always write fp32 partial slabs [split][N][K] into the workspace
+// (even for split == 1) and leave the reduction to ib_slab_reduce_multi (one launch for several gradients).
+int wgrad_gemm(const void* dz, int64_t lddz, const void* x, int64_t ldx, float* dw, int64_t lddw, int accumulate,
+               void* workspace, size_t workspace_bytes, int64_t M, int64_t N, int64_t K, int dtype, hipStream_t s,
+               bool slabs_only, int* split_out) {
+  GemmParams p;
+  int split, tiles, chunk;
+  const int rc = wgrad_params(dz, lddz, x, ldx, dw, lddw, accumulate, workspace, workspace_bytes, M, N, K, dtype,
+                              slabs_only, p, &split, &tiles, &chunk);
+  if (rc != IB_OK) return rc;
+  if (dtype == IB_F32) {
+    hipLaunchKernelGGL((gemm_kernel<float, false, false, EPI_WGRAD>), dim3(tiles * split), dim3(NTHREADS), 0, s, p);
+  } else {
     if (ring_ok(p, IB_BF16, p.K, chunk))
       hipLaunchKernelGGL((gemm_ring_kernel<false, false, EPI_WGRAD>), dim3(tiles * split), dim3(NTHREADS), 0, s, p);
     else
@@ -979,4 +1018,30 @@ extern "C" int ib_linear_wgrad_slabs(const void* dz, int64_t lddz, const void* x
   if (!nslab_out) return IB_E_ARG;
   return wgrad_gemm(dz, lddz, x, ldx, nullptr, 0, 0, workspace, workspace_bytes, M, N, K, dtype, ib_s(stream), true,
                     nslab_out);
+}
+
+extern "C" int ib_linear_wgrad_slabs_multi(int n, const void* const* dz, const int64_t* lddz, const void* const* x,
+                                           const int64_t* ldx, void* const* workspace, const size_t* workspace_bytes,
+                                           int32_t* nslab_out, const int64_t* M, const int64_t* N, const int64_t* K,
+                                           int dtype, ib_stream_t stream) {
+  if (n <= 0 || n > WG_MAX || !dz || !lddz || !x || !ldx || !workspace || !workspace_bytes || !nslab_out || !M || !N || !K)
+    return IB_E_ARG;
+  if (dtype != IB_BF16) return IB_E_UNSUPPORTED;
+  WgradMulti m{};
+  m.n = n;
+  int blocks = 0;
+  for (int j = 0; j < n; ++j) {
+    int split, tiles, chunk;
+    const int rc = wgrad_params(dz[j], lddz[j], x[j], ldx[j], nullptr, 0, 0, workspace[j], workspace_bytes[j], M[j], N[j],
+                                K[j], dtype, true, m.p[j], &split, &tiles, &chunk);
+    if (rc != IB_OK) return rc;
+    if (!ring_ok(m.p[j], IB_BF16, m.p[j].K, chunk)) return IB_E_UNSUPPORTED;   // caller falls back to single launches
+    nslab_out[j] = split;
+    m.blk0[j] = blocks;
+    blocks += tiles * split;
+  }
+  m.blk0[n] = blocks;
+  hipLaunchKernelGGL(gemm_ring_wgrad_multi_kernel, dim3(blocks), dim3(NTHREADS), 0, ib_s(stream), m);
+  IB_CHECK_LAUNCH();
+  return IB_OK;
 }

@@ -43,6 +43,7 @@ _SIGS = {
     "ib_linear_wgrad": (_c.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _c.c_int, _vp, _sz, _i64, _i64, _i64, _c.c_int, _vp]),
     "ib_linear_wgrad_slabs_workspace": (_sz, [_i64, _i64, _i64]),
     "ib_linear_wgrad_slabs": (_c.c_int, [_vp, _i64, _vp, _i64, _vp, _sz, _vp, _i64, _i64, _i64, _c.c_int, _vp]),
+    "ib_linear_wgrad_slabs_multi": (_c.c_int, [_c.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _c.c_int, _vp]),
     "ib_slab_reduce_multi": (_c.c_int, [_c.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _c.c_int, _vp]),
     "ib_step_reduce": (_c.c_int, [_c.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _c.c_int, _vp, _vp, _vp, _vp, _vp,
                                   _c.c_int, _vp]),
@@ -467,6 +468,43 @@ def linear_wgrad_slabs(dz, x, workspace) -> int:
                                        ctypes.cast(ctypes.pointer(n), ctypes.c_void_p), M, N, K, dtype_code(dt),
                                        stream_ptr()), "ib_linear_wgrad_slabs")
     return n.value if not _dry_run else 1
+
+
+def linear_wgrad_slabs_multi(problems):
+    """problems: [(dz, x, workspace)] -- split-M slabs of every dW = dz^T x in ONE launch.  Returns the slab counts, or
+    None when the shapes do not all qualify for the ring kernel (issue linear_wgrad_slabs one by one then)."""
+    n = len(problems)
+    dt = problems[0][0].dtype
+    geo = []
+    for dz, x, ws in problems:
+        M, N, lddz = _mat(dz, "dz", dt)
+        Mx, K, ldx = _mat(x, "x", dt)
+        if Mx != M:
+            raise HipError("linear_wgrad_slabs_multi: dz / x row counts differ")
+        need = int(lib().ib_linear_wgrad_slabs_workspace(M, N, K))
+        if ws.numel() * ws.element_size() < need:
+            raise HipError("linear_wgrad_slabs_multi: workspace too small")
+        geo.append((M, N, K, lddz, ldx))
+    if _dry_run:
+        lib().ib_linear_wgrad_slabs_multi(n, None, None, None, None, None, None, None, None, None, None, dtype_code(dt), None)
+        return [1] * n
+    cv = lambda a: ctypes.cast(a, ctypes.c_void_p)
+    A = (ctypes.c_void_p * n)(*[p_[0].data_ptr() for p_ in problems])
+    X = (ctypes.c_void_p * n)(*[p_[1].data_ptr() for p_ in problems])
+    W = (ctypes.c_void_p * n)(*[p_[2].data_ptr() for p_ in problems])
+    WB = (ctypes.c_size_t * n)(*[p_[2].numel() * p_[2].element_size() for p_ in problems])
+    LA = (ctypes.c_int64 * n)(*[g_[3] for g_ in geo])
+    LX = (ctypes.c_int64 * n)(*[g_[4] for g_ in geo])
+    Ms = (ctypes.c_int64 * n)(*[g_[0] for g_ in geo])
+    Ns = (ctypes.c_int64 * n)(*[g_[1] for g_ in geo])
+    Ks = (ctypes.c_int64 * n)(*[g_[2] for g_ in geo])
+    out = (ctypes.c_int32 * n)()
+    rc = lib().ib_linear_wgrad_slabs_multi(n, cv(A), cv(LA), cv(X), cv(LX), cv(W), cv(WB), cv(out), cv(Ms), cv(Ns), cv(Ks),
+                                           dtype_code(dt), stream_ptr())
+    if rc == -5:          # IB_E_UNSUPPORTED
+        return None
+    _check(rc, "ib_linear_wgrad_slabs_multi")
+    return list(out)
 
 
 def slab_reduce_multi(items, accumulate=False):

@@ -114,6 +114,23 @@ def _colsum(buf: Buffers, tag: str, x2d: torch.Tensor, out_vec: torch.Tensor, ac
         hip.segment_colsum(part, out_vec.view(1, N), seg=part.shape[0], mode=0, accumulate=accumulate)
 
 
+def _wgrad_group(buf: Buffers, problems, defer: list):
+    """problems: [(dz, x, dw, ws_tag)] -- the slabs of every problem in ONE launch when they all qualify for the ring
+    kernel (one by one otherwise); appends (workspace, nslab, dw) to `defer` for the step's single reduction."""
+    items = []
+    for dz, x, dw, tag in problems:
+        M, N = dz.shape
+        K = x.shape[1]
+        if K % 4 != 0 or dw.stride(0) % 4 != 0:
+            raise hip.HipError("_wgrad_group: gradient rows must be 16-byte aligned")
+        items.append((dz, x, buf.bytes(tag, int(hip.lib().ib_linear_wgrad_slabs_workspace(M, N, K)))))
+    ns = hip.linear_wgrad_slabs_multi(items) if 1 < len(items) <= 6 else None
+    if ns is None:
+        ns = [hip.linear_wgrad_slabs(dz, x, ws) for dz, x, ws in items]
+    for (dz, x, ws), n, pr in zip(items, ns, problems):
+        defer.append((ws, n, pr[2]))
+
+
 def _wgrad(buf: Buffers, dz: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, accumulate: bool, ws_tag: str = "wgrad.ws",
            defer: Optional[list] = None):
     """`ws_tag`: launches that may run concurrently (different branches) must not share a slab workspace.
@@ -555,21 +572,22 @@ class DenoiserMLPPlan:
             de32 = g("dm.de32", (B, Hs), torch.float32)
             for i in range(L):
                 hip.segment_colsum(dz[i], de32[:, i * H:(i + 1) * H], seg=T, mode=0, out_bf16=de_lp[:, i * H:(i + 1) * H])
-        # at most FOUR concurrent streams (a fifth branch of the captured graph was observed to start only after
-        # another finished): main + 3 branches, large GEMMs spread one per stream
-        def wg(i):
-            hin = h[i - 1] if i > 0 else xt
-            _wgrad(self.buf, dz[i], hin, P.g(f"blocks.{i}.linear.weight"), accumulate, ws_tag=f"dm.ws{i}", defer=defer)
-
-        # measured on one box, same process set: main + time-MLP branch + block branch 0.282 ms; a third branch for the
-        # head 0.308; everything inline 0.320 -- forks are expensive, the dependent time-MLP chain still needs its own
+        # Streams: a fifth concurrent branch of the captured graph only started when another finished, and every fork /
+        # join costs tens of microseconds (same box: main + 2 branches 0.282 ms, + a head branch 0.308, none 0.320).
+        # So: ONE branch for the dependent time-MLP chain; every independent weight-gradient GEMM of the step
+        # (head, blocks, time_mlp.2) goes into ONE grouped launch on the main stream.
         self.branch.run(lambda: self.time.backward_hidden(de32, de_lp, P, accumulate, defer=defer, ready=False))
-
-        def blocks_side():           # every block's weight gradient, back to back on one branch
-            for i in range(L - 1, -1, -1):
-                wg(i)
-        self.br_blk[0].run(blocks_side)
-        _wgrad(self.buf, dpred, h[L - 1], P.g("head.weight"), accumulate, ws_tag="dm.wsH", defer=defer)
+        grouped = defer is not None and not accumulate
+        probs = [(dpred, h[L - 1], P.g("head.weight"), "dm.wsH")]
+        for i in range(L - 1, -1, -1):
+            probs.append((dz[i], h[i - 1] if i > 0 else xt, P.g(f"blocks.{i}.linear.weight"), f"dm.ws{i}"))
+        s_, u_, zu_ = self.time.ctx
+        probs.append((de_lp, u_, P.g("time_mlp.2.weight"), self.time.tag + ".ws2"))
+        if grouped and len(probs) <= 6:
+            _wgrad_group(self.buf, probs, defer)
+        else:
+            for dz_, x_, dw_, tag in probs:
+                _wgrad(self.buf, dz_, x_, dw_, accumulate, ws_tag=tag, defer=defer)
         # main stream: every small gradient (LayerNorm gains / biases, linear biases, head bias, time_mlp.2.bias) and
         # the loss in one launch
         tb2 = P.g("time_mlp.2.bias")
@@ -586,7 +604,6 @@ class DenoiserMLPPlan:
                 hip.colsum_segments(part, nwg, segs[-1:], accumulate=False)
             else:
                 hip.colsum_segments(part, nwg, segs, accumulate=False)
-        self.time.backward_out_layer(None, de_lp, P, accumulate, defer=defer, ready=False)
         for b in self.branches():
             b.join()
         if merged:               # every slab set + every small gradient + the loss: one launch

@@ -195,6 +195,29 @@ def test_deferred_wgrad_slabs_match_fused_wgrad(hip):
         assert torch.equal(dw, ref + ref)
 
 
+def test_grouped_wgrad_launch_is_bitwise_equal_to_single_launches(hip):
+    shapes = [(12800, 304, 512), (12800, 512, 512), (12800, 512, 304), (256, 1024, 512)]
+    probs, singles = [], []
+    for j, (M, N, K) in enumerate(shapes):
+        dz = rnd((M, N), 170 + j).to(BF).to(DEV)
+        x = rnd((M, K), 180 + j).to(BF).to(DEV)
+        nb = int(hip.lib().ib_linear_wgrad_slabs_workspace(M, N, K))
+        ws1 = torch.zeros(nb, dtype=torch.uint8, device=DEV)
+        ws2 = torch.zeros(nb, dtype=torch.uint8, device=DEV)
+        singles.append((ws1, hip.linear_wgrad_slabs(dz, x, ws1)))
+        probs.append((dz, x, ws2))
+    ns = hip.linear_wgrad_slabs_multi(probs)
+    torch.cuda.synchronize()
+    assert ns is not None and ns == [n for _, n in singles]
+    for (ws1, n), (_, _, ws2) in zip(singles, probs):
+        assert torch.equal(ws1, ws2)
+    # a ragged reduction length does not qualify for the ring kernel: the caller is told to fall back
+    dz = rnd((100, 64), 1).to(BF).to(DEV)
+    x = rnd((100, 32), 2).to(BF).to(DEV)
+    ws = torch.zeros(int(hip.lib().ib_linear_wgrad_slabs_workspace(100, 64, 32)), dtype=torch.uint8, device=DEV)
+    assert hip.linear_wgrad_slabs_multi([(dz, x, ws), (dz, x, ws.clone())]) is None
+
+
 def test_colsum_segments_ragged(hip):
     part = rnd((37, 132), 90).to(torch.float32).to(DEV)
     a, b, c = torch.zeros(70, device=DEV), torch.ones(3, device=DEV), torch.zeros(1, device=DEV)
