@@ -161,6 +161,17 @@ int ib_mse_loss_finalize(const void* workspace, size_t workspace_bytes, float* r
 int ib_optim_step(int opt, float* p, const float* g, float* s1, float* s2, int64_t n, float lr,
                   float grad_scale, int32_t step, int32_t* step_dev, int32_t* ticket, void* shadow_bf16,
                   ib_stream_t stream);
+/* ib_optim_step whose gradient, for up to 28 ranges [start, start+len) of the flat buffer, is still a set of partial sums:
+ * kind 1 = split-M slabs (base = [count][len] fp32, `stride` elements apart), kind 2 = column sums over `count` rows of a
+ * row-major partial array (base = first column, `stride` = row pitch), times scale.  The optimizer sums them itself in the
+ * fixed order of ib_step_reduce; elsewhere it reads g.  Optionally also writes *loss_out = loss_scale * sum of one column.
+ * Single-GPU steps only (an all-reduce needs the reduced gradient in memory).  Host arrays; n % 4 == 0. */
+int ib_optim_step_sources(int opt, float* p, const float* g, float* s1, float* s2, int64_t n, float lr,
+                          float grad_scale, int32_t step, int32_t* step_dev, int32_t* ticket, void* shadow_bf16,
+                          int nsrc, const int64_t* start, const int64_t* len, const int32_t* kind,
+                          const void* const* base, const int64_t* stride, const int32_t* count, const float* scale,
+                          const float* loss_col, int64_t loss_ld, int64_t loss_rows, float loss_scale, float* loss_out,
+                          ib_stream_t stream);
 /* ticket (optional, zero-initialised int32 device word): self-counting mode -- *step_dev then holds the number of
  * COMPLETED steps, the kernel uses *step_dev + 1 and its last-exiting block publishes it (no separate counter launch). */
 

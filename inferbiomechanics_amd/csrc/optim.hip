@@ -12,6 +12,25 @@ struct OptArgs {
   int64_t n; float lr; float gscale; int step; int32_t* step_dev; int32_t* ticket; int opt;
 };
 
+// Gradient SOURCES (ib_optim_step_sources): ranges of the flat buffer whose gradient is still a set of partial sums when
+// the optimizer runs -- the split-M slabs of a weight-gradient GEMM, or per-workgroup partial rows (column sums).  The
+// optimizer sums them itself, in the same fixed order as ib_step_reduce, so the reduction launch, its kernel boundary
+// and the round trip of the reduced gradient through HBM disappear (single-GPU steps only: an all-reduce needs the
+// reduced gradient in memory).
+constexpr int OPT_MAXSRC = 28;
+struct GradSrc {
+  int64_t start, len;          // flat element range (start % 4 == 0)
+  const float* base;           // slabs: [nslab][len] ; column sums: part + col0
+  int64_t stride;              // slabs: elements between slabs ; column sums: row pitch of part
+  int count;                   // slabs: nslab ; column sums: rows
+  int kind;                    // 1 = slabs, 2 = column sums
+  float scale;
+};
+struct OptSources {
+  GradSrc s[OPT_MAXSRC]; int n;
+  const float* loss_col; int64_t loss_ld; int loss_rows; float loss_scale; float* loss_out;   // optional scalar
+};
+
 __device__ __forceinline__ float opt_update(const OptArgs& a, float p, float g, float& s1, float& s2, float bc1,
                                             float bc2s) {
   switch (a.opt) {
@@ -45,7 +64,62 @@ __device__ __forceinline__ float opt_update(const OptArgs& a, float p, float g, 
   }
 }
 
-__global__ __launch_bounds__(256) void optim_kernel(OptArgs a) {
+// slab-backed ranges are summed by whichever thread owns the element; column-sum ranges are left to the dedicated
+// cooperative blocks below (a single thread summing 256 strided rows was a 100-us tail)
+__device__ __forceinline__ bool source_grad4(const OptSources& S, const float* g, int64_t idx, float4& t) {
+  for (int j = 0; j < S.n; ++j) {
+    const GradSrc& r = S.s[j];
+    if (idx >= r.start && idx < r.start + r.len) {
+      if (r.kind != 1) return false;
+      const int64_t o = idx - r.start;
+      t = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4* q = reinterpret_cast<const float4*>(r.base + o);
+      const int64_t st4 = r.stride >> 2;
+      int k = 0;
+      for (; k + 4 <= r.count; k += 4) {      // same order as slab_reduce_multi: 4 slabs in flight, added in sequence
+        const float4 a = q[(int64_t)k * st4], b = q[(int64_t)(k + 1) * st4], c = q[(int64_t)(k + 2) * st4],
+                     d = q[(int64_t)(k + 3) * st4];
+        t.x += a.x; t.y += a.y; t.z += a.z; t.w += a.w;
+        t.x += b.x; t.y += b.y; t.z += b.z; t.w += b.w;
+        t.x += c.x; t.y += c.y; t.z += c.z; t.w += c.w;
+        t.x += d.x; t.y += d.y; t.z += d.z; t.w += d.w;
+      }
+      for (; k < r.count; ++k) { const float4 a = q[(int64_t)k * st4]; t.x += a.x; t.y += a.y; t.z += a.z; t.w += a.w; }
+      return true;
+    }
+  }
+  t = *reinterpret_cast<const float4*>(g + idx);
+  return true;
+}
+
+__device__ __forceinline__ void apply4(const OptArgs& a, int64_t i, float4 g, float bc1, float bc2s, int nvalid) {
+  // nvalid < 4 only at the ragged end of a column-sum range (the remaining lanes belong to alignment padding)
+  const bool has1 = a.s1 != nullptr, has2 = a.s2 != nullptr;
+  float4 p = reinterpret_cast<float4*>(a.p)[i];
+  float4 s1 = has1 ? reinterpret_cast<float4*>(a.s1)[i] : make_float4(0, 0, 0, 0);
+  float4 s2 = has2 ? reinterpret_cast<float4*>(a.s2)[i] : make_float4(0, 0, 0, 0);
+  const float4 p0 = p, s10 = s1, s20 = s2;
+  p.x = opt_update(a, p.x, g.x * a.gscale, s1.x, s2.x, bc1, bc2s);
+  p.y = opt_update(a, p.y, g.y * a.gscale, s1.y, s2.y, bc1, bc2s);
+  p.z = opt_update(a, p.z, g.z * a.gscale, s1.z, s2.z, bc1, bc2s);
+  p.w = opt_update(a, p.w, g.w * a.gscale, s1.w, s2.w, bc1, bc2s);
+  if (nvalid < 4) { p.w = p0.w; s1.w = s10.w; s2.w = s20.w; }
+  if (nvalid < 3) { p.z = p0.z; s1.z = s10.z; s2.z = s20.z; }
+  if (nvalid < 2) { p.y = p0.y; s1.y = s10.y; s2.y = s20.y; }
+  reinterpret_cast<float4*>(a.p)[i] = p;
+  if (has1) reinterpret_cast<float4*>(a.s1)[i] = s1;
+  if (has2) reinterpret_cast<float4*>(a.s2)[i] = s2;
+  if (a.shadow) {
+    bf16x4_t o;
+    o[0] = (bf16_t)p.x; o[1] = (bf16_t)p.y; o[2] = (bf16_t)p.z; o[3] = (bf16_t)p.w;
+    reinterpret_cast<bf16x4_t*>(a.shadow)[i] = o;
+  }
+}
+
+// SRC: blocks [0, main_blocks) walk the flat buffer (skipping column-sum ranges); block main_blocks + b owns 64 columns of
+// a column-sum range: 16 float4 columns x 16 row groups, LDS combine in the order of colsum_segments_kernel, update.
+template <bool SRC>
+__global__ __launch_bounds__(256) void optim_kernel(OptArgs a, OptSources S, int main_blocks) {
   // self-counting mode (ticket != NULL): *step_dev holds the number of COMPLETED steps; every block reads it on
   // entry, and the block that draws the last exit ticket publishes step and resets the ticket -- it exits after
   // every other block has entered (and therefore read the old value), so no block can see the new count.
@@ -55,9 +129,56 @@ __global__ __launch_bounds__(256) void optim_kernel(OptArgs a) {
   const float bc2s = (float)sqrt(1.0 - pow(0.999, (double)step));
   const int64_t n4 = a.n / 4;
   const bool has1 = a.s1 != nullptr, has2 = a.s2 != nullptr;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+  if (SRC && (int)blockIdx.x >= main_blocks) {
+    __shared__ float4 red[16][16];
+    int rb = (int)blockIdx.x - main_blocks, j = 0;
+    for (; j < S.n; ++j) {                      // which column-sum range, which 64-column chunk of it
+      if (S.s[j].kind != 2) continue;
+      const int nb = (int)((S.s[j].len + 63) / 64);
+      if (rb < nb) break;
+      rb -= nb;
+    }
+    if (j < S.n) {
+      const GradSrc& r = S.s[j];
+      const int c4 = threadIdx.x & 15, rg = threadIdx.x >> 4;
+      const int64_t o = (int64_t)rb * 64 + 4 * c4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (o < r.len) {
+        const float* q = r.base + o;
+        if (o + 4 <= r.len) {
+          for (int row = rg; row < r.count; row += 16) {
+            const float4 w = *reinterpret_cast<const float4*>(q + (int64_t)row * r.stride);
+            v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+          }
+        } else {
+          for (int row = rg; row < r.count; row += 16) {
+            const float* w = q + (int64_t)row * r.stride;
+            v.x += w[0];
+            if (o + 1 < r.len) v.y += w[1];
+            if (o + 2 < r.len) v.z += w[2];
+          }
+        }
+      }
+      red[rg][c4] = v;
+      __syncthreads();
+      if (rg == 0 && o < r.len) {
+        float4 t = red[0][c4];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) { const float4 w = red[k][c4]; t.x += w.x; t.y += w.y; t.z += w.z; t.w += w.w; }
+        t.x *= r.scale; t.y *= r.scale; t.z *= r.scale; t.w *= r.scale;
+        apply4(a, (r.start + o) >> 2, t, bc1, bc2s, (int)min((int64_t)4, r.len - o));
+      }
+    }
+  } else {
+  const int64_t gstride = (int64_t)(SRC ? main_blocks : (int)gridDim.x) * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gstride) {
     float4 p = reinterpret_cast<float4*>(a.p)[i];
-    float4 g = reinterpret_cast<const float4*>(a.g)[i];
+    float4 g;
+    if constexpr (SRC) {
+      if (!source_grad4(S, a.g, i * 4, g)) continue;
+    } else {
+      g = reinterpret_cast<const float4*>(a.g)[i];
+    }
     float4 s1 = has1 ? reinterpret_cast<float4*>(a.s1)[i] : make_float4(0, 0, 0, 0);
     float4 s2 = has2 ? reinterpret_cast<float4*>(a.s2)[i] : make_float4(0, 0, 0, 0);
     p.x = opt_update(a, p.x, g.x * a.gscale, s1.x, s2.x, bc1, bc2s);
@@ -75,13 +196,31 @@ __global__ __launch_bounds__(256) void optim_kernel(OptArgs a) {
   }
   // tail (n % 4)
   const int64_t t0 = n4 * 4;
-  for (int64_t i = t0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * blockDim.x) {
+  for (int64_t i = t0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += gstride) {
     float s1 = has1 ? a.s1[i] : 0.f, s2 = has2 ? a.s2[i] : 0.f;
     const float p = opt_update(a, a.p[i], a.g[i] * a.gscale, s1, s2, bc1, bc2s);
     a.p[i] = p;
     if (has1) a.s1[i] = s1;
     if (has2) a.s2[i] = s2;
     if (a.shadow) a.shadow[i] = (bf16_t)p;
+  }
+  }   // main blocks
+  if constexpr (SRC) {
+    if (S.loss_out && blockIdx.x == 0) {       // the step's loss scalar: one column of the partial rows, fixed order
+      __shared__ float lred[16];
+      float v = 0.f;
+      const int rg = threadIdx.x >> 4;
+      if ((threadIdx.x & 15) == 0)
+        for (int r = rg; r < S.loss_rows; r += 16) v += S.loss_col[(int64_t)r * S.loss_ld];
+      if ((threadIdx.x & 15) == 0) lred[rg] = v;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        float t = lred[0];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) t += lred[k];
+        *S.loss_out = t * S.loss_scale;
+      }
+    }
   }
   if (a.ticket) {
     __syncthreads();
@@ -110,7 +249,50 @@ extern "C" int ib_optim_step(int opt, float* p, const float* g, float* s1, float
     return IB_E_ARG;
   OptArgs a{p, g, need1 ? s1 : nullptr, need2 ? s2 : nullptr, reinterpret_cast<bf16_t*>(shadow_bf16),
             n, lr, grad_scale, step, step_dev, ticket, opt};
-  hipLaunchKernelGGL(optim_kernel, dim3(ib_grid_1d(n / 4 + 1, 256)), dim3(256), 0, ib_s(stream), a);
+  hipLaunchKernelGGL(optim_kernel<false>, dim3(ib_grid_1d(n / 4 + 1, 256)), dim3(256), 0, ib_s(stream), a, OptSources{}, 0);
+  IB_CHECK_LAUNCH();
+  return IB_OK;
+}
+
+extern "C" int ib_optim_step_sources(int opt, float* p, const float* g, float* s1, float* s2, int64_t n, float lr,
+                                     float grad_scale, int32_t step, int32_t* step_dev, int32_t* ticket,
+                                     void* shadow_bf16, int nsrc, const int64_t* start, const int64_t* len,
+                                     const int32_t* kind, const void* const* base, const int64_t* stride,
+                                     const int32_t* count, const float* scale, const float* loss_col, int64_t loss_ld,
+                                     int64_t loss_rows, float loss_scale, float* loss_out, ib_stream_t stream) {
+  if (!p || !g || n <= 0 || opt < IB_OPT_SGD || opt > IB_OPT_ADAMAX) return IB_E_ARG;
+  if (ticket && !step_dev) return IB_E_ARG;
+  if (nsrc < 0 || nsrc > OPT_MAXSRC || (nsrc > 0 && (!start || !len || !kind || !base || !stride || !count))) return IB_E_ARG;
+  if (n % 4 != 0) return IB_E_UNSUPPORTED;
+  const bool need1 = opt != IB_OPT_SGD;
+  const bool need2 = (opt == IB_OPT_ADAM || opt == IB_OPT_ADADELTA || opt == IB_OPT_ADAMAX);
+  if ((need1 && !s1) || (need2 && !s2)) return IB_E_ARG;
+  auto al16 = [](const void* q) { return !q || (reinterpret_cast<uintptr_t>(q) % 16) == 0; };
+  if (!al16(p) || !al16(g) || !al16(s1) || !al16(s2) || (shadow_bf16 && reinterpret_cast<uintptr_t>(shadow_bf16) % 8))
+    return IB_E_ARG;
+  OptSources S{};
+  S.n = nsrc;
+  for (int j = 0; j < nsrc; ++j) {
+    if (start[j] < 0 || len[j] <= 0 || start[j] % 4 != 0 || start[j] + len[j] > n || !base[j] || count[j] <= 0) return IB_E_ARG;
+    if (kind[j] == 1) {
+      if (len[j] % 4 != 0 || stride[j] % 4 != 0 || !al16(base[j])) return IB_E_ARG;
+    } else if (kind[j] == 2) {
+      if (stride[j] % 4 != 0 || !al16(base[j])) return IB_E_ARG;
+    } else return IB_E_ARG;
+    S.s[j] = GradSrc{start[j], len[j], reinterpret_cast<const float*>(base[j]), stride[j], count[j], kind[j],
+                     scale ? scale[j] : 1.f};
+  }
+  if (loss_out) {
+    if (!loss_col || loss_rows <= 0) return IB_E_ARG;
+    S.loss_col = loss_col; S.loss_ld = loss_ld; S.loss_rows = (int)loss_rows; S.loss_scale = loss_scale; S.loss_out = loss_out;
+  }
+  OptArgs a{p, g, need1 ? s1 : nullptr, need2 ? s2 : nullptr, reinterpret_cast<bf16_t*>(shadow_bf16),
+            n, lr, grad_scale, step, step_dev, ticket, opt};
+  const int main_blocks = ib_grid_1d(n / 4 + 1, 256);
+  int cs_blocks = 0;
+  for (int j = 0; j < nsrc; ++j)
+    if (kind[j] == 2) cs_blocks += (int)((len[j] + 63) / 64);
+  hipLaunchKernelGGL(optim_kernel<true>, dim3(main_blocks + cs_blocks), dim3(256), 0, ib_s(stream), a, S, main_blocks);
   IB_CHECK_LAUNCH();
   return IB_OK;
 }

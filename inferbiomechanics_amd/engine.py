@@ -278,6 +278,7 @@ class HipTrainer:
             B, T, D = x0.shape
             M = B * T
             if hasattr(plan, "chain_ok") and plan.chain_ok(D):
+                plan.fuse_reduce_into_optimizer = not self.ddp and not os.environ.get("IB_NO_OPT_FUSE")
                 # MLP denoiser, bf16: q_sample + forward + loss + the dgrad chain are ONE launch (csrc/chain.hip)
                 plan.chain_step(x0, eps, t, tabs, P, self.result)
                 return self._finish_step(cut)
@@ -322,9 +323,12 @@ class HipTrainer:
                     self.buckets.launch(0)           # one bucket = the whole flat gradient, after all joins
                 self.buckets.finish()
         # self-counting optimizer launch: uses *step_dev + 1 and publishes it itself (no separate counter launch)
+        src = getattr(self.plan, "pending_sources", None)
+        if src is not None:
+            self.plan.pending_sources = None
         hip.optim_step(self.opt_type, self.flat, self.grad, self.s1, self.s2, self.lr, step=0, step_dev=self.step_dev,
                        ticket=self.ticket, grad_scale=1.0 / self.world,
-                       shadow=m._shadow if dt == torch.bfloat16 else None)
+                       shadow=m._shadow if dt == torch.bfloat16 else None, sources=src)
 
     def _stage(self, batch) -> Dict[str, torch.Tensor]:
         """copy the batch into the static input buffers the (captured) launch sequence reads"""

@@ -67,6 +67,8 @@ _SIGS = {
     "ib_mse_loss_partial": (_c.c_int, [_vp, _i64, _vp, _vp, _i64, _vp, _sz, _i64, _i64, _c.c_int, _vp]),
     "ib_mse_loss_finalize": (_c.c_int, [_vp, _sz, _vp, _i64, _vp]),
     "ib_optim_step": (_c.c_int, [_c.c_int, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _i32, _vp, _vp, _vp, _vp]),
+    "ib_optim_step_sources": (_c.c_int, [_c.c_int, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _i32, _vp, _vp, _vp, _c.c_int, _vp,
+                                         _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _f32, _vp, _vp]),
     "ib_gather_rows": (_c.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _c.c_int, _vp]),
     "ib_mlp_chain_supported": (_c.c_int, [_i64, _i64, _c.c_int]),
     "ib_mlp_chain_packed_elems": (_sz, [_i64, _i64, _c.c_int]),
@@ -856,7 +858,11 @@ def mse_loss_finalize(workspace, result, n):
 # --------------------------------------------------------------------------------------------
 # optimizer
 # --------------------------------------------------------------------------------------------
-def optim_step(opt: str, p, g, s1, s2, lr, step=1, step_dev=None, grad_scale=1.0, shadow=None, ticket=None):
+def optim_step(opt: str, p, g, s1, s2, lr, step=1, step_dev=None, grad_scale=1.0, shadow=None, ticket=None,
+               sources=None):
+    """sources = (items, part, rows, segs): the gradient of some ranges of g is still partial sums -- items =
+    [(slab workspace, nslab, dw view into g)], segs = [(col0, ncols, dst view into g | the loss scalar, dst2, scale)] over
+    part[:rows].  The optimizer sums them itself (ib_optim_step_sources) instead of a separate ib_step_reduce launch."""
     _req(p, "p", torch.float32, 1)
     _req(g, "g", torch.float32, 1)
     n = p.numel()
@@ -875,6 +881,40 @@ def optim_step(opt: str, p, g, s1, s2, lr, step=1, step_dev=None, grad_scale=1.0
         _req(step_dev, "step_dev", torch.int32)
     if ticket is not None:
         _req(ticket, "ticket", torch.int32)
+    if sources is not None:
+        items, part, rows, segs = sources
+        pr, pc, ld = _mat(part, "part", torch.float32)
+        g0, g1 = g.data_ptr(), g.data_ptr() + 4 * n
+        ent, loss = [], None                      # (start, len, kind, base, stride, count, scale)
+
+        def flat_off(t, what):
+            a = t.data_ptr()
+            if not (g0 <= a < g1) or (a - g0) % 16 or not t.is_contiguous():
+                raise HipError(f"optim_step sources: {what} must be a contiguous, 16-byte aligned view into g")
+            return (a - g0) // 4
+        for ws, ns, dw in items:
+            ent.append((flat_off(dw, "dw"), dw.numel(), 1, ws.data_ptr(), dw.numel(), int(ns), 1.0))
+        for c0, nc, d, d2, sc in segs:
+            if not (g0 <= d.data_ptr() < g1):     # the loss scalar lives outside the flat buffer
+                if nc != 1 or loss is not None:
+                    raise HipError("optim_step sources: at most one scalar destination outside g")
+                loss = (part.data_ptr() + 4 * c0, float(sc), d)
+                continue
+            for dd in (d, d2):
+                if dd is not None:
+                    ent.append((flat_off(dd, "dst"), nc, 2, part.data_ptr() + 4 * c0, ld, int(rows), float(sc)))
+        m = len(ent)
+        cv = lambda a: ctypes.cast(a, ctypes.c_void_p)
+        A = lambda ct, k: (ct * m)(*[e[k] for e in ent])
+        start, ln, kind = A(ctypes.c_int64, 0), A(ctypes.c_int64, 1), A(ctypes.c_int32, 2)
+        base, stride, count, scale = A(ctypes.c_void_p, 3), A(ctypes.c_int64, 4), A(ctypes.c_int32, 5), A(ctypes.c_float, 6)
+        _check(lib().ib_optim_step_sources(OPT[opt], _ptr(p), _ptr(g), _ptr(s1), _ptr(s2), n, float(lr), float(grad_scale),
+                                           int(step), _ptr(step_dev), _ptr(ticket), _ptr(shadow), m, cv(start), cv(ln),
+                                           cv(kind), cv(base), cv(stride), cv(count), cv(scale),
+                                           ctypes.c_void_p(loss[0]) if loss else None, ld, int(rows),
+                                           loss[1] if loss else 0.0, _ptr(loss[2]) if loss else None, stream_ptr()),
+               "ib_optim_step_sources")
+        return
     _check(lib().ib_optim_step(OPT[opt], _ptr(p), _ptr(g), _ptr(s1), _ptr(s2), n, float(lr), float(grad_scale),
                                int(step), _ptr(step_dev), _ptr(ticket), _ptr(shadow), stream_ptr()), "ib_optim_step")
 

@@ -414,6 +414,8 @@ class DenoiserMLPPlan:
         self.br_tout = Branch(device, name="time_out")  # time-MLP backward: output-layer gradients
         self.br_tfwd = Branch(device, name="time_fwd")  # time-MLP forward (beside q_sample + the first block's GEMM)
         self.br_pack = Branch(device, name="pack")      # chain path: weight packing beside the time-MLP forward
+        self.fuse_reduce_into_optimizer = False         # set by HipTrainer for single-GPU steps
+        self.pending_sources = None
 
     def branches(self) -> List[Branch]:
         return [self.br_head, self.branch, self.br_tout, self.br_tfwd, self.br_pack] + self.br_blk
@@ -606,7 +608,11 @@ class DenoiserMLPPlan:
                 hip.colsum_segments(part, nwg, segs, accumulate=False)
         for b in self.branches():
             b.join()
-        if merged:               # every slab set + every small gradient + the loss: one launch
+        self.pending_sources = None
+        if merged and self.fuse_reduce_into_optimizer:
+            # single GPU: the optimizer sums the slabs / partial rows itself (ib_optim_step_sources)
+            self.pending_sources = (list(defer), part, nwg, segs)
+        elif merged:             # every slab set + every small gradient + the loss: one launch
             hip.step_reduce(defer, part, nwg, segs)
         elif defer:
             hip.slab_reduce_multi(defer, accumulate=accumulate)

@@ -275,3 +275,41 @@ def test_chain_trainer_tracks_per_op_trainer():
     for k in pa:                       # pa / pb: parameter MOVEMENT over the 12 SGD steps
         dlt = (pa[k] - pb[k]).abs().max().item()
         assert dlt <= 0.1 * max(pb[k].abs().max().item(), 1e-6), (k, dlt, pb[k].abs().max().item())
+
+
+def test_optimizer_sources_bitwise_equal_to_step_reduce():
+    """single-GPU steps let the optimizer sum the weight-gradient slabs and the partial rows itself
+    (ib_optim_step_sources); the result must be BITWISE the parameters of the separate ib_step_reduce + ib_optim_step"""
+    import os
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from inferbiomechanics_amd.engine import HipTrainer
+    from inferbiomechanics_amd.models.DiffusionDenoisers import DiffusionMLP
+
+    def run(fused):
+        if fused:
+            os.environ.pop("IB_NO_OPT_FUSE", None)
+        else:
+            os.environ["IB_NO_OPT_FUSE"] = "1"
+        try:
+            m = DiffusionMLP(300, [512, 512], compute_dtype=BF).to(DEV)
+            sd = R.det_params(R.denoiser_mlp_param_shapes(300, [512, 512]), seed0=7.0)
+            m.load_state_dict({k: v.to(torch.float32) for k, v in sd.items()})
+            tr = HipTrainer(m, "diffusion", "adam", 1e-3, use_graph=True)
+            losses = []
+            for s_ in range(6):
+                g = torch.Generator().manual_seed(300 + s_)
+                x0 = torch.randn(64, 50, 300, generator=g).to(DEV)
+                eps = torch.randn(64, 50, 300, generator=g).to(DEV)
+                t = torch.randint(0, 1000, (64,), generator=g).to(DEV)
+                tr.step((x0, t, eps))
+                losses.append(tr.loss_value())
+            return losses, {k: v.detach().float().cpu() for k, v in m.state_dict().items()}
+        finally:
+            os.environ.pop("IB_NO_OPT_FUSE", None)
+
+    la, pa = run(True)
+    lb, pb = run(False)
+    assert la == lb, (la, lb)
+    for k in pa:
+        assert torch.equal(pa[k], pb[k]), k
