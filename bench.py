@@ -114,6 +114,8 @@ def cpu_baseline(kind, T, D, B, budget_s=15.0):
 KERNEL_OF = {   # C-ABI entry -> device kernel it launches (names as rocprofv3 --kernel-trace reports them)
     "ib_mlp_chain_train": "mlp_chain_kernel<4, 3, 10>", "ib_mlp_chain_prep": "time_mlp_fwd_kernel<4, 4> (+ weight packing blocks)",
     "ib_linear_wgrad_slabs": "gemm_ring_kernel<false, false, EPI_WGRAD>", "ib_slab_reduce_multi": "slab_reduce_multi_kernel",
+    "ib_linear_wgrad_slabs_multi": "gemm_ring_wgrad_multi_kernel", "ib_optim_step_sources": "optim_kernel<true>",
+    "ib_step_reduce": "step_reduce_kernel",
     "ib_colsum_segments": "colsum_segments_kernel",
     "ib_linear_fwd": "gemm_kernel<T, true, true, EPI_FWD>", "ib_linear_dgrad": "gemm_kernel<T, true, false, EPI_DGRAD>",
     "ib_linear_wgrad": "gemm_kernel<T, false, false, EPI_WGRAD> (+ slab_reduce_kernel)",
@@ -191,7 +193,10 @@ def roofline_leg(trainer, batches, dtype_name):
     avg_us = top["us"] / top["launches"]
     out = {"kernel": KERNEL_OF.get(top_e, top_e), "entry": top_e, "launches_per_step": top["launches"],
            "avg_launch_us": round(avg_us, 2), "share_of_step_device_time": round(top["us"] / total, 3),
-           "shapes": [r["dims"][-4:-1] for r in rows if r["entry"] == top_e], "traffic": None}
+           "shapes": [(r["dims"][-5:] if top_e == "ib_mlp_chain_train" else r["dims"][-4:-1]) for r in rows if r["entry"] == top_e],
+           "traffic": None}
+    if top_e == "ib_mlp_chain_train":
+        out["shape_fields"] = ["tokens M = B*T", "T", "D", "H", "blocks L"]
     if top["flops"]:
         ach = top["flops"] / (top["us"] * 1e-6) / 1e12
         out.update({"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_TFLOPS[dtype_name], "unit": "TFLOP/s",

@@ -17,7 +17,9 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ENTRY_OF = [("mlp_chain_kernel", "", "ib_mlp_chain_train"), ("time_mlp_fwd_kernel", "", "ib_mlp_chain_prep"),
+ENTRY_OF = [("mlp_chain_kernel", "", "ib_mlp_chain_train"), ("gemm_ring_wgrad_multi_kernel", "", "ib_linear_wgrad_slabs_multi"),
+            ("optim_kernel<true>", "", "ib_optim_step_sources"), ("optim_kernelILb1", "", "ib_optim_step_sources"),
+            ("step_reduce_kernel", "", "ib_step_reduce"), ("time_mlp_fwd_kernel", "", "ib_mlp_chain_prep"),
             ("gemm_ring_kernel", "Lb0ELb0ELi2", "ib_linear_wgrad_slabs"), ("gemm_ring_kernel", "Lb1ELb1ELi0", "ib_linear_fwd"),
             ("gemm_ring_kernel", "Lb1ELb0ELi1", "ib_linear_dgrad"), ("slab_reduce_multi_kernel", "", "ib_slab_reduce_multi"),
             ("colsum_segments_kernel", "", "ib_colsum_segments"),
