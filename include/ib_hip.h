@@ -220,8 +220,12 @@ int ib_mlp_chain_train(const void* x0, const void* eps, const int64_t* t, const 
                        const void* packed, const float* const* bias, const float* const* gamma,
                        const float* const* beta, void* xt, int64_t ld_xt, void* const* u, void* const* h,
                        void* const* dz, void* dpred, int64_t ld_dpred, float* partial, int64_t ld_part,
-                       void* de_lp, int64_t ld_de, int64_t M, int64_t T, int64_t D, int64_t H, int L, float ln_eps,
-                       ib_stream_t stream);
+                       void* de_lp, int64_t ld_de, const void* const* in_slots, int64_t M, int64_t T, int64_t D,
+                       int64_t H, int L, float ln_eps, ib_stream_t stream);
+/* in_slots (chain_train / chain_prep): optional DEVICE array {x0, eps, t} the kernels dereference at their start instead
+ * of the pointer arguments -- a captured graph then consumes each step's batch where it lies (ib_set_ptrs before the
+ * graph launch) instead of through a staging copy. */
+int ib_set_ptrs(void* slots, int n, const void* const* ptrs, ib_stream_t stream);   /* n <= 4, ptrs = host array */
 /* dst_s[c] (+)= scale_s * sum_r part[r][col0_s + c], c < ncols_s, for nseg <= 24 segments in ONE launch (fixed
  * summation order); dst2 (array or NULL; entries may be NULL) receives a second copy.  Host arrays. */
 int ib_colsum_segments(const float* part, int64_t ld, int64_t rows, int nseg, const int32_t* col0,
@@ -240,7 +244,7 @@ int ib_mlp_chain_prep(const float* table, int64_t table_rows, const int64_t* t, 
                       const float* b1, const void* w2, int64_t ldw2, const float* b2, void* s, void* zu, void* u,
                       void* e, int64_t ld_e, int64_t B, int64_t temb, int64_t hidden, int64_t out,
                       const void* const* w, const int64_t* ldw, void* packed, int64_t D, int64_t H, int L,
-                      ib_stream_t stream);
+                      const void* const* in_slots, ib_stream_t stream);
 /* ib_slab_reduce_multi + ib_colsum_segments in ONE launch (the reductions that finish a training step's gradients) */
 int ib_step_reduce(int n, const void* const* slabs, const int32_t* nslab, float* const* dw, const int64_t* lddw,
                    const int32_t* N, const int32_t* K, const float* part, int64_t ld, int64_t rows, int nseg,

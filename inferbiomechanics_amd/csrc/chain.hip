@@ -26,6 +26,8 @@ long long* g_chain_prof = nullptr;
 
 struct ChainParams {
   const bf16_t* x0; const bf16_t* eps; const int64_t* t;
+  const void* const* slots;        // optional device array {x0, eps, t}: read at kernel start instead of the three above (a
+                                   // captured graph then consumes each step's batch in place, no staging copy)
   const float* sqrt_ab; const float* sqrt_1mab; int table_rows;
   const bf16_t* e; int64_t ld_e;
   int M, T, D, L, P;             // P = tokens per workgroup (<= 64)
@@ -253,6 +255,9 @@ __global__ __launch_bounds__(CH_THREADS) void mlp_chain_kernel(ChainParams p) {
   const int g = lane >> 4, l16 = lane & 15;
   const int r0 = blockIdx.x * p.P;
   const int D = p.D, M = p.M;
+  const bf16_t* in_x0 = p.slots ? reinterpret_cast<const bf16_t*>(p.slots[0]) : p.x0;
+  const bf16_t* in_eps = p.slots ? reinterpret_cast<const bf16_t*>(p.slots[1]) : p.eps;
+  const int64_t* in_t = p.slots ? reinterpret_cast<const int64_t*>(p.slots[2]) : p.t;
   const int nrows = min(p.P, M - r0);                      // valid token rows of this panel
   const float invH = 1.f / (float)H;
   CH_STAMP(0);
@@ -280,14 +285,14 @@ __global__ __launch_bounds__(CH_THREADS) void mlp_chain_kernel(ChainParams p) {
     uint2 rx[KBD], re[KBD];
 #pragma unroll
     for (int j = 0; j < KBD; ++j) {
-      rx[j] = in_piece8(p.x0 + (int64_t)r0 * D, D, nrows, ppr, TIDV + j * CH_THREADS);
-      re[j] = in_piece8(p.eps + (int64_t)r0 * D, D, nrows, ppr, TIDV + j * CH_THREADS);
+      rx[j] = in_piece8(in_x0 + (int64_t)r0 * D, D, nrows, ppr, TIDV + j * CH_THREADS);
+      re[j] = in_piece8(in_eps + (int64_t)r0 * D, D, nrows, ppr, TIDV + j * CH_THREADS);
     }
     float2* coef = redA;
     if (tid < CH_ROWS) {
       float2 c = make_float2(0.f, 0.f);
       if (tid < nrows) {
-        int64_t k = p.t[(r0 + tid) / p.T];
+        int64_t k = in_t[(r0 + tid) / p.T];
         k = k < 0 ? 0 : (k >= p.table_rows ? p.table_rows - 1 : k);
         c = make_float2(p.sqrt_ab[k], p.sqrt_1mab[k]);
       }
@@ -428,7 +433,7 @@ __global__ __launch_bounds__(CH_THREADS) void mlp_chain_kernel(ChainParams p) {
     f32x4_t acc[4][NTD];
     zero_acc<NTD>(acc);
     bf16_t* hlast = p.h[p.L - 1] + (int64_t)r0 * H;
-    const bf16_t* epsg = p.eps + (int64_t)r0 * D;
+    const bf16_t* epsg = in_eps + (int64_t)r0 * D;
     auto side = [&](int kb, auto kbc) {
       constexpr int KB = decltype(kbc)::value;
 #pragma unroll
@@ -800,8 +805,8 @@ extern "C" int ib_mlp_chain_train(const void* x0, const void* eps, const int64_t
                                   const void* packed, const float* const* bias, const float* const* gamma,
                                   const float* const* beta, void* xt, int64_t ld_xt, void* const* u, void* const* h,
                                   void* const* dz, void* dpred, int64_t ld_dpred, float* partial, int64_t ld_part,
-                                  void* de_lp, int64_t ld_de, int64_t M, int64_t T, int64_t D, int64_t H, int L,
-                                  float ln_eps, ib_stream_t stream) {
+                                  void* de_lp, int64_t ld_de, const void* const* in_slots, int64_t M, int64_t T,
+                                  int64_t D, int64_t H, int L, float ln_eps, ib_stream_t stream) {
   ChainShape s;
   if (L < 1 || L > CH_MAXL || !chain_shape(D, H, &s)) return IB_E_UNSUPPORTED;
   if (!x0 || !eps || !t || !sqrt_ab || !sqrt_1mab || !e || !packed || !bias || !gamma || !beta || !xt || !u || !h ||
@@ -815,7 +820,8 @@ extern "C" int ib_mlp_chain_train(const void* x0, const void* eps, const int64_t
   PackLayout lo;
   chain_layout(D, H, L, s, &lo);
   ChainParams p{};
-  p.x0 = (const bf16_t*)x0; p.eps = (const bf16_t*)eps; p.t = t; p.sqrt_ab = sqrt_ab; p.sqrt_1mab = sqrt_1mab;
+  p.x0 = (const bf16_t*)x0; p.eps = (const bf16_t*)eps; p.t = t; p.slots = in_slots;
+  p.sqrt_ab = sqrt_ab; p.sqrt_1mab = sqrt_1mab;
   p.table_rows = (int)table_rows; p.e = (const bf16_t*)e; p.ld_e = ld_e;
   p.M = (int)M; p.T = (int)T; p.D = (int)D; p.L = L;
   int P;
@@ -892,6 +898,7 @@ __device__ __forceinline__ void reg_gemm(const bf16x8_t (&wr)[KB][NT], const uns
 
 struct TimeFwdParams {
   const float* table; int64_t table_rows; const int64_t* t;
+  const void* const* slots;        // optional {.., .., t} device array (see ChainParams)
   const bf16_t* w1; int64_t ldw1; const float* b1;
   const bf16_t* w2; int64_t ldw2; const float* b2;
   bf16_t* s; bf16_t* zu; bf16_t* u; bf16_t* e; int64_t ld_e;
@@ -924,12 +931,13 @@ __global__ __launch_bounds__(CH_THREADS) void time_mlp_fwd_kernel(TimeFwdParams 
   // table loads, then the stores (a per-row load -> load -> store loop serialised NG dependent round trips)
   {
     constexpr int PPR = TE / 4, RPI = CH_THREADS / PPR, NG = CH_ROWS / RPI;
+    const int64_t* tsrc = p.slots ? reinterpret_cast<const int64_t*>(p.slots[2]) : p.t;
     const int c = (tid % PPR) * 4, rb = tid / PPR;
     int64_t kk[NG];
 #pragma unroll
     for (int j = 0; j < NG; ++j) {
       const int row = rb + j * RPI;
-      int64_t k = p.t[r0 + min(row, nrows - 1)];
+      int64_t k = tsrc[r0 + min(row, nrows - 1)];
       kk[j] = k < 0 ? 0 : (k >= p.table_rows ? p.table_rows - 1 : k);
     }
     float4 v[NG];
@@ -1012,7 +1020,7 @@ namespace {
 int time_fwd_launch(const float* table, int64_t table_rows, const int64_t* t, const void* w1, int64_t ldw1,
                     const float* b1, const void* w2, int64_t ldw2, const float* b2, void* s, void* zu, void* u, void* e,
                     int64_t ld_e, int64_t B, int64_t temb, int64_t hidden, int64_t out, const PackParams& pp,
-                    hipStream_t st) {
+                    const void* const* in_slots, hipStream_t st) {
   if (!ib_time_mlp_fwd_supported(temb, hidden, out)) return IB_E_UNSUPPORTED;
   if (!table || !t || !w1 || !b1 || !w2 || !b2 || !s || !zu || !u || !e || B <= 0 || table_rows <= 0) return IB_E_ARG;
   if (ldw1 < temb || ldw2 < hidden || ld_e < out || ldw1 % 8 != 0 || ldw2 % 8 != 0 || ld_e % 4 != 0) return IB_E_ARG;
@@ -1021,7 +1029,7 @@ int time_fwd_launch(const float* table, int64_t table_rows, const int64_t* t, co
       !al(u, 8) || !al(e, 8))
     return IB_E_ARG;
   TimeFwdParams p{};
-  p.table = table; p.table_rows = table_rows; p.t = t;
+  p.table = table; p.table_rows = table_rows; p.t = t; p.slots = in_slots;
   p.w1 = (const bf16_t*)w1; p.ldw1 = ldw1; p.b1 = b1; p.w2 = (const bf16_t*)w2; p.ldw2 = ldw2; p.b2 = b2;
   p.s = (bf16_t*)s; p.zu = (bf16_t*)zu; p.u = (bf16_t*)u; p.e = (bf16_t*)e; p.ld_e = ld_e;
   p.B = (int)B; p.out = (int)out;
@@ -1043,7 +1051,7 @@ extern "C" int ib_time_mlp_fwd(const float* table, int64_t table_rows, const int
                                ib_stream_t stream) {
   PackParams pp{};
   return time_fwd_launch(table, table_rows, t, w1, ldw1, b1, w2, ldw2, b2, s, zu, u, e, ld_e, B, temb, hidden, out, pp,
-                         ib_s(stream));
+                         nullptr, ib_s(stream));
 }
 
 // one launch for everything the chain kernel waits on: the time-embedding MLP forward AND the weight packing
@@ -1051,12 +1059,12 @@ extern "C" int ib_mlp_chain_prep(const float* table, int64_t table_rows, const i
                                  const float* b1, const void* w2, int64_t ldw2, const float* b2, void* s, void* zu,
                                  void* u, void* e, int64_t ld_e, int64_t B, int64_t temb, int64_t hidden, int64_t out,
                                  const void* const* w, const int64_t* ldw, void* packed, int64_t D, int64_t H, int L,
-                                 ib_stream_t stream) {
+                                 const void* const* in_slots, ib_stream_t stream) {
   PackParams pp;
   const int rc = build_pack(w, ldw, packed, D, H, L, pp);
   if (rc != IB_OK) return rc;
   return time_fwd_launch(table, table_rows, t, w1, ldw1, b1, w2, ldw2, b2, s, zu, u, e, ld_e, B, temb, hidden, out, pp,
-                         ib_s(stream));
+                         in_slots, ib_s(stream));
 }
 
 // out = scale * sum(partial[0..parts))   (fixed order; the chain kernel's per-workgroup loss sums)

@@ -76,13 +76,12 @@ __device__ __forceinline__ bool source_grad4(const OptSources& S, const float* g
       const float4* q = reinterpret_cast<const float4*>(r.base + o);
       const int64_t st4 = r.stride >> 2;
       int k = 0;
-      for (; k + 4 <= r.count; k += 4) {      // same order as slab_reduce_multi: 4 slabs in flight, added in sequence
-        const float4 a = q[(int64_t)k * st4], b = q[(int64_t)(k + 1) * st4], c = q[(int64_t)(k + 2) * st4],
-                     d = q[(int64_t)(k + 3) * st4];
-        t.x += a.x; t.y += a.y; t.z += a.z; t.w += a.w;
-        t.x += b.x; t.y += b.y; t.z += b.z; t.w += b.w;
-        t.x += c.x; t.y += c.y; t.z += c.z; t.w += c.w;
-        t.x += d.x; t.y += d.y; t.z += d.z; t.w += d.w;
+      for (; k + 8 <= r.count; k += 8) {      // 8 slabs in flight, added strictly in sequence (= slab_reduce_multi's order)
+        float4 v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = q[(int64_t)(k + e) * st4];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { t.x += v[e].x; t.y += v[e].y; t.z += v[e].z; t.w += v[e].w; }
       }
       for (; k < r.count; ++k) { const float4 a = q[(int64_t)k * st4]; t.x += a.x; t.y += a.y; t.z += a.z; t.w += a.w; }
       return true;

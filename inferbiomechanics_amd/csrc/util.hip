@@ -97,3 +97,21 @@ extern "C" int ib_debug_stamp(void* slot, ib_stream_t stream) {
   IB_CHECK_LAUNCH();
   return IB_OK;
 }
+
+// Input slots: a device array of pointers that captured kernels dereference at their start (ib_mlp_chain_train /
+// ib_mlp_chain_prep `in_slots`).  The pointers travel as KERNEL ARGUMENTS of this one-thread launch, so any number of
+// steps may be queued ahead without a host-side buffer to keep alive.
+namespace {
+struct Ptrs4 { const void* p[4]; };
+__global__ void set_ptrs_kernel(const void** slots, Ptrs4 v, int n) {
+  for (int i = 0; i < n; ++i) slots[i] = v.p[i];
+}
+}  // namespace
+extern "C" int ib_set_ptrs(void* slots, int n, const void* const* ptrs, ib_stream_t stream) {
+  if (!slots || !ptrs || n <= 0 || n > 4) return IB_E_ARG;
+  Ptrs4 v{};
+  for (int i = 0; i < n; ++i) v.p[i] = ptrs[i];
+  hipLaunchKernelGGL(set_ptrs_kernel, dim3(1), dim3(1), 0, ib_s(stream), reinterpret_cast<const void**>(slots), v, n);
+  IB_CHECK_LAUNCH();
+  return IB_OK;
+}

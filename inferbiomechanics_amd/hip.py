@@ -76,15 +76,16 @@ _SIGS = {
     "ib_mlp_chain_pack": (_c.c_int, [_vp, _vp, _vp, _i64, _i64, _c.c_int, _vp]),
     "ib_mlp_chain_partial_width": (_i64, [_i64, _i64, _c.c_int]),
     "ib_mlp_chain_train": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp,
-                                      _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _i64, _c.c_int,
+                                      _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _c.c_int,
                                       _f32, _vp]),
+    "ib_set_ptrs": (_c.c_int, [_vp, _c.c_int, _vp, _vp]),
     "ib_colsum_segments": (_c.c_int, [_vp, _i64, _i64, _c.c_int, _vp, _vp, _vp, _vp, _vp, _c.c_int, _vp]),
     "ib_debug_set_chain_prof": (_c.c_int, [_vp]),
     "ib_debug_set_gemm_prof": (_c.c_int, [_vp]),
     "ib_debug_stamp": (_c.c_int, [_vp, _vp]),
     "ib_time_mlp_fwd_supported": (_c.c_int, [_i64, _i64, _i64]),
     "ib_mlp_chain_prep": (_c.c_int, [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64,
-                                     _i64, _i64, _vp, _vp, _vp, _i64, _i64, _c.c_int, _vp]),
+                                     _i64, _i64, _vp, _vp, _vp, _i64, _i64, _c.c_int, _vp, _vp]),
     "ib_time_mlp_fwd": (_c.c_int, [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64,
                                    _i64, _i64, _vp]),
     "ib_sum_partials": (_c.c_int, [_vp, _i64, _f32, _vp, _vp]),
@@ -965,7 +966,7 @@ def time_mlp_fwd_supported(temb: int, hidden: int, out: int) -> bool:
     return bool(lib().ib_time_mlp_fwd_supported(temb, hidden, out))
 
 
-def time_mlp_fwd(table, t, w1, b1, w2, b2, s, zu, u, e, pack=None):
+def time_mlp_fwd(table, t, w1, b1, w2, b2, s, zu, u, e, pack=None, slots=None):
     """fused time-embedding MLP forward (bf16 weights as stored); fills s, zu, u (backward operands) and e.
     pack=(weights, packed, D, H): the same launch also packs the chain kernel's weights (ib_mlp_chain_prep)"""
     bt = torch.bfloat16
@@ -998,7 +999,7 @@ def time_mlp_fwd(table, t, w1, b1, w2, b2, s, zu, u, e, pack=None):
         ld = (ctypes.c_int64 * len(weights))(*[w.stride(0) for w in weights])
         _check(lib().ib_mlp_chain_prep(_ptr(table), rows, _ptr(t), _ptr(w1), ldw1, _ptr(b1), _ptr(w2), ldw2, _ptr(b2),
                                        _ptr(s), _ptr(zu), _ptr(u), _ptr(e), lde, B, temb, hid, out, wp,
-                                       ctypes.cast(ld, ctypes.c_void_p), _ptr(packed), D, H, L, stream_ptr()),
+                                       ctypes.cast(ld, ctypes.c_void_p), _ptr(packed), D, H, L, _ptr(slots), stream_ptr()),
                "ib_mlp_chain_prep")
         return e
     _check(lib().ib_time_mlp_fwd(_ptr(table), rows, _ptr(t), _ptr(w1), ldw1, _ptr(b1), _ptr(w2), ldw2, _ptr(b2),
@@ -1049,8 +1050,18 @@ def mlp_chain_rows_per_workgroup(M: int) -> int:
     return p.value
 
 
+def set_ptrs(slots, tensors):
+    """slots: int64 device tensor (>= len(tensors)); writes the tensors' addresses into it on the current stream"""
+    _req(slots, "slots", torch.int64, 1)
+    n = len(tensors)
+    if slots.numel() < n or n > 4:
+        raise HipError("set_ptrs: at most 4 pointers, slots too small")
+    arr = (ctypes.c_void_p * n)(*[t.data_ptr() for t in tensors])
+    _check(lib().ib_set_ptrs(_ptr(slots), n, ctypes.cast(arr, ctypes.c_void_p), stream_ptr()), "ib_set_ptrs")
+
+
 def mlp_chain_train(x0, eps, t, sqrt_ab, sqrt_1mab, e, packed, bias, gamma, beta, xt, u, h, dz, dpred, partial,
-                    T: int, de_lp=None, ln_eps: float = 1e-5):
+                    T: int, de_lp=None, ln_eps: float = 1e-5, slots=None):
     """x0 / eps: contiguous bf16 [B,T,D]; e: bf16 [B, L*H]; xt / dpred: bf16 2-D [B*T, D] (row pitch % 4 == 0);
     u / h / dz: L contiguous bf16 [B*T, H]; bias: L+1 fp32 vectors; gamma / beta: L fp32 vectors;
     partial: fp32 [workgroups, >= mlp_chain_partial_width] (column layout: include/ib_hip.h);
@@ -1102,8 +1113,8 @@ def mlp_chain_train(x0, eps, t, sqrt_ab, sqrt_1mab, e, packed, bias, gamma, beta
     k4, pu = _ptr_array(u); k5, ph = _ptr_array(h); k6, pdz = _ptr_array(dz)
     _check(lib().ib_mlp_chain_train(_ptr(x0), _ptr(eps), _ptr(t), _ptr(sqrt_ab), _ptr(sqrt_1mab), sqrt_ab.numel(),
                                     _ptr(e), lde, _ptr(packed), pb, pg, pbe, _ptr(xt), xt.stride(0), pu, ph, pdz,
-                                    _ptr(dpred), dpred.stride(0), _ptr(partial), ldp, _ptr(de_lp), ldd, M, T, D, H, L,
-                                    float(ln_eps), stream_ptr()), "ib_mlp_chain_train")
+                                    _ptr(dpred), dpred.stride(0), _ptr(partial), ldp, _ptr(de_lp), ldd, _ptr(slots), M, T, D, H,
+                                    L, float(ln_eps), stream_ptr()), "ib_mlp_chain_train")
     return nwg
 
 

@@ -331,7 +331,7 @@ class TimeMLPPlan:
         return self.dtype == torch.bfloat16 and not os.environ.get("IB_NO_TIME_FUSE") \
             and hip.time_mlp_fwd_supported(table.shape[1], w1.shape[0], w2.shape[0])
 
-    def forward(self, t: torch.Tensor, table: torch.Tensor, P: ParamSource, pack=None) -> torch.Tensor:
+    def forward(self, t: torch.Tensor, table: torch.Tensor, P: ParamSource, pack=None, slots=None) -> torch.Tensor:
         """pack: (weights, packed, D, H) of the chain kernel -- packed by the same launch when the fused kernel runs
         (the caller checks fused_ok() first)"""
         B = t.shape[0]
@@ -343,7 +343,8 @@ class TimeMLPPlan:
         e = g(tg + ".e", (B, w2.shape[0]), dt)
         if self.fused_ok(table, P):
             # one launch instead of gather + two M = B GEMMs (three latency-bound launches on the critical path)
-            hip.time_mlp_fwd(table, t, w1, P.v("time_mlp.0.bias"), w2, P.v("time_mlp.2.bias"), s, zu, u, e, pack=pack)
+            hip.time_mlp_fwd(table, t, w1, P.v("time_mlp.0.bias"), w2, P.v("time_mlp.2.bias"), s, zu, u, e, pack=pack,
+                             slots=slots if pack is not None else None)
             self.ctx = (s, u, zu)
             return e
         hip.gather_rows(table, t, s)
@@ -415,6 +416,7 @@ class DenoiserMLPPlan:
         self.br_tfwd = Branch(device, name="time_fwd")  # time-MLP forward (beside q_sample + the first block's GEMM)
         self.br_pack = Branch(device, name="pack")      # chain path: weight packing beside the time-MLP forward
         self.fuse_reduce_into_optimizer = False         # set by HipTrainer for single-GPU steps
+        self.slots_used = False                         # the last chain_step read its batch through input slots
         self.pending_sources = None
 
     def branches(self) -> List[Branch]:
@@ -530,7 +532,7 @@ class DenoiserMLPPlan:
         return all(h == H for h in self.hidden) and hip.mlp_chain_supported(D, H, len(self.hidden))
 
     def chain_step(self, x0: torch.Tensor, eps: torch.Tensor, t: torch.Tensor, tabs, P: ParamSource,
-                   result: torch.Tensor, accumulate=False):
+                   result: torch.Tensor, accumulate=False, slots: Optional[torch.Tensor] = None):
         """the whole diffusion training step up to the gradients (HipTrainer's diffusion path for this model):
         [weight pack || time-MLP forward] -> chain kernel -> {weight-gradient GEMMs (slabs only), one multi-segment
         reduction for every small gradient + the loss, time-MLP backward} -> one slab reduction for all GEMMs."""
@@ -542,8 +544,12 @@ class DenoiserMLPPlan:
         # the weight packing rides in the time-MLP forward's launch (every fork / join of the captured graph costs
         # tens of microseconds here: they are independent, but NOT worth a branch)
         weights = [P.w(n) for n in names]
+        self.slots_used = False
         if self.time.fused_ok(tabs.temb, P):
-            e = self.time.forward(t, tabs.temb, P, pack=(weights, packed, D, H))   # [B, L*H]
+            # `slots` (device array {x0, eps, t}): both launches read the batch through it, so a captured graph can
+            # consume every step's batch where it lies (HipTrainer sets the slots before each replay)
+            e = self.time.forward(t, tabs.temb, P, pack=(weights, packed, D, H), slots=slots)   # [B, L*H]
+            self.slots_used = slots is not None
         else:
             hip.mlp_chain_pack(weights, packed, D, H)
             e = self.time.forward(t, tabs.temb, P)
@@ -563,7 +569,7 @@ class DenoiserMLPPlan:
                             [P.v(f"blocks.{i}.linear.bias") for i in range(L)] + [P.v("head.bias")],
                             [P.v(f"blocks.{i}.norm.weight") for i in range(L)],
                             [P.v(f"blocks.{i}.norm.bias") for i in range(L)], xt, u, h, dz, dpred, part, T,
-                            de_lp=de_lp if window_panels else None)
+                            de_lp=de_lp if window_panels else None, slots=slots if self.slots_used else None)
 
         # every gradient operand now sits in HBM.  Issue order = the order the graph's ready nodes get the machine:
         # the time-MLP backward first (a dependent chain of small launches; started late it becomes the step's tail),
