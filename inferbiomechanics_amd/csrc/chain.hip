@@ -150,6 +150,9 @@ __device__ __forceinline__ void row_reduce2(float (&a)[NM], float (&b)[NM], floa
 
 // NTH: n-tiles per wave for the hidden width (H = 128 * NTH);  NTD / KBD: n-tiles per wave and k-blocks for the
 // feature width (D <= 128 * NTD, D <= 32 * KBD).
+#ifndef IB_CHAIN_NHF
+#define IB_CHAIN_NHF 2
+#endif
 constexpr int CH_NWIN = 8;                                 // windows whose time embedding is staged per panel
 template <int NTH, int NTD, int KBD>
 struct ChainCfg {
@@ -240,6 +243,7 @@ template <int NTH, int NTD, int KBD>
 __global__ __launch_bounds__(CH_THREADS) void mlp_chain_kernel(ChainParams p) {
   using C = ChainCfg<NTH, NTD, KBD>;
   constexpr int H = C::H, RS = C::RS, PPR = H / 8, NPH = 2 * NTH;   // NPH: 16-byte pieces per thread of a [64, H] image
+  constexpr int NHF = IB_CHAIN_NHF, MPH = 4 / NHF;                  // backward epilogue: m-tile groups processed one after another
   __shared__ __attribute__((aligned(16))) unsigned char smem[C::LDS];
   unsigned char* buf0 = smem;
   unsigned char* buf1 = smem + C::BUF;
@@ -573,18 +577,20 @@ __global__ __launch_bounds__(CH_THREADS) void mlp_chain_kernel(ChainParams p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) { dg[u][r] = 0.f; db[u][r] = 0.f; }
 #pragma unroll
-    for (int hf = 0; hf < 2; ++hf) {
-      bf16x4_t xh[2][NTH];             // xhat, bf16 (its only later use multiplies it into the bf16 dz)
-      bf16x4_t dsl[2][NTH];            // silu'(u), bf16
-      float sa[2] = {0.f, 0.f}, sb[2] = {0.f, 0.f};
+    for (int hf = 0; hf < NHF; ++hf) {
+      bf16x4_t xh[MPH][NTH];             // xhat, bf16 (its only later use multiplies it into the bf16 dz)
+      bf16x4_t dsl[MPH][NTH];            // silu'(u), bf16
+      float sa[MPH], sb[MPH];
+#pragma unroll
+      for (int m2 = 0; m2 < MPH; ++m2) { sa[m2] = 0.f; sb[m2] = 0.f; }
 #pragma unroll
       for (int u = 0; u < NTH; ++u) {
         const int col = colb + 16 * u;
         const float4 g4 = *reinterpret_cast<const float4*>(p.gamma[i] + col);
         const float gg[4] = {g4.x, g4.y, g4.z, g4.w};
 #pragma unroll
-        for (int m2 = 0; m2 < 2; ++m2) {
-          const int mt = 2 * hf + m2;
+        for (int m2 = 0; m2 < MPH; ++m2) {
+          const int mt = MPH * hf + m2;
           const bf16x4_t ub = *reinterpret_cast<const bf16x4_t*>(nxt + (16 * mt + l16) * RS + col * 2);
           float ds[4], xq[4];
 #pragma unroll
@@ -609,11 +615,11 @@ __global__ __launch_bounds__(CH_THREADS) void mlp_chain_kernel(ChainParams p) {
       }
       __builtin_amdgcn_sched_barrier(0);    // keep the dgamma / dbeta FMAs inside their pass (hipcc deferred them with their operands spilled)
       CH_STAMP(6 + 4 * p.L + 9 * (p.L - 1 - i) + 2 * hf);
-      row_reduce2<2>(sa, sb, hf ? redA : redB, lane, wave, 2 * hf);
+      row_reduce2<MPH>(sa, sb, hf ? redA : redB, lane, wave, MPH * hf);
       CH_STAMP(7 + 4 * p.L + 9 * (p.L - 1 - i) + 2 * hf);
 #pragma unroll
-      for (int m2 = 0; m2 < 2; ++m2) {
-        const int mt = 2 * hf + m2;
+      for (int m2 = 0; m2 < MPH; ++m2) {
+        const int mt = MPH * hf + m2;
         const float ma = sa[m2] * invH, mb = sb[m2] * invH, rsd = rstd[mt];
 #pragma unroll
         for (int u = 0; u < NTH; ++u) {
