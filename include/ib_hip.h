@@ -64,6 +64,15 @@ size_t ib_linear_wgrad_workspace(int64_t M, int64_t N, int64_t K);
 int ib_linear_wgrad(const void* dz, int64_t lddz, const void* x, int64_t ldx, float* dw, int64_t lddw,
                     int accumulate, void* workspace, size_t workspace_bytes,
                     int64_t M, int64_t N, int64_t K, int dtype, ib_stream_t stream);
+/* y = LayerNorm(res + x W^T + bias) * gamma + beta for small token counts (the DDIM sampler): a K-split GEMM into fp32
+ * slabs whose reduction kernel is the LayerNorm (TransformerBaseline.py:29-31 / 34-36: Linear -> add -> norm).  bf16,
+ * N % 64 == 0, N <= 1024 (N in {64,128,256,512,1024}), K % 32 == 0, 16-byte aligned operand rows; IB_E_UNSUPPORTED
+ * otherwise (use ib_linear_fwd + ib_layernorm_fwd).  a_out / mean / rstd: optional (what a backward pass needs). */
+size_t ib_linear_ln_fwd_workspace(int64_t M, int64_t N, int64_t K);
+int ib_linear_ln_fwd(const void* x, int64_t ldx, const void* w, int64_t ldw, const float* bias, const void* res,
+                     int64_t ldres, const float* gamma, const float* beta, void* y, int64_t ldy, void* a_out,
+                     float* mean, float* rstd, void* workspace, size_t workspace_bytes, int64_t M, int64_t N,
+                     int64_t K, float eps, int dtype, ib_stream_t stream);
 /* Deferred form for a step that computes several weight gradients: ib_linear_wgrad_slabs writes only the split-M
  * partial slabs ([*nslab_out][N][K] fp32, workspace of ib_linear_wgrad_slabs_workspace bytes); ONE
  * ib_slab_reduce_multi launch (n <= 8 gradients, K % 4 == 0, host arrays) then sums every slab set into its dw. */

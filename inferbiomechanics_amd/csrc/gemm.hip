@@ -1045,3 +1045,135 @@ extern "C" int ib_linear_wgrad_slabs_multi(int n, const void* const* dz, const i
   IB_CHECK_LAUNCH();
   return IB_OK;
 }
+
+// ---- y = LayerNorm(res + x W^T + b) for small token counts (the DDIM sampler: M = B*T = 3200): the GEMM is split over
+// K into fp32 slabs so that a [3200, 512, 2048] problem fills the chip (25 x 4 tiles x 4 slices instead of 100
+// workgroups walking 64 K steps each), and the slab reduction IS the LayerNorm kernel (bias + residual + statistics +
+// affine), so the separate LayerNorm launch and the bf16 round trip of the GEMM output disappear.
+namespace {
+// N = 4 * LPR * NCH columns; LPR lanes per row, a lane holds NCH float4 (columns (c * LPR + l) * 4 ..).  Wide rows use a
+// whole wave per row (3200 rows = 12 waves per CU; with 16 lanes per row the launch was 3 waves per CU and each lane
+// walked 32 dependent-ish loads: 17 us for 26 MB)
+template <int LPR, int NCH>
+__global__ __launch_bounds__(256) void slab_ln_kernel(const float* __restrict__ slabs, int nslab, int64_t slab_stride,
+                                                      const float* __restrict__ bias, const bf16_t* __restrict__ res,
+                                                      int64_t ldres, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, bf16_t* __restrict__ y, int64_t ldy,
+                                                      bf16_t* __restrict__ a_out, float* __restrict__ mean,
+                                                      float* __restrict__ rstd, int M, float eps) {
+  constexpr int N = 4 * LPR * NCH, RPB = 256 / LPR;
+  const int l = threadIdx.x % LPR;
+  const int row = blockIdx.x * RPB + threadIdx.x / LPR;
+  if (row >= M) return;
+  float4 v[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) v[c] = *reinterpret_cast<const float4*>(slabs + (int64_t)row * N + (c * LPR + l) * 4);
+  for (int k = 1; k < nslab; ++k) {
+    float4 w[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+      w[c] = *reinterpret_cast<const float4*>(slabs + (int64_t)k * slab_stride + (int64_t)row * N + (c * LPR + l) * 4);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) { v[c].x += w[c].x; v[c].y += w[c].y; v[c].z += w[c].z; v[c].w += w[c].w; }
+  }
+  float s1 = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int col = (c * LPR + l) * 4;
+    float4 t = v[c];
+    if (bias) { const float4 b = *reinterpret_cast<const float4*>(bias + col); t.x += b.x; t.y += b.y; t.z += b.z; t.w += b.w; }
+    if (a_out) {      // the GEMM output itself (what the per-op plan stores between the two launches), bf16
+      bf16x4_t o; o[0] = (bf16_t)t.x; o[1] = (bf16_t)t.y; o[2] = (bf16_t)t.z; o[3] = (bf16_t)t.w;
+      *reinterpret_cast<bf16x4_t*>(a_out + (int64_t)row * N + col) = o;
+      t.x = (float)o[0]; t.y = (float)o[1]; t.z = (float)o[2]; t.w = (float)o[3];
+    }
+    if (res) {
+      const bf16x4_t r = *reinterpret_cast<const bf16x4_t*>(res + (int64_t)row * ldres + col);
+      t.x += (float)r[0]; t.y += (float)r[1]; t.z += (float)r[2]; t.w += (float)r[3];
+    }
+    v[c] = t;
+    s1 += (t.x + t.y) + (t.z + t.w);
+  }
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) s1 += __shfl_xor(s1, o, 64);
+  const float mu = s1 * (1.f / N);
+  float s2 = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const float a = v[c].x - mu, b = v[c].y - mu, cc = v[c].z - mu, d = v[c].w - mu;
+    s2 += (a * a + b * b) + (cc * cc + d * d);
+  }
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) s2 += __shfl_xor(s2, o, 64);
+  const float rs = 1.f / sqrtf(s2 * (1.f / N) + eps);
+  if (l == 0) {
+    if (mean) mean[row] = mu;
+    if (rstd) rstd[row] = rs;
+  }
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int col = (c * LPR + l) * 4;
+    const float4 g = *reinterpret_cast<const float4*>(gamma + col), b = *reinterpret_cast<const float4*>(beta + col);
+    bf16x4_t o;
+    o[0] = (bf16_t)((v[c].x - mu) * rs * g.x + b.x); o[1] = (bf16_t)((v[c].y - mu) * rs * g.y + b.y);
+    o[2] = (bf16_t)((v[c].z - mu) * rs * g.z + b.z); o[3] = (bf16_t)((v[c].w - mu) * rs * g.w + b.w);
+    *reinterpret_cast<bf16x4_t*>(y + (int64_t)row * ldy + col) = o;
+  }
+}
+
+int linear_ln_split(int64_t M, int64_t N, int64_t K, int* chunk_out) {
+  const int64_t tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+  int64_t want = (384 + tiles - 1) / tiles;              // ~1.5 workgroups per CU
+  if (want > K / 128) want = K / 128;                      // at least four 32-deep K steps per slice
+  if (want < 1) want = 1;
+  int64_t chunk = ((K + want - 1) / want + 31) / 32 * 32;
+  *chunk_out = (int)chunk;
+  return (int)((K + chunk - 1) / chunk);
+}
+}  // namespace
+
+extern "C" size_t ib_linear_ln_fwd_workspace(int64_t M, int64_t N, int64_t K) {
+  int chunk;
+  return (size_t)linear_ln_split(M, N, K, &chunk) * (size_t)M * (size_t)N * sizeof(float);
+}
+
+extern "C" int ib_linear_ln_fwd(const void* x, int64_t ldx, const void* w, int64_t ldw, const float* bias, const void* res,
+                                int64_t ldres, const float* gamma, const float* beta, void* y, int64_t ldy, void* a_out,
+                                float* mean, float* rstd, void* workspace, size_t workspace_bytes, int64_t M, int64_t N,
+                                int64_t K, float eps, int dtype, ib_stream_t stream) {
+  if (!x || !w || !gamma || !beta || !y || !workspace || M <= 0 || N <= 0 || K <= 0 || ldx < K || ldw < K || ldy < N)
+    return IB_E_ARG;
+  if (res && ldres < N) return IB_E_ARG;
+  if (dtype != IB_BF16 || N % 64 != 0 || N > 1024 || K % 32 != 0) return IB_E_UNSUPPORTED;
+  int chunk;
+  const int split = linear_ln_split(M, N, K, &chunk);
+  if (workspace_bytes < (size_t)split * M * N * sizeof(float)) return IB_E_WORKSPACE;
+  if (!aligned(workspace, 16) || !aligned(gamma, 16) || !aligned(beta, 16) || (bias && !aligned(bias, 16)) ||
+      !aligned(y, 8) || ldy % 4 != 0 || (res && (!aligned(res, 8) || ldres % 4 != 0)) || (a_out && !aligned(a_out, 8)))
+    return IB_E_ARG;
+  GemmParams p{};
+  p.A = x; p.lda = ldx; p.B = w; p.ldb = ldw; p.M = (int)M; p.N = (int)N; p.K = (int)K;
+  p.seg = 1; p.act = IB_ACT_NONE; p.ablate = g_ablate; p.prof = g_gemm_prof;
+  p.vecA = vec_load_ok<bf16_t>(p.A, p.lda); p.vecB = vec_load_ok<bf16_t>(p.B, p.ldb);
+  p.gldsA = glds_ok<bf16_t>(p.A, p.lda); p.gldsB = glds_ok<bf16_t>(p.B, p.ldb);
+  p.tiles_n = (p.N + BN - 1) / BN; p.tiles_m = (p.M + BM - 1) / BM;
+  p.k_chunk = chunk; p.xcd_group = 1;
+  p.C = workspace; p.ldc = N; p.slab_stride = (int64_t)M * N; p.accumulate = 0; p.vecC = 1;
+  if (!ring_ok(p, IB_BF16, p.K, chunk)) return IB_E_UNSUPPORTED;
+  hipStream_t s = ib_s(stream);
+  hipLaunchKernelGGL((gemm_ring_kernel<true, true, EPI_WGRAD>), dim3(p.tiles_m * p.tiles_n * split), dim3(NTHREADS), 0, s, p);
+  IB_CHECK_LAUNCH();
+#define IB_SLAB_LN(LPR, NCH)                                                                                            \
+  hipLaunchKernelGGL((slab_ln_kernel<LPR, NCH>), dim3((unsigned)((M + 256 / LPR - 1) / (256 / LPR))), dim3(256), 0, s,     \
+                     reinterpret_cast<const float*>(workspace), split, (int64_t)M * N, bias,                               \
+                     reinterpret_cast<const bf16_t*>(res), ldres, gamma, beta, reinterpret_cast<bf16_t*>(y), ldy,           \
+                     reinterpret_cast<bf16_t*>(a_out), mean, rstd, (int)M, eps)
+  switch (N) {
+    case 64: IB_SLAB_LN(16, 1); break; case 128: IB_SLAB_LN(16, 2); break; case 256: IB_SLAB_LN(64, 1); break;
+    case 512: IB_SLAB_LN(64, 2); break; case 1024: IB_SLAB_LN(64, 4); break;
+    default: return IB_E_UNSUPPORTED;
+  }
+#undef IB_SLAB_LN
+  IB_CHECK_LAUNCH();
+  return IB_OK;
+}

@@ -62,6 +62,17 @@ class DDIMSampler:
         ctr.zero_()
         hip.fill_i64(t_vec, int(tabs.ddim_t[0]))
         P = m.param_source()
+        plan = m._get_plan(dev)
+        if hasattr(plan, "set_inference"):
+            plan.set_inference(True)             # weights are frozen for the whole loop
+            plan.prepare_inference(P, x.shape[1], x.shape[2])
+        try:
+            return self._loop(x, t_vec, ctr, tabs, P, steps)
+        finally:
+            if hasattr(plan, "set_inference"):
+                plan.set_inference(False)
+
+    def _loop(self, x, t_vec, ctr, tabs, P, steps):
         n = self.S if steps is None else min(steps, self.S)
         done = 0
         if self.use_graph and self._graph is None:

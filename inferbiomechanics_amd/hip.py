@@ -41,6 +41,9 @@ _SIGS = {
                                    _c.c_int, _vp]),
     "ib_linear_wgrad_workspace": (_sz, [_i64, _i64, _i64]),
     "ib_linear_wgrad": (_c.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _c.c_int, _vp, _sz, _i64, _i64, _i64, _c.c_int, _vp]),
+    "ib_linear_ln_fwd_workspace": (_sz, [_i64, _i64, _i64]),
+    "ib_linear_ln_fwd": (_c.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _sz,
+                                    _i64, _i64, _i64, _f32, _c.c_int, _vp]),
     "ib_linear_wgrad_slabs_workspace": (_sz, [_i64, _i64, _i64]),
     "ib_linear_wgrad_slabs": (_c.c_int, [_vp, _i64, _vp, _i64, _vp, _sz, _vp, _i64, _i64, _i64, _c.c_int, _vp]),
     "ib_linear_wgrad_slabs_multi": (_c.c_int, [_c.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _c.c_int, _vp]),
@@ -453,6 +456,39 @@ def linear_wgrad(dz, x, dw, workspace, accumulate=False):
     _check(lib().ib_linear_wgrad(_ptr(dz), lddz, _ptr(x), ldx, _ptr(dw), lddw, int(accumulate), _ptr(workspace), wsb,
                                  M, N, K, dtype_code(dt), stream_ptr()), "ib_linear_wgrad")
     return dw
+
+
+def linear_ln_fwd(x, w, bias, res, gamma, beta, y, workspace, eps=1e-5) -> bool:
+    """y = LayerNorm(res + x w^T + bias) as a K-split GEMM + one fused reduction / LayerNorm launch.  Returns False when
+    the shape does not qualify (the caller then issues linear_fwd + layernorm_fwd)."""
+    dt = x.dtype
+    M, K, ldx = _mat(x, "x", dt)
+    N, Kw, ldw = _mat(w, "w", dt)
+    if Kw != K:
+        raise HipError("linear_ln_fwd: x / w reduction lengths differ")
+    My, Ny, ldy = _mat(y, "y", dt)
+    if (My, Ny) != (M, N):
+        raise HipError("linear_ln_fwd: y must be [M, N]")
+    ldres = 0
+    if res is not None:
+        Mr, Nr, ldres = _mat(res, "res", dt)
+        if (Mr, Nr) != (M, N):
+            raise HipError("linear_ln_fwd: res must be [M, N]")
+    for t, n in ((gamma, "gamma"), (beta, "beta")) + (((bias, "bias"),) if bias is not None else ()):
+        _req(t, n, torch.float32, 1)
+        if t.numel() != N:
+            raise HipError(f"linear_ln_fwd: {n} must be fp32 [N]")
+    need = int(lib().ib_linear_ln_fwd_workspace(M, N, K))
+    wsb = workspace.numel() * workspace.element_size()
+    if wsb < need:
+        raise HipError(f"linear_ln_fwd: workspace of {need} bytes required, got {wsb}")
+    rc = lib().ib_linear_ln_fwd(_ptr(x), ldx, _ptr(w), ldw, _ptr(bias), _ptr(res), ldres, _ptr(gamma), _ptr(beta), _ptr(y),
+                                ldy, None, None, None, _ptr(workspace), wsb, M, N, K, float(eps), dtype_code(dt),
+                                stream_ptr())
+    if rc == -5:
+        return False
+    _check(rc, "ib_linear_ln_fwd")
+    return True
 
 
 def linear_wgrad_slabs(dz, x, workspace) -> int:

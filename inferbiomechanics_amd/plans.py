@@ -220,6 +220,7 @@ class TransformerLayerPlan:
         # they run on this layer's side stream (each with its own slab workspace)
         self.branch = Branch(device, name="layer")
         self.join_on_exit = True     # a parent plan sets this False and joins all layers once at the end
+        self.inference = False       # forward only (DDIM sampler): Linear + residual + LayerNorm fused, nothing saved
 
     def branches(self) -> List["Branch"]:
         return [self.branch]
@@ -235,19 +236,33 @@ class TransformerLayerPlan:
         attn = g(tg + ".attn", (B, T, d), dt)
         lse = g(tg + ".lse", (B, self.h, T), torch.float32)
         hip.attention_fwd(qkv, attn, lse, self.h)
-        a = g(tg + ".a", (M, d), dt)
-        hip.linear_fwd(attn.view(M, d), P.w(p + "multihead_attention.out_proj.weight"),
-                       P.v(p + "multihead_attention.out_proj.bias"), a)
         x1 = g(tg + ".x1", (M, d), dt)
-        m1, r1 = g(tg + ".m1", (M,), torch.float32), g(tg + ".r1", (M,), torch.float32)
-        hip.layernorm_fwd(a, P.v(p + "norm1.weight"), P.v(p + "norm1.bias"), x1, m1, r1, res=x)
-        f1 = g(tg + ".f1", (M, self.ffn), dt)
-        hip.linear_fwd(x1, P.w(p + "feedforward.0.weight"), P.v(p + "feedforward.0.bias"), f1, act="relu")
-        f2 = g(tg + ".f2", (M, d), dt)
-        hip.linear_fwd(f1, P.w(p + "feedforward.2.weight"), P.v(p + "feedforward.2.bias"), f2)
         x2 = out if out is not None else g(tg + ".x2", (B, T, d), dt)
-        m2, r2 = g(tg + ".m2", (M,), torch.float32), g(tg + ".r2", (M,), torch.float32)
-        hip.layernorm_fwd(f2, P.v(p + "norm2.weight"), P.v(p + "norm2.bias"), x2.view(M, d), m2, r2, res=x1)
+        f1 = g(tg + ".f1", (M, self.ffn), dt)
+        fuse = self.inference and dt == torch.bfloat16 and not os.environ.get("IB_NO_LINEAR_LN")
+
+        def lin_ln(inp, wname, bname, nname, res, y, wtag):
+            """Linear -> +res -> LayerNorm as one K-split GEMM + fused reduction (small M); False = not applicable"""
+            w = P.w(p + wname)
+            if w.shape[1] < 1024:      # measured at M = 3200: K = 2048 43.6 -> 30.5 us fused, K = 512 20.4 -> 26.2 (two
+                return False           # short kernels instead of two short kernels: nothing to split)
+            ws = self.buf.bytes(tg + wtag, int(hip.lib().ib_linear_ln_fwd_workspace(M, w.shape[0], w.shape[1])))
+            return hip.linear_ln_fwd(inp, w, P.v(p + bname), res, P.v(p + nname + ".weight"), P.v(p + nname + ".bias"), y, ws)
+
+        a = m1 = r1 = f2 = m2 = r2 = None
+        if not (fuse and lin_ln(attn.view(M, d), "multihead_attention.out_proj.weight",
+                                "multihead_attention.out_proj.bias", "norm1", x, x1, ".lnws1")):
+            a = g(tg + ".a", (M, d), dt)
+            hip.linear_fwd(attn.view(M, d), P.w(p + "multihead_attention.out_proj.weight"),
+                           P.v(p + "multihead_attention.out_proj.bias"), a)
+            m1, r1 = g(tg + ".m1", (M,), torch.float32), g(tg + ".r1", (M,), torch.float32)
+            hip.layernorm_fwd(a, P.v(p + "norm1.weight"), P.v(p + "norm1.bias"), x1, m1, r1, res=x)
+        hip.linear_fwd(x1, P.w(p + "feedforward.0.weight"), P.v(p + "feedforward.0.bias"), f1, act="relu")
+        if not (fuse and lin_ln(f1, "feedforward.2.weight", "feedforward.2.bias", "norm2", x1, x2.view(M, d), ".lnws2")):
+            f2 = g(tg + ".f2", (M, d), dt)
+            hip.linear_fwd(f1, P.w(p + "feedforward.2.weight"), P.v(p + "feedforward.2.bias"), f2)
+            m2, r2 = g(tg + ".m2", (M,), torch.float32), g(tg + ".r2", (M,), torch.float32)
+            hip.layernorm_fwd(f2, P.v(p + "norm2.weight"), P.v(p + "norm2.bias"), x2.view(M, d), m2, r2, res=x1)
         self.ctx = (x, qkv, attn, lse, a, x1, m1, r1, f1, f2, m2, r2, B, T)
         return x2
 
@@ -639,6 +654,25 @@ class DenoiserTransformerPlan:
         for lp in self.layers:
             lp.join_on_exit = False          # joined once, at the end of the whole backward
         self.ctx = None
+        self._posproj_T = None
+
+    def set_inference(self, on: bool):
+        """forward-only mode with frozen weights (the DDIM sampler): fused Linear + residual + LayerNorm in every layer,
+        the frame-embedding projection computed once"""
+        self.inference = bool(on)
+        self._posproj_T = None
+        for lp in self.layers:
+            lp.inference = bool(on)
+
+    def prepare_inference(self, P: ParamSource, T: int, D: int):
+        """once per sampling loop (weights frozen from here on): the frame-embedding half of the input projection"""
+        w_in = P.w("in_proj.weight")
+        pos = P.w("temporal_embedding.embedding.weight")[:T]
+        posproj = self.buf.get("dt.posproj", (T, self.d), self.dtype)
+        hip.linear_fwd(pos, w_in[:, D:], None, posproj)
+        self._posproj_T = T
+
+    inference = False
 
     def branches(self) -> List[Branch]:
         return [lp.branch for lp in self.layers]
@@ -657,7 +691,8 @@ class DenoiserTransformerPlan:
         w_in = P.w("in_proj.weight")                                         # [d, D + Pd]
         pos = P.w("temporal_embedding.embedding.weight")[:T]                 # [T, Pd]
         posproj = g("dt.posproj", (T, self.d), dt)
-        hip.linear_fwd(pos, w_in[:, D:], None, posproj)
+        if not (self.inference and self._posproj_T == T):    # frozen weights (sampling): projected once per sample()
+            hip.linear_fwd(pos, w_in[:, D:], None, posproj)
         h0 = g("dt.h0", (B, T, self.d), dt)
         hip.linear_fwd(x2, w_in[:, :D], P.v("in_proj.bias"), h0.view(M, self.d), add_div=e,
                        add_mod=posproj, seg=T)

@@ -429,3 +429,29 @@ def test_segment_colsum_bf16_side_output_and_deferred_ln_reduce(hip):
     hip.layernorm_bwd(dy, xx, gm, mu, rs, dx2, None, None, ws)
     hip.layernorm_bwd_reduce(ws, dg2, db2, M, N)
     assert torch.equal(dx1, dx2) and torch.equal(dg1, dg2) and torch.equal(db1, db2)
+
+
+@pytest.mark.parametrize("M,N,K", [(3200, 512, 2048), (3200, 512, 512), (100, 128, 256), (37, 64, 64), (640, 1024, 512)])
+def test_linear_ln_fwd_matches_unfused(hip, M, N, K):
+    """K-split GEMM + fused (bias + residual + LayerNorm) reduction == linear_fwd + layernorm_fwd within bf16 rounding
+    (the fused form keeps the GEMM output in fp32 up to the LayerNorm, so it is compared with a float64 restatement)"""
+    bf = torch.bfloat16
+    x = rnd((M, K), 1, 1.0, bf).to(DEV)
+    w = rnd((N, K), 2, K ** -0.5, bf).to(DEV)
+    b = rnd((N,), 3, 0.1).to(DEV)
+    res = rnd((M, N), 4, 1.0, bf).to(DEV)
+    g = (1.0 + rnd((N,), 5, 0.2)).to(torch.float32).to(DEV)
+    be = rnd((N,), 6, 0.1).to(DEV)
+    y = torch.zeros(M, N, dtype=bf, device=DEV)
+    ws = torch.zeros(int(hip.lib().ib_linear_ln_fwd_workspace(M, N, K)), dtype=torch.uint8, device=DEV)
+    assert hip.linear_ln_fwd(x, w, b, res, g, be, y, ws)
+    torch.cuda.synchronize()
+    z = x.double().cpu() @ w.double().cpu().T + b.double().cpu() + res.double().cpu()
+    mu = z.mean(-1, keepdim=True)
+    exp = (z - mu) / torch.sqrt(((z - mu) ** 2).mean(-1, keepdim=True) + 1e-5) * g.double().cpu() + be.double().cpu()
+    close(y, exp, 2e-2, "linear_ln_fwd")
+    # shapes outside the fused kernel's domain are reported, not mis-computed
+    y2 = torch.zeros(M, 96, dtype=bf, device=DEV)
+    ws2 = torch.zeros(int(hip.lib().ib_linear_ln_fwd_workspace(M, 96, K)), dtype=torch.uint8, device=DEV)
+    assert not hip.linear_ln_fwd(x, rnd((96, K), 7, 0.1, bf).to(DEV), None, None, torch.ones(96, device=DEV),
+                                 torch.zeros(96, device=DEV), y2, ws2)

@@ -204,6 +204,38 @@ def test_diffusion_transformer_matches_oracle(dtype, rt):
         close(q.grad, p[k].grad, rt * (1 if dtype == torch.float32 else 2), "grad/" + k, atol=rt * 0.05 * gn)
 
 
+@pytest.mark.parametrize("dtype,rt", [(torch.float32, 2e-3), (torch.bfloat16, 8e-2)])
+def test_ddim_sampler_loop_matches_oracle(dtype, rt):
+    """the whole sampling loop (device step counter, one captured step replayed) against the oracle's ddim_sample over
+    the oracle denoiser; bf16 additionally runs the fused Linear + residual + LayerNorm inference path and must agree
+    with the unfused launches"""
+    import os
+    from inferbiomechanics_amd.diffusion.sampler import DDIMSampler
+    from inferbiomechanics_amd.models.DiffusionDenoisers import DiffusionTransformer
+    B, T, D, S = 3, 24, 44, 10
+    model = DiffusionTransformer(D, T, d_model=128, num_heads=2, dim_feedforward=256, num_layers=2, device=DEV,
+                                 compute_dtype=dtype)
+    load_det(model)
+    xT = R.det_fill((B, T, D), 11, 1.0, torch.float32)
+    got = DDIMSampler(model, S, use_graph=True).sample(xT.to(DEV))
+    p = {k: v.detach() for k, v in _oracle_params(model).items()}
+    with torch.no_grad():
+        exp = R.ddim_sample(lambda x, t: R.denoiser_transformer_forward(p, x, t, 2, 2), xT.double(), 1000, S)
+    close(got, exp, rt, "x_0")
+    if dtype == torch.bfloat16:
+        os.environ["IB_NO_LINEAR_LN"] = "1"
+        try:
+            ref = DDIMSampler(model, S, use_graph=False).sample(xT.to(DEV))
+        finally:
+            os.environ.pop("IB_NO_LINEAR_LN", None)
+        close(got, ref, 3e-2, "fused vs unfused inference path")
+    # a second call reuses the captured step and must reproduce the first bit for bit
+    smp = DDIMSampler(model, S, use_graph=True)
+    a = smp.sample(xT.to(DEV))
+    b = smp.sample(xT.to(DEV))
+    assert torch.equal(a, b)
+
+
 def test_backward_after_newer_forward_fails_loudly():
     from inferbiomechanics_amd import hip
     from inferbiomechanics_amd.models.DiffusionDenoisers import DiffusionMLP
