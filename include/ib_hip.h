@@ -209,7 +209,8 @@ int ib_fill_i64(int64_t* dst, int64_t value, int64_t n, ib_stream_t stream);
  * (Linear + time embedding + SiLU + LayerNorm), the head, MSE loss with dL/dpred, and the backward chain through the
  * head, LayerNorm/SiLU and the block weights.  Token rows never mix, so a workgroup owns <= 64 tokens and keeps their
  * activations in LDS.  The weight gradients stay ib_linear_wgrad launches over the operands this leaves in HBM.
- *   hidden width H in {128, 256, 512} for every block, L <= 4 blocks, D % 4 == 0 (see ib_mlp_chain_supported).
+ *   hidden width H in {128, 256, 512} for every block, L <= 4 blocks, D % 4 == 0 and D <= 512 at H = 512 (narrower
+ *   sets for H = 128 / 256: ib_mlp_chain_supported says).
  *   packed: the bf16 weights in MFMA-fragment order (ib_mlp_chain_pack; re-pack after every optimizer step).
  *   bias[L+1], gamma[L], beta[L], u[L], h[L], dz[L]: HOST arrays of device pointers.
  *   u_i = W_i h_{i-1} + b_i + e[window] (bf16), h_i = LN(silu(u_i)), dz_i = dL/du_i, all [M, H] contiguous.

@@ -712,15 +712,19 @@ __global__ __launch_bounds__(256) void mlp_chain_pack_kernel(PackParams p) {
 struct ChainShape { int nth, ntd, kbd; };
 bool chain_shape(int64_t D, int64_t H, ChainShape* s) {
   if (H != 128 && H != 256 && H != 512) return false;
-  if (D <= 0 || D % 4 != 0) return false;
+  if (D <= 0 || D % 4 != 0 || D > 512) return false;
   s->nth = (int)(H / 128);
-  if (D <= 64) { s->ntd = 1; s->kbd = 2; }
-  else if (D <= 128) { s->ntd = 1; s->kbd = 4; }
-  else if (D > 256 && D <= 320) { s->ntd = 3; s->kbd = 10; }
-  else return false;
-  // the instantiated set (below)
-  if (s->ntd == 3) return H == 512 || H == 256;
-  return H == 128;
+  // feature-width geometries (n-tiles per wave, k-blocks), smallest first; the instantiated set per hidden width
+  static const int geo[6][2] = {{1, 2}, {1, 4}, {2, 8}, {3, 10}, {3, 12}, {4, 16}};
+  const int kb_need = (int)((D + 31) / 32), nt_need = (int)(((D + 15) / 16 + 7) / 8);
+  for (int j = 0; j < 6; ++j) {
+    if (geo[j][0] < nt_need || geo[j][1] < kb_need) continue;
+    const bool have = H == 512 || (H == 256 && j == 3) || (H == 128 && j < 2);
+    if (!have) continue;
+    s->ntd = geo[j][0]; s->kbd = geo[j][1];
+    return true;
+  }
+  return false;
 }
 
 // packed image layout (elements): forward blocks 0..L-1, head, then transposed blocks 1..L-1, head^T
@@ -858,6 +862,11 @@ extern "C" int ib_mlp_chain_train(const void* x0, const void* eps, const int64_t
 #define IB_CHAIN_LAUNCH(NTH, NTD, KBD) \
   hipLaunchKernelGGL((mlp_chain_kernel<NTH, NTD, KBD>), dim3(nwg), dim3(CH_THREADS), 0, st, p)
   if (s.nth == 4 && s.ntd == 3 && s.kbd == 10) IB_CHAIN_LAUNCH(4, 3, 10);
+  else if (s.nth == 4 && s.ntd == 1 && s.kbd == 2) IB_CHAIN_LAUNCH(4, 1, 2);
+  else if (s.nth == 4 && s.ntd == 1 && s.kbd == 4) IB_CHAIN_LAUNCH(4, 1, 4);
+  else if (s.nth == 4 && s.ntd == 2 && s.kbd == 8) IB_CHAIN_LAUNCH(4, 2, 8);
+  else if (s.nth == 4 && s.ntd == 3 && s.kbd == 12) IB_CHAIN_LAUNCH(4, 3, 12);
+  else if (s.nth == 4 && s.ntd == 4 && s.kbd == 16) IB_CHAIN_LAUNCH(4, 4, 16);
   else if (s.nth == 2 && s.ntd == 3 && s.kbd == 10) IB_CHAIN_LAUNCH(2, 3, 10);
   else if (s.nth == 1 && s.ntd == 1 && s.kbd == 2) IB_CHAIN_LAUNCH(1, 1, 2);
   else if (s.nth == 1 && s.ntd == 1 && s.kbd == 4) IB_CHAIN_LAUNCH(1, 1, 4);

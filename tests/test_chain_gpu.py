@@ -45,7 +45,8 @@ CASES = [(256, 50, 300, 512, 2),     # BASELINE configs[1]: 12800 tokens -> 256 
          (300, 50, 300, 512, 3),     # 15000 tokens: 64-token panels, three blocks
          (5, 13, 48, 128, 1),        # small widths, one block
          (3, 50, 100, 128, 2),
-         (9, 20, 300, 256, 2)]
+         (9, 20, 300, 256, 2),
+         (6, 50, 40, 512, 2), (6, 50, 100, 512, 1), (6, 50, 200, 512, 2), (6, 50, 384, 512, 2), (6, 50, 512, 512, 2)]
 
 
 @pytest.mark.parametrize("B,T,D,H,L", CASES)
