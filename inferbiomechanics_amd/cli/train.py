@@ -71,6 +71,10 @@ class TrainCommand(AbstractCommand):
                        help='Reference-style loop (autograd node + torch.optim + torch DDP) instead of the fused trainer.')
         p.add_argument('--no-graph', action='store_true', help='Do not replay the step from hipGraphs.')
         p.add_argument('--bucket-mb', type=float, default=4.0, help='Gradient all-reduce bucket size.')
+        p.add_argument('--window-cache', type=str, default=None,
+                       help='Packed-window file (data/WindowCache.py): loaded if it exists, else built from the training '
+                            'set and saved; the regression models then train from an on-device window cache (one '
+                            'gather launch per batch instead of the DataLoader pipeline).')
 
     # ------------------------------------------------------------------------------------------
     def run(self, args: argparse.Namespace):
@@ -147,6 +151,19 @@ class TrainCommand(AbstractCommand):
             trainer = HipTrainer(model, "diffusion" if diffusion else "regression", args.opt_type, args.learning_rate,
                                  args=args, use_graph=not args.no_graph, bucket_mb=args.bucket_mb)
 
+        cache = None
+        if args.window_cache and trainer is not None and not diffusion:
+            from ..data.WindowCache import DeviceWindowCache, PackedWindows
+            if os.path.exists(args.window_cache):
+                pack = PackedWindows.load(args.window_cache)
+            else:
+                print(f"Packing {len(train_dataset)} training windows into {args.window_cache} ...")
+                pack = PackedWindows.from_windows(train_dataset)
+                if rank == 0:
+                    pack.save(args.window_cache)
+            cache = DeviceWindowCache(pack, device)
+            print(f"[rank={rank}] window cache: {len(cache)} windows, {cache.table.numel() * 4 / 2**20:.1f} MiB in HBM")
+
         epoch_checkpoint, _ = self.load_latest_checkpoint(model, optimizer=trainer if trainer is not None else optimizer,
                                                           checkpoint_dir=checkpoint_dir)
         gen = torch.Generator().manual_seed(1234 + rank)
@@ -184,9 +201,16 @@ class TrainCommand(AbstractCommand):
                 dist.barrier()
             print(f'[rank={rank}] Running Training Epoch {epoch}')
             model.train()
-            n_batches = len(train_dataloader)
-            for i, batch in enumerate(train_dataloader):
-                if diffusion:
+            if cache is not None:
+                train_batches = list(cache.batches(args.batch_size, rank=rank, world=world_size))
+            else:
+                train_batches = train_dataloader
+            n_batches = len(train_batches)
+            for i, batch in enumerate(train_batches):
+                if cache is not None:
+                    trainer.step_windows(cache, batch)
+                    train_eval.record_result(trainer.result)
+                elif diffusion:
                     x0, t, eps = diffusion_batch(batch)
                     if trainer is not None:
                         loss = trainer.step((x0.to(device, non_blocking=True), t.to(device, non_blocking=True),

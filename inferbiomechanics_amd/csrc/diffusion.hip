@@ -178,3 +178,76 @@ extern "C" int ib_fill_i64(int64_t* dst, int64_t value, int64_t n, ib_stream_t s
   IB_CHECK_LAUNCH();
   return IB_OK;
 }
+
+// ---- on-device window cache (replaces AddBiomechanicsDataset.__getitem__ `:161-285` + the
+// DataLoader collate + the model's torch.concat `FeedForwardRegressionBaseline.py:97-108` for cached windows):
+// one packed fp32 row per window = [model input, frame-major F x 147 | labels, key-major: cop F x 6, force F x 6,
+// torque F x 6, wrench F x 12].  One launch gathers a batch of rows into the model's input tensor (compute dtype) and the
+// four contiguous label tensors the loss kernel takes.
+namespace {
+struct GatherWin {
+  const float* table; int64_t row_elems, rows; const int64_t* idx; int64_t B;
+  void* x_out; int64_t x_elems, x_pad; int x_bf16;
+  float* lab[4]; int64_t lab_elems[4];
+};
+__global__ __launch_bounds__(256) void gather_windows_kernel(GatherWin p) {
+  const int64_t per = p.row_elems / 4;                     // float4 pieces per window row (row_elems % 4 == 0)
+  const int64_t n = p.B * per;
+  const int64_t xq = p.x_pad / 4;
+  const bool xvec = (p.x_elems & 3) == 0;               // 1470 inputs per window at the reference defaults: not a multiple of 4
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = i / per, q = i % per;
+    int64_t r = p.idx[b];
+    r = r < 0 ? 0 : (r >= p.rows ? p.rows - 1 : r);
+    const float4 v = *reinterpret_cast<const float4*>(p.table + r * p.row_elems + 4 * q);
+    if (q < xq) {
+      if (!xvec) {                       // rows of the model input are then only element-aligned: scalar stores
+        const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int64_t c = 4 * q + k;
+          if (c < p.x_elems) {
+            if (p.x_bf16) reinterpret_cast<bf16_t*>(p.x_out)[b * p.x_elems + c] = (bf16_t)e[k];
+            else reinterpret_cast<float*>(p.x_out)[b * p.x_elems + c] = e[k];
+          }
+        }
+      } else if (p.x_bf16) {
+        bf16x4_t o; o[0] = (bf16_t)v.x; o[1] = (bf16_t)v.y; o[2] = (bf16_t)v.z; o[3] = (bf16_t)v.w;
+        *reinterpret_cast<bf16x4_t*>(reinterpret_cast<bf16_t*>(p.x_out) + b * p.x_elems + 4 * q) = o;
+      } else {
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.x_out) + b * p.x_elems + 4 * q) = v;
+      }
+    } else {
+      int64_t d = 4 * (q - xq);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (d < p.lab_elems[k]) { *reinterpret_cast<float4*>(p.lab[k] + b * p.lab_elems[k] + d) = v; break; }
+        d -= p.lab_elems[k];
+      }
+    }
+  }
+}
+}  // namespace
+
+extern "C" int ib_gather_windows(const float* table, int64_t row_elems, int64_t rows, const int64_t* idx, int64_t B,
+                                 void* x_out, int64_t x_elems, int dtype_x, float* const* lab_out,
+                                 const int64_t* lab_elems, ib_stream_t stream) {
+  if (!table || !idx || !x_out || !lab_out || !lab_elems || rows <= 0 || B <= 0 || x_elems <= 0) return IB_E_ARG;
+  if (dtype_x != IB_F32 && dtype_x != IB_BF16) return IB_E_DTYPE;
+  const int64_t x_pad = (x_elems + 3) / 4 * 4;             // the input segment of a packed row is padded to 16 bytes
+  int64_t total = x_pad;
+  GatherWin p{};
+  for (int k = 0; k < 4; ++k) {
+    if (!lab_out[k] || lab_elems[k] <= 0 || lab_elems[k] % 4 != 0 || (reinterpret_cast<uintptr_t>(lab_out[k]) % 16)) return IB_E_ARG;
+    p.lab[k] = lab_out[k]; p.lab_elems[k] = lab_elems[k];
+    total += lab_elems[k];
+  }
+  if (total != row_elems || (reinterpret_cast<uintptr_t>(table) % 16) ||
+      (reinterpret_cast<uintptr_t>(x_out) % (dtype_x == IB_BF16 ? 8 : 16)))
+    return IB_E_ARG;
+  p.table = table; p.row_elems = row_elems; p.rows = rows; p.idx = idx; p.B = B;
+  p.x_out = x_out; p.x_elems = x_elems; p.x_pad = x_pad; p.x_bf16 = dtype_x == IB_BF16;
+  hipLaunchKernelGGL(gather_windows_kernel, dim3(ib_grid_1d(B * (row_elems / 4), 256)), dim3(256), 0, ib_s(stream), p);
+  IB_CHECK_LAUNCH();
+  return IB_OK;
+}

@@ -304,9 +304,13 @@ class HipTrainer:
             plan.backward(dpred, P, accumulate=False)
             self._br_loss.join()
         else:
-            B = st["in0"].shape[0]
+            B = st["lab0"].shape[0]
             x = plan.buf.get("ff.x", (B, m.input_size), dt)
-            hip.concat_keys([st[f"in{i}"] for i in range(len(INPUT_KEY_ORDER))], x)
+            if "widx" in st:
+                # cached windows: ONE gather launch fills the model input and the four label tensors
+                hip.gather_windows(self._cache.table, st["widx"], x, [st[f"lab{i}"] for i in range(4)])
+            else:
+                hip.concat_keys([st[f"in{i}"] for i in range(len(INPUT_KEY_ORDER))], x)
             out = plan.forward(x, P)
             F = m.num_output_frames
             views = m.split_output(out)
@@ -356,6 +360,18 @@ class HipTrainer:
                 st[name] = b
             if self._slots is not None:
                 hip.set_ptrs(self._slots, srcs)
+        elif isinstance(batch, tuple) and len(batch) == 3 and batch[0] == "windows":
+            _, cache, idx = batch
+            if cache.x_elems != self.model.input_size or cache.out_frames != self.model.num_output_frames:
+                raise hip.HipError(f"window cache geometry (x {cache.x_elems}, F' {cache.out_frames}) does not match the "
+                                   f"model (input {self.model.input_size}, F' {self.model.num_output_frames})")
+            if self._cache is not cache:
+                self._cache, self._rec, self._sig = cache, None, None      # another table: re-capture
+            b = self._sbuf("widx", idx, torch.int64)
+            b.copy_(idx, non_blocking=True)
+            st["widx"] = b
+            for i, shp in enumerate(cache.label_shapes(idx.numel())):
+                st[f"lab{i}"] = self._sbuf(f"lab{i}", torch.empty(shp, device="meta"), torch.float32)
         else:
             inputs, labels = batch
             for i, k in enumerate(INPUT_KEY_ORDER):
@@ -378,6 +394,15 @@ class HipTrainer:
             r = self._step(batch)
         cur.wait_stream(self.stream)
         return r
+
+    _cache = None
+
+    def step_windows(self, cache, idx: torch.Tensor) -> torch.Tensor:
+        """one fused regression step over windows `idx` (int64, on the device) of a `data.WindowCache.DeviceWindowCache`:
+        the batch is gathered on the device by one launch -- no host-side window assembly, no collate, no H2D copy"""
+        if self.task != "regression":
+            raise hip.HipError("step_windows: the window cache feeds the regression models")
+        return self.step(("windows", cache, idx))
 
     def _step(self, batch) -> torch.Tensor:
         st = self._stage(batch)

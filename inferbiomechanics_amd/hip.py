@@ -72,6 +72,7 @@ _SIGS = {
     "ib_optim_step": (_c.c_int, [_c.c_int, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _i32, _vp, _vp, _vp, _vp]),
     "ib_optim_step_sources": (_c.c_int, [_c.c_int, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _i32, _vp, _vp, _vp, _c.c_int, _vp,
                                          _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _f32, _vp, _vp]),
+    "ib_gather_windows": (_c.c_int, [_vp, _i64, _i64, _vp, _i64, _vp, _i64, _c.c_int, _vp, _vp, _vp]),
     "ib_gather_rows": (_c.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _c.c_int, _vp]),
     "ib_mlp_chain_supported": (_c.c_int, [_i64, _i64, _c.c_int]),
     "ib_mlp_chain_packed_elems": (_sz, [_i64, _i64, _c.c_int]),
@@ -969,6 +970,32 @@ def gather_rows(table, idx, out):
     _check(lib().ib_gather_rows(_ptr(table), _ptr(idx), _ptr(out), B, dim, table.shape[0], dtype_code(out.dtype),
                                 stream_ptr()), "ib_gather_rows")
     return out
+
+
+def gather_windows(table, idx, x_out, labels):
+    """table: packed fp32 [rows, row_elems] window cache; idx: int64 [B]; x_out: [B, x_elems] (fp32 / bf16);
+    labels: 4 contiguous fp32 tensors [B, F, c] (cop, force, torque, wrench) -- one launch"""
+    rows, row_elems, _ = _mat(table, "table", torch.float32)
+    if not table.is_contiguous():
+        raise HipError("gather_windows: table must be contiguous")
+    _req(idx, "idx", torch.int64, 1)
+    B = idx.numel()
+    _req(x_out, "x_out", None, 2)
+    if x_out.shape[0] != B or not x_out.is_contiguous():
+        raise HipError("gather_windows: x_out must be contiguous [B, x_elems]")
+    le = []
+    for t in labels:
+        _req(t, "label", torch.float32)
+        if t.shape[0] != B or not t.is_contiguous():
+            raise HipError("gather_windows: labels must be contiguous fp32 [B, ...]")
+        le.append(t.numel() // B)
+    if len(labels) != 4 or (x_out.shape[1] + 3) // 4 * 4 + sum(le) != row_elems:
+        raise HipError("gather_windows: x_out + labels do not add up to the packed row")
+    lp = (ctypes.c_void_p * 4)(*[t.data_ptr() for t in labels])
+    ln = (ctypes.c_int64 * 4)(*le)
+    _check(lib().ib_gather_windows(_ptr(table), row_elems, rows, _ptr(idx), B, _ptr(x_out), x_out.shape[1],
+                                   dtype_code(x_out.dtype), ctypes.cast(lp, ctypes.c_void_p),
+                                   ctypes.cast(ln, ctypes.c_void_p), stream_ptr()), "ib_gather_windows")
 
 
 def q_sample(x0, eps, t, sqrt_ab, sqrt_1mab, x_t):

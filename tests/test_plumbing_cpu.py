@@ -126,3 +126,61 @@ def test_chain_step_plumbing(dry):
         assert "ib_linear_wgrad_slabs_multi" in names            # every independent dW GEMM: one launch
         assert "ib_q_sample" not in names and "ib_layernorm_fwd" not in names
         assert names[-1] == "ib_optim_step_sources"              # single GPU: the optimizer sums the partials itself
+
+
+def test_packed_windows_roundtrip_and_reference_pickle_blocks(tmp_path):
+    """the packed row reproduces the reference tuple layout exactly; file round trip (memory-mapped); the reference's
+    `pickle-data` blocks (torch.save of a list of window tuples, pickle_data.py:52-64) pack to the same rows"""
+    import numpy as np
+    from inferbiomechanics_amd.data.AddBiomechanicsDataset import (INPUT_KEY_ORDER, LOSS_KEY_ORDER,
+                                                                   SyntheticWindowDataset)
+    from inferbiomechanics_amd.data.WindowCache import DeviceWindowCache, PackedWindows
+    ds = SyntheticWindowDataset(37, history_len=50, stride=5, seed=3)
+    pack = PackedWindows.from_windows(ds)
+    assert len(pack) == 37 and pack.frames == 10 and pack.x_elems == 1470 and pack.rows.shape[1] == 1472 + 300
+    for i in (0, 5, 36):
+        inputs, labels, s, t = pack.window(i)
+        ri, rl, rs, rt = ds[i]
+        assert (s, t) == (rs, rt)
+        for k in INPUT_KEY_ORDER:
+            assert torch.equal(inputs[k], ri[k])
+        for k in LOSS_KEY_ORDER:
+            assert torch.equal(labels[k], rl[k])
+        # the model-input part of the row is exactly the model's own concatenation
+        x = torch.cat([ri[k] for k in INPUT_KEY_ORDER], dim=-1).reshape(-1)
+        assert torch.equal(torch.from_numpy(np.array(pack.rows[i][:1470])), x)
+    path = str(tmp_path / "w.ibw")
+    pack.save(path)
+    back = PackedWindows.load(path)
+    assert np.array_equal(np.asarray(back.rows), pack.rows) and np.array_equal(back.trials, pack.trials)
+    with open(path, "r+b") as f:            # a truncated file is refused
+        f.truncate(4096 + 100)
+    with pytest.raises(ValueError):
+        PackedWindows.load(path)
+    blocks = []
+    for b, (lo, hi) in enumerate(((0, 20), (20, 37))):
+        bp = str(tmp_path / f"train_{b}.pkl")
+        torch.save([ds[j] for j in range(lo, hi)], bp)
+        blocks.append(bp)
+    assert np.array_equal(PackedWindows.from_pickled_blocks(blocks).rows, pack.rows)
+    # sampler semantics: DistributedSampler(shuffle=False, drop_last=True), then whole batches only
+    cache = DeviceWindowCache(pack, "cpu")
+    got = [b.tolist() for b in cache.batches(4, rank=1, world=2)]
+    assert got == [[1, 3, 5, 7], [9, 11, 13, 15], [17, 19, 21, 23], [25, 27, 29, 31]]
+
+
+def test_window_cache_trainer_plumbing(dry):
+    from inferbiomechanics_amd.data.AddBiomechanicsDataset import SyntheticWindowDataset
+    from inferbiomechanics_amd.data.WindowCache import DeviceWindowCache, PackedWindows
+    from inferbiomechanics_amd.engine import HipTrainer
+    from inferbiomechanics_amd.models.FeedForwardRegressionBaseline import FeedForwardBaseline
+    import argparse
+    cache = DeviceWindowCache(PackedWindows.from_windows(SyntheticWindowDataset(16, 50, 5)), "cpu")
+    m = FeedForwardBaseline(23, 2, 50, "all_frames", "sigmoid", 5, 10)
+    args = argparse.Namespace(predict_grf_components=list(range(6)), predict_cop_components=[],
+                              predict_moment_components=[], predict_wrench_components=[])
+    tr = HipTrainer(m, "regression", "rmsprop", 1e-4, args=args, use_graph=False)
+    dry.lib().calls.clear()
+    tr.step_windows(cache, next(cache.batches(8)))
+    names = dry.lib().calls
+    assert names[0] == "ib_gather_windows" and "ib_concat_keys" not in names and "ib_regression_loss" in names

@@ -143,3 +143,51 @@ def test_regression_trainer_matches_oracle():
         got.append(tr.loss_value())
     for a, e in zip(got, ref):
         assert abs(a - e) <= 1e-3 * abs(e), (got, ref)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_window_cache_step_is_bitwise_the_dict_batch_step(dtype):
+    """training from the on-device window cache (one gather launch per batch) must be EXACTLY
+    training from the reference-layout dict batches of the same windows (gather + cast vs concat + cast: same values)"""
+    from torch.utils.data import DataLoader
+    from inferbiomechanics_amd.data.AddBiomechanicsDataset import SyntheticWindowDataset
+    from inferbiomechanics_amd.data.WindowCache import DeviceWindowCache, PackedWindows
+    from inferbiomechanics_amd.engine import HipTrainer
+    from inferbiomechanics_amd.models.FeedForwardRegressionBaseline import FeedForwardBaseline
+    args = argparse.Namespace(predict_grf_components=list(range(6)), predict_cop_components=list(range(6)),
+                              predict_moment_components=list(range(6)), predict_wrench_components=list(range(12)))
+    ds = SyntheticWindowDataset(96, history_len=50, stride=5, seed=11)
+
+    def fresh():
+        m = FeedForwardBaseline(23, 2, 50, "all_frames", "sigmoid", 5, 10, device=DEV, compute_dtype=dtype)
+        load_det(m)
+        return m, HipTrainer(m, "regression", "rmsprop", 1e-3, args=args)
+
+    ma, ta = fresh()
+    la = []
+    for inputs, labels, _, _ in DataLoader(ds, batch_size=32, shuffle=False, drop_last=True):
+        ta.step(({k: v.to(DEV) for k, v in inputs.items()}, {k: v.to(DEV) for k, v in labels.items()}))
+        la.append(ta.loss_value())
+    mb, tb = fresh()
+    cache = DeviceWindowCache(PackedWindows.from_windows(ds), DEV)
+    lb = []
+    for idx in cache.batches(32):
+        tb.step_windows(cache, idx)
+        lb.append(tb.loss_value())
+    assert len(la) == len(lb) == 3 and la == lb, (la, lb)
+    for (k, a), (_, b) in zip(ma.state_dict().items(), mb.state_dict().items()):
+        assert torch.equal(a, b), k
+    # a ragged gather (indices out of order, repeated) through the kernel alone
+    from inferbiomechanics_amd import hip
+    idx = torch.tensor([95, 0, 17, 17, 3], device=DEV)
+    x = torch.zeros(5, 1470, dtype=dtype, device=DEV)
+    labs = [torch.zeros(5, 10, c, device=DEV) for c in (6, 6, 6, 12)]
+    hip.gather_windows(cache.table, idx, x, labs)
+    torch.cuda.synchronize()
+    for j, w in enumerate(idx.tolist()):
+        inputs, labels, _, _ = ds[w]
+        from inferbiomechanics_amd.data.AddBiomechanicsDataset import INPUT_KEY_ORDER, LOSS_KEY_ORDER
+        xe = torch.cat([inputs[k] for k in INPUT_KEY_ORDER], dim=-1).reshape(-1).to(dtype)
+        assert torch.equal(x[j].cpu(), xe)
+        for t, k in zip(labs, LOSS_KEY_ORDER):
+            assert torch.equal(t[j].cpu(), labels[k])
