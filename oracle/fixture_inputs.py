@@ -13,6 +13,15 @@ def ff_inputs(B, F, num_dofs, stride, dtype=torch.float32):
     return {k: det_fill((B, F, w), 10 + i, 1.0, dtype) for i, (k, w) in enumerate(zip(INPUT_KEY_ORDER, ws))}
 
 
+def gl_inputs(B, F, num_dofs=23, root_history_len=10, dtype=torch.float32):
+    """Groundlink inputs: history keys are root_history_len*3 wide (Groundlink.py:116-118), joint centers 12*3"""
+    ws = [num_dofs, num_dofs, num_dofs, 3, 3, 3, 3, 36, root_history_len * 3, root_history_len * 3]
+    return {k: det_fill((B, F, w), 70 + i, 1.0, dtype) for i, (k, w) in enumerate(zip(INPUT_KEY_ORDER, ws))}
+
+
+GL_CASES = [("all_frames_F10", "all_frames", 10), ("last_frame_F10", "last_frame", 10), ("all_frames_F5", "all_frames", 5)]
+
+
 def ff_labels(B, F, dtype=torch.float32):
     lab = {
         K_COP: det_fill((B, F, 6), 31, 0.3, dtype),

@@ -22,8 +22,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 sys.path.insert(0, ROOT)
 from oracle.ref_cpu import K_COP, K_FORCE, K_TORQUE, K_WRENCH, det_fill  # noqa: E402
-from oracle.fixture_inputs import (FF_CASES, LOSS_SUBSETS, TL_CASES, det_state, ff_inputs,  # noqa: E402
-                                   ff_labels, loss_case_outputs)
+from oracle.fixture_inputs import (FF_CASES, GL_CASES, LOSS_SUBSETS, TL_CASES, det_state, ff_inputs,  # noqa: E402
+                                   ff_labels, gl_inputs, loss_case_outputs)
 
 REF = os.environ.get("IB_REFERENCE", "/root/reference")
 OUT = os.path.join(ROOT, "tests", "golden")
@@ -118,6 +118,33 @@ def gen_transformer_layer(TL):
         print("tl", name, float(y.sum()))
 
 
+def gen_groundlink(RLE):
+    """Groundlink (src/models/Groundlink.py:19-156) in eval mode (its fc Dropout(0.2) draws from torch's generator in
+    train mode and cannot be pinned); outputs, loss through the reference evaluator, gradient norms + slices."""
+    from models.Groundlink import Groundlink
+    B = 3
+    for name, fmt, F in GL_CASES:
+        model = Groundlink(23, 12, 10, fmt)
+        model.eval()
+        load_det_state(model, seed0=5.0)
+        inputs = gl_inputs(B, F)
+        Fo = F if fmt == "all_frames" else 1
+        labels = ff_labels(B, Fo)
+        out = model({k: v.clone() for k, v in inputs.items()})
+        ev = RLE(dataset=None, split="train")
+        loss = ev({}, dict(out), {k: v.clone() for k, v in labels.items()}, [], [], train_args())
+        loss.backward()
+        d = {"meta_torch": np.array(torch.__version__), "loss": np_(loss)}
+        for k, v in out.items():
+            d["out/" + k] = np_(v)
+        for k, q in model.named_parameters():
+            g = q.grad
+            d["gnorm/" + k] = np_(g.norm())
+            d["gslice/" + k] = np_(g.reshape(-1)[:64])
+        np.savez_compressed(os.path.join(OUT, f"gl_{name}.npz"), **d)
+        print("groundlink", name, float(loss))
+
+
 def gen_loss(RLE):
     B, F = 5, 7
     outs = loss_case_outputs(B, F)
@@ -168,6 +195,7 @@ def main():
     FF, TL, RLE = import_reference()
     gen_feedforward(FF, RLE)
     gen_transformer_layer(TL)
+    gen_groundlink(RLE)
     gen_loss(RLE)
     gen_optim()
 

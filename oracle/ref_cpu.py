@@ -72,6 +72,8 @@ def act(name: str, x: torch.Tensor) -> torch.Tensor:
         return 1.0 / (1.0 + torch.exp(-x))
     if name == "silu":
         return x / (1.0 + torch.exp(-x))
+    if name == "elu":                                   # torch.nn.ELU(alpha=1): x > 0 ? x : exp(x) - 1
+        return torch.where(x > 0, x, torch.exp(torch.clamp_max(x, 0)) - 1.0)
     if name in ("none", "identity"):
         return x
     raise KeyError(name)
@@ -116,6 +118,56 @@ def feedforward_forward(layers: List[Tuple[torch.Tensor, torch.Tensor]],
         K_TORQUE: x[:, 12 * F:18 * F].reshape(B, F, 6),
         K_WRENCH: x[:, 18 * F:30 * F].reshape(B, F, 12),
     }
+
+
+# --------------------------------------------------------------------------
+# Groundlink (src/models/Groundlink.py:19-156)
+# --------------------------------------------------------------------------
+def conv1d_replicate(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor]) -> torch.Tensor:
+    """torch.nn.Conv1d(C_in, C_out, k, padding=k//2, padding_mode="replicate") on channels-LAST data
+    (Groundlink.py:41): x [N,F,C_in], w [C_out,C_in,k] -> y [N,F,C_out],
+    y[n,f,o] = b[o] + sum_{c,j} w[o,c,j] * x[n, clamp(f + j - k//2, 0, F-1), c]  (explicit gather + matmul)."""
+    N, F, C = x.shape
+    k = w.shape[2]
+    idx = (torch.arange(F)[:, None] + torch.arange(k)[None, :] - k // 2).clamp(0, F - 1)      # [F,k]
+    col = x[:, idx, :]                                       # [N,F,k,C]
+    col = col.permute(0, 1, 3, 2).reshape(N, F, C * k)       # column index c*k + j == w.view(C_out, C_in*k)
+    y = col @ w.reshape(w.shape[0], C * k).transpose(0, 1)
+    return y if b is None else y + b
+
+
+def groundlink_forward(p: Dict[str, torch.Tensor], inputs: Dict[str, torch.Tensor],
+                       output_data_format: str = "all_frames") -> Dict[str, torch.Tensor]:
+    """Groundlink.forward (Groundlink.py:105-156) in eval mode (Dropout = identity; cnn_dropout = 0.0 and
+    fc_dropout = 0.2 only act in train mode, :20): concat of the ten input keys (:122-133), four
+    Conv1d(k=7, replicate) + ELU (:41-48, channels 177 -> 128 -> 128 -> 256 -> 256 at the reference sizes), then per
+    frame Linear+ELU x2 and Linear(256 -> 30, no bias) (:51-62); `last_frame` feeds only the last frame to the
+    fully-connected part (:145-148); outputs are slices of the last dimension (:151-156).
+    p: the reference state_dict (cnn.{1,4,7,10}.{weight,bias}, fc.{2,5}.{weight,bias}, fc.8.weight)."""
+    x = torch.cat([inputs[k] for k in INPUT_KEY_ORDER], dim=-1)           # [N,F,C0]
+    for i in (1, 4, 7, 10):
+        x = act("elu", conv1d_replicate(x, p[f"cnn.{i}.weight"], p[f"cnn.{i}.bias"]))
+    if output_data_format != "all_frames":
+        x = x[:, -1:, :]
+    for i in (2, 5):
+        x = act("elu", linear(x, p[f"fc.{i}.weight"], p[f"fc.{i}.bias"]))
+    x = linear(x, p["fc.8.weight"], None)
+    return {K_COP: x[:, :, 0:6], K_FORCE: x[:, :, 6:12], K_TORQUE: x[:, :, 12:18], K_WRENCH: x[:, :, 18:30]}
+
+
+def groundlink_param_shapes(num_dofs: int = 23, num_joints: int = 12, root_history_len: int = 10, k: int = 7
+                            ) -> Dict[str, Tuple[int, ...]]:
+    c0 = num_dofs * 3 + 12 + num_joints * 3 + root_history_len * 6        # Groundlink.py:26
+    feats = [c0, 128, 128, 256, 256]
+    s: Dict[str, Tuple[int, ...]] = {}
+    for i, (ci, co) in zip((1, 4, 7, 10), zip(feats[:-1], feats[1:])):
+        s[f"cnn.{i}.weight"] = (co, ci, k)
+        s[f"cnn.{i}.bias"] = (co,)
+    for i in (2, 5):
+        s[f"fc.{i}.weight"] = (256, 256)
+        s[f"fc.{i}.bias"] = (256,)
+    s["fc.8.weight"] = (30, 256)
+    return s
 
 
 # --------------------------------------------------------------------------

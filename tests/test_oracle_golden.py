@@ -8,8 +8,8 @@ import pytest
 import torch
 
 from oracle import ref_cpu as R
-from oracle.fixture_inputs import (FF_CASES, LOSS_SUBSETS, TL_CASES, det_state, ff_inputs, ff_labels,
-                                   loss_case_outputs)
+from oracle.fixture_inputs import (FF_CASES, GL_CASES, LOSS_SUBSETS, TL_CASES, det_state, ff_inputs, ff_labels,
+                                   gl_inputs, loss_case_outputs)
 
 
 def load(golden_dir, name):
@@ -64,6 +64,28 @@ def test_feedforward_matches_reference(golden_dir, name, hist, stride, actn):
             st = R.optim_init_state(opt, p32)
             new = R.optim_step(opt, p32, g32, st, 1e-4, 1)
             close(new.reshape(-1)[:64], g[f"step_{opt}/" + k], rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize("name,fmt,F", GL_CASES)
+def test_groundlink_matches_reference(golden_dir, name, fmt, F):
+    """oracle Groundlink (explicit replicate-padded gather + matmul convolution, ELU, per-frame MLP) against the real
+    reference class in eval mode: outputs, loss through the reference evaluator, every parameter gradient"""
+    g = load(golden_dir, f"gl_{name}.npz")
+    dt = torch.float64
+    sd = {k: v.to(torch.float32).to(dt).requires_grad_(True)
+          for k, v in det_state(R.groundlink_param_shapes(), 5.0).items()}
+    inputs = {k: v.to(dt) for k, v in gl_inputs(3, F).items()}
+    Fo = F if fmt == "all_frames" else 1
+    labels = {k: v.to(dt) for k, v in ff_labels(3, Fo).items()}
+    out = R.groundlink_forward(sd, inputs, fmt)
+    for k, v in out.items():
+        close(v.detach(), g["out/" + k], rtol=2e-4)
+    loss, _, _ = R.regression_loss(out, labels, range(6), range(6), range(6), range(12))
+    close(loss.detach(), g["loss"], rtol=5e-5)
+    loss.backward()
+    for k, p in sd.items():
+        close(p.grad.norm(), g["gnorm/" + k], rtol=5e-4)
+        close(p.grad.reshape(-1)[:64], g["gslice/" + k], rtol=5e-4, atol=2e-6 * float(g["gnorm/" + k]))
 
 
 @pytest.mark.parametrize("name,d,h,ffn,B,T,dt", TL_CASES)
