@@ -28,7 +28,8 @@ typedef void* ib_stream_t; /* hipStream_t */
 
 enum { IB_F32 = 0, IB_BF16 = 1 };
 /* ACTIVATION_FUNCS: src/models/FeedForwardRegressionBaseline.py:7-11 (+ silu, build-defined) */
-enum { IB_ACT_NONE = 0, IB_ACT_RELU = 1, IB_ACT_TANH = 2, IB_ACT_SIGMOID = 3, IB_ACT_SILU = 4 };
+enum { IB_ACT_NONE = 0, IB_ACT_RELU = 1, IB_ACT_TANH = 2, IB_ACT_SIGMOID = 3, IB_ACT_SILU = 4,
+       IB_ACT_ELU = 5 /* torch.nn.ELU(alpha=1), Groundlink.py:48,57; derivative operand = the layer OUTPUT */ };
 /* --opt-type choices: src/cli/train.py:183-194 */
 enum { IB_OPT_SGD = 0, IB_OPT_ADAM = 1, IB_OPT_RMSPROP = 2, IB_OPT_ADAGRAD = 3, IB_OPT_ADADELTA = 4,
        IB_OPT_ADAMAX = 5 };
@@ -150,6 +151,16 @@ int ib_regression_loss(const void* o_cop, const void* o_force, const void* o_tor
                        void* workspace, size_t workspace_bytes, int64_t B, int64_t F, int dtype,
                        ib_stream_t stream);
 
+/* the same with explicit FRAME strides (elements between frames of an output / gradient key; NULL = dense 6,6,6,12):
+ * Groundlink's output is [B,F,30] with the four keys interleaved per frame (Groundlink.py:151-156 slices the last dim),
+ * i.e. frame stride 30 for every key. */
+int ib_regression_loss_strided(const void* o_cop, const void* o_force, const void* o_torque, const void* o_wrench,
+                               const int64_t* o_bs, const int64_t* o_fs, const float* l_cop, const float* l_force,
+                               const float* l_torque, const float* l_wrench, const float* comp_w, float threshold,
+                               float* result, void* g_cop, void* g_force, void* g_torque, void* g_wrench,
+                               const int64_t* g_bs, const int64_t* g_fs, void* workspace, size_t workspace_bytes,
+                               int64_t B, int64_t F, int dtype, ib_stream_t stream);
+
 /* diffusion eps-prediction loss [BUILD-DEFINED; no reference counterpart, SURVEY.md §0.1]:
  * loss = mean((pred - target)^2) -> result[0]; dpred = 2 (pred - target) / n. */
 size_t ib_mse_loss_workspace(int64_t n);
@@ -209,6 +220,20 @@ int ib_ddim_step(void* x, const void* eps, const float* coef, const int64_t* tim
 int ib_gather_windows(const float* table, int64_t row_elems, int64_t rows, const int64_t* idx, int64_t B,
                       void* x_out, int64_t x_elems, int dtype_x, float* const* lab_out, const int64_t* lab_elems,
                       ib_stream_t stream);
+/* ---- Groundlink (src/models/Groundlink.py:41-48): Conv1d(k, padding=k/2, replicate) over the
+ * frames of a window as a GEMM over an explicit im2col.  x: [N*F, C] channels-last rows; col: [N*F, ldcol >= C*k] with
+ * col[(n,f)][c*k + j] = x[(n, clamp(f + j - k/2, 0, F-1))][c]  (column order == weight.view(C_out, C_in*k)), columns beyond
+ * C*k are zero-filled.  col2im is its transpose (fixed summation order) times the activation derivative of the layer
+ * below (act' evaluated on `aux`, that layer's OUTPUT; aux NULL or act NONE = plain). */
+int ib_im2col_replicate(const void* x, void* col, int64_t ldcol, int64_t N, int64_t F, int64_t C, int k, int dtype,
+                        ib_stream_t stream);
+int ib_col2im_replicate(const void* dcol, int64_t ldcol, const void* aux, int act, void* dx, int64_t N, int64_t F,
+                        int64_t C, int k, int dtype, ib_stream_t stream);
+/* inverted dropout y = x * m / (1 - p), m ~ Bernoulli(1 - p) from a counter-based hash of (seed, step, element): the same
+ * call on the gradient reproduces the mask (torch.nn.Dropout, Groundlink.py:54,59; the mask STREAM differs from torch's
+ * generator, the distribution does not).  step_dev (device int32, may be NULL -> `step`) makes it graph-replayable. */
+int ib_dropout(const void* x, void* y, int64_t n, float p, uint32_t seed, int32_t step, const int32_t* step_dev, int dtype,
+               ib_stream_t stream);
 int ib_counter_add(int32_t* counter, int32_t delta, ib_stream_t stream);
 int ib_fill_i64(int64_t* dst, int64_t value, int64_t n, ib_stream_t stream);
 

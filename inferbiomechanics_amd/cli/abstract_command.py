@@ -69,9 +69,12 @@ class AbstractCommand:
                                         dim_feedforward=dim_feedforward, num_layers=num_layers, device=dev,
                                         compute_dtype=compute_dtype)
         if model_type == 'groundlink':
-            # the reference registry call itself raises TypeError (abstract_command.py:74-79 vs Groundlink.py:20);
-            # the Conv1d model is a "next" row of SURVEY.md §8f
-            raise NotImplementedError("model type 'groundlink' is not on the HIP hot path yet (SURVEY.md §8f rank 3)")
+            # the reference registry call raises TypeError (abstract_command.py:74-79 passes the feedforward argument
+            # list to Groundlink.__init__, Groundlink.py:20); here the constructor gets its own arguments.  12 joint
+            # centres per frame (AddBiomechanicsDataset.py:221-223), root history of `root_history_len` frames.
+            from ..models.Groundlink import Groundlink
+            return Groundlink(num_dofs, 12, root_history_len, output_data_format=output_data_format,
+                              fc_dropout=dropout_prob if dropout else 0.2, device=dev, compute_dtype=compute_dtype)
         assert (model_type == 'analytical')
         raise NotImplementedError("model type 'analytical' is a nimblephysics CPU heuristic with no parameters "
                                   "(src/models/AnalyticalBaseline.py); it is outside the GPU hot path")

@@ -295,6 +295,7 @@ __device__ __forceinline__ float act_fwd_t(float v) {
   else if constexpr (ACT == IB_ACT_TANH) return tanhf(v);
   else if constexpr (ACT == IB_ACT_SIGMOID) return 1.f / (1.f + (sizeof(T) == 2 ? __expf(-v) : expf(-v)));
   else if constexpr (ACT == IB_ACT_SILU) return v / (1.f + (sizeof(T) == 2 ? __expf(-v) : expf(-v)));
+  else if constexpr (ACT == IB_ACT_ELU) return v > 0.f ? v : (sizeof(T) == 2 ? __expf(v) : expf(v)) - 1.f;
   else return v;
 }
 template <typename T, int ACT>
@@ -302,6 +303,7 @@ __device__ __forceinline__ float act_bwd_t(float aux) {
   if constexpr (ACT == IB_ACT_RELU) return aux > 0.f ? 1.f : 0.f;
   else if constexpr (ACT == IB_ACT_TANH) return 1.f - aux * aux;
   else if constexpr (ACT == IB_ACT_SIGMOID) return aux * (1.f - aux);
+  else if constexpr (ACT == IB_ACT_ELU) return aux > 0.f ? 1.f : aux + 1.f;
   else if constexpr (ACT == IB_ACT_SILU) {
     const float sg = 1.f / (1.f + (sizeof(T) == 2 ? __expf(-aux) : expf(-aux)));
     return sg * (1.f + aux * (1.f - sg));
@@ -566,6 +568,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmParams p) {
     case IB_ACT_TANH: epilogue<T, EPI, IB_ACT_TANH>(p, acc, i0, j0, wi, wj, lane, split_id); break;
     case IB_ACT_SIGMOID: epilogue<T, EPI, IB_ACT_SIGMOID>(p, acc, i0, j0, wi, wj, lane, split_id); break;
     case IB_ACT_SILU: epilogue<T, EPI, IB_ACT_SILU>(p, acc, i0, j0, wi, wj, lane, split_id); break;
+    case IB_ACT_ELU: epilogue<T, EPI, IB_ACT_ELU>(p, acc, i0, j0, wi, wj, lane, split_id); break;
     default: epilogue<T, EPI, IB_ACT_NONE>(p, acc, i0, j0, wi, wj, lane, split_id); break;
   }
 }
@@ -732,6 +735,7 @@ __device__ __forceinline__ void gemm_ring_body(const GemmParams& p, unsigned cha
     case IB_ACT_TANH: epilogue<bf16_t, EPI, IB_ACT_TANH>(p, acc, i0, j0, wi, wj, lane, split_id); break;
     case IB_ACT_SIGMOID: epilogue<bf16_t, EPI, IB_ACT_SIGMOID>(p, acc, i0, j0, wi, wj, lane, split_id); break;
     case IB_ACT_SILU: epilogue<bf16_t, EPI, IB_ACT_SILU>(p, acc, i0, j0, wi, wj, lane, split_id); break;
+    case IB_ACT_ELU: epilogue<bf16_t, EPI, IB_ACT_ELU>(p, acc, i0, j0, wi, wj, lane, split_id); break;
     default: epilogue<bf16_t, EPI, IB_ACT_NONE>(p, acc, i0, j0, wi, wj, lane, split_id); break;
   }
   RING_STAMP(4);
@@ -891,7 +895,7 @@ extern "C" int ib_linear_fwd(const void* x, int64_t ldx, const void* w, int64_t 
   if (!x || !w || !y || M <= 0 || N <= 0 || K <= 0 || ldx < K || ldw < K || ldy < N) return IB_E_ARG;
   if ((add_div || add_mod) && seg <= 0) return IB_E_ARG;
   if (z && ldz < N) return IB_E_ARG;
-  if (act < IB_ACT_NONE || act > IB_ACT_SILU) return IB_E_ARG;
+  if (act < IB_ACT_NONE || act > IB_ACT_ELU) return IB_E_ARG;
   GemmParams p{};
   p.A = x; p.lda = ldx; p.B = w; p.ldb = ldw; p.M = (int)M; p.N = (int)N; p.K = (int)K;
   p.C = y; p.ldc = ldy; p.Z = z; p.ldz = ldz; p.bias = bias;
@@ -908,7 +912,7 @@ extern "C" int ib_linear_dgrad(const void* dz, int64_t lddz, const void* w, int6
   if (!dz || !w || !dx || M <= 0 || N <= 0 || K <= 0 || lddz < N || ldw < K || lddx < K) return IB_E_ARG;
   if (addend && ldadd < K) return IB_E_ARG;
   if (act_below != IB_ACT_NONE && (!aux || ldaux < K)) return IB_E_ARG;
-  if (act_below < IB_ACT_NONE || act_below > IB_ACT_SILU) return IB_E_ARG;
+  if (act_below < IB_ACT_NONE || act_below > IB_ACT_ELU) return IB_E_ARG;
   // C[M,K] = sum_n dz[m][n] * w[n][k]:  reduction length N, B(j=k, kk=n) = w[n*ldw + k]  (k-strided)
   GemmParams p{};
   p.A = dz; p.lda = lddz; p.B = w; p.ldb = ldw; p.M = (int)M; p.N = (int)K; p.K = (int)N;

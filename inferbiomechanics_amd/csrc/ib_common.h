@@ -34,15 +34,17 @@ __device__ __forceinline__ float ib_act_fwd(int act, float v) {
     case IB_ACT_TANH: return tanhf(v);
     case IB_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
     case IB_ACT_SILU: return v / (1.f + expf(-v));
+    case IB_ACT_ELU: return v > 0.f ? v : expf(v) - 1.f;
     default: return v;
   }
 }
-// derivative factor given aux (= layer OUTPUT for relu/tanh/sigmoid, PRE-activation for silu)
+// derivative factor given aux (= layer OUTPUT for relu/tanh/sigmoid/elu, PRE-activation for silu)
 __device__ __forceinline__ float ib_act_bwd(int act, float aux) {
   switch (act) {
     case IB_ACT_RELU: return aux > 0.f ? 1.f : 0.f;
     case IB_ACT_TANH: return 1.f - aux * aux;
     case IB_ACT_SIGMOID: return aux * (1.f - aux);
+    case IB_ACT_ELU: return aux > 0.f ? 1.f : aux + 1.f;     // aux = output y = exp(x) - 1 for x <= 0
     case IB_ACT_SILU: {
       float s = 1.f / (1.f + expf(-aux));
       return s * (1.f + aux * (1.f - s));

@@ -19,11 +19,12 @@ template <typename T>
 __global__ __launch_bounds__(256) void regression_loss_partial_kernel(
     const T* __restrict__ o_cop, const T* __restrict__ o_force, const T* __restrict__ o_torque,
     const T* __restrict__ o_wrench, int64_t bs_cop, int64_t bs_force, int64_t bs_torque, int64_t bs_wrench,
+    int fo_cop, int fo_force, int fo_torque, int fo_wrench,      // elements between frames of an output / gradient key
     const float* __restrict__ l_cop, const float* __restrict__ l_force,
     const float* __restrict__ l_torque, const float* __restrict__ l_wrench, const float* __restrict__ comp_w,
     float threshold, T* __restrict__ g_cop, T* __restrict__ g_force, T* __restrict__ g_torque, T* __restrict__ g_wrench,
-    int64_t gs_cop, int64_t gs_force, int64_t gs_torque, int64_t gs_wrench, float* __restrict__ partial, int B,
-    int F) {
+    int64_t gs_cop, int64_t gs_force, int64_t gs_torque, int64_t gs_wrench, int fg_cop, int fg_force, int fg_torque,
+    int fg_wrench, float* __restrict__ partial, int B, int F) {
   __shared__ float red[4][NPART];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float acc[NPART];
@@ -38,11 +39,11 @@ __global__ __launch_bounds__(256) void regression_loss_partial_kernel(
     // ---- force (also feeds the CoP mask and the COM-acc metric)
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
-      of[c] = ib_to_f32(o_force[(int64_t)b * bs_force + f * 6 + c]);
+      of[c] = ib_to_f32(o_force[(int64_t)b * bs_force + f * fo_force + c]);
       lf[c] = l_force[(int64_t)row * 6 + c];
       d6[c] = of[c] - lf[c];
       acc[c] += d6[c] * d6[c];
-      if (g_force) g_force[(int64_t)b * gs_force + f * 6 + c] = ib_from_f32<T>(comp_w[c] * gscale * d6[c]);
+      if (g_force) g_force[(int64_t)b * gs_force + f * fg_force + c] = ib_from_f32<T>(comp_w[c] * gscale * d6[c]);
     }
     float mask[2];
 #pragma unroll
@@ -61,19 +62,19 @@ __global__ __launch_bounds__(256) void regression_loss_partial_kernel(
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
       const float m = mask[c / 3];
-      const float o = ib_to_f32(o_cop[(int64_t)b * bs_cop + f * 6 + c]);
+      const float o = ib_to_f32(o_cop[(int64_t)b * bs_cop + f * fo_cop + c]);
       d6[c] = o * m - l_cop[(int64_t)row * 6 + c] * m;
       acc[6 + c] += d6[c] * d6[c];
-      if (g_cop) g_cop[(int64_t)b * gs_cop + f * 6 + c] = ib_from_f32<T>(comp_w[6 + c] * gscale * d6[c] * m);
+      if (g_cop) g_cop[(int64_t)b * gs_cop + f * fg_cop + c] = ib_from_f32<T>(comp_w[6 + c] * gscale * d6[c] * m);
     }
     if (last)
       acc[32] += sqrtf(d6[0] * d6[0] + d6[1] * d6[1] + d6[2] * d6[2]) + sqrtf(d6[3] * d6[3] + d6[4] * d6[4] + d6[5] * d6[5]);
     // ---- moment
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
-      d6[c] = ib_to_f32(o_torque[(int64_t)b * bs_torque + f * 6 + c]) - l_torque[(int64_t)row * 6 + c];
+      d6[c] = ib_to_f32(o_torque[(int64_t)b * bs_torque + f * fo_torque + c]) - l_torque[(int64_t)row * 6 + c];
       acc[12 + c] += d6[c] * d6[c];
-      if (g_torque) g_torque[(int64_t)b * gs_torque + f * 6 + c] = ib_from_f32<T>(comp_w[12 + c] * gscale * d6[c]);
+      if (g_torque) g_torque[(int64_t)b * gs_torque + f * fg_torque + c] = ib_from_f32<T>(comp_w[12 + c] * gscale * d6[c]);
     }
     if (last)
       acc[31] += sqrtf(d6[0] * d6[0] + d6[1] * d6[1] + d6[2] * d6[2]) + sqrtf(d6[3] * d6[3] + d6[4] * d6[4] + d6[5] * d6[5]);
@@ -81,9 +82,9 @@ __global__ __launch_bounds__(256) void regression_loss_partial_kernel(
     float d12[12];
 #pragma unroll
     for (int c = 0; c < 12; ++c) {
-      d12[c] = ib_to_f32(o_wrench[(int64_t)b * bs_wrench + f * 12 + c]) - l_wrench[(int64_t)row * 12 + c];
+      d12[c] = ib_to_f32(o_wrench[(int64_t)b * bs_wrench + f * fo_wrench + c]) - l_wrench[(int64_t)row * 12 + c];
       acc[18 + c] += d12[c] * d12[c];
-      if (g_wrench) g_wrench[(int64_t)b * gs_wrench + f * 12 + c] = ib_from_f32<T>(comp_w[18 + c] * gscale * d12[c]);
+      if (g_wrench) g_wrench[(int64_t)b * gs_wrench + f * fg_wrench + c] = ib_from_f32<T>(comp_w[18 + c] * gscale * d12[c]);
     }
     if (last) {
       float n0 = 0.f, n1 = 0.f;
@@ -205,18 +206,24 @@ extern "C" size_t ib_regression_loss_workspace(int64_t B, int64_t F) {
   return (size_t)rl_parts(B * F) * NPART * sizeof(float);
 }
 
-extern "C" int ib_regression_loss(const void* o_cop, const void* o_force, const void* o_torque, const void* o_wrench,
-                                  const int64_t* o_bs, const float* l_cop, const float* l_force, const float* l_torque,
-                                  const float* l_wrench, const float* comp_w, float threshold, float* result, void* g_cop,
-                                  void* g_force, void* g_torque, void* g_wrench, const int64_t* g_bs, void* workspace,
-                                  size_t workspace_bytes, int64_t B, int64_t F, int dtype, ib_stream_t stream) {
+extern "C" int ib_regression_loss_strided(const void* o_cop, const void* o_force, const void* o_torque, const void* o_wrench,
+                                          const int64_t* o_bs, const int64_t* o_fs, const float* l_cop,
+                                          const float* l_force, const float* l_torque, const float* l_wrench,
+                                          const float* comp_w, float threshold, float* result, void* g_cop, void* g_force,
+                                          void* g_torque, void* g_wrench, const int64_t* g_bs, const int64_t* g_fs,
+                                          void* workspace, size_t workspace_bytes, int64_t B, int64_t F, int dtype,
+                                          ib_stream_t stream) {
   if (!o_cop || !o_force || !o_torque || !o_wrench || !l_cop || !l_force || !l_torque || !l_wrench || !comp_w || !result)
     return IB_E_ARG;
   if (B <= 0 || F <= 0 || !o_bs) return IB_E_ARG;
   const bool has_g = g_cop || g_force || g_torque || g_wrench;
   if (has_g && (!g_cop || !g_force || !g_torque || !g_wrench || !g_bs)) return IB_E_ARG;
-  const int64_t zero4[4] = {0, 0, 0, 0};
+  const int64_t zero4[4] = {0, 0, 0, 0}, dense[4] = {6, 6, 6, 12};
   const int64_t* gb = has_g ? g_bs : zero4;
+  const int64_t* of = o_fs ? o_fs : dense;
+  const int64_t* gf = g_fs ? g_fs : dense;
+  for (int k = 0; k < 4; ++k)
+    if (of[k] < dense[k] || gf[k] < dense[k]) return IB_E_ARG;
   const int parts = rl_parts(B * F);
   if (!workspace || workspace_bytes < (size_t)parts * NPART * sizeof(float)) return IB_E_WORKSPACE;
   float* partial = reinterpret_cast<float*>(workspace);
@@ -224,14 +231,16 @@ extern "C" int ib_regression_loss(const void* o_cop, const void* o_force, const 
   if (dtype == IB_F32) {
     hipLaunchKernelGGL((regression_loss_partial_kernel<float>), dim3(parts), dim3(256), 0, s, (const float*)o_cop,
                        (const float*)o_force, (const float*)o_torque, (const float*)o_wrench, o_bs[0], o_bs[1], o_bs[2],
-                       o_bs[3], l_cop, l_force, l_torque, l_wrench, comp_w, threshold, (float*)g_cop, (float*)g_force,
-                       (float*)g_torque, (float*)g_wrench, gb[0], gb[1], gb[2], gb[3], partial, (int)B, (int)F);
+                       o_bs[3], (int)of[0], (int)of[1], (int)of[2], (int)of[3], l_cop, l_force, l_torque, l_wrench, comp_w,
+                       threshold, (float*)g_cop, (float*)g_force, (float*)g_torque, (float*)g_wrench, gb[0], gb[1], gb[2],
+                       gb[3], (int)gf[0], (int)gf[1], (int)gf[2], (int)gf[3], partial, (int)B, (int)F);
   } else if (dtype == IB_BF16) {
     hipLaunchKernelGGL((regression_loss_partial_kernel<bf16_t>), dim3(parts), dim3(256), 0, s, (const bf16_t*)o_cop,
                        (const bf16_t*)o_force, (const bf16_t*)o_torque, (const bf16_t*)o_wrench, o_bs[0], o_bs[1],
-                       o_bs[2], o_bs[3], l_cop, l_force, l_torque, l_wrench, comp_w, threshold, (bf16_t*)g_cop,
-                       (bf16_t*)g_force, (bf16_t*)g_torque, (bf16_t*)g_wrench, gb[0], gb[1], gb[2], gb[3], partial,
-                       (int)B, (int)F);
+                       o_bs[2], o_bs[3], (int)of[0], (int)of[1], (int)of[2], (int)of[3], l_cop, l_force, l_torque,
+                       l_wrench, comp_w, threshold, (bf16_t*)g_cop, (bf16_t*)g_force, (bf16_t*)g_torque,
+                       (bf16_t*)g_wrench, gb[0], gb[1], gb[2], gb[3], (int)gf[0], (int)gf[1], (int)gf[2], (int)gf[3],
+                       partial, (int)B, (int)F);
   } else {
     return IB_E_DTYPE;
   }
@@ -239,6 +248,16 @@ extern "C" int ib_regression_loss(const void* o_cop, const void* o_force, const 
   hipLaunchKernelGGL(regression_loss_final_kernel, dim3(1), dim3(64), 0, s, partial, parts, comp_w, result, (int)B, (int)F);
   IB_CHECK_LAUNCH();
   return IB_OK;
+}
+
+extern "C" int ib_regression_loss(const void* o_cop, const void* o_force, const void* o_torque, const void* o_wrench,
+                                  const int64_t* o_bs, const float* l_cop, const float* l_force, const float* l_torque,
+                                  const float* l_wrench, const float* comp_w, float threshold, float* result, void* g_cop,
+                                  void* g_force, void* g_torque, void* g_wrench, const int64_t* g_bs, void* workspace,
+                                  size_t workspace_bytes, int64_t B, int64_t F, int dtype, ib_stream_t stream) {
+  return ib_regression_loss_strided(o_cop, o_force, o_torque, o_wrench, o_bs, nullptr, l_cop, l_force, l_torque, l_wrench,
+                                    comp_w, threshold, result, g_cop, g_force, g_torque, g_wrench, g_bs, nullptr, workspace,
+                                    workspace_bytes, B, F, dtype, stream);
 }
 
 extern "C" size_t ib_mse_loss_workspace(int64_t n) { return (size_t)mse_parts(n) * sizeof(float); }

@@ -269,6 +269,15 @@ class HipTrainer:
             self._static[key] = t
         return t
 
+    def _in_size(self, frames: int) -> int:
+        """width of the regression model's input matrix: fixed by the feedforward ctor, per window length for Groundlink"""
+        m = self.model
+        return m.input_size_for(frames) if hasattr(m, "input_size_for") else m.input_size
+
+    def _out_frames(self, frames: int) -> int:
+        m = self.model
+        return m.output_frames_for(frames) if hasattr(m, "output_frames_for") else m.num_output_frames
+
     # ---- the launch sequence ---------------------------------------------------------------------
     def _launches(self, st: Dict[str, torch.Tensor], cut=None):
         m, plan, dt = self.model, self.plan, self.model.compute_dtype
@@ -305,14 +314,20 @@ class HipTrainer:
             self._br_loss.join()
         else:
             B = st["lab0"].shape[0]
-            x = plan.buf.get("ff.x", (B, m.input_size), dt)
+            frames_in = self._cache.frames if "widx" in st else st["in0"].shape[1]
+            x = plan.buf.get("ff.x", (B, self._in_size(frames_in)), dt)
             if "widx" in st:
                 # cached windows: ONE gather launch fills the model input and the four label tensors
                 hip.gather_windows(self._cache.table, st["widx"], x, [st[f"lab{i}"] for i in range(4)])
             else:
                 hip.concat_keys([st[f"in{i}"] for i in range(len(INPUT_KEY_ORDER))], x)
-            out = plan.forward(x, P)
-            F = m.num_output_frames
+            if hasattr(m, "output_frames_for"):
+                # Groundlink: [B, F', 30] with the four outputs interleaved per frame; the dropout masks are keyed on
+                # the device-resident step counter, so a replayed graph draws fresh masks every step
+                out = plan.forward(x, P, training=m.training, step_dev=self.step_dev)
+            else:
+                out = plan.forward(x, P)
+            F = self._out_frames(frames_in)
             views = m.split_output(out)
             outs = tuple(views[k] for k in LOSS_KEY_ORDER)
             G = plan.buf.get("tr.dout", out.shape, dt)
@@ -362,9 +377,9 @@ class HipTrainer:
                 hip.set_ptrs(self._slots, srcs)
         elif isinstance(batch, tuple) and len(batch) == 3 and batch[0] == "windows":
             _, cache, idx = batch
-            if cache.x_elems != self.model.input_size or cache.out_frames != self.model.num_output_frames:
+            if cache.x_elems != self._in_size(cache.frames) or cache.out_frames != self._out_frames(cache.frames):
                 raise hip.HipError(f"window cache geometry (x {cache.x_elems}, F' {cache.out_frames}) does not match the "
-                                   f"model (input {self.model.input_size}, F' {self.model.num_output_frames})")
+                                   f"model (input {self._in_size(cache.frames)}, F' {self._out_frames(cache.frames)})")
             if self._cache is not cache:
                 self._cache, self._rec, self._sig = cache, None, None      # another table: re-capture
             b = self._sbuf("widx", idx, torch.int64)

@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libib_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "ib_hip.h")
 
 F32, BF16 = 0, 1
-ACT = {"none": 0, "identity": 0, None: 0, "relu": 1, "tanh": 2, "sigmoid": 3, "silu": 4}
+ACT = {"none": 0, "identity": 0, None: 0, "relu": 1, "tanh": 2, "sigmoid": 3, "silu": 4, "elu": 5}
 OPT = {"sgd": 0, "adam": 1, "rmsprop": 2, "adagrad": 3, "adadelta": 4, "adamax": 5}
 OPT_NUM_STATES = {"sgd": 0, "adam": 2, "rmsprop": 1, "adagrad": 1, "adadelta": 2, "adamax": 2}
 
@@ -65,6 +65,8 @@ _SIGS = {
     "ib_regression_loss_workspace": (_sz, [_i64, _i64]),
     "ib_regression_loss": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp,
                                       _vp, _vp, _vp, _sz, _i64, _i64, _c.c_int, _vp]),
+    "ib_regression_loss_strided": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp,
+                                              _vp, _vp, _vp, _vp, _sz, _i64, _i64, _c.c_int, _vp]),
     "ib_mse_loss_workspace": (_sz, [_i64]),
     "ib_mse_loss": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _sz, _i64, _c.c_int, _vp]),
     "ib_mse_loss_partial": (_c.c_int, [_vp, _i64, _vp, _vp, _i64, _vp, _sz, _i64, _i64, _c.c_int, _vp]),
@@ -72,6 +74,9 @@ _SIGS = {
     "ib_optim_step": (_c.c_int, [_c.c_int, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _i32, _vp, _vp, _vp, _vp]),
     "ib_optim_step_sources": (_c.c_int, [_c.c_int, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _i32, _vp, _vp, _vp, _c.c_int, _vp,
                                          _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _f32, _vp, _vp]),
+    "ib_im2col_replicate": (_c.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _c.c_int, _c.c_int, _vp]),
+    "ib_col2im_replicate": (_c.c_int, [_vp, _i64, _vp, _c.c_int, _vp, _i64, _i64, _i64, _c.c_int, _c.c_int, _vp]),
+    "ib_dropout": (_c.c_int, [_vp, _vp, _i64, _f32, _c.c_uint32, _i32, _vp, _c.c_int, _vp]),
     "ib_gather_windows": (_c.c_int, [_vp, _i64, _i64, _vp, _i64, _vp, _i64, _c.c_int, _vp, _vp, _vp]),
     "ib_gather_rows": (_c.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _c.c_int, _vp]),
     "ib_mlp_chain_supported": (_c.c_int, [_i64, _i64, _c.c_int]),
@@ -788,12 +793,14 @@ def regression_loss_workspace_bytes(B, F) -> int:
 
 
 def _bfc(t: torch.Tensor, name: str, dt, C: int):
-    """[B,F,C] tensor whose (F,C) block is contiguous -> batch stride."""
+    """[B,F,C] tensor with unit component stride -> (batch stride, frame stride).  Dense keys have frame stride C;
+    Groundlink's interleaved output (a slice of the last dim of [B,F,30]) has frame stride 30."""
     _req(t, name, dt, 3)
     B, F, c = t.shape
-    if c != C or t.stride(2) != 1 or (F > 1 and t.stride(1) != C):
-        raise HipError(f"{name}: expected [B,F,{C}] with contiguous (F,C) block, got {tuple(t.shape)} strides {t.stride()}")
-    return t.stride(0) if B > 1 else F * C
+    if c != C or t.stride(2) != 1 or (F > 1 and t.stride(1) < C):
+        raise HipError(f"{name}: expected [B,F,{C}] with unit component stride, got {tuple(t.shape)} strides {t.stride()}")
+    fs = t.stride(1) if F > 1 else C
+    return (t.stride(0) if B > 1 else F * fs), fs
 
 
 def regression_loss(outs, labels, comp_w, result, workspace, grads=None, threshold=10.0):
@@ -801,7 +808,9 @@ def regression_loss(outs, labels, comp_w, result, workspace, grads=None, thresho
     dt = outs[0].dtype
     B, F, _ = outs[0].shape
     Cs = (6, 6, 6, 12)
-    obs = (ctypes.c_int64 * 4)(*[_bfc(t, f"out[{i}]", dt, Cs[i]) for i, t in enumerate(outs)])
+    og = [_bfc(t, f"out[{i}]", dt, Cs[i]) for i, t in enumerate(outs)]
+    obs = (ctypes.c_int64 * 4)(*[g_[0] for g_ in og])
+    ofs = (ctypes.c_int64 * 4)(*[g_[1] for g_ in og])
     for i, t in enumerate(outs):
         if tuple(t.shape) != (B, F, Cs[i]):
             raise HipError(f"out[{i}] must be [{B},{F},{Cs[i]}], got {tuple(t.shape)}")
@@ -809,10 +818,12 @@ def regression_loss(outs, labels, comp_w, result, workspace, grads=None, thresho
         _req(t, f"label[{i}]", torch.float32, 3)
         if tuple(t.shape) != (B, F, Cs[i]) or not t.is_contiguous():
             raise HipError(f"label[{i}] must be contiguous fp32 [{B},{F},{Cs[i]}], got {tuple(t.shape)}")
-    gbs = None
+    gbs = gfs = None
     gp = [None] * 4
     if grads is not None:
-        gbs = (ctypes.c_int64 * 4)(*[_bfc(t, f"grad[{i}]", dt, Cs[i]) for i, t in enumerate(grads)])
+        gg = [_bfc(t, f"grad[{i}]", dt, Cs[i]) for i, t in enumerate(grads)]
+        gbs = (ctypes.c_int64 * 4)(*[g_[0] for g_ in gg])
+        gfs = (ctypes.c_int64 * 4)(*[g_[1] for g_ in gg])
         gp = [t.data_ptr() for t in grads]
         for i, t in enumerate(grads):
             if tuple(t.shape) != (B, F, Cs[i]):
@@ -824,11 +835,12 @@ def regression_loss(outs, labels, comp_w, result, workspace, grads=None, thresho
     wsb = workspace.numel() * workspace.element_size()
     if wsb < regression_loss_workspace_bytes(B, F):
         raise HipError("regression_loss: workspace too small")
-    _check(lib().ib_regression_loss(_ptr(outs[0]), _ptr(outs[1]), _ptr(outs[2]), _ptr(outs[3]), ctypes.cast(obs, ctypes.c_void_p),
-                                    _ptr(labels[0]), _ptr(labels[1]), _ptr(labels[2]), _ptr(labels[3]), _ptr(comp_w),
-                                    float(threshold), _ptr(result), gp[0], gp[1], gp[2], gp[3],
-                                    None if gbs is None else ctypes.cast(gbs, ctypes.c_void_p), _ptr(workspace),
-                                    wsb, B, F, dtype_code(dt), stream_ptr()), "ib_regression_loss")
+    cv = lambda a: None if a is None else ctypes.cast(a, ctypes.c_void_p)
+    _check(lib().ib_regression_loss_strided(_ptr(outs[0]), _ptr(outs[1]), _ptr(outs[2]), _ptr(outs[3]), cv(obs), cv(ofs),
+                                            _ptr(labels[0]), _ptr(labels[1]), _ptr(labels[2]), _ptr(labels[3]),
+                                            _ptr(comp_w), float(threshold), _ptr(result), gp[0], gp[1], gp[2], gp[3],
+                                            cv(gbs), cv(gfs), _ptr(workspace), wsb, B, F, dtype_code(dt), stream_ptr()),
+           "ib_regression_loss_strided")
     return result
 
 
@@ -970,6 +982,45 @@ def gather_rows(table, idx, out):
     _check(lib().ib_gather_rows(_ptr(table), _ptr(idx), _ptr(out), B, dim, table.shape[0], dtype_code(out.dtype),
                                 stream_ptr()), "ib_gather_rows")
     return out
+
+
+def im2col_replicate(x, col, N: int, F: int, k: int):
+    """x: contiguous [N*F, C]; col: [N*F, >= C*k] (row pitch may be padded; pad columns are zero-filled)"""
+    dt = x.dtype
+    M, C, ldx = _mat(x, "x", dt)
+    Mc, Kc, ldc = _mat(col, "col", dt)
+    if M != N * F or Mc != M or Kc < C * k or not x.is_contiguous():
+        raise HipError("im2col_replicate: shapes")
+    _check(lib().ib_im2col_replicate(_ptr(x), _ptr(col), ldc, N, F, C, int(k), dtype_code(dt), stream_ptr()),
+           "ib_im2col_replicate")
+    return col
+
+
+def col2im_replicate(dcol, dx, N: int, F: int, k: int, act="none", aux=None):
+    dt = dcol.dtype
+    M, Kc, ldc = _mat(dcol, "dcol", dt)
+    Mx, C, _ = _mat(dx, "dx", dt)
+    if M != N * F or Mx != M or Kc < C * k or not dx.is_contiguous():
+        raise HipError("col2im_replicate: shapes")
+    if aux is not None:
+        _req(aux, "aux", dt)
+        if aux.shape != dx.shape or not aux.is_contiguous():
+            raise HipError("col2im_replicate: aux must match dx")
+    _check(lib().ib_col2im_replicate(_ptr(dcol), ldc, _ptr(aux), ACT[act], _ptr(dx), N, F, C, int(k), dtype_code(dt),
+                                     stream_ptr()), "ib_col2im_replicate")
+    return dx
+
+
+def dropout(x, y, p: float, seed: int, step: int = 0, step_dev=None):
+    """y = x * mask / (1 - p); the same (seed, step) reproduces the mask (apply to the gradient in the backward)"""
+    _req(x, "x"); _req(y, "y", x.dtype)
+    if x.numel() != y.numel() or not x.is_contiguous() or not y.is_contiguous():
+        raise HipError("dropout: contiguous tensors of equal size required")
+    if step_dev is not None:
+        _req(step_dev, "step_dev", torch.int32)
+    _check(lib().ib_dropout(_ptr(x), _ptr(y), x.numel(), float(p), int(seed) & 0xFFFFFFFF, int(step), _ptr(step_dev),
+                            dtype_code(x.dtype), stream_ptr()), "ib_dropout")
+    return y
 
 
 def gather_windows(table, idx, x_out, labels):

@@ -207,6 +207,147 @@ class DenseStackPlan:
         return dx
 
 
+class GroundlinkPlan:
+    """Groundlink (src/models/Groundlink.py:34-62): four Conv1d(k=7, replicate) + ELU over the frames of a window, then per
+    frame [Dropout, Linear, ELU] x2 and [Dropout, Linear(no bias)].  A convolution = im2col (clamped-frame gather) + the
+    fused Linear+bias+ELU GEMM over `weight.view(C_out, C_in*k)`; its backward = wgrad over the saved im2col, dgrad into
+    the im2col gradient, col2im with the ELU derivative of the layer below fused.  Dropout is a counter-based mask
+    (seed, step, element) regenerated in the backward.  The first convolution's reduction (177 x 7 = 1239) is not a
+    multiple of 8: its im2col rows are pitched to 1240 and the forward GEMM reads a zero-padded copy of the weight, so
+    every operand piece stays a 16-byte load."""
+
+    CONV = (1, 4, 7, 10)
+    FC = (2, 5)
+
+    def __init__(self, output_data_format: str, dtype, device, fc_dropout: float = 0.2, k: int = 7, seed: int = 0x1B3):
+        self.fmt, self.dtype, self.p, self.k, self.seed = output_data_format, dtype, float(fc_dropout), k, seed
+        self.buf = Buffers(device)
+        self.ctx = None
+
+    def _conv_weight(self, li: int, w: torch.Tensor) -> torch.Tensor:
+        co, ci, k = w.shape
+        K = ci * k
+        Kp = (K + 7) // 8 * 8
+        if Kp == K:
+            return w.view(co, K)
+        wp = self.buf.get(f"gl.wp{li}", (co, Kp), self.dtype)
+        wp[:, K:].zero_()
+        wp[:, :K].copy_(w.view(co, K))
+        return wp
+
+    def forward(self, x: torch.Tensor, P: ParamSource, out: Optional[torch.Tensor] = None, training: bool = False,
+                step: int = 0, step_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """x: [N, F*C0] (frame-major concat of the input keys = channels-last rows [N*F, C0]) -> [N, F', 30]"""
+        g, dt, k = self.buf.get, self.dtype, self.k
+        c0 = P.w("cnn.1.weight").shape[1]
+        N, F = x.shape[0], x.shape[1] // c0
+        if F * c0 != x.shape[1]:
+            raise hip.HipError(f"groundlink: input width {x.shape[1]} is not a multiple of {c0} channels")
+        h = x.view(N * F, c0)
+        convs = []
+        for li, idx in enumerate(self.CONV):
+            w = P.w(f"cnn.{idx}.weight")
+            co, ci, _ = w.shape
+            w2 = self._conv_weight(li, w)
+            col = g(f"gl.col{li}", (N * F, w2.shape[1]), dt)
+            hip.im2col_replicate(h, col, N, F, k)
+            y = g(f"gl.y{li}", (N * F, co), dt)
+            hip.linear_fwd(col, w2, P.v(f"cnn.{idx}.bias"), y, act="elu")
+            convs.append((col, y))
+            h = y
+        last = self.fmt != "all_frames"
+        R = N if last else N * F
+        C = h.shape[1]
+        if last:                                                   # Groundlink.py:148: only the last frame feeds fc
+            hin = g("gl.hin", (N, C), dt)
+            hin.copy_(h.view(N, F, C)[:, -1, :])
+        else:
+            hin = h
+        drop = training and self.p > 0.0
+        fcs = []
+        a = hin
+        for j, idx in enumerate(self.FC):
+            d = a
+            if drop:
+                d = g(f"gl.d{j}", (R, C), dt)
+                hip.dropout(a, d, self.p, self.seed + j, step, step_dev)
+            y = g(f"gl.a{j}", (R, C), dt)
+            hip.linear_fwd(d, P.w(f"fc.{idx}.weight"), P.v(f"fc.{idx}.bias"), y, act="elu")
+            fcs.append((d, y))
+            a = y
+        d = a
+        if drop:
+            d = g("gl.d2", (R, C), dt)
+            hip.dropout(a, d, self.p, self.seed + 2, step, step_dev)
+        Fo = 1 if last else F
+        out = out if out is not None else g("gl.out", (N, Fo, 30), dt)
+        hip.linear_fwd(d, P.w("fc.8.weight"), None, out.view(R, 30))
+        self.ctx = (convs, hin, fcs, d, N, F, drop, step, step_dev)
+        return out
+
+    def ready_order(self) -> List[str]:
+        o = ["fc.8.weight"]
+        for idx in reversed(self.FC):
+            o += [f"fc.{idx}.weight", f"fc.{idx}.bias"]
+        for idx in reversed(self.CONV):
+            o += [f"cnn.{idx}.weight", f"cnn.{idx}.bias"]
+        return o
+
+    def backward(self, dout: torch.Tensor, P: ParamSource, accumulate=False):
+        convs, hin, fcs, d_last, N, F, drop, step, step_dev = self.ctx
+        g, dt, k = self.buf.get, self.dtype, self.k
+        last = self.fmt != "all_frames"
+        R = N if last else N * F
+        C = d_last.shape[1]
+        dz = dout.reshape(R, 30)
+        # fc.8 (no bias), then back through [ELU, Dropout] of fc.5 and fc.2.  The ELU derivative is fused into the dgrad
+        # epilogue; it is elementwise, so it commutes with the dropout mask applied right after.
+        _wgrad(self.buf, dz, d_last, P.g("fc.8.weight"), accumulate, ws_tag="gl.ws8")
+        P.ready("fc.8.weight")
+        wname = "fc.8.weight"
+        for j in range(len(self.FC) - 1, -1, -1):
+            idx = self.FC[j]
+            d_in, y = fcs[j]
+            dy = g(f"gl.da{j}", (R, C), dt)
+            hip.linear_dgrad(dz, P.w(wname), dy, act_below="elu", aux=y)
+            if drop:
+                hip.dropout(dy, dy, self.p, self.seed + j + 1, step, step_dev)
+            dz = dy
+            wname = f"fc.{idx}.weight"
+            _wgrad(self.buf, dz, d_in, P.g(wname), accumulate, ws_tag=f"gl.wsf{j}")
+            P.ready(wname)
+            _colsum(self.buf, f"gl.bf{j}", dz, P.g(f"fc.{idx}.bias"), accumulate)
+            P.ready(f"fc.{idx}.bias")
+        # into the last convolution's output: (dz W_fc2) x ELU'(y3) [x dropout mask 0]
+        dh = g("gl.dh", (R, C), dt)
+        hip.linear_dgrad(dz, P.w(wname), dh, act_below="elu", aux=hin)
+        if drop:
+            hip.dropout(dh, dh, self.p, self.seed, step, step_dev)
+        if last:                                                   # frames before the last one get no gradient from fc
+            dz = g("gl.dzc3", (N * F, C), dt)
+            dz.zero_()
+            dz.view(N, F, C)[:, -1, :].copy_(dh)
+        else:
+            dz = dh
+        for li in range(len(self.CONV) - 1, -1, -1):
+            idx = self.CONV[li]
+            col, y = convs[li]
+            w = P.w(f"cnn.{idx}.weight")
+            co, ci, _ = w.shape
+            K = ci * k
+            _wgrad(self.buf, dz, col[:, :K], P.g(f"cnn.{idx}.weight").view(co, K), accumulate, ws_tag=f"gl.wsc{li}")
+            P.ready(f"cnn.{idx}.weight")
+            _colsum(self.buf, f"gl.bc{li}", dz, P.g(f"cnn.{idx}.bias"), accumulate)
+            P.ready(f"cnn.{idx}.bias")
+            if li > 0:
+                dcol = g(f"gl.dcol{li}", (N * F, K), dt)
+                hip.linear_dgrad(dz, w.view(co, K), dcol)
+                nxt = g(f"gl.dzc{li - 1}", (N * F, ci), dt)
+                hip.col2im_replicate(dcol, nxt, N, F, k, act="elu", aux=convs[li - 1][1])
+                dz = nxt
+        return None
+
+
 # ------------------------------------------------------------------------------------------------
 class TransformerLayerPlan:
     """Post-norm encoder layer (TransformerBaseline.py:24-38): x=LN1(x+MHA(x)); x=LN2(x+W2 relu(W1 x))."""

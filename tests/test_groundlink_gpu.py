@@ -1,0 +1,290 @@
+"""Groundlink on the HIP path: the convolution helpers against plain torch, the model against the
+golden vectors of the real reference class (eval mode) and the float64 oracle, train-mode dropout consistency, and the
+fused trainer step."""
+import argparse
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as Fn
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+from oracle import ref_cpu as R  # noqa: E402
+from oracle.fixture_inputs import GL_CASES, det_state, ff_labels, gl_inputs  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from inferbiomechanics_amd import hip
+    hip.lib()
+
+
+def close(actual, expected, rtol, what="", atol=0.0):
+    a = torch.as_tensor(np.asarray(actual.detach().cpu().double() if isinstance(actual, torch.Tensor) else actual),
+                        dtype=torch.float64)
+    e = torch.as_tensor(np.asarray(expected.detach().cpu().double() if isinstance(expected, torch.Tensor) else expected),
+                        dtype=torch.float64)
+    assert a.shape == e.shape, (what, a.shape, e.shape)
+    assert torch.isfinite(a).all(), f"{what}: non-finite"
+    err = (a - e).abs().max().item() if a.numel() else 0.0
+    ref = max(e.abs().max().item(), 1e-30) if e.numel() else 1.0
+    assert err <= atol + rtol * ref, f"{what}: max err {err:.3e} > {atol:.1e} + {rtol:.1e} * {ref:.3e}"
+
+
+def train_args():
+    return argparse.Namespace(predict_grf_components=list(range(6)), predict_cop_components=list(range(6)),
+                              predict_moment_components=list(range(6)), predict_wrench_components=list(range(12)))
+
+
+def load_det(module, seed0=5.0):
+    sd = module.state_dict()
+    new = det_state({k: tuple(v.shape) for k, v in sd.items()}, seed0)
+    module.load_state_dict({k: v.to(sd[k].dtype) for k, v in new.items()})
+
+
+def torch_im2col(x, N, F, k):
+    """[N*F, C] channels-last -> [N*F, C*k] (channel-major, tap-minor = Conv1d weight.view(Co, Ci*k) order)"""
+    C = x.shape[1]
+    xp = Fn.pad(x.view(N, F, C).permute(0, 2, 1), (k // 2, k // 2), mode="replicate")      # [N, C, F + k - 1]
+    return xp.unfold(2, k, 1).permute(0, 2, 1, 3).reshape(N * F, C * k)                     # [N, F, C, k]
+
+
+@pytest.mark.parametrize("N,F,C,k,pitch", [(3, 10, 177, 7, 1240), (2, 5, 128, 7, 896), (4, 1, 16, 3, 48), (2, 3, 8, 7, 64)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_im2col_and_col2im_replicate(N, F, C, k, pitch, dtype):
+    """gather = exact copy (bit-equal to torch's replicate pad + unfold); scatter = the gather's transpose in a fixed
+    order, with the activation derivative of the layer below fused"""
+    from inferbiomechanics_amd import hip
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(N * F, C, generator=g).to(DEV, dtype)
+    col = torch.full((N * F, pitch), 7.0, device=DEV, dtype=dtype)
+    hip.im2col_replicate(x, col, N, F, k)
+    exp = torch_im2col(x.float(), N, F, k)
+    assert torch.equal(col[:, :C * k].float(), exp)
+    assert (col[:, C * k:] == 0).all()
+    # col2im: gradient of the gather
+    dcol = torch.randn(N * F, C * k, generator=g).to(DEV, dtype)
+    aux = torch.randn(N * F, C, generator=g).to(DEV, dtype)
+    xr = x.float().clone().requires_grad_(True)
+    (torch_im2col(xr, N, F, k) * dcol.float()).sum().backward()
+    dx = torch.empty_like(x)
+    hip.col2im_replicate(dcol, dx, N, F, k)
+    close(dx, xr.grad, 1e-5 if dtype == torch.float32 else 8e-3, "col2im")
+    hip.col2im_replicate(dcol, dx, N, F, k, act="elu", aux=aux)
+    af = aux.float()
+    close(dx, xr.grad * torch.where(af > 0, torch.ones_like(af), af + 1.0), 1e-5 if dtype == torch.float32 else 8e-3,
+          "col2im x elu'")
+
+
+@pytest.mark.parametrize("dtype,rt", [(torch.float32, 2e-5), (torch.bfloat16, 1.5e-2)])
+def test_conv1d_as_im2col_gemm_matches_torch(dtype, rt):
+    """Conv1d(k=7, padding_mode='replicate') + ELU = im2col + fused Linear/bias/ELU GEMM over weight.view(Co, Ci*k)"""
+    from inferbiomechanics_amd import hip
+    N, F, Ci, Co, k = 4, 10, 177, 128, 7
+    g = torch.Generator().manual_seed(5)
+    conv = torch.nn.Conv1d(Ci, Co, k, padding=k // 2, padding_mode="replicate")
+    x = torch.randn(N, F, Ci, generator=g)
+    exp = Fn.elu(conv(x.permute(0, 2, 1))).permute(0, 2, 1).reshape(N * F, Co)
+    K, Kp = Ci * k, (Ci * k + 7) // 8 * 8
+    wp = torch.zeros(Co, Kp, device=DEV, dtype=dtype)
+    wp[:, :K] = conv.weight.detach().view(Co, K).to(DEV, dtype)
+    col = torch.empty(N * F, Kp, device=DEV, dtype=dtype)
+    hip.im2col_replicate(x.reshape(N * F, Ci).to(DEV, dtype), col, N, F, k)
+    y = torch.empty(N * F, Co, device=DEV, dtype=dtype)
+    hip.linear_fwd(col, wp, conv.bias.detach().to(DEV), y, act="elu")
+    close(y, exp, rt, "conv+elu")
+    # unpadded weight view (odd row pitch): the GEMM's scalar-piece path gives the same numbers
+    y2 = torch.empty_like(y)
+    hip.linear_fwd(col[:, :K], conv.weight.detach().view(Co, K).to(DEV, dtype).contiguous(), conv.bias.detach().to(DEV), y2,
+                   act="elu")
+    close(y2, exp, rt, "conv+elu (unpadded)")
+    # ELU derivative through the dgrad epilogue: aux = the layer's OUTPUT
+    dz = torch.randn(N * F, 64, generator=g).to(DEV, dtype)
+    w = (torch.randn(64, Co, generator=g) / 8).to(DEV, dtype)
+    dx = torch.empty(N * F, Co, device=DEV, dtype=dtype)
+    hip.linear_dgrad(dz, w, dx, act_below="elu", aux=y)
+    yf = y.float()
+    close(dx, (dz.float() @ w.float()) * torch.where(yf > 0, torch.ones_like(yf), yf + 1.0), rt, "dgrad x elu'")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_dropout_mask_is_reproducible_and_scaled(dtype):
+    from inferbiomechanics_amd import hip
+    n, p = 1 << 20, 0.2
+    x = torch.ones(n, device=DEV, dtype=dtype)
+    y1, y2, y3, y4 = (torch.empty_like(x) for _ in range(4))
+    hip.dropout(x, y1, p, seed=11, step=5)
+    hip.dropout(x, y2, p, seed=11, step=5)
+    hip.dropout(x, y3, p, seed=11, step=6)
+    hip.dropout(x, y4, p, seed=12, step=5)
+    assert torch.equal(y1, y2) and not torch.equal(y1, y3) and not torch.equal(y1, y4)
+    kept = (y1 != 0)
+    assert abs(kept.float().mean().item() - (1 - p)) < 2e-3                       # 1M draws: sigma = 4e-4
+    close(y1[kept], torch.full((int(kept.sum()),), 1 / (1 - p)), 4e-3 if dtype == torch.bfloat16 else 1e-6, "scale")
+    # masks of different steps / seeds are independent: joint keep rate = (1-p)^2
+    assert abs(((y1 != 0) & (y3 != 0)).float().mean().item() - (1 - p) ** 2) < 3e-3
+    assert abs(((y1 != 0) & (y4 != 0)).float().mean().item() - (1 - p) ** 2) < 3e-3
+    # the device-resident step counter overrides the host value (captured graphs replay with fresh masks)
+    sd = torch.tensor([6], dtype=torch.int32, device=DEV)
+    hip.dropout(x, y2, p, seed=11, step=0, step_dev=sd)
+    assert torch.equal(y2, y3)
+    # in place (the backward applies the mask to the gradient in place)
+    z = x.clone()
+    hip.dropout(z, z, p, seed=11, step=5)
+    assert torch.equal(z, y1)
+    hip.dropout(x, y2, 0.0, seed=1)
+    assert torch.equal(y2, x)
+
+
+@pytest.mark.parametrize("name,fmt,F", GL_CASES)
+def test_groundlink_matches_reference_golden(golden_dir, name, fmt, F):
+    """eval mode (dropout off), fp32: outputs, the loss through the evaluator, every parameter gradient -- against
+    the vectors generated from the real reference class (oracle/make_golden.py:gen_groundlink)"""
+    from inferbiomechanics_amd.loss.RegressionLossEvaluator import RegressionLossEvaluator
+    from inferbiomechanics_amd.models.Groundlink import Groundlink
+    g = np.load(os.path.join(golden_dir, f"gl_{name}.npz"))
+    model = Groundlink(23, 12, 10, fmt, device=DEV)
+    model.eval()
+    load_det(model)
+    Fo = F if fmt == "all_frames" else 1
+    out = model(gl_inputs(3, F))
+    for k, v in out.items():
+        assert v.shape == g["out/" + k].shape
+        close(v, g["out/" + k], 1e-3, "out/" + k)
+    ev = RegressionLossEvaluator(dataset=None, split="train", device=DEV)
+    loss = ev({}, out, ff_labels(3, Fo), [], [], train_args())
+    close(loss, g["loss"], 1e-4, "loss")
+    loss.backward()
+    for k, p in model.named_parameters():
+        gn = float(g["gnorm/" + k])
+        close(p.grad.norm(), g["gnorm/" + k], 1e-3, "gnorm/" + k)
+        close(p.grad.reshape(-1)[:64], g["gslice/" + k], 1e-3, "gslice/" + k, atol=1e-5 * gn)
+
+
+@pytest.mark.parametrize("fmt", ["all_frames", "last_frame"])
+def test_groundlink_bf16_close_to_oracle(fmt):
+    from inferbiomechanics_amd.models.Groundlink import Groundlink
+    model = Groundlink(23, 12, 10, fmt, device=DEV, compute_dtype=torch.bfloat16)
+    model.eval()
+    load_det(model)
+    inputs = gl_inputs(5, 12)
+    out = model(inputs)
+    sd = {k: v.detach().cpu().double().requires_grad_(True) for k, v in model.state_dict().items()}
+    exp = R.groundlink_forward(sd, {k: v.double() for k, v in inputs.items()}, fmt)
+    for k in exp:
+        close(out[k], exp[k].detach(), 3e-2, "bf16 " + k)      # bf16 storage: 8 significant bits
+    torch.cat([v.reshape(5, -1) for v in out.values()], 1).float().sum().backward()
+    torch.cat([v.reshape(5, -1) for v in exp.values()], 1).sum().backward()
+    for k, p in model.named_parameters():
+        close(p.grad, sd[k].grad, 4e-2, "bf16 grad " + k)
+
+
+def test_groundlink_default_init_follows_the_reference_recipe():
+    """xavier-normal with the relu gain on every layer an ELU follows, zero biases; fc.8 keeps the Linear default
+    (Groundlink.py:79-103)"""
+    from inferbiomechanics_amd.models.Groundlink import Groundlink
+    torch.manual_seed(0)
+    m = Groundlink(23, 12, 10)
+    sd = m.state_dict()
+    for k, shp in R.groundlink_param_shapes().items():
+        v = sd[k]
+        if k.endswith("bias"):
+            assert (v == 0).all()
+        elif k != "fc.8.weight":
+            rf = shp[2] if len(shp) == 3 else 1
+            std = (2.0 ** 0.5) * (2.0 / ((shp[0] + shp[1]) * rf)) ** 0.5
+            assert abs(v.std().item() / std - 1) < 0.05, k
+    assert sd["fc.8.weight"].abs().max().item() <= 1 / 16 + 1e-6        # kaiming-uniform(a=sqrt 5): U(-1/sqrt(256), ..)
+
+
+@pytest.mark.parametrize("fmt", ["all_frames", "last_frame"])
+def test_groundlink_train_mode_dropout_is_consistent(fmt):
+    """train mode: the backward regenerates the forward's masks.  With masks m_j recovered from the plan's own buffers,
+    a float64 restatement (oracle forward with those masks applied) must reproduce outputs and gradients."""
+    from inferbiomechanics_amd.models.Groundlink import Groundlink
+    model = Groundlink(23, 12, 10, fmt, device=DEV)
+    model.train()
+    load_det(model)
+    inputs = gl_inputs(3, 10)
+    out = model(inputs)
+    plan = model._plan
+    convs, hin, fcs, d_last, N, F, drop, step, _ = plan.ctx
+    assert drop
+    keep = 1.0 / (1.0 - model.fc_dropout)
+    masks = []
+    for src, dst in ((hin, fcs[0][0]), (fcs[0][1], fcs[1][0]), (fcs[1][1], d_last)):
+        m = (dst != 0) | (src == 0)
+        close(dst, src * m * keep, 1e-6, "dropout output")
+        assert 0.7 < m.float().mean().item() < 0.9
+        masks.append(m.cpu().double() * keep)
+    assert not torch.equal(masks[0], masks[1]) and not torch.equal(masks[1], masks[2])
+    sd = {k: v.detach().cpu().double().requires_grad_(True) for k, v in model.state_dict().items()}
+    # float64 restatement with the recovered masks
+    from inferbiomechanics_amd.data.AddBiomechanicsDataset import INPUT_KEY_ORDER
+    x = torch.cat([inputs[k].double() for k in INPUT_KEY_ORDER], -1)                  # [N, F, C]
+    h = x
+    for i in (1, 4, 7, 10):
+        h = R.act("elu", R.conv1d_replicate(h, sd[f"cnn.{i}.weight"], sd[f"cnn.{i}.bias"]))
+    if fmt != "all_frames":
+        h = h[:, -1:, :]
+    R_, C = masks[0].shape
+    h = h.reshape(R_, C)
+    h = R.act("elu", (h * masks[0]) @ sd["fc.2.weight"].T + sd["fc.2.bias"])
+    h = R.act("elu", (h * masks[1]) @ sd["fc.5.weight"].T + sd["fc.5.bias"])
+    y = ((h * masks[2]) @ sd["fc.8.weight"].T).reshape(3, -1, 30)
+    got = torch.cat([out[k] for k in ('groundContactCenterOfPressureInRootFrame', 'groundContactForceInRootFrame',
+                                      'groundContactTorqueInRootFrame', 'groundContactWrenchesInRootFrame')], -1)
+    close(got, y.detach(), 1e-3, "train-mode output")
+    wsum = torch.linspace(0.5, 1.5, y.numel(), dtype=torch.float64).reshape(y.shape)
+    (got * wsum.to(DEV, torch.float32)).sum().backward()
+    (y * wsum).sum().backward()
+    for k, p in model.named_parameters():
+        close(p.grad, sd[k].grad, 1e-3, "train-mode grad " + k, atol=1e-5 * float(sd[k].grad.norm()))
+    # a second forward draws other masks
+    first = d_last.clone()
+    model(inputs)
+    assert model._plan.ctx[7] != step and not torch.equal(model._plan.ctx[3], first)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_groundlink_fused_trainer_matches_module_path(dtype):
+    """HipTrainer (captured graph, fused optimizer) against forward -> evaluator -> backward -> torch.optim on the module
+    path, eval-mode arithmetic (dropout 0) so both see the same function; then train mode: finite loss, masks change
+    from step to step under graph replay"""
+    from inferbiomechanics_amd.engine import HipTrainer
+    from inferbiomechanics_amd.loss.RegressionLossEvaluator import RegressionLossEvaluator
+    from inferbiomechanics_amd.models.Groundlink import Groundlink
+    inputs, labels = gl_inputs(8, 10), ff_labels(8, 10)
+    a = Groundlink(23, 12, 10, "all_frames", fc_dropout=0.0, device=DEV, compute_dtype=dtype)
+    b = Groundlink(23, 12, 10, "all_frames", fc_dropout=0.0, device=DEV, compute_dtype=dtype)
+    load_det(a)
+    load_det(b)
+    tr = HipTrainer(a, "regression", "sgd", 1e-3, args=train_args())
+    opt = torch.optim.SGD(b.parameters(), lr=1e-3)
+    ev = RegressionLossEvaluator(dataset=None, split="train", device=DEV)
+    for it in range(4):                         # steps 3.. replay the captured graph
+        la = tr.step((inputs, labels))
+        opt.zero_grad()
+        lb = ev({}, b(inputs), labels, [], [], train_args())
+        lb.backward()
+        opt.step()
+        close(la, lb, 2e-5 if dtype == torch.float32 else 2e-2, f"loss step {it}")
+    pa, pb = dict(a.named_parameters()), dict(b.named_parameters())
+    p0 = det_state({k: tuple(v.shape) for k, v in a.state_dict().items()}, 5.0)
+    for k in pa:
+        mv = (pb[k].detach().cpu().double() - p0[k]).abs().max().item()
+        close(pa[k], pb[k], 0, "param " + k, atol=(1e-4 if dtype == torch.float32 else 0.15) * mv + 1e-9)
+    # train mode with dropout under graph replay
+    c = Groundlink(23, 12, 10, "all_frames", device=DEV, compute_dtype=dtype)
+    load_det(c)
+    c.train()
+    tr = HipTrainer(c, "regression", "sgd", 0.0, args=train_args())       # lr 0: the same function every step
+    losses = [float(tr.step((inputs, labels))) for _ in range(6)]
+    assert all(np.isfinite(losses)) and len(set(losses)) == 6             # fresh masks per step (device step counter)

@@ -36,7 +36,7 @@ def test_feedforward_plan_plumbing(dry):
             loss.backward()
             assert all(p.grad is not None and p.grad.shape == p.shape for p in m.parameters())
     names = dry.lib().calls
-    assert "ib_concat_keys" in names and "ib_linear_wgrad" in names and "ib_regression_loss" in names
+    assert "ib_concat_keys" in names and "ib_linear_wgrad" in names and "ib_regression_loss_strided" in names
 
 
 def test_transformer_layer_plumbing(dry):
@@ -183,4 +183,39 @@ def test_window_cache_trainer_plumbing(dry):
     dry.lib().calls.clear()
     tr.step_windows(cache, next(cache.batches(8)))
     names = dry.lib().calls
-    assert names[0] == "ib_gather_windows" and "ib_concat_keys" not in names and "ib_regression_loss" in names
+    assert names[0] == "ib_gather_windows" and "ib_concat_keys" not in names and "ib_regression_loss_strided" in names
+
+
+def test_groundlink_plumbing_registry_and_state_dict(dry):
+    """reference constructor / parameter names (src/models/Groundlink.py:20,34-62), both output formats, autograd path and
+    fused-trainer path (dropout keyed on the device step counter)"""
+    from inferbiomechanics_amd.cli.abstract_command import AbstractCommand
+    from inferbiomechanics_amd.engine import HipTrainer
+    from inferbiomechanics_amd.loss.RegressionLossEvaluator import RegressionLossEvaluator
+    from inferbiomechanics_amd.models.Groundlink import Groundlink
+    from oracle.fixture_inputs import gl_inputs
+    from oracle.ref_cpu import groundlink_param_shapes
+    for fmt, Fo in (("all_frames", 10), ("last_frame", 1)):
+        for dt in (torch.float32, torch.bfloat16):
+            m = Groundlink(23, 12, 10, output_data_format=fmt, compute_dtype=dt)
+            assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == groundlink_param_shapes(23, 12, 10)
+            m.train()
+            out = m(gl_inputs(3, 10, 23, 10))
+            assert out['groundContactWrenchesInRootFrame'].shape == (3, Fo, 12)
+            labels = {k: torch.zeros_like(v, dtype=torch.float32) for k, v in out.items()}
+            RegressionLossEvaluator(None, 'train', device='cpu')({}, out, labels, [], [], targs()).backward()
+            assert all(p.grad is not None and p.grad.shape == p.shape for p in m.parameters())
+    names = dry.lib().calls
+    assert "ib_im2col_replicate" in names and "ib_col2im_replicate" in names and "ib_dropout" in names
+    m = AbstractCommand().get_model(23, 2, model_type='groundlink', root_history_len=10)
+    assert isinstance(m, Groundlink) and m.channels == 23 * 3 + 12 + 36 + 60
+    tr = HipTrainer(m, "regression", "adam", 1e-4, args=targs(), use_graph=False)
+    dry.lib().calls.clear()
+    inputs = gl_inputs(4, 10, 23, 10)
+    labels = {k: torch.zeros(4, 10, c) for k, c in zip(
+        ('groundContactCenterOfPressureInRootFrame', 'groundContactForceInRootFrame', 'groundContactTorqueInRootFrame',
+         'groundContactWrenchesInRootFrame'), (6, 6, 6, 12))}
+    tr.step((inputs, labels))
+    names = dry.lib().calls
+    assert names.count("ib_im2col_replicate") == 4 and names.count("ib_col2im_replicate") == 3
+    assert names.count("ib_dropout") == 6 and names[-1].startswith("ib_optim_step")
