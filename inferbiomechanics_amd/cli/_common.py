@@ -51,7 +51,8 @@ def open_dataset(args, split: str, history_len: int, stride: int, output_data_fo
         if is_diffusion(model_type):
             return SyntheticMotionWindows(n, window=history_len // stride if stride > 1 else history_len,
                                           feat=args.feat_dim, seed=seed)
-        return SyntheticWindowDataset(n, history_len, stride, output_data_format=output_data_format, seed=seed)
+        return SyntheticWindowDataset(n, history_len, stride, output_data_format=output_data_format, seed=seed,
+                                      history_width=30 if model_type == 'groundlink' else 0)   # root_history_len = 10
     path = os.path.abspath(os.path.join(args.dataset_home, split))
     try:
         import nimblephysics  # noqa: F401

@@ -66,8 +66,9 @@ class SyntheticWindowDataset(Dataset):
     Label forces are ~10*N(0,1) so the CoP mask (> 10 N/kg) is exercised."""
 
     def __init__(self, num_windows: int, history_len: int = 50, stride: int = 5, num_dofs: int = 23,
-                 output_data_format: str = 'all_frames', seed: int = 0):
+                 output_data_format: str = 'all_frames', seed: int = 0, history_width: int = 0):
         self.num_windows, self.history_len, self.stride = num_windows, history_len, stride
+        self.history_width = history_width or stride * 3       # groundlink: root_history_len * 3 (Groundlink.py:116-118)
         self.num_dofs, self.num_contact_bodies = num_dofs, 2
         self.output_data_format = output_data_format
         self.seed = seed
@@ -79,7 +80,7 @@ class SyntheticWindowDataset(Dataset):
 
     def __getitem__(self, index: int) -> Tuple[Dict[str, torch.Tensor], Dict[str, torch.Tensor], int, int]:
         g = torch.Generator().manual_seed(self.seed * 1000003 + index)
-        ws = input_key_widths(self.num_dofs, self.stride * 3)
+        ws = input_key_widths(self.num_dofs, self.history_width)
         inputs = {k: torch.randn(self.frames, w, generator=g) for k, w in zip(INPUT_KEY_ORDER, ws)}
         F = self.out_frames
         labels = {

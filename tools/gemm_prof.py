@@ -51,5 +51,6 @@ def run(kind, M, N, K):
 
 if __name__ == "__main__":
     for kind, M, N, K in [("fwd", 12800, 512, 512), ("dgrad", 12800, 512, 512), ("wgrad", 12800, 512, 512),
-                          ("fwd", 12800, 2048, 512), ("wgrad", 12800, 2048, 512)]:
+                          ("fwd", 12800, 2048, 512), ("fwd", 12800, 512, 2048), ("fwd", 12800, 1536, 512),
+                          ("dgrad", 12800, 512, 2048), ("dgrad", 12800, 2048, 512), ("wgrad", 12800, 2048, 512)]:
         run(kind, M, N, K)
