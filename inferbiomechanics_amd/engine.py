@@ -321,6 +321,8 @@ class HipTrainer:
                 hip.gather_windows(self._cache.table, st["widx"], x, [st[f"lab{i}"] for i in range(4)])
             else:
                 hip.concat_keys([st[f"in{i}"] for i in range(len(INPUT_KEY_ORDER))], x)
+            if hasattr(plan, "fuse_reduce_into_optimizer"):
+                plan.fuse_reduce_into_optimizer = not self.ddp and not os.environ.get("IB_NO_OPT_FUSE")
             if hasattr(m, "output_frames_for"):
                 # Groundlink: [B, F', 30] with the four outputs interleaved per frame; the dropout masks are keyed on
                 # the device-resident step counter, so a replayed graph draws fresh masks every step

@@ -912,7 +912,7 @@ def optim_step(opt: str, p, g, s1, s2, lr, step=1, step_dev=None, grad_scale=1.0
                sources=None):
     """sources = (items, part, rows, segs): the gradient of some ranges of g is still partial sums -- items =
     [(slab workspace, nslab, dw view into g)], segs = [(col0, ncols, dst view into g | the loss scalar, dst2, scale)] over
-    part[:rows].  The optimizer sums them itself (ib_optim_step_sources) instead of a separate ib_step_reduce launch."""
+    part[:rows], or 7-tuples (.., part_i, rows_i) that name their own partial matrix (part may then be None).  The optimizer sums them itself (ib_optim_step_sources) instead of a separate ib_step_reduce launch."""
     _req(p, "p", torch.float32, 1)
     _req(g, "g", torch.float32, 1)
     n = p.numel()
@@ -933,7 +933,9 @@ def optim_step(opt: str, p, g, s1, s2, lr, step=1, step_dev=None, grad_scale=1.0
         _req(ticket, "ticket", torch.int32)
     if sources is not None:
         items, part, rows, segs = sources
-        pr, pc, ld = _mat(part, "part", torch.float32)
+        ld = 0
+        if part is not None:
+            pr, pc, ld = _mat(part, "part", torch.float32)
         g0, g1 = g.data_ptr(), g.data_ptr() + 4 * n
         ent, loss = [], None                      # (start, len, kind, base, stride, count, scale)
 
@@ -944,7 +946,14 @@ def optim_step(opt: str, p, g, s1, s2, lr, step=1, step_dev=None, grad_scale=1.0
             return (a - g0) // 4
         for ws, ns, dw in items:
             ent.append((flat_off(dw, "dw"), dw.numel(), 1, ws.data_ptr(), dw.numel(), int(ns), 1.0))
-        for c0, nc, d, d2, sc in segs:
+        for seg in segs:
+            c0, nc, d, d2, sc = seg[:5]
+            if len(seg) > 5:                      # a segment with its own partial matrix: (.., part_i, rows_i)
+                _, _, ld_i = _mat(seg[5], "part_i", torch.float32)
+                for dd in (d, d2):
+                    if dd is not None:
+                        ent.append((flat_off(dd, "dst"), nc, 2, seg[5].data_ptr() + 4 * c0, ld_i, int(seg[6]), float(sc)))
+                continue
             if not (g0 <= d.data_ptr() < g1):     # the loss scalar lives outside the flat buffer
                 if nc != 1 or loss is not None:
                     raise HipError("optim_step sources: at most one scalar destination outside g")

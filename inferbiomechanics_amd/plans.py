@@ -223,6 +223,8 @@ class GroundlinkPlan:
         self.fmt, self.dtype, self.p, self.k, self.seed = output_data_format, dtype, float(fc_dropout), k, seed
         self.buf = Buffers(device)
         self.ctx = None
+        self.fuse_reduce_into_optimizer = False         # set by HipTrainer for single-GPU steps
+        self.pending_sources = None
 
     def _conv_weight(self, li: int, w: torch.Tensor) -> torch.Tensor:
         co, ci, k = w.shape
@@ -293,17 +295,31 @@ class GroundlinkPlan:
             o += [f"cnn.{idx}.weight", f"cnn.{idx}.bias"]
         return o
 
+    def _dbias(self, tag: str, dz: torch.Tensor, dst: torch.Tensor, accumulate: bool, later: list):
+        """d bias = column sums of dz: short matrices in one launch; long ones leave per-128-row partial sums for the
+        step's final reduction (the optimizer itself on one GPU)"""
+        M, Nc = dz.shape
+        if M <= 512:
+            hip.segment_colsum(dz, dst.view(1, Nc), seg=M, mode=0, accumulate=accumulate)
+            return
+        part = self.buf.get(tag + ".colsum", ((M + 127) // 128, Nc), torch.float32)
+        hip.segment_colsum(dz, part, seg=128, mode=0)
+        later.append((part, part.shape[0], dst))
+
     def backward(self, dout: torch.Tensor, P: ParamSource, accumulate=False):
+        """Every dgrad first (the chain of dependent launches), the weight gradients after it in grouped launches whose
+        split-M slabs -- like the bias partial sums -- are reduced once: by ib_optim_step_sources when the trainer fuses
+        the reduction into the optimizer (one GPU), by one ib_slab_reduce_multi launch otherwise."""
         convs, hin, fcs, d_last, N, F, drop, step, step_dev = self.ctx
         g, dt, k = self.buf.get, self.dtype, self.k
         last = self.fmt != "all_frames"
         R = N if last else N * F
         C = d_last.shape[1]
         dz = dout.reshape(R, 30)
+        wg, later = [], []                 # (dz, x, dw, workspace tag) ; (partial sums, rows, bias gradient)
         # fc.8 (no bias), then back through [ELU, Dropout] of fc.5 and fc.2.  The ELU derivative is fused into the dgrad
         # epilogue; it is elementwise, so it commutes with the dropout mask applied right after.
-        _wgrad(self.buf, dz, d_last, P.g("fc.8.weight"), accumulate, ws_tag="gl.ws8")
-        P.ready("fc.8.weight")
+        wg.append((dz, d_last, P.g("fc.8.weight"), "gl.ws8"))
         wname = "fc.8.weight"
         for j in range(len(self.FC) - 1, -1, -1):
             idx = self.FC[j]
@@ -314,10 +330,8 @@ class GroundlinkPlan:
                 hip.dropout(dy, dy, self.p, self.seed + j + 1, step, step_dev)
             dz = dy
             wname = f"fc.{idx}.weight"
-            _wgrad(self.buf, dz, d_in, P.g(wname), accumulate, ws_tag=f"gl.wsf{j}")
-            P.ready(wname)
-            _colsum(self.buf, f"gl.bf{j}", dz, P.g(f"fc.{idx}.bias"), accumulate)
-            P.ready(f"fc.{idx}.bias")
+            wg.append((dz, d_in, P.g(wname), f"gl.wsf{j}"))
+            self._dbias(f"gl.bf{j}", dz, P.g(f"fc.{idx}.bias"), accumulate, later)
         # into the last convolution's output: (dz W_fc2) x ELU'(y3) [x dropout mask 0]
         dh = g("gl.dh", (R, C), dt)
         hip.linear_dgrad(dz, P.w(wname), dh, act_below="elu", aux=hin)
@@ -335,16 +349,34 @@ class GroundlinkPlan:
             w = P.w(f"cnn.{idx}.weight")
             co, ci, _ = w.shape
             K = ci * k
-            _wgrad(self.buf, dz, col[:, :K], P.g(f"cnn.{idx}.weight").view(co, K), accumulate, ws_tag=f"gl.wsc{li}")
-            P.ready(f"cnn.{idx}.weight")
-            _colsum(self.buf, f"gl.bc{li}", dz, P.g(f"cnn.{idx}.bias"), accumulate)
-            P.ready(f"cnn.{idx}.bias")
+            wg.append((dz, col[:, :K], P.g(f"cnn.{idx}.weight").view(co, K), f"gl.wsc{li}"))
+            self._dbias(f"gl.bc{li}", dz, P.g(f"cnn.{idx}.bias"), accumulate, later)
             if li > 0:
                 dcol = g(f"gl.dcol{li}", (N * F, K), dt)
                 hip.linear_dgrad(dz, w.view(co, K), dcol)
                 nxt = g(f"gl.dzc{li - 1}", (N * F, ci), dt)
                 hip.col2im_replicate(dcol, nxt, N, F, k, act="elu", aux=convs[li - 1][1])
                 dz = nxt
+        # ---- weight gradients: slabs of up to 6 problems per launch; odd reductions (177 x 7) take the direct kernel
+        defer, group = [], []
+        for prob in wg:
+            if prob[1].shape[1] % 4 == 0 and prob[2].stride(0) % 4 == 0:
+                group.append(prob)
+            else:
+                _wgrad(self.buf, prob[0], prob[1], prob[2], accumulate, ws_tag=prob[3])
+        for a in range(0, len(group), 6):
+            _wgrad_group(self.buf, group[a:a + 6], defer)
+        self.pending_sources = None
+        if self.fuse_reduce_into_optimizer and not accumulate:
+            segs = [(0, part.shape[1], dst, None, 1.0, part, rows) for part, rows, dst in later]
+            self.pending_sources = (defer, None, 0, segs)
+        else:
+            if defer:
+                hip.slab_reduce_multi(defer, accumulate=accumulate)
+            for part, rows, dst in later:      # ib_colsum_segments sums in the optimizer's order (bitwise the fused path)
+                hip.colsum_segments(part, rows, [(0, part.shape[1], dst, None, 1.0)], accumulate=accumulate)
+        for name in self.ready_order():
+            P.ready(name)
         return None
 
 

@@ -289,3 +289,25 @@ def test_groundlink_fused_trainer_matches_module_path(dtype):
     tr = HipTrainer(c, "regression", "sgd", 0.0, args=train_args())       # lr 0: the same function every step
     losses = [float(tr.step((inputs, labels))) for _ in range(6)]
     assert all(np.isfinite(losses)) and len(set(losses)) == 6             # fresh masks per step (device step counter)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_groundlink_fused_reduction_is_bitwise_the_separate_reduction(dtype, monkeypatch):
+    """one GPU: the optimizer sums the wgrad slabs / bias partial sums itself; data-parallel runs reduce them in their own
+    launches before the all-reduce.  Same fixed order -> bitwise the same parameters."""
+    from inferbiomechanics_amd.engine import HipTrainer
+    from inferbiomechanics_amd.models.Groundlink import Groundlink
+    inputs, labels = gl_inputs(64, 10), ff_labels(64, 10)            # 640 rows: bias sums go through the partial matrices
+    res = []
+    for fuse in (True, False):
+        if not fuse:
+            monkeypatch.setenv("IB_NO_OPT_FUSE", "1")
+        torch.manual_seed(0)
+        m = Groundlink(23, 12, 10, "all_frames", device=DEV, compute_dtype=dtype)
+        m.train()
+        tr = HipTrainer(m, "regression", "adam", 1e-3, args=train_args())
+        losses = [float(tr.step((inputs, labels))) for _ in range(4)]
+        assert (tr.plan.pending_sources is None) and tr.plan.fuse_reduce_into_optimizer == fuse
+        res.append((losses, tr.flat.clone()))
+    assert res[0][0] == res[1][0]
+    assert torch.equal(res[0][1], res[1][1])
