@@ -303,6 +303,18 @@ def main():
         el = float(tt.cpu())
     loss = trainer.loss_value()
 
+    # distribution of single-step times (median, p10 / p90): one event per step on the caller's stream,
+    # read back after the run -- no host synchronisation inside it
+    nq = min(a.steps, 400)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(nq + 1)]
+    evs[0].record()
+    for i in range(nq):
+        trainer.step(batches[i % len(batches)])
+        evs[i + 1].record()
+    sync()
+    dts = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(nq))
+    pct = lambda q: round(dts[min(nq - 1, int(q * nq))], 4)
+
     if rank == 0:
         value = world * B * a.steps / el
         line = {
@@ -315,6 +327,7 @@ def main():
                        "optimizer": a.opt_type, "hipgraph": not a.no_graph, "parallelism": f"dp{world}",
                        "grad_buckets": len(trainer.buckets.ranges) if trainer.ddp else 0,
                        "overlap_comm": bool(trainer.overlap_comm)},
+            "step_ms": {"p10": pct(0.10), "median": pct(0.50), "p90": pct(0.90), "samples": nq},
             "final_loss": round(loss, 6),
             "train_tflops": round(value * train_flops_per_window(kind, T, D) / 1e12, 2),
         }
@@ -324,7 +337,7 @@ def main():
         line["step_breakdown"] = breakdown
         if not a.no_ddim:
             line["ddim"] = ddim_leg(dev, dtype)
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:            # rank 0 at N=1 only (the other ranks wait at the barrier)
             line["cpu_baseline"] = cpu_baseline(kind, T, D, B)
         print(json.dumps(line), flush=True)
     if world > 1 or selftest:
