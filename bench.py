@@ -336,7 +336,8 @@ def main():
         line["step_sum_of_kernel_us"] = round(dev_us, 1)
         line["step_breakdown"] = breakdown
         if not a.no_ddim:
-            line["ddim"] = ddim_leg(dev, dtype)
+            line["ddim"] = ddim_leg(dev, dtype)                                  # B = 16: the quoted figure
+            line["ddim_batches"] = [ddim_leg(dev, dtype, B=b) for b in (1, 256)]   # B in {1,16,256}
         if not a.no_cpu_baseline and world == 1:            # rank 0 at N=1 only (the other ranks wait at the barrier)
             line["cpu_baseline"] = cpu_baseline(kind, T, D, B)
         print(json.dumps(line), flush=True)

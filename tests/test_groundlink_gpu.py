@@ -255,18 +255,19 @@ def test_groundlink_train_mode_dropout_is_consistent(fmt):
     assert model._plan.ctx[7] != step and not torch.equal(model._plan.ctx[3], first)
 
 
+@pytest.mark.parametrize("fmt", ["all_frames", "last_frame"])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_groundlink_fused_trainer_matches_module_path(dtype):
+def test_groundlink_fused_trainer_matches_module_path(dtype, fmt):
     """HipTrainer (captured graph, fused optimizer) against forward -> evaluator -> backward -> torch.optim on the module
     path, eval-mode arithmetic (dropout 0) so both see the same function; then train mode: finite loss, masks change
     from step to step under graph replay"""
     from inferbiomechanics_amd.engine import HipTrainer
     from inferbiomechanics_amd.loss.RegressionLossEvaluator import RegressionLossEvaluator
     from inferbiomechanics_amd.models.Groundlink import Groundlink
-    inputs, labels = gl_inputs(8, 10), ff_labels(8, 10)
+    inputs, labels = gl_inputs(8, 10), ff_labels(8, 10 if fmt == "all_frames" else 1)
     torch.manual_seed(0)
-    a = Groundlink(23, 12, 10, "all_frames", fc_dropout=0.0, device=DEV, compute_dtype=dtype)
-    b = Groundlink(23, 12, 10, "all_frames", fc_dropout=0.0, device=DEV, compute_dtype=dtype)
+    a = Groundlink(23, 12, 10, fmt, fc_dropout=0.0, device=DEV, compute_dtype=dtype)
+    b = Groundlink(23, 12, 10, fmt, fc_dropout=0.0, device=DEV, compute_dtype=dtype)
     b.load_state_dict(a.state_dict())             # the reference initialisation (the fixture state diverges under SGD)
     p0 = {k: v.detach().cpu().double().clone() for k, v in a.state_dict().items()}
     tr = HipTrainer(a, "regression", "sgd", 1e-4, args=train_args())
@@ -284,7 +285,7 @@ def test_groundlink_fused_trainer_matches_module_path(dtype):
         mv = (pb[k].detach().cpu().double() - p0[k]).abs().max().item()
         close(pa[k], pb[k], 0, "param " + k, atol=(1e-4 if dtype == torch.float32 else 0.15) * mv + 1e-9)
     # train mode with dropout under graph replay
-    c = Groundlink(23, 12, 10, "all_frames", device=DEV, compute_dtype=dtype)
+    c = Groundlink(23, 12, 10, fmt, device=DEV, compute_dtype=dtype)
     c.train()
     tr = HipTrainer(c, "regression", "sgd", 0.0, args=train_args())       # lr 0: the same function every step
     losses = [float(tr.step((inputs, labels))) for _ in range(6)]
