@@ -59,6 +59,15 @@ int ib_linear_dgrad(const void* dz, int64_t lddz, const void* w, int64_t ldw, in
                     const void* aux, int64_t ldaux, const void* addend, int64_t ldadd, void* dx, int64_t lddx,
                     int64_t M, int64_t N, int64_t K, int dtype, ib_stream_t stream);
 
+/* The same product for FEW rows and a long reduction (the time-embedding MLP's hidden layer: one row per window of the
+ * batch; autograd of `nn.Linear` + activation as in ib_linear_dgrad), plus the bias gradient of the layer below:
+ * dbias[K] (fp32, may be NULL) (+)= column sums of the stored dx.  One workgroup per 16 output columns sees every row, so
+ * the sums need no second launch.  bf16, M <= 256, N <= 1024, N % 128 == 0, K % 16 == 0; IB_E_UNSUPPORTED otherwise
+ * (callers fall back to ib_linear_dgrad + ib_segment_colsum). */
+int ib_linear_dgrad_skinny(const void* dz, int64_t lddz, const void* w, int64_t ldw, int act_below, const void* aux,
+                           int64_t ldaux, void* dx, int64_t lddx, float* dbias, int accumulate,
+                           int64_t M, int64_t N, int64_t K, int dtype, ib_stream_t stream);
+
 /* dw[N,K] (fp32) (+)= dz[M,N]^T . x[M,K]   split over M; partial slabs go to `workspace`
  * (deterministic: slabs are summed in a fixed order by a second kernel, no float atomics). */
 size_t ib_linear_wgrad_workspace(int64_t M, int64_t N, int64_t K);

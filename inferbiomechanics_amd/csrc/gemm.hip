@@ -923,6 +923,131 @@ extern "C" int ib_linear_dgrad(const void* dz, int64_t lddz, const void* w, int6
   return IB_E_DTYPE;
 }
 
+// ---- skinny dgrad: few rows (a batch of time embeddings), long reduction --------------------------------------------
+// dx[M,K] = (dz[M,N] . w[N,K]) * act'(aux), M <= 256.  The tiled kernels give such a problem 8 workgroups that each walk
+// the whole reduction alone (measured 40 us for [256, 1024] x [1024, 512], on the step's critical path).  Here a
+// workgroup owns 16 OUTPUT COLUMNS and all rows: K/16 workgroups, the w slice [N,16] transposed into LDS once, the dz
+// rows streamed straight into MFMA fragments through a 4-deep register ring (each wave its own rows: nothing to share),
+// and -- because a workgroup sees every row of its columns -- the bias gradient (column sums of dx) comes out of the
+// same launch in a fixed order.
+namespace skinny {
+constexpr int NMAX = 1024, WS = NMAX + 8, PD = 4;       // w image: 16 columns x (N + 8 pad) bf16, k-contiguous
+
+template <int ACT>
+__global__ __launch_bounds__(256) void dgrad_skinny_kernel(const bf16_t* __restrict__ dz, int64_t lddz,
+                                                           const bf16_t* __restrict__ w, int64_t ldw,
+                                                           const bf16_t* __restrict__ aux, int64_t ldaux,
+                                                           bf16_t* __restrict__ dx, int64_t lddx, float* __restrict__ dbias,
+                                                           int accumulate, int M, int N) {
+  __shared__ __attribute__((aligned(16))) bf16_t wimg[16 * WS];
+  __shared__ float red[4][16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c0 = blockIdx.x * 16;
+  // w[:, c0 .. c0+16) -> wimg[col][k]: one 16-byte piece = 8 columns of one reduction row
+  for (int pce = tid; pce < N * 2; pce += 256) {
+    const int k = pce >> 1, half = pce & 1;
+    bf16x8_t v;
+    __builtin_memcpy(&v, __builtin_assume_aligned(w + (int64_t)k * ldw + c0 + 8 * half, 16), 16);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) wimg[(8 * half + e) * WS + k] = v[e];
+  }
+  __syncthreads();
+  const int mt_total = (M + 15) / 16;
+  const int r = lane & 15, kq = lane >> 4;
+  const bf16_t* arow[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = min((wave + 4 * j) * 16 + r, M - 1);   // tiles past the last row read valid memory and store nothing
+    arow[j] = dz + (int64_t)row * lddz + 8 * kq;
+  }
+  f32x4_t acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  bf16x8_t ar[PD][4];
+  const int nkb = N / 32;                                  // a multiple of PD by the launch conditions
+#pragma unroll
+  for (int sl = 0; sl < PD; ++sl)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) __builtin_memcpy(&ar[sl][j], __builtin_assume_aligned(arow[j] + sl * 32, 16), 16);
+  const bf16_t* brow = wimg + r * WS + 8 * kq;
+  for (int kb0 = 0; kb0 < nkb; kb0 += PD) {
+#pragma unroll
+    for (int sl = 0; sl < PD; ++sl) {
+      const int kb = kb0 + sl;
+      bf16x8_t b;
+      __builtin_memcpy(&b, __builtin_assume_aligned(brow + kb * 32, 16), 16);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, ar[sl][j], acc[j], 0, 0, 0);
+      const int kn = min(kb + PD, nkb - 1);                // the last PD refills re-read the final block (never used)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) __builtin_memcpy(&ar[sl][j], __builtin_assume_aligned(arow[j] + kn * 32, 16), 16);
+    }
+  }
+  // swapped operands: this lane holds columns c0 + 4*kq .. +3 of row (tile, r)
+  float cs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = (wave + 4 * j) * 16 + r;
+    if (wave + 4 * j >= mt_total || row >= M) continue;
+    float v[4] = {acc[j][0], acc[j][1], acc[j][2], acc[j][3]};
+    if constexpr (ACT != IB_ACT_NONE) {
+      bf16x4_t a4;
+      __builtin_memcpy(&a4, __builtin_assume_aligned(aux + (int64_t)row * ldaux + c0 + 4 * kq, 8), 8);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] *= act_bwd_t<bf16_t, ACT>((float)a4[e]);
+    }
+    bf16x4_t o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      o[e] = (bf16_t)v[e];
+      cs[e] += (float)o[e];                                // the bias gradient is the column sum of the STORED tensor
+    }
+    __builtin_memcpy(__builtin_assume_aligned(dx + (int64_t)row * lddx + c0 + 4 * kq, 8), &o, 8);
+  }
+  if (dbias) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) cs[e] += __shfl_xor(cs[e], o, 64);     // the 16 rows of a tile: fixed butterfly
+      if (r == 0) red[wave][4 * kq + e] = cs[e];
+    }
+    __syncthreads();
+    if (tid < 16) {
+      const float sum = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+      dbias[c0 + tid] = accumulate ? dbias[c0 + tid] + sum : sum;
+    }
+  }
+}
+}  // namespace skinny
+
+extern "C" int ib_linear_dgrad_skinny(const void* dz, int64_t lddz, const void* w, int64_t ldw, int act_below,
+                                      const void* aux, int64_t ldaux, void* dx, int64_t lddx, float* dbias, int accumulate,
+                                      int64_t M, int64_t N, int64_t K, int dtype, ib_stream_t stream) {
+  if (!dz || !w || !dx || M <= 0 || N <= 0 || K <= 0 || lddz < N || ldw < K || lddx < K) return IB_E_ARG;
+  if (act_below != IB_ACT_NONE && (!aux || ldaux < K)) return IB_E_ARG;
+  if (act_below < IB_ACT_NONE || act_below > IB_ACT_ELU) return IB_E_ARG;
+  if (dtype != IB_BF16 || M > 256 || N > skinny::NMAX || N % (32 * skinny::PD) != 0 || K % 16 != 0) return IB_E_UNSUPPORTED;
+  if (!aligned(dz, 16) || lddz % 8 != 0 || !aligned(w, 16) || ldw % 8 != 0 || !aligned(dx, 8) || lddx % 4 != 0 ||
+      (aux && (!aligned(aux, 8) || ldaux % 4 != 0)))
+    return IB_E_UNSUPPORTED;
+  const dim3 grid((unsigned)(K / 16)), block(256);
+  hipStream_t s = ib_s(stream);
+#define IB_SKINNY(ACT)                                                                                                  \
+  hipLaunchKernelGGL((skinny::dgrad_skinny_kernel<ACT>), grid, block, 0, s, (const bf16_t*)dz, lddz, (const bf16_t*)w, ldw, \
+                     (const bf16_t*)aux, ldaux, (bf16_t*)dx, lddx, dbias, accumulate, (int)M, (int)N)
+  switch (act_below) {
+    case IB_ACT_RELU: IB_SKINNY(IB_ACT_RELU); break;
+    case IB_ACT_TANH: IB_SKINNY(IB_ACT_TANH); break;
+    case IB_ACT_SIGMOID: IB_SKINNY(IB_ACT_SIGMOID); break;
+    case IB_ACT_SILU: IB_SKINNY(IB_ACT_SILU); break;
+    case IB_ACT_ELU: IB_SKINNY(IB_ACT_ELU); break;
+    default: IB_SKINNY(IB_ACT_NONE); break;
+  }
+#undef IB_SKINNY
+  IB_CHECK_LAUNCH();
+  return IB_OK;
+}
+
 extern "C" size_t ib_linear_wgrad_workspace(int64_t M, int64_t N, int64_t K) {
   int chunk;
   const int split = wgrad_split(M, N, K, 64, &chunk);

@@ -39,6 +39,8 @@ _SIGS = {
                                  _i64, _i64, _i64, _i64, _c.c_int, _vp]),
     "ib_linear_dgrad": (_c.c_int, [_vp, _i64, _vp, _i64, _c.c_int, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64,
                                    _c.c_int, _vp]),
+    "ib_linear_dgrad_skinny": (_c.c_int, [_vp, _i64, _vp, _i64, _c.c_int, _vp, _i64, _vp, _i64, _vp, _c.c_int, _i64, _i64,
+                                          _i64, _c.c_int, _vp]),
     "ib_linear_wgrad_workspace": (_sz, [_i64, _i64, _i64]),
     "ib_linear_wgrad": (_c.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _c.c_int, _vp, _sz, _i64, _i64, _i64, _c.c_int, _vp]),
     "ib_linear_ln_fwd_workspace": (_sz, [_i64, _i64, _i64]),
@@ -442,6 +444,34 @@ def linear_dgrad(dz, w, dx, act_below="none", aux=None, addend=None):
     _check(lib().ib_linear_dgrad(_ptr(dz), lddz, _ptr(w), ldw, ACT[act_below], _ptr(aux), ldaux, _ptr(addend), ldadd,
                                  _ptr(dx), lddx, M, N, K, dtype_code(dt), stream_ptr()), "ib_linear_dgrad")
     return dx
+
+
+def linear_dgrad_skinny(dz, w, dx, act_below="none", aux=None, dbias=None, accumulate=False) -> bool:
+    """few-row dgrad with the bias gradient of the layer below fused (dbias (+)= column sums of dx); False when the shape
+    does not qualify (the caller then uses linear_dgrad + a column-sum launch)"""
+    dt = dz.dtype
+    M, N, lddz = _mat(dz, "dz", dt)
+    Nw, K, ldw = _mat(w, "w", dt)
+    Mx, Kx, lddx = _mat(dx, "dx", dt)
+    if Nw != N or Mx != M or Kx != K:
+        raise HipError(f"linear_dgrad_skinny shape mismatch: dz{tuple(dz.shape)} w{tuple(w.shape)} dx{tuple(dx.shape)}")
+    ldaux = 0
+    if ACT[act_below] != 0:
+        if aux is None:
+            raise HipError("linear_dgrad_skinny: activation below needs aux")
+        Ma, Ka, ldaux = _mat(aux, "aux", dt)
+        if (Ma, Ka) != (M, K):
+            raise HipError("aux shape mismatch")
+    if dbias is not None:
+        _req(dbias, "dbias", torch.float32)
+        if dbias.numel() != K or not dbias.is_contiguous():
+            raise HipError("dbias must be a contiguous fp32 vector of length K")
+    rc = lib().ib_linear_dgrad_skinny(_ptr(dz), lddz, _ptr(w), ldw, ACT[act_below], _ptr(aux), ldaux, _ptr(dx), lddx,
+                                      _ptr(dbias), int(accumulate), M, N, K, dtype_code(dt), stream_ptr())
+    if rc == -5:                       # IB_E_UNSUPPORTED
+        return False
+    _check(rc, "ib_linear_dgrad_skinny")
+    return True
 
 
 def linear_wgrad_workspace_bytes(M, N, K) -> int:

@@ -567,11 +567,19 @@ class TimeMLPPlan:
         s, u, zu = self.ctx
         tg = self.tag
         du = self.buf.get(tg + ".du", u.shape, self.dtype)
-        hip.linear_dgrad(self._de(de32, de_lp), P.w("time_mlp.2.weight"), du, act_below="silu", aux=zu)
+        de = self._de(de32, de_lp)
+        # one row per window: the few-row kernel (16 output columns per workgroup, the bias sums in the same launch);
+        # shapes it does not take go through the tiled dgrad + a column-sum launch
+        fused = self.dtype == torch.bfloat16 and not os.environ.get("IB_NO_SKINNY") and \
+            hip.linear_dgrad_skinny(de, P.w("time_mlp.2.weight"), du, act_below="silu", aux=zu,
+                                    dbias=P.g("time_mlp.0.bias"), accumulate=accumulate)
+        if not fused:
+            hip.linear_dgrad(de, P.w("time_mlp.2.weight"), du, act_below="silu", aux=zu)
         _wgrad(self.buf, du, s, P.g("time_mlp.0.weight"), accumulate, ws_tag=tg + ".ws0", defer=defer)
         if ready:
             P.ready("time_mlp.0.weight")
-        _colsum(self.buf, tg + ".b1", du, P.g("time_mlp.0.bias"), accumulate)
+        if not fused:
+            _colsum(self.buf, tg + ".b1", du, P.g("time_mlp.0.bias"), accumulate)
         if ready:
             P.ready("time_mlp.0.bias")
 

@@ -353,3 +353,32 @@ def test_zero_copy_batches_equal_staged_batches():
     la, lb = run(True), run(False)
     assert la == lb, (la, lb)
     assert len(set(la)) > 4                           # different batches really were consumed
+
+
+@pytest.mark.parametrize("M,N,K,act", [(256, 1024, 512, "silu"), (100, 512, 128, "silu"), (16, 128, 16, "none"),
+                                       (256, 256, 64, "relu"), (7, 1024, 512, "elu")])
+def test_linear_dgrad_skinny_with_bias_sums(hip, M, N, K, act):
+    """few-row dgrad (the time-embedding MLP's hidden layer): dx = (dz w) * act'(aux) and dbias = column sums of the STORED
+    dx from one launch; ragged row counts (partial / missing row tiles), accumulate, strided operands"""
+    dz_w = rnd((M, N + 8), 1).to(BF).to(DEV)
+    dz = dz_w[:, :N]                                           # row pitch N + 8
+    w = rnd((N, K), 2, N ** -0.5).to(BF).to(DEV)
+    aux = rnd((M, K), 3).to(BF).to(DEV)
+    dx = torch.full((M, K), 7.0, dtype=BF, device=DEV)
+    db = torch.full((K,), 3.0, dtype=torch.float32, device=DEV)
+    assert hip.linear_dgrad_skinny(dz, w, dx, act_below=act, aux=aux if act != "none" else None, dbias=db)
+    a = aux.double().cpu()
+    fac = {"none": torch.ones_like(a), "relu": (a > 0).double(), "elu": torch.where(a > 0, torch.ones_like(a), a + 1),
+           "silu": torch.sigmoid(a) * (1 + a * (1 - torch.sigmoid(a)))}[act]
+    exp = (dz.double().cpu() @ w.double().cpu()) * fac
+    close(dx, exp, 1e-2, "dx")
+    close(db, dx.double().sum(0), 1e-5, "dbias = column sums of the stored dx")
+    # the tiled kernel gives the same tensor within bf16 rounding
+    ref = torch.empty_like(dx)
+    hip.linear_dgrad(dz, w, ref, act_below=act, aux=aux if act != "none" else None)
+    close(dx, ref.double(), 1e-2, "vs tiled dgrad")
+    hip.linear_dgrad_skinny(dz, w, dx, act_below=act, aux=aux if act != "none" else None, dbias=db, accumulate=True)
+    close(db, 2 * dx.double().sum(0), 1e-5, "accumulate")
+    # shapes outside the kernel's range are refused (the caller falls back), never mis-computed
+    assert not hip.linear_dgrad_skinny(torch.zeros(300, N, dtype=BF, device=DEV), w, torch.zeros(300, K, dtype=BF, device=DEV))
+    assert not hip.linear_dgrad_skinny(torch.zeros(M, 96, dtype=BF, device=DEV), torch.zeros(96, K, dtype=BF, device=DEV), dx)
