@@ -17,7 +17,7 @@ struct OptArgs {
 // optimizer sums them itself, in the same fixed order as ib_step_reduce, so the reduction launch, its kernel boundary
 // and the round trip of the reduced gradient through HBM disappear (single-GPU steps only: an all-reduce needs the
 // reduced gradient in memory).
-constexpr int OPT_MAXSRC = 28;
+constexpr int OPT_MAXSRC = 64;   // 4 transformer layers x (4 slab sets + 4 bias sums + 4 LayerNorm sums) + the projections
 struct GradSrc {
   int64_t start, len;          // flat element range (start % 4 == 0)
   const float* base;           // slabs: [nslab][len] ; column sums: part + col0
@@ -66,10 +66,12 @@ __device__ __forceinline__ float opt_update(const OptArgs& a, float p, float g, 
 
 // slab-backed ranges are summed by whichever thread owns the element; column-sum ranges are left to the dedicated
 // cooperative blocks below (a single thread summing 256 strided rows was a 100-us tail)
+// (the host passes the sources sorted by start: the scan stops at the first one that begins beyond idx)
 __device__ __forceinline__ bool source_grad4(const OptSources& S, const float* g, int64_t idx, float4& t) {
   for (int j = 0; j < S.n; ++j) {
     const GradSrc& r = S.s[j];
-    if (idx >= r.start && idx < r.start + r.len) {
+    if (idx < r.start) break;
+    if (idx < r.start + r.len) {
       if (r.kind != 1) return false;
       const int64_t o = idx - r.start;
       t = make_float4(0.f, 0.f, 0.f, 0.f);

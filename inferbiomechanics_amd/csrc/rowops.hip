@@ -421,7 +421,10 @@ int launch_ln_fwd(const void* x, const void* res, int act, const float* gamma, c
 
 int ln_bwd_parts(int64_t M) {
   int64_t g = (M + 15) / 16;
-  if (g > 256) g = 256;   // one 8-wave block per CU; the fixed-order reduction over the partial rows stays short
+  // one 8-wave block per CU; the fixed-order reduction over the partial rows stays short.  [12800, 512] bf16: 128 blocks
+  // 31 us, 256: 24.5, 512: 27.8 (the second-stage sum grows with the partial rows); the row loop is VALU-bound
+  // (a next-row prefetch changed nothing), N = 512 as one row per wave (64 lanes x 8) is 11 % faster than two
+  if (g > 256) g = 256;
   if (g < 1) g = 1;
   return (int)g;
 }
@@ -450,7 +453,7 @@ inline bool al(const void* p, size_t a) { return !p || (reinterpret_cast<uintptr
 // stays near 128 VGPRs (>= 3 waves per SIMD); at 256 VGPRs it ran at 1 wave per SIMD and 4x off the HBM roofline
 #define LN_DISPATCH_BWD(FN, T, ...)                                                          \
   (N <= 128 ? FN<T, 16, 1>(__VA_ARGS__) : N <= 256 ? FN<T, 16, 2>(__VA_ARGS__)              \
-   : N <= 512 ? FN<T, 32, 2>(__VA_ARGS__) : N <= 1024 ? FN<T, 64, 2>(__VA_ARGS__) : FN<T, 64, 4>(__VA_ARGS__))
+   : N <= 512 ? FN<T, 64, 1>(__VA_ARGS__) : N <= 1024 ? FN<T, 64, 2>(__VA_ARGS__) : FN<T, 64, 4>(__VA_ARGS__))
 #define LN_DISPATCH(FN, T, ...)                                                              \
   (N <= 128 ? FN<T, 16, 1>(__VA_ARGS__) : N <= 256 ? FN<T, 16, 2>(__VA_ARGS__)              \
    : N <= 512 ? FN<T, 16, 4>(__VA_ARGS__) : N <= 1024 ? FN<T, 64, 2>(__VA_ARGS__) : FN<T, 64, 4>(__VA_ARGS__))

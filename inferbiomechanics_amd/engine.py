@@ -300,6 +300,8 @@ class HipTrainer:
                 return self._finish_step(cut)
             # activations that are D (= 300) wide live in buffers with a 16-byte-aligned row pitch (304): the GEMM
             # operand pieces are then aligned 16-byte loads (the unpadded rows were 8-byte aligned: +11 us per wgrad)
+            if hasattr(plan, "fuse_reduce_into_optimizer"):
+                plan.fuse_reduce_into_optimizer = not self.ddp and not os.environ.get("IB_NO_OPT_FUSE")
             Dp = D if os.environ.get("IB_NO_PAD") else (D + 7) // 8 * 8
             xt = plan.buf.get("tr.xt", (M, Dp), dt)[:, :D]
             pred = plan.buf.get("tr.pred", (M, Dp), dt)[:, :D]

@@ -992,6 +992,7 @@ def optim_step(opt: str, p, g, s1, s2, lr, step=1, step_dev=None, grad_scale=1.0
             for dd in (d, d2):
                 if dd is not None:
                     ent.append((flat_off(dd, "dst"), nc, 2, part.data_ptr() + 4 * c0, ld, int(rows), float(sc)))
+        ent.sort(key=lambda e: e[0])              # the kernel's range scan stops at the first source beyond the element
         m = len(ent)
         cv = lambda a: ctypes.cast(a, ctypes.c_void_p)
         A = lambda ct, k: (ct * m)(*[e[k] for e in ent])

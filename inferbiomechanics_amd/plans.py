@@ -394,6 +394,10 @@ class TransformerLayerPlan:
         self.branch = Branch(device, name="layer")
         self.join_on_exit = True     # a parent plan sets this False and joins all layers once at the end
         self.inference = False       # forward only (DDIM sampler): Linear + residual + LayerNorm fused, nothing saved
+        # set by a parent plan whose trainer lets the optimizer sum partial gradients (one GPU): weight-gradient slabs go
+        # to `defer` [(workspace, nslab, dw)], bias / LayerNorm partial sums to `later` [(partial rows, rows, gradient)]
+        self.defer: Optional[list] = None
+        self.later: Optional[list] = None
 
     def branches(self) -> List["Branch"]:
         return [self.branch]
@@ -451,41 +455,60 @@ class TransformerLayerPlan:
         M, d = x.shape
         g, dt, p, tg = self.buf.get, self.dtype, self.p, self.tag
         lnws = self.buf.bytes("ln.ws", hip.layernorm_bwd_workspace_bytes(M, max(d, 1)))
+        defer, later = self.defer, self.later
+
+        def ln_bwd(which, dy, xin, mean, rstd, dxo, res):
+            """LayerNorm backward; parameter gradients finished here, or their per-block partial sums left for the optimizer"""
+            gw, gb = P.g(p + which + ".weight"), P.g(p + which + ".bias")
+            if later is None:
+                hip.layernorm_bwd(dy, xin, P.v(p + which + ".weight"), mean, rstd, dxo, gw, gb, lnws, res=res,
+                                  accumulate=accumulate)
+            else:
+                nb = hip.layernorm_bwd_workspace_bytes(M, d)
+                ws = self.buf.bytes(tg + ".lnws." + which, nb)              # one per LayerNorm: read at the end of the step
+                hip.layernorm_bwd(dy, xin, P.v(p + which + ".weight"), mean, rstd, dxo, None, None, ws, res=res)
+                parts = nb // (2 * d * 4)
+                part = ws[:nb].view(torch.float32).view(2 * parts, d)
+                later.append((part[:parts], parts, gw))
+                later.append((part[parts:], parts, gb))
+            P.ready(p + which + ".weight"); P.ready(p + which + ".bias")
+
+        def dbias(tag, dz, name):
+            if later is None or dz.shape[0] <= 512:
+                _colsum(self.buf, tag, dz, P.g(p + name), accumulate)
+            else:
+                part = self.buf.get(tag + ".colsum", ((dz.shape[0] + 127) // 128, dz.shape[1]), torch.float32)
+                hip.segment_colsum(dz, part, seg=128, mode=0)
+                later.append((part, part.shape[0], P.g(p + name)))
+            P.ready(p + name)
         # LN2: d(f2 + x1)
         ds2 = g(tg + ".ds2", (M, d), dt)
-        hip.layernorm_bwd(dx2.view(M, d), f2, P.v(p + "norm2.weight"), m2, r2, ds2, P.g(p + "norm2.weight"),
-                          P.g(p + "norm2.bias"), lnws, res=x1, accumulate=accumulate)
-        P.ready(p + "norm2.weight"); P.ready(p + "norm2.bias")
+        ln_bwd("norm2", dx2.view(M, d), f2, m2, r2, ds2, x1)
 
         def g_ffn2():
-            _wgrad(self.buf, ds2, f1, P.g(p + "feedforward.2.weight"), accumulate, ws_tag=tg + ".ws2")
+            _wgrad(self.buf, ds2, f1, P.g(p + "feedforward.2.weight"), accumulate, ws_tag=tg + ".ws2", defer=defer)
             P.ready(p + "feedforward.2.weight")
-            _colsum(self.buf, tg + ".b2", ds2, P.g(p + "feedforward.2.bias"), accumulate)
-            P.ready(p + "feedforward.2.bias")
+            dbias(tg + ".b2", ds2, "feedforward.2.bias")
         self.branch.run(g_ffn2)
         dz1 = g(tg + ".dz1", (M, self.ffn), dt)
         hip.linear_dgrad(ds2, P.w(p + "feedforward.2.weight"), dz1, act_below="relu", aux=f1)
 
         def g_ffn1():
-            _wgrad(self.buf, dz1, x1, P.g(p + "feedforward.0.weight"), accumulate, ws_tag=tg + ".ws1")
+            _wgrad(self.buf, dz1, x1, P.g(p + "feedforward.0.weight"), accumulate, ws_tag=tg + ".ws1", defer=defer)
             P.ready(p + "feedforward.0.weight")
-            _colsum(self.buf, tg + ".b1", dz1, P.g(p + "feedforward.0.bias"), accumulate)
-            P.ready(p + "feedforward.0.bias")
+            dbias(tg + ".b1", dz1, "feedforward.0.bias")
         self.branch.run(g_ffn1)
         dx1 = g(tg + ".dx1", (M, d), dt)
         hip.linear_dgrad(dz1, P.w(p + "feedforward.0.weight"), dx1, addend=ds2)       # + residual path
         # LN1: d(a + x)
         ds1 = g(tg + ".ds1", (M, d), dt)
-        hip.layernorm_bwd(dx1, a, P.v(p + "norm1.weight"), m1, r1, ds1, P.g(p + "norm1.weight"),
-                          P.g(p + "norm1.bias"), lnws, res=x, accumulate=accumulate)
-        P.ready(p + "norm1.weight"); P.ready(p + "norm1.bias")
+        ln_bwd("norm1", dx1, a, m1, r1, ds1, x)
 
         def g_out():
             _wgrad(self.buf, ds1, attn.view(M, d), P.g(p + "multihead_attention.out_proj.weight"), accumulate,
-                   ws_tag=tg + ".wso")
+                   ws_tag=tg + ".wso", defer=defer)
             P.ready(p + "multihead_attention.out_proj.weight")
-            _colsum(self.buf, tg + ".bo", ds1, P.g(p + "multihead_attention.out_proj.bias"), accumulate)
-            P.ready(p + "multihead_attention.out_proj.bias")
+            dbias(tg + ".bo", ds1, "multihead_attention.out_proj.bias")
         self.branch.run(g_out)
         dattn = g(tg + ".dattn", (B, T, d), dt)
         hip.linear_dgrad(ds1, P.w(p + "multihead_attention.out_proj.weight"), dattn.view(M, d))
@@ -494,10 +517,10 @@ class TransformerLayerPlan:
         dq2 = dqkv.view(M, 3 * d)
 
         def g_in():
-            _wgrad(self.buf, dq2, x, P.g(p + "multihead_attention.in_proj_weight"), accumulate, ws_tag=tg + ".wsi")
+            _wgrad(self.buf, dq2, x, P.g(p + "multihead_attention.in_proj_weight"), accumulate, ws_tag=tg + ".wsi",
+                   defer=defer)
             P.ready(p + "multihead_attention.in_proj_weight")
-            _colsum(self.buf, tg + ".bi", dq2, P.g(p + "multihead_attention.in_proj_bias"), accumulate)
-            P.ready(p + "multihead_attention.in_proj_bias")
+            dbias(tg + ".bi", dq2, "multihead_attention.in_proj_bias")
         self.branch.run(g_in)
         dx = g(tg + ".dx", (B, T, d), dt)
         hip.linear_dgrad(dq2, P.w(p + "multihead_attention.in_proj_weight"), dx.view(M, d), addend=ds1)
@@ -836,6 +859,8 @@ class DenoiserTransformerPlan:
             lp.join_on_exit = False          # joined once, at the end of the whole backward
         self.ctx = None
         self._posproj_T = None
+        self.fuse_reduce_into_optimizer = False         # set by HipTrainer for single-GPU steps
+        self.pending_sources = None
 
     def set_inference(self, on: bool):
         """forward-only mode with frozen weights (the DDIM sampler): fused Linear + residual + LayerNorm in every layer,
@@ -897,7 +922,15 @@ class DenoiserTransformerPlan:
         M, D = x.shape
         g, dt = self.buf.get, self.dtype
         dout = dout3 if dout3.dim() == 2 else dout3.view(M, D)
-        _wgrad(self.buf, dout, hlast.view(M, self.d), P.g("out_proj.weight"), accumulate)
+        # one GPU: every split-M slab set and every per-block partial sum of a bias / LayerNorm gradient is left for the
+        # optimizer launch to add up (ib_optim_step_sources, at most 64 sources): per step this removes one reduction
+        # launch per weight, one per bias and one per LayerNorm
+        fuse = self.fuse_reduce_into_optimizer and not accumulate and 12 * len(self.layers) + 4 <= 60
+        defer, later = ([], []) if fuse else (None, None)
+        for lp in self.layers:
+            lp.defer, lp.later = defer, later
+        self.pending_sources = None
+        _wgrad(self.buf, dout, hlast.view(M, self.d), P.g("out_proj.weight"), accumulate, ws_tag="dt.wso", defer=defer)
         P.ready("out_proj.weight")
         _colsum(self.buf, "dt.bo", dout, P.g("out_proj.bias"), accumulate)
         P.ready("out_proj.bias")
@@ -932,3 +965,6 @@ class DenoiserTransformerPlan:
         self.time.backward(de32, P, accumulate)
         for lp in self.layers:
             lp.branch.join()
+        if fuse:
+            self.pending_sources = (defer, None, 0, [(0, part.shape[1], dst, None, 1.0, part, rows)
+                                                     for part, rows, dst in later])

@@ -191,3 +191,36 @@ def test_window_cache_step_is_bitwise_the_dict_batch_step(dtype):
         assert torch.equal(x[j].cpu(), xe)
         for t, k in zip(labs, LOSS_KEY_ORDER):
             assert torch.equal(t[j].cpu(), labels[k])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_transformer_fused_reductions_match_separate_reductions(dtype, monkeypatch):
+    """one GPU: the optimizer launch adds up the weight-gradient slabs and the per-block partial sums of every bias /
+    LayerNorm gradient of the transformer denoiser (<= 64 sources); under data parallelism each is reduced by its own
+    launch.  Same numbers up to fp32 summation order: compared after 3 SGD steps on the parameter MOVEMENT."""
+    from inferbiomechanics_amd.engine import HipTrainer
+    from inferbiomechanics_amd.models.DiffusionDenoisers import DiffusionTransformer
+    B, T, D = 24, 30, 44                                     # 720 tokens: bias sums go through partial-sum matrices
+    bs = batches(3, B, T, D, seed=11)
+    res = []
+    for fuse in (True, False):
+        if not fuse:
+            monkeypatch.setenv("IB_NO_OPT_FUSE", "1")
+        torch.manual_seed(0)
+        model = DiffusionTransformer(D, T, d_model=128, num_heads=4, dim_feedforward=256, num_layers=3, device=DEV,
+                                     compute_dtype=dtype)
+        p0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        tr = HipTrainer(model, "diffusion", "sgd", 1e-2)
+        losses = []
+        for i in range(4):
+            x0, t, eps = bs[i % 3]
+            tr.step((x0.to(DEV, dtype), t.to(DEV), eps.to(DEV, dtype)))
+            losses.append(tr.loss_value())
+        assert tr.plan.fuse_reduce_into_optimizer == fuse and tr.plan.pending_sources is None
+        res.append((losses, {k: v.detach() - p0[k] for k, v in model.state_dict().items()}))
+    for a, b in zip(res[0][0], res[1][0]):
+        assert abs(a - b) <= 1e-5 * abs(b), (res[0][0], res[1][0])
+    for k, mv in res[1][1].items():
+        ref = mv.abs().max().item()
+        assert ref > 0, k
+        assert (res[0][1][k] - mv).abs().max().item() <= 2e-4 * ref, k
