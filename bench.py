@@ -253,6 +253,12 @@ def main():
                     help="data-parallel policy: all-reduce buckets during the backward (on) or once after it (off)")
     a = ap.parse_args()
 
+    # stdout carries exactly ONE line (the JSON): libraries that print banners to fd 1 (RCCL prints its version there
+    # at communicator creation) are sent to stderr for the whole run; the result is written to the saved descriptor
+    sys.stdout.flush()
+    out_fd = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -340,7 +346,8 @@ def main():
             line["ddim_batches"] = [ddim_leg(dev, dtype, B=b) for b in (1, 256)]   # B in {1,16,256}
         if not a.no_cpu_baseline and world == 1:            # rank 0 at N=1 only (the other ranks wait at the barrier)
             line["cpu_baseline"] = cpu_baseline(kind, T, D, B)
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(out_fd, (json.dumps(line) + "\n").encode())
     if world > 1 or selftest:
         dist.barrier()
         dist.destroy_process_group()

@@ -17,6 +17,11 @@ def main():
     kind, T, D, B = bench.WORKLOADS[wl]
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
+    import os
+    if os.environ.get("IB_DDP_SELFTEST") == "1":     # the data-parallel launch sequence on one rank (RCCL, world = 1)
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29544")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     model = bench.build_model(kind, T, D, torch.bfloat16, dev)
     batches = bench.make_batches(4, B, T, D, torch.bfloat16, dev, seed=0)
     with hip.stamp_launches(only=only) as sl:
