@@ -224,3 +224,34 @@ def test_transformer_fused_reductions_match_separate_reductions(dtype, monkeypat
         ref = mv.abs().max().item()
         assert ref > 0, k
         assert (res[0][1][k] - mv).abs().max().item() <= 2e-4 * ref, k
+
+
+def test_bench_data_parallel_launch_sequence_on_one_rank():
+    """bench.py end to end in a child process, twice: the single-GPU step (reductions fused into the optimizer, one graph)
+    and -- IB_DDP_SELFTEST=1, world size 1 -- the data-parallel sequence (gradient materialised, graph cut around an RCCL
+    all-reduce, plain optimizer).  Both must print exactly ONE stdout line (the JSON; RCCL's banner goes to stderr) and,
+    because every reduction has a fixed order, end on the bitwise same loss."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for ddp in (False, True):
+        env = dict(os.environ)
+        env.pop("IB_DDP_SELFTEST", None)
+        if ddp:
+            env.update(IB_DDP_SELFTEST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", RANK="0", WORLD_SIZE="1",
+                       LOCAL_RANK="0")
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "40", "--warmup", "4",
+                            "--no-cpu-baseline", "--no-ddim"], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+        assert len(lines) == 1, r.stdout[:500]
+        outs.append(json.loads(lines[0]))
+    a, b = outs
+    assert a["config"]["grad_buckets"] == 0 and b["config"]["grad_buckets"] == 1
+    assert a["final_loss"] == b["final_loss"]
+    for o in outs:
+        assert o["unit"] == "windows/s" and o["n_gpus"] == 1 and o["steps"] == 40 and o["value"] > 0
+        assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(o["roofline"])
