@@ -214,7 +214,10 @@ def roofline_leg(trainer, batches, dtype_name):
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
-            out["traffic"] = json.load(open(tpath)).get(top_e)
+            t = json.load(open(tpath)).get(top_e)
+            if t:                                    # `traffic`: HBM bytes per launch (a number, like `achieved`)
+                out["traffic"] = t["hbm_bytes_per_launch"]
+                out["traffic_source"] = {k: v for k, v in t.items() if k != "hbm_bytes_per_launch"}
         except Exception:
             pass
     return out, rows[:14], total
