@@ -70,7 +70,7 @@ class TrainCommand(AbstractCommand):
         p.add_argument('--eager', action='store_true',
                        help='Reference-style loop (autograd node + torch.optim + torch DDP) instead of the fused trainer.')
         p.add_argument('--no-graph', action='store_true', help='Do not replay the step from hipGraphs.')
-        p.add_argument('--bucket-mb', type=float, default=4.0, help='Gradient all-reduce bucket size.')
+        p.add_argument('--bucket-mb', type=float, default=13.0, help='Gradient all-reduce bucket size (MiB).')
         p.add_argument('--window-cache', type=str, default=None,
                        help='Packed-window file (data/WindowCache.py): loaded if it exists, else built from the training '
                             'set and saved; the regression models then train from an on-device window cache (one '

@@ -149,7 +149,7 @@ class HipTrainer:
     """
 
     def __init__(self, model: HipModule, task: str, opt_type: str = "rmsprop", lr: float = 1e-4, args=None,
-                 group=None, bucket_mb: float = 4.0, use_graph: bool = True, overlap_comm: Optional[bool] = None):
+                 group=None, bucket_mb: float = 13.0, use_graph: bool = True, overlap_comm: Optional[bool] = None):
         if task not in ("diffusion", "regression"):
             raise ValueError(task)
         if opt_type not in hip.OPT:
