@@ -171,9 +171,14 @@ class HipTrainer:
         # buckets are all-reduced while the backward is still running (events on the main stream), branches OFF.
         nparam_bytes = sum(p.numel() for p in model.parameters()) * 4
         self.overlap_comm = self.ddp and (nparam_bytes >= (16 << 20) if overlap_comm is None else bool(overlap_comm))
-        if self.overlap_comm and hasattr(self.plan, "branches"):
+        self._flush_mode = False
+        if self.overlap_comm and hasattr(self.plan, "flush_each_layer"):
+            # side streams stay on; completed buckets are launched at the plan's flush points (all streams joined there)
+            self.plan.flush_each_layer(True)
+            self._flush_mode = True
+        elif self.overlap_comm and hasattr(self.plan, "branches"):
             for br in self.plan.branches():
-                br.on = False               # gradient-bucket events are recorded on one stream only
+                br.on = False               # a bucket's all-reduce is ordered after ONE stream only
         # ---- flat buffers in gradient-ready order
         order = self.plan.ready_order()
         params = OrderedDict(model.named_parameters())
@@ -241,15 +246,28 @@ class HipTrainer:
         v = lambda k: params[k].data
         g = lambda k: self._gviews[k]
 
+        pending: List[int] = []
+
+        def launch(b: int):
+            if cut is not None:
+                cut(b)
+            else:
+                self.buckets.launch(b)
+
         def ready(name: str):
             self._ready_seen.append(name)
             b = self.buckets.mark_ready(name)
             if b is not None and self.overlap_comm:
-                if cut is not None:
-                    cut(b)
+                if self._flush_mode:
+                    pending.append(b)       # possibly inside a forked side stream: launched at the next flush point
                 else:
-                    self.buckets.launch(b)
-        return ParamSource(w, v, g, ready)
+                    launch(b)
+
+        def flush():
+            for b in pending:
+                launch(b)
+            pending.clear()
+        return ParamSource(w, v, g, ready, flush)
 
     _slots = None          # device array {x0, eps, t} the chain / prep kernels read their batch through
     _zero_copy = False
@@ -308,6 +326,7 @@ class HipTrainer:
             self._br_loss.run(lambda: hip.mse_loss_finalize(ws, self.result, n))   # the scalar: off the chain
             plan.backward(dpred, P, accumulate=False)
             self._br_loss.join()
+            P.flush()                                  # buckets completed after the plan's last flush point
         else:
             B = st["lab0"].shape[0]
             frames_in = self._cache.frames if "widx" in st else st["in0"].shape[1]
@@ -335,6 +354,7 @@ class HipTrainer:
             ws = plan.buf.bytes("tr.rl", hip.regression_loss_workspace_bytes(B, F))
             hip.regression_loss(outs, labs, self.comp_w, self.result, ws, grads=grads, threshold=10.0)
             plan.backward(G, P, accumulate=False)
+            P.flush()
         self._finish_step(cut)
 
     def _finish_step(self, cut):

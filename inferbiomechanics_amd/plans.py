@@ -57,8 +57,11 @@ class ParamSource:
 
     def __init__(self, w: Callable[[str], torch.Tensor], v: Callable[[str], torch.Tensor],
                  g: Optional[Callable[[str], torch.Tensor]] = None,
-                 ready: Optional[Callable[[str], None]] = None):
+                 ready: Optional[Callable[[str], None]] = None, flush: Optional[Callable[[], None]] = None):
         self.w, self.v, self.g = w, v, g
+        # called by a plan at points where NO side stream is forked (after its joins): the trainer then launches the
+        # all-reduce of every gradient bucket completed so far (it cuts the captured graph there)
+        self.flush = flush if flush is not None else (lambda: None)
         # called by a plan's backward right after the launches that complete d loss / d param[name] are
         # enqueued, in the order given by the plan's ready_order(): lets the trainer start the RCCL
         # all-reduce of a gradient bucket while the rest of the backward is still running
@@ -398,6 +401,8 @@ class TransformerLayerPlan:
         # to `defer` [(workspace, nslab, dw)], bias / LayerNorm partial sums to `later` [(partial rows, rows, gradient)]
         self.defer: Optional[list] = None
         self.later: Optional[list] = None
+        self.flush_on_exit = False   # data parallel with overlapped all-reduces: join the side stream and let the trainer
+                                     # launch the completed buckets at the end of every layer's backward
 
     def branches(self) -> List["Branch"]:
         return [self.branch]
@@ -524,8 +529,10 @@ class TransformerLayerPlan:
         self.branch.run(g_in)
         dx = g(tg + ".dx", (B, T, d), dt)
         hip.linear_dgrad(dq2, P.w(p + "multihead_attention.in_proj_weight"), dx.view(M, d), addend=ds1)
-        if self.join_on_exit:
+        if self.join_on_exit or self.flush_on_exit:
             self.branch.join()
+        if self.flush_on_exit:
+            P.flush()
         return dx
 
 
@@ -862,6 +869,12 @@ class DenoiserTransformerPlan:
         self.fuse_reduce_into_optimizer = False         # set by HipTrainer for single-GPU steps
         self.pending_sources = None
 
+    def flush_each_layer(self, on: bool):
+        """overlapped data-parallel steps: keep the layers' side streams, hand completed gradient buckets to the trainer at
+        every layer boundary (ParamSource.flush) instead of running the whole backward on one stream"""
+        for lp in self.layers:
+            lp.flush_on_exit = bool(on)
+
     def set_inference(self, on: bool):
         """forward-only mode with frozen weights (the DDIM sampler): fused Linear + residual + LayerNorm in every layer,
         the frame-embedding projection computed once"""
@@ -936,6 +949,7 @@ class DenoiserTransformerPlan:
         P.ready("out_proj.bias")
         dh = g("dt.dh", (B, T, self.d), dt)
         hip.linear_dgrad(dout, P.w("out_proj.weight"), dh.view(M, self.d))
+        P.flush()
         for lp in reversed(self.layers):
             dh = lp.backward(dh, P, accumulate)
         dz0 = dh.view(M, self.d)
@@ -965,6 +979,7 @@ class DenoiserTransformerPlan:
         self.time.backward(de32, P, accumulate)
         for lp in self.layers:
             lp.branch.join()
+        P.flush()
         if fuse:
             self.pending_sources = (defer, None, 0, [(0, part.shape[1], dst, None, 1.0, part, rows)
                                                      for part, rows, dst in later])
