@@ -71,6 +71,23 @@ def _worker(rank, world, port, q):
                 tr.step((torch.randn(2, 5, 12), torch.tensor([1, 2]), torch.randn(2, 5, 12)))
                 assert tr.buckets._works == [] and all(v == 0 for v in tr.buckets._pending)
                 assert torch.all(tr.grad == 3.0)      # dry-run kernels write nothing: the SUM of the fills remains
+        # 4) transformer denoiser, overlapped policy: the layers' side streams stay on and completed buckets are launched
+        #    at the plan's flush points (every layer boundary) -- every bucket exactly once, all gradients summed
+        from inferbiomechanics_amd.models.DiffusionDenoisers import DiffusionTransformer
+        torch.manual_seed(rank)
+        mt = DiffusionTransformer(12, 5, d_model=16, num_heads=2, dim_feedforward=32, num_layers=3)
+        tr = HipTrainer(mt, "diffusion", "adam", 1e-3, bucket_mb=0.004, overlap_comm=True)
+        assert tr._flush_mode and len(tr.buckets.ranges) > 3 and all(lp.flush_on_exit for lp in tr.plan.layers)
+        launches = []
+        orig = tr.buckets.launch
+        tr.buckets.launch = lambda b, inline=False: (launches.append(b), orig(b, inline))[1]
+        for _ in range(2):
+            launches.clear()
+            tr.grad.fill_(float(rank + 1))
+            tr.step((torch.randn(2, 5, 12), torch.tensor([1, 2]), torch.randn(2, 5, 12)))
+            assert sorted(launches) == list(range(len(tr.buckets.ranges))), launches
+            assert tr.buckets._works == [] and all(v == 0 for v in tr.buckets._pending)
+            assert torch.all(tr.grad == 3.0)
         hip.set_dry_run(False)
         dist.barrier()
         dist.destroy_process_group()
