@@ -15,6 +15,25 @@ constexpr int NPART = 40;  // 30 component sums + 8 metric sums (+2 pad)
 //                 [30] force-norm sum, [31] moment-norm sum, [32] cop-norm sum, [33] wrench6-norm sum,
 //                 [34] wrench-moment-left norm sum, [35] wrench-moment-right norm sum, [36] com-acc norm sum
 
+// 64-lane sum without the LDS crossbar: four DPP adds give every lane its 16-lane row total, the four row totals are
+// read out as scalars and added in a fixed order.  (37 butterflies of ds_bpermute shuffles were most of this kernel.)
+template <int CTRL>
+__device__ __forceinline__ float rl_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float rl_wave_sum(float v) {
+  v += rl_dpp<0xB1>(v);     // quad_perm [1,0,3,2]
+  v += rl_dpp<0x4E>(v);     // quad_perm [2,3,0,1]
+  v += rl_dpp<0x141>(v);    // row_half_mirror
+  v += rl_dpp<0x140>(v);    // row_mirror
+  const int i = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 0));
+  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 32));
+  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 48));
+  return ((r0 + r1) + r2) + r3;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void regression_loss_partial_kernel(
     const T* __restrict__ o_cop, const T* __restrict__ o_force, const T* __restrict__ o_torque,
@@ -97,7 +116,7 @@ __global__ __launch_bounds__(256) void regression_loss_partial_kernel(
   }
 #pragma unroll
   for (int i = 0; i < NPART; ++i) {
-    const float s = ib_wave_sum(acc[i]);
+    const float s = rl_wave_sum(acc[i]);
     if (lane == 0) red[wave][i] = s;
   }
   __syncthreads();
