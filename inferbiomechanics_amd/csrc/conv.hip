@@ -101,6 +101,27 @@ __global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, T
   }
 }
 
+// bf16, n % 8 == 0, 16-byte aligned: 8 elements per thread through one 16-byte load and store (same mask as above)
+__global__ __launch_bounds__(256) void dropout_vec8_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int64_t n8,
+                                                            float p, uint32_t seed, int step,
+                                                            const int32_t* __restrict__ step_dev) {
+  const uint32_t st = (uint32_t)(step_dev ? *step_dev : step);
+  const uint32_t key = mix32(seed ^ mix32(st + 0x9e3779b9u));
+  const float keep = 1.f / (1.f - p);
+  const uint32_t thr = (uint32_t)(p * 4294967296.0);
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n8; g += (int64_t)gridDim.x * blockDim.x) {
+    bf16x8_t v;
+    __builtin_memcpy(&v, __builtin_assume_aligned(x + 8 * g, 16), 16);
+    const uint32_t hi = mix32((uint32_t)((8 * g) >> 32) + key);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const uint32_t r = mix32((uint32_t)(8 * g + e) ^ key) ^ hi;       // (8g + e) >> 32 is the same for all 8
+      v[e] = r < thr ? (bf16_t)0.f : (bf16_t)((float)v[e] * keep);
+    }
+    __builtin_memcpy(__builtin_assume_aligned(y + 8 * g, 16), &v, 16);
+  }
+}
+
 }  // namespace
 
 extern "C" int ib_im2col_replicate(const void* x, void* col, int64_t ldcol, int64_t N, int64_t F, int64_t C, int k, int dtype,
@@ -146,6 +167,12 @@ extern "C" int ib_col2im_replicate(const void* dcol, int64_t ldcol, const void* 
 extern "C" int ib_dropout(const void* x, void* y, int64_t n, float p, uint32_t seed, int32_t step, const int32_t* step_dev,
                           int dtype, ib_stream_t stream) {
   if (!x || !y || n <= 0 || !(p >= 0.f) || !(p < 1.f)) return IB_E_ARG;
+  if (dtype == IB_BF16 && n % 8 == 0 && (reinterpret_cast<uintptr_t>(x) % 16) == 0 && (reinterpret_cast<uintptr_t>(y) % 16) == 0) {
+    hipLaunchKernelGGL(dropout_vec8_kernel, dim3(ib_grid_1d(n / 8, 256)), dim3(256), 0, ib_s(stream), (const bf16_t*)x,
+                       (bf16_t*)y, n / 8, p, seed, step, step_dev);
+    IB_CHECK_LAUNCH();
+    return IB_OK;
+  }
   const int grid = ib_grid_1d(n, 256);
   if (dtype == IB_F32)
     hipLaunchKernelGGL((dropout_kernel<float>), dim3(grid), dim3(256), 0, ib_s(stream), (const float*)x, (float*)y, n, p, seed,

@@ -141,6 +141,11 @@ def test_dropout_mask_is_reproducible_and_scaled(dtype):
     assert torch.equal(z, y1)
     hip.dropout(x, y2, 0.0, seed=1)
     assert torch.equal(y2, x)
+    # the 16-byte-piece kernel (bf16, size % 8 == 0) draws the same mask as the element-per-thread kernel
+    xs = torch.ones(n + 4, device=DEV, dtype=dtype)
+    ys = torch.empty_like(xs)
+    hip.dropout(xs, ys, p, seed=11, step=5)
+    assert torch.equal(ys[:n], y1)
 
 
 @pytest.mark.parametrize("name,fmt,F", GL_CASES)
