@@ -842,6 +842,229 @@ bool ring_ok(const GemmParams& p, int dtype, int red_len, int red_chunk) {
          p.lda >= 8 && p.ldb >= 8;
 }
 
+// ---- small-M forward -------------------------------------------------------------------------------------------------
+// y[M,N] = act(x[M,K] w[N,K]^T + bias) when the 128 x 128 tiling yields only a handful of workgroups (a batch of a few
+// hundred rows: the reference's regression models, batch-1 analysis): 64 x 16 output tiles, and the four waves of a
+// workgroup split the REDUCTION (k-blocks w, w+4, ...), so every wave walks a quarter of K.  Both operands are
+// k-contiguous: fragments come straight from global memory (no LDS staging), the four partial accumulators are combined
+// through LDS in a fixed order.  [256, 512, 1470]: 8 workgroups x 46 serial K steps -> 128 workgroups x 12.
+namespace smallm {
+constexpr int TM = 64, TN = 16, PD = 3;
+
+__device__ __forceinline__ bf16x8_t ldfrag(const bf16_t* __restrict__ rowp, int ks, int K) {
+  bf16x8_t v;
+  const int nv = K - ks;
+  if (nv >= 8) {
+    __builtin_memcpy(&v, __builtin_assume_aligned(rowp + ks, 4), 16);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = e < nv ? rowp[ks + e] : (bf16_t)0.f;
+  }
+  return v;
+}
+
+template <int ACT>
+__global__ __launch_bounds__(256) void fwd_smallm_kernel(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ w,
+                                                         int64_t ldw, const float* __restrict__ bias, bf16_t* __restrict__ y,
+                                                         int64_t ldy, int M, int N, int K) {
+  __shared__ __attribute__((aligned(16))) float red[4][TM * TN];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, kq = lane >> 4;
+  const int i0 = blockIdx.y * TM, j0 = blockIdx.x * TN;
+  const bf16_t* arow[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) arow[t] = x + (int64_t)min(i0 + 16 * t + r, M - 1) * ldx;
+  const bf16_t* brow = w + (int64_t)min(j0 + r, N - 1) * ldw;
+  const int nkb = (K + 31) / 32;
+  const int nmine = wave < nkb ? (nkb - wave + 3) / 4 : 0;
+  f32x4_t acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  bf16x8_t fa[PD][4], fb[PD];
+  auto load = [&](int s, int it) {
+    const int ks = (wave + 4 * it) * 32 + 8 * kq;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) fa[s][t] = ldfrag(arow[t], ks, K);
+    fb[s] = ldfrag(brow, ks, K);
+  };
+#pragma unroll
+  for (int s = 0; s < PD; ++s)
+    if (s < nmine) load(s, s);
+  for (int it0 = 0; it0 < nmine; it0 += PD) {
+#pragma unroll
+    for (int s = 0; s < PD; ++s) {
+      const int it = it0 + s;
+      if (it < nmine) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[s], fa[s][t], acc[t], 0, 0, 0);
+        if (it + PD < nmine) load(s, it + PD);
+      }
+    }
+  }
+  // swapped operands: this lane holds columns 4*kq .. +3 of row 16*t + r
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+    *reinterpret_cast<float4*>(&red[wave][(16 * t + r) * TN + 4 * kq]) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+  __syncthreads();
+  const int row = tid >> 2, c4 = (tid & 3) * 4;            // 256 threads x 4 outputs = the 64 x 16 tile
+  const int gi = i0 + row, gj = j0 + c4;
+  if (gi < M && gj < N) {
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int o = row * TN + c4 + e;
+      v[e] = ((red[0][o] + red[1][o]) + red[2][o]) + red[3][o];
+      if (bias && gj + e < N) v[e] += bias[gj + e];
+      v[e] = act_fwd_t<bf16_t, ACT>(v[e]);
+    }
+    bf16_t* dst = y + (int64_t)gi * ldy + gj;
+    if (gj + 4 <= N && (ldy % 4) == 0 && (reinterpret_cast<uintptr_t>(y) % 8) == 0) {
+      bf16x4_t o4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o4[e] = (bf16_t)v[e];
+      *reinterpret_cast<bf16x4_t*>(dst) = o4;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (gj + e < N) dst[e] = (bf16_t)v[e];
+    }
+  }
+}
+
+// dx[M,K] = (dz[M,N] w[N,K]) * act'(aux): the same tiling for the backward.  w is k-STRIDED here (its rows are the
+// reduction index), so the workgroup first transposes its slice w[:, 16 columns] into LDS (rows beyond N zero-filled);
+// dz fragments come straight from global memory.
+constexpr int RMAX = 1024, WS = RMAX + 8;
+template <int ACT>
+__global__ __launch_bounds__(256) void dgrad_smallm_kernel(const bf16_t* __restrict__ dz, int64_t lddz,
+                                                           const bf16_t* __restrict__ w, int64_t ldw,
+                                                           const bf16_t* __restrict__ aux, int64_t ldaux,
+                                                           bf16_t* __restrict__ dx, int64_t lddx, int M, int N) {
+  __shared__ __attribute__((aligned(16))) bf16_t wimg[16 * WS];
+  __shared__ __attribute__((aligned(16))) float red[4][TM * TN];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, kq = lane >> 4;
+  const int i0 = blockIdx.y * TM, j0 = blockIdx.x * TN;
+  const int nkb = (N + 31) / 32;
+  for (int pce = tid; pce < nkb * 64; pce += 256) {        // one 16-byte piece = 8 columns of one reduction row
+    const int k = pce >> 1, half = pce & 1;
+    bf16x8_t v;
+    if (k < N) __builtin_memcpy(&v, __builtin_assume_aligned(w + (int64_t)k * ldw + j0 + 8 * half, 16), 16);
+    else
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (bf16_t)0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) wimg[(8 * half + e) * WS + k] = v[e];
+  }
+  __syncthreads();
+  const bf16_t* arow[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) arow[t] = dz + (int64_t)min(i0 + 16 * t + r, M - 1) * lddz;
+  const bf16_t* brow = wimg + r * WS;
+  const int nmine = wave < nkb ? (nkb - wave + 3) / 4 : 0;
+  f32x4_t acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  bf16x8_t fa[PD][4];
+  auto load = [&](int s, int it) {
+    const int ks = (wave + 4 * it) * 32 + 8 * kq;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) fa[s][t] = ldfrag(arow[t], ks, N);
+  };
+#pragma unroll
+  for (int s = 0; s < PD; ++s)
+    if (s < nmine) load(s, s);
+  for (int it0 = 0; it0 < nmine; it0 += PD) {
+#pragma unroll
+    for (int s = 0; s < PD; ++s) {
+      const int it = it0 + s;
+      if (it < nmine) {
+        bf16x8_t b;
+        __builtin_memcpy(&b, __builtin_assume_aligned(brow + (wave + 4 * it) * 32 + 8 * kq, 16), 16);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, fa[s][t], acc[t], 0, 0, 0);
+        if (it + PD < nmine) load(s, it + PD);
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+    *reinterpret_cast<float4*>(&red[wave][(16 * t + r) * TN + 4 * kq]) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+  __syncthreads();
+  const int row = tid >> 2, c4 = (tid & 3) * 4;
+  const int gi = i0 + row, gj = j0 + c4;
+  if (gi < M) {
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int o = row * TN + c4 + e;
+      v[e] = ((red[0][o] + red[1][o]) + red[2][o]) + red[3][o];
+    }
+    if constexpr (ACT != IB_ACT_NONE) {
+      bf16x4_t a4;
+      __builtin_memcpy(&a4, __builtin_assume_aligned(aux + (int64_t)gi * ldaux + gj, 8), 8);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] *= act_bwd_t<bf16_t, ACT>((float)a4[e]);
+    }
+    bf16x4_t o4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o4[e] = (bf16_t)v[e];
+    __builtin_memcpy(__builtin_assume_aligned(dx + (int64_t)gi * lddx + gj, 8), &o4, 8);
+  }
+}
+
+// GemmParams of a dgrad: A = dz [M, red], B = w [red, cols], C = dx [M, cols]; p.N = output columns, p.K = reduction length
+inline bool dgrad_ok(const GemmParams& p) {
+  static const int off = []() { const char* e = getenv("IB_NO_SMALLM"); return e ? atoi(e) : 0; }();
+  const int64_t tiles = (int64_t)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+  return !off && tiles <= 32 && !p.addend && p.K >= 64 && p.K <= RMAX && p.N % 16 == 0 && p.lda % 2 == 0 && aligned(p.A, 4) &&
+         p.ldb % 8 == 0 && aligned(p.B, 16) && p.ldc % 4 == 0 && aligned(p.C, 8) &&
+         (p.act == IB_ACT_NONE || (p.aux && p.ldaux % 4 == 0 && aligned(p.aux, 8)));
+}
+int launch_dgrad(const GemmParams& p, hipStream_t s) {
+  const dim3 grid((unsigned)(p.N / TN), (unsigned)((p.M + TM - 1) / TM)), block(256);
+#define IB_SMALLM(ACT)                                                                                                    \
+  hipLaunchKernelGGL((dgrad_smallm_kernel<ACT>), grid, block, 0, s, (const bf16_t*)p.A, p.lda, (const bf16_t*)p.B, p.ldb,   \
+                     (const bf16_t*)p.aux, p.ldaux, (bf16_t*)p.C, p.ldc, p.M, p.K)
+  switch (p.act) {
+    case IB_ACT_RELU: IB_SMALLM(IB_ACT_RELU); break;
+    case IB_ACT_TANH: IB_SMALLM(IB_ACT_TANH); break;
+    case IB_ACT_SIGMOID: IB_SMALLM(IB_ACT_SIGMOID); break;
+    case IB_ACT_SILU: IB_SMALLM(IB_ACT_SILU); break;
+    case IB_ACT_ELU: IB_SMALLM(IB_ACT_ELU); break;
+    default: IB_SMALLM(IB_ACT_NONE); break;
+  }
+#undef IB_SMALLM
+  IB_CHECK_LAUNCH();
+  return IB_OK;
+}
+
+// few 128 x 128 tiles, plain epilogue (bias + activation), rows 4-byte aligned
+inline bool ok(const GemmParams& p) {
+  static const int off = []() { const char* e = getenv("IB_NO_SMALLM"); return e ? atoi(e) : 0; }();
+  const int64_t tiles = (int64_t)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+  return !off && tiles <= 32 && !p.Z && !p.add_div && !p.add_mod && p.lda % 2 == 0 && p.ldb % 2 == 0 &&
+         aligned(p.A, 4) && aligned(p.B, 4) && p.K >= 64;
+}
+int launch(const GemmParams& p, hipStream_t s) {
+  const dim3 grid((unsigned)((p.N + TN - 1) / TN), (unsigned)((p.M + TM - 1) / TM)), block(256);
+#define IB_SMALLM(ACT)                                                                                                   \
+  hipLaunchKernelGGL((fwd_smallm_kernel<ACT>), grid, block, 0, s, (const bf16_t*)p.A, p.lda, (const bf16_t*)p.B, p.ldb, p.bias, \
+                     (bf16_t*)p.C, p.ldc, p.M, p.N, p.K)
+  switch (p.act) {
+    case IB_ACT_RELU: IB_SMALLM(IB_ACT_RELU); break;
+    case IB_ACT_TANH: IB_SMALLM(IB_ACT_TANH); break;
+    case IB_ACT_SIGMOID: IB_SMALLM(IB_ACT_SIGMOID); break;
+    case IB_ACT_SILU: IB_SMALLM(IB_ACT_SILU); break;
+    case IB_ACT_ELU: IB_SMALLM(IB_ACT_ELU); break;
+    default: IB_SMALLM(IB_ACT_NONE); break;
+  }
+#undef IB_SMALLM
+  IB_CHECK_LAUNCH();
+  return IB_OK;
+}
+}  // namespace smallm
+
 template <typename T>
 int launch_fwd(GemmParams& p, hipStream_t s) {
   p.ablate = g_ablate; p.prof = g_gemm_prof;
@@ -855,6 +1078,7 @@ int launch_fwd(GemmParams& p, hipStream_t s) {
   p.tiles_n = (p.N + BN - 1) / BN; p.tiles_m = (p.M + BM - 1) / BM;
   p.k_chunk = p.K; p.slab_stride = 0; p.xcd_group = 1;
   const int tiles = p.tiles_m * p.tiles_n;
+  if (sizeof(T) == 2 && smallm::ok(p)) return smallm::launch(p, s);
   if (sizeof(T) == 2 && ring_ok(p, IB_BF16, p.K, p.K)) {
     hipLaunchKernelGGL((gemm_ring_kernel<true, true, EPI_FWD>), dim3(tiles, 1), dim3(NTHREADS), 0, s, p);
     IB_CHECK_LAUNCH();
@@ -877,6 +1101,7 @@ int launch_dgrad(GemmParams& p, hipStream_t s) {
   p.tiles_n = (p.N + BN - 1) / BN; p.tiles_m = (p.M + BM - 1) / BM;
   p.k_chunk = p.K; p.slab_stride = 0; p.xcd_group = 1;
   const int tiles = p.tiles_m * p.tiles_n;
+  if (sizeof(T) == 2 && smallm::dgrad_ok(p)) return smallm::launch_dgrad(p, s);
   if (sizeof(T) == 2 && ring_ok(p, IB_BF16, p.K, p.K)) {
     hipLaunchKernelGGL((gemm_ring_kernel<true, false, EPI_DGRAD>), dim3(tiles, 1), dim3(NTHREADS), 0, s, p);
     IB_CHECK_LAUNCH();

@@ -455,3 +455,32 @@ def test_linear_ln_fwd_matches_unfused(hip, M, N, K):
     ws2 = torch.zeros(int(hip.lib().ib_linear_ln_fwd_workspace(M, 96, K)), dtype=torch.uint8, device=DEV)
     assert not hip.linear_ln_fwd(x, rnd((96, K), 7, 0.1, bf).to(DEV), None, None, torch.ones(96, device=DEV),
                                  torch.zeros(96, device=DEV), y2, ws2)
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 512, 1470), (256, 300, 512), (32, 512, 512), (1, 300, 512), (100, 72, 200),
+                                   (1000, 512, 512), (64, 16, 64)])
+@pytest.mark.parametrize("act", ["none", "sigmoid", "elu"])
+def test_small_m_forward_and_dgrad_tiles(hip, M, N, K, act):
+    """batches of a few hundred rows take the 64 x 16 tiles whose four waves split the reduction (ragged K tail, ragged
+    column tile, rows that are only 4-byte aligned); the results must agree with float64 like the 128 x 128 kernels'"""
+    bf = torch.bfloat16
+    x = rnd((M, K), 1, 1.0, bf).to(DEV)
+    w = rnd((N, K), 2, K ** -0.5, bf).to(DEV)
+    b = rnd((N,), 3, 0.1).to(DEV)
+    y = torch.full((M, N), 7.0, dtype=bf, device=DEV)
+    hip.linear_fwd(x, w, b, y, act=act)
+    close(y, R.act(act, x.double() @ w.double().T + b.double()), TIGHT[bf], "small-M forward")
+    hip.linear_fwd(x, w, None, y)
+    close(y, x.double() @ w.double().T, TIGHT[bf], "small-M forward, no bias")
+    # dgrad: dx[M, Kout] = (dz[M, Nred] w[Nred, Kout]) * act'(aux); output columns % 16 == 0 for the small tiles
+    Kout = (K + 15) // 16 * 16
+    dz = rnd((M, N), 4, 1.0, bf).to(DEV)
+    w2 = rnd((N, Kout), 5, N ** -0.5, bf).to(DEV)
+    aux = rnd((M, Kout), 6, 1.0, bf).to(DEV)
+    if act == "sigmoid":
+        aux = torch.sigmoid(aux.float()).to(bf)
+    dx = torch.full((M, Kout), 7.0, dtype=bf, device=DEV)
+    hip.linear_dgrad(dz, w2, dx, act_below=act, aux=aux if act != "none" else None)
+    a = aux.double()
+    fac = {"none": torch.ones_like(a), "sigmoid": a * (1 - a), "elu": torch.where(a > 0, torch.ones_like(a), a + 1)}[act]
+    close(dx, (dz.double() @ w2.double()) * fac, TIGHT[bf], "small-M dgrad")
