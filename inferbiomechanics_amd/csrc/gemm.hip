@@ -1013,11 +1013,17 @@ __global__ __launch_bounds__(256) void dgrad_smallm_kernel(const bf16_t* __restr
   }
 }
 
+// up to this many 128 x 128 tiles the small tiles win (Groundlink F=10 step: cap 32 0.528 ms, 64 0.489, 128 0.491,
+// 256 0.502; the DDIM step at M = 3200, 100 tiles: 492 us of kernels at 32 / 64, 515 at 128)
+inline int tile_cap() {
+  static const int cap = []() { const char* e = getenv("IB_SMALLM_TILES"); return e ? atoi(e) : 64; }();
+  return cap;
+}
 // GemmParams of a dgrad: A = dz [M, red], B = w [red, cols], C = dx [M, cols]; p.N = output columns, p.K = reduction length
 inline bool dgrad_ok(const GemmParams& p) {
   static const int off = []() { const char* e = getenv("IB_NO_SMALLM"); return e ? atoi(e) : 0; }();
   const int64_t tiles = (int64_t)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-  return !off && tiles <= 32 && !p.addend && p.K >= 64 && p.K <= RMAX && p.N % 16 == 0 && p.lda % 2 == 0 && aligned(p.A, 4) &&
+  return !off && tiles <= tile_cap() && !p.addend && p.K >= 64 && p.K <= RMAX && p.N % 16 == 0 && p.lda % 2 == 0 && aligned(p.A, 4) &&
          p.ldb % 8 == 0 && aligned(p.B, 16) && p.ldc % 4 == 0 && aligned(p.C, 8) &&
          (p.act == IB_ACT_NONE || (p.aux && p.ldaux % 4 == 0 && aligned(p.aux, 8)));
 }
@@ -1043,7 +1049,7 @@ int launch_dgrad(const GemmParams& p, hipStream_t s) {
 inline bool ok(const GemmParams& p) {
   static const int off = []() { const char* e = getenv("IB_NO_SMALLM"); return e ? atoi(e) : 0; }();
   const int64_t tiles = (int64_t)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-  return !off && tiles <= 32 && !p.Z && !p.add_div && !p.add_mod && p.lda % 2 == 0 && p.ldb % 2 == 0 &&
+  return !off && tiles <= tile_cap() && !p.Z && !p.add_div && !p.add_mod && p.lda % 2 == 0 && p.ldb % 2 == 0 &&
          aligned(p.A, 4) && aligned(p.B, 4) && p.K >= 64;
 }
 int launch(const GemmParams& p, hipStream_t s) {
