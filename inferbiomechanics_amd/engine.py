@@ -79,19 +79,23 @@ class GradBuckets:
         return b if self._pending[b] == 0 else None
 
     def launch(self, b: int, inline: bool = False):
-        """all-reduce bucket b.  `inline` (the whole gradient in one call after the backward: nothing to overlap with): a
-        synchronous collective, ordered on the CURRENT stream.  Otherwise an asynchronous one: c10d's own communication
-        stream first waits for everything enqueued on the current stream so far, the backward keeps running beside it,
-        and finish() makes the current stream wait for it.  (An extra stream of our own around the call added two more
-        event hops per bucket: 51 us of idle GPU between the backward and the optimizer of a 0.25-ms step.)"""
+        """all-reduce bucket b as an ASYNCHRONOUS c10d collective: c10d's own communication stream first waits for
+        everything enqueued on the current stream so far, the backward keeps running beside it, and finish() makes the
+        current stream wait for it.  `inline` (the whole gradient in one call after the backward: nothing to overlap
+        with) waits right away.  Two things measured / learnt here: an extra stream of our own around the call added two
+        more event hops per bucket (51 us of idle GPU between the backward and the optimizer of a 0.25-ms step); and a
+        SYNCHRONOUS collective, which c10d runs on the current stream, leaves its completion event on the very stream
+        the trainer captures its graphs on -- c10d's watchdog thread then queries that event in the middle of a later
+        capture and HIP refuses (the process aborts).  Asynchronous collectives keep their events on c10d's stream."""
         if not self.active:
             return
         lo, hi = self.ranges[b]
         t = self.flat[lo:hi]
+        w = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         if inline:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            w.wait()
         else:
-            self._works.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self._works.append(w)
 
     def finish(self):
         """make the compute stream wait for every outstanding bucket (a stream-level wait on the GPU path: no host block)"""
