@@ -863,29 +863,41 @@ __device__ __forceinline__ bf16x8_t ldfrag(const bf16_t* __restrict__ rowp, int 
   return v;
 }
 
-template <int ACT>
+// NT = output-tile width / 16.  Only NT = 1 is instantiated: 64 x 64 tiles (NT = 4) were measured for the sampling loop's
+// mid-sized problems (M = 3200, where 128 x 128 tiles leave most CUs idle) and lost to the ring kernel -- [3200, 1536,
+// 512] 35.6 vs 17.6 us, [3200, 2048, 512] 48 vs 20 -- fragment loads straight from global memory are 16 rows x 64 bytes
+// each and do not reach the rate of whole-row LDS-DMA staging once the tile count is in the hundreds.
+template <int ACT, int NT>
 __global__ __launch_bounds__(256) void fwd_smallm_kernel(const bf16_t* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ w,
-                                                         int64_t ldw, const float* __restrict__ bias, bf16_t* __restrict__ y,
-                                                         int64_t ldy, int M, int N, int K) {
-  __shared__ __attribute__((aligned(16))) float red[4][TM * TN];
+                                                         int64_t ldw, const float* __restrict__ bias,
+                                                         const bf16_t* __restrict__ add_div, int64_t ld_ad,
+                                                         const bf16_t* __restrict__ add_mod, int64_t ld_am, int seg,
+                                                         bf16_t* __restrict__ y, int64_t ldy, int M, int N, int K) {
+  constexpr int TNV = 16 * NT;
+  __shared__ __attribute__((aligned(16))) float red[4][TM * TNV];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, kq = lane >> 4;
-  const int i0 = blockIdx.y * TM, j0 = blockIdx.x * TN;
+  const int i0 = blockIdx.y * TM, j0 = blockIdx.x * TNV;
   const bf16_t* arow[4];
+  const bf16_t* brow[NT];
 #pragma unroll
   for (int t = 0; t < 4; ++t) arow[t] = x + (int64_t)min(i0 + 16 * t + r, M - 1) * ldx;
-  const bf16_t* brow = w + (int64_t)min(j0 + r, N - 1) * ldw;
+#pragma unroll
+  for (int u = 0; u < NT; ++u) brow[u] = w + (int64_t)min(j0 + 16 * u + r, N - 1) * ldw;
   const int nkb = (K + 31) / 32;
   const int nmine = wave < nkb ? (nkb - wave + 3) / 4 : 0;
-  f32x4_t acc[4];
+  f32x4_t acc[4][NT];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  bf16x8_t fa[PD][4], fb[PD];
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int u = 0; u < NT; ++u) acc[t][u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  bf16x8_t fa[PD][4], fb[PD][NT];
   auto load = [&](int s, int it) {
     const int ks = (wave + 4 * it) * 32 + 8 * kq;
 #pragma unroll
     for (int t = 0; t < 4; ++t) fa[s][t] = ldfrag(arow[t], ks, K);
-    fb[s] = ldfrag(brow, ks, K);
+#pragma unroll
+    for (int u = 0; u < NT; ++u) fb[s][u] = ldfrag(brow[u], ks, K);
   };
 #pragma unroll
   for (int s = 0; s < PD; ++s)
@@ -896,29 +908,43 @@ __global__ __launch_bounds__(256) void fwd_smallm_kernel(const bf16_t* __restric
       const int it = it0 + s;
       if (it < nmine) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[s], fa[s][t], acc[t], 0, 0, 0);
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int u = 0; u < NT; ++u)
+            acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[s][u], fa[s][t], acc[t][u], 0, 0, 0);
         if (it + PD < nmine) load(s, it + PD);
       }
     }
   }
-  // swapped operands: this lane holds columns 4*kq .. +3 of row 16*t + r
+  // swapped operands: this lane holds columns 16*u + 4*kq .. +3 of row 16*t + r
 #pragma unroll
   for (int t = 0; t < 4; ++t)
-    *reinterpret_cast<float4*>(&red[wave][(16 * t + r) * TN + 4 * kq]) = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+#pragma unroll
+    for (int u = 0; u < NT; ++u)
+      *reinterpret_cast<float4*>(&red[wave][(16 * t + r) * TNV + 16 * u + 4 * kq]) =
+          make_float4(acc[t][u][0], acc[t][u][1], acc[t][u][2], acc[t][u][3]);
   __syncthreads();
-  const int row = tid >> 2, c4 = (tid & 3) * 4;            // 256 threads x 4 outputs = the 64 x 16 tile
-  const int gi = i0 + row, gj = j0 + c4;
-  if (gi < M && gj < N) {
+  const bool vst = (ldy % 4) == 0 && (reinterpret_cast<uintptr_t>(y) % 8) == 0;
+#pragma unroll
+  for (int g = 0; g < NT; ++g) {                            // 256 threads x 4 outputs per pass
+    const int o0 = (g * 256 + tid) * 4;
+    const int row = o0 / TNV, c4 = o0 % TNV;
+    const int gi = i0 + row, gj = j0 + c4;
+    if (gi >= M || gj >= N) continue;
     float v[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const int o = row * TN + c4 + e;
+      const int o = o0 + e;
       v[e] = ((red[0][o] + red[1][o]) + red[2][o]) + red[3][o];
-      if (bias && gj + e < N) v[e] += bias[gj + e];
+      if (gj + e < N) {
+        if (bias) v[e] += bias[gj + e];
+        if (add_div) v[e] += (float)add_div[(int64_t)(gi / seg) * ld_ad + gj + e];
+        if (add_mod) v[e] += (float)add_mod[(int64_t)(gi % seg) * ld_am + gj + e];
+      }
       v[e] = act_fwd_t<bf16_t, ACT>(v[e]);
     }
     bf16_t* dst = y + (int64_t)gi * ldy + gj;
-    if (gj + 4 <= N && (ldy % 4) == 0 && (reinterpret_cast<uintptr_t>(y) % 8) == 0) {
+    if (gj + 4 <= N && vst) {
       bf16x4_t o4;
 #pragma unroll
       for (int e = 0; e < 4; ++e) o4[e] = (bf16_t)v[e];
@@ -1045,17 +1071,19 @@ int launch_dgrad(const GemmParams& p, hipStream_t s) {
   return IB_OK;
 }
 
-// few 128 x 128 tiles, plain epilogue (bias + activation), rows 4-byte aligned
+// few 128 x 128 tiles (tile_cap()), plain epilogue (bias, the two row-broadcast addends, activation), rows 4-byte aligned
 inline bool ok(const GemmParams& p) {
   static const int off = []() { const char* e = getenv("IB_NO_SMALLM"); return e ? atoi(e) : 0; }();
   const int64_t tiles = (int64_t)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-  return !off && tiles <= tile_cap() && !p.Z && !p.add_div && !p.add_mod && p.lda % 2 == 0 && p.ldb % 2 == 0 &&
-         aligned(p.A, 4) && aligned(p.B, 4) && p.K >= 64;
+  return !off && tiles <= tile_cap() && !p.Z && p.lda % 2 == 0 && p.ldb % 2 == 0 && aligned(p.A, 4) && aligned(p.B, 4) &&
+         p.K >= 64;
 }
+template <int NT>
 int launch(const GemmParams& p, hipStream_t s) {
-  const dim3 grid((unsigned)((p.N + TN - 1) / TN), (unsigned)((p.M + TM - 1) / TM)), block(256);
-#define IB_SMALLM(ACT)                                                                                                   \
-  hipLaunchKernelGGL((fwd_smallm_kernel<ACT>), grid, block, 0, s, (const bf16_t*)p.A, p.lda, (const bf16_t*)p.B, p.ldb, p.bias, \
+  const dim3 grid((unsigned)((p.N + 16 * NT - 1) / (16 * NT)), (unsigned)((p.M + TM - 1) / TM)), block(256);
+#define IB_SMALLM(ACT)                                                                                                      \
+  hipLaunchKernelGGL((fwd_smallm_kernel<ACT, NT>), grid, block, 0, s, (const bf16_t*)p.A, p.lda, (const bf16_t*)p.B, p.ldb,   \
+                     p.bias, (const bf16_t*)p.add_div, p.ld_add_div, (const bf16_t*)p.add_mod, p.ld_add_mod, p.seg,         \
                      (bf16_t*)p.C, p.ldc, p.M, p.N, p.K)
   switch (p.act) {
     case IB_ACT_RELU: IB_SMALLM(IB_ACT_RELU); break;
@@ -1084,7 +1112,7 @@ int launch_fwd(GemmParams& p, hipStream_t s) {
   p.tiles_n = (p.N + BN - 1) / BN; p.tiles_m = (p.M + BM - 1) / BM;
   p.k_chunk = p.K; p.slab_stride = 0; p.xcd_group = 1;
   const int tiles = p.tiles_m * p.tiles_n;
-  if (sizeof(T) == 2 && smallm::ok(p)) return smallm::launch(p, s);
+  if (sizeof(T) == 2 && smallm::ok(p)) return smallm::launch<1>(p, s);
   if (sizeof(T) == 2 && ring_ok(p, IB_BF16, p.K, p.K)) {
     hipLaunchKernelGGL((gemm_ring_kernel<true, true, EPI_FWD>), dim3(tiles, 1), dim3(NTHREADS), 0, s, p);
     IB_CHECK_LAUNCH();
