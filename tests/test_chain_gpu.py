@@ -173,7 +173,9 @@ def test_time_mlp_fwd_matches_float64(hip, B, temb, hid, out):
 
 
 def test_deferred_wgrad_slabs_match_fused_wgrad(hip):
-    """ib_linear_wgrad_slabs + ONE ib_slab_reduce_multi == ib_linear_wgrad, bitwise (same slabs, same order)"""
+    """ib_linear_wgrad_slabs + ONE ib_slab_reduce_multi == ib_linear_wgrad: bitwise where both take the split-M kernel (same
+    slabs, same order); for short reductions (<= 1024 rows) ib_linear_wgrad is the one-pass kernel, which adds the same
+    products in another order -- equal within fp32 rounding"""
     shapes = [(12800, 512, 300), (12800, 300, 512), (256, 1024, 512), (256, 512, 128), (100, 64, 32)]
     items, refs = [], []
     for j, (M, N, K) in enumerate(shapes):
@@ -188,12 +190,16 @@ def test_deferred_wgrad_slabs_match_fused_wgrad(hip):
         refs.append(ref)
     hip.slab_reduce_multi(items)
     torch.cuda.synchronize()
-    for (ws2, n, dw), ref in zip(items, refs):
-        assert torch.equal(dw, ref)
+    for (M, N, K), (ws2, n, dw), ref in zip(shapes, items, refs):
+        if M > 1024:
+            assert torch.equal(dw, ref)
+        else:
+            close(dw, ref.double(), 2e-6, f"short reduction {M}x{N}x{K}")
+    before = [dw.clone() for _, _, dw in items]
     hip.slab_reduce_multi(items, accumulate=True)
     torch.cuda.synchronize()
-    for (ws2, n, dw), ref in zip(items, refs):
-        assert torch.equal(dw, ref + ref)
+    for (ws2, n, dw), b in zip(items, before):
+        assert torch.equal(dw, b + b)
 
 
 def test_grouped_wgrad_launch_matches_single_launches(hip):
