@@ -1510,6 +1510,16 @@ extern "C" int ib_linear_wgrad_slabs(const void* dz, int64_t lddz, const void* x
                                      size_t workspace_bytes, int* nslab_out, int64_t M, int64_t N, int64_t K,
                                      int dtype, ib_stream_t stream) {
   if (!nslab_out) return IB_E_ARG;
+  if (dz && x && workspace && M > 0 && N > 0 && K > 0 && lddz >= N && ldx >= K && K % 4 == 0 &&
+      workspace_bytes >= (size_t)N * K * sizeof(float) && aligned(workspace, 16) && wsmall::ok(dz, lddz, x, ldx, M, dtype)) {
+    // short reduction: the one-pass kernel writes the whole gradient as a single "slab"
+    hipLaunchKernelGGL(wsmall::wgrad_smallm_kernel, dim3((unsigned)((K + 63) / 64), (unsigned)((N + 63) / 64)), dim3(256), 0,
+                       ib_s(stream), (const bf16_t*)dz, lddz, (const bf16_t*)x, ldx, reinterpret_cast<float*>(workspace), K, 0,
+                       (int)M, (int)N, (int)K);
+    IB_CHECK_LAUNCH();
+    *nslab_out = 1;
+    return IB_OK;
+  }
   return wgrad_gemm(dz, lddz, x, ldx, nullptr, 0, 0, workspace, workspace_bytes, M, N, K, dtype, ib_s(stream), true,
                     nslab_out);
 }
