@@ -74,6 +74,13 @@ size_t ib_linear_wgrad_workspace(int64_t M, int64_t N, int64_t K);
 int ib_linear_wgrad(const void* dz, int64_t lddz, const void* x, int64_t ldx, float* dw, int64_t lddw,
                     int accumulate, void* workspace, size_t workspace_bytes,
                     int64_t M, int64_t N, int64_t K, int dtype, ib_stream_t stream);
+/* Weight AND bias gradient of a Linear layer from one launch, for short reductions (M <= 1024 rows: the reference's
+ * regression models at their batch sizes; autograd of nn.Linear, FeedForwardRegressionBaseline.py:68-77): dw[N,K] (+)=
+ * dz^T x as in ib_linear_wgrad, dbias[N] (+)= column sums of dz (rows added in order).  bf16, 4-byte aligned operand rows;
+ * IB_E_UNSUPPORTED otherwise (callers fall back to ib_linear_wgrad + ib_segment_colsum). */
+int ib_linear_wgrad_bias(const void* dz, int64_t lddz, const void* x, int64_t ldx, float* dw, int64_t lddw, float* dbias,
+                         int accumulate, int64_t M, int64_t N, int64_t K, int dtype, ib_stream_t stream);
+
 /* y = LayerNorm(res + x W^T + bias) * gamma + beta for small token counts (the DDIM sampler): a K-split GEMM into fp32
  * slabs whose reduction kernel is the LayerNorm (TransformerBaseline.py:29-31 / 34-36: Linear -> add -> norm).  bf16,
  * N % 64 == 0, N <= 1024 (N in {64,128,256,512,1024}), K % 32 == 0, 16-byte aligned operand rows; IB_E_UNSUPPORTED

@@ -1415,7 +1415,8 @@ __device__ __forceinline__ bf16x8_t frag_tr(const bf16_t* img, int rbase, int la
 
 __global__ __launch_bounds__(256) void wgrad_smallm_kernel(const bf16_t* __restrict__ dz, int64_t lddz,
                                                            const bf16_t* __restrict__ x, int64_t ldx, float* __restrict__ dw,
-                                                           int64_t lddw, int accumulate, int M, int N, int K) {
+                                                           int64_t lddw, float* __restrict__ dbias, int accumulate, int M,
+                                                           int N, int K) {
   __shared__ __attribute__((aligned(16))) bf16_t aimg[CH * PITCH];
   __shared__ __attribute__((aligned(16))) bf16_t bimg[CH * PITCH];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1426,6 +1427,7 @@ __global__ __launch_bounds__(256) void wgrad_smallm_kernel(const bf16_t* __restr
   for (int t = 0; t < 2; ++t)
 #pragma unroll
     for (int u = 0; u < 2; ++u) acc[t][u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;
   for (int m0 = 0; m0 < M; m0 += CH) {
     if (m0) __syncthreads();                               // the previous chunk's fragments have been read
     const int rows = min(CH, M - m0), rows32 = (rows + 31) / 32 * 32;
@@ -1443,6 +1445,13 @@ __global__ __launch_bounds__(256) void wgrad_smallm_kernel(const bf16_t* __restr
       __builtin_memcpy(__builtin_assume_aligned(bimg + m * PITCH + c, 16), &vb, 16);
     }
     __syncthreads();
+    // the bias gradient of the same layer = column sums of dz: the first workgroup of every row of tiles has the slice
+    // in LDS anyway (one thread per column, rows added in order)
+    if (dbias && blockIdx.x == 0 && tid < 64) {
+      float sacc = 0.f;
+      for (int m = 0; m < rows; ++m) sacc += (float)aimg[m * PITCH + tid];
+      bsum += sacc;
+    }
     for (int ks = 0; ks < rows32; ks += 32) {
       bf16x8_t fa[2], fb[2];
 #pragma unroll
@@ -1456,6 +1465,7 @@ __global__ __launch_bounds__(256) void wgrad_smallm_kernel(const bf16_t* __restr
         for (int u = 0; u < 2; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[u], fa[t], acc[t][u], 0, 0, 0);
     }
   }
+  if (dbias && blockIdx.x == 0 && tid < 64 && n0 + tid < N) dbias[n0 + tid] = accumulate ? dbias[n0 + tid] + bsum : bsum;
   // swapped operands: this lane holds output columns (k) 16*u + 4*(lane >> 4) .. +3 of output row (n) 16*t + (lane & 15)
   const bool vst = (lddw % 4) == 0 && (reinterpret_cast<uintptr_t>(dw) % 16) == 0;
 #pragma unroll
@@ -1492,12 +1502,24 @@ extern "C" int ib_linear_wgrad(const void* dz, int64_t lddz, const void* x, int6
                                int64_t M, int64_t N, int64_t K, int dtype, ib_stream_t stream) {
   if (dz && x && dw && M > 0 && N > 0 && K > 0 && lddz >= N && ldx >= K && lddw >= K && wsmall::ok(dz, lddz, x, ldx, M, dtype)) {
     hipLaunchKernelGGL(wsmall::wgrad_smallm_kernel, dim3((unsigned)((K + 63) / 64), (unsigned)((N + 63) / 64)), dim3(256), 0,
-                       ib_s(stream), (const bf16_t*)dz, lddz, (const bf16_t*)x, ldx, dw, lddw, accumulate, (int)M, (int)N, (int)K);
+                       ib_s(stream), (const bf16_t*)dz, lddz, (const bf16_t*)x, ldx, dw, lddw, nullptr, accumulate, (int)M, (int)N, (int)K);
     IB_CHECK_LAUNCH();
     return IB_OK;
   }
   return wgrad_gemm(dz, lddz, x, ldx, dw, lddw, accumulate, workspace, workspace_bytes, M, N, K, dtype, ib_s(stream),
                     false, nullptr);
+}
+
+extern "C" int ib_linear_wgrad_bias(const void* dz, int64_t lddz, const void* x, int64_t ldx, float* dw, int64_t lddw,
+                                    float* dbias, int accumulate, int64_t M, int64_t N, int64_t K, int dtype,
+                                    ib_stream_t stream) {
+  if (!dz || !x || !dw || !dbias || M <= 0 || N <= 0 || K <= 0 || lddz < N || ldx < K || lddw < K) return IB_E_ARG;
+  if (!wsmall::ok(dz, lddz, x, ldx, M, dtype)) return IB_E_UNSUPPORTED;
+  hipLaunchKernelGGL(wsmall::wgrad_smallm_kernel, dim3((unsigned)((K + 63) / 64), (unsigned)((N + 63) / 64)), dim3(256), 0,
+                     ib_s(stream), (const bf16_t*)dz, lddz, (const bf16_t*)x, ldx, dw, lddw, dbias, accumulate, (int)M, (int)N,
+                     (int)K);
+  IB_CHECK_LAUNCH();
+  return IB_OK;
 }
 
 extern "C" size_t ib_linear_wgrad_slabs_workspace(int64_t M, int64_t N, int64_t K) {
@@ -1514,8 +1536,8 @@ extern "C" int ib_linear_wgrad_slabs(const void* dz, int64_t lddz, const void* x
       workspace_bytes >= (size_t)N * K * sizeof(float) && aligned(workspace, 16) && wsmall::ok(dz, lddz, x, ldx, M, dtype)) {
     // short reduction: the one-pass kernel writes the whole gradient as a single "slab"
     hipLaunchKernelGGL(wsmall::wgrad_smallm_kernel, dim3((unsigned)((K + 63) / 64), (unsigned)((N + 63) / 64)), dim3(256), 0,
-                       ib_s(stream), (const bf16_t*)dz, lddz, (const bf16_t*)x, ldx, reinterpret_cast<float*>(workspace), K, 0,
-                       (int)M, (int)N, (int)K);
+                       ib_s(stream), (const bf16_t*)dz, lddz, (const bf16_t*)x, ldx, reinterpret_cast<float*>(workspace), K,
+                       nullptr, 0, (int)M, (int)N, (int)K);
     IB_CHECK_LAUNCH();
     *nslab_out = 1;
     return IB_OK;

@@ -41,6 +41,7 @@ _SIGS = {
                                    _c.c_int, _vp]),
     "ib_linear_dgrad_skinny": (_c.c_int, [_vp, _i64, _vp, _i64, _c.c_int, _vp, _i64, _vp, _i64, _vp, _c.c_int, _i64, _i64,
                                           _i64, _c.c_int, _vp]),
+    "ib_linear_wgrad_bias": (_c.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _c.c_int, _i64, _i64, _i64, _c.c_int, _vp]),
     "ib_linear_wgrad_workspace": (_sz, [_i64, _i64, _i64]),
     "ib_linear_wgrad": (_c.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _c.c_int, _vp, _sz, _i64, _i64, _i64, _c.c_int, _vp]),
     "ib_linear_ln_fwd_workspace": (_sz, [_i64, _i64, _i64]),
@@ -471,6 +472,28 @@ def linear_dgrad_skinny(dz, w, dx, act_below="none", aux=None, dbias=None, accum
     if rc == -5:                       # IB_E_UNSUPPORTED
         return False
     _check(rc, "ib_linear_dgrad_skinny")
+    return True
+
+
+def linear_wgrad_bias(dz, x, dw, dbias, accumulate=False) -> bool:
+    """dw (+)= dz^T x and dbias (+)= column sums of dz from ONE launch (short reductions); False when the shape does not
+    qualify (the caller then issues linear_wgrad + a column-sum launch)"""
+    dt = dz.dtype
+    M, N, lddz = _mat(dz, "dz", dt)
+    Mx, K, ldx = _mat(x, "x", dt)
+    if Mx != M:
+        raise HipError("linear_wgrad_bias: dz / x row counts differ")
+    Nw, Kw, lddw = _mat(dw, "dw", torch.float32)
+    if (Nw, Kw) != (N, K):
+        raise HipError(f"linear_wgrad_bias: dw must be [{N},{K}], got {tuple(dw.shape)}")
+    _req(dbias, "dbias", torch.float32)
+    if dbias.numel() != N or not dbias.is_contiguous():
+        raise HipError("dbias must be a contiguous fp32 vector of length N")
+    rc = lib().ib_linear_wgrad_bias(_ptr(dz), lddz, _ptr(x), ldx, _ptr(dw), lddw, _ptr(dbias), int(accumulate), M, N, K,
+                                    dtype_code(dt), stream_ptr())
+    if rc == -5:
+        return False
+    _check(rc, "ib_linear_wgrad_bias")
     return True
 
 

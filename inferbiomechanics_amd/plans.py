@@ -195,9 +195,12 @@ class DenseStackPlan:
             wn, bn = self.names[i]
             xin = self.saved[i]
             xin_y = xin[0] if isinstance(xin, tuple) else xin
-            _wgrad(self.buf, dz, xin_y, P.g(wn), accumulate)
+            # short reductions (a batch of a few hundred rows): weight and bias gradient from one launch
+            if not (self.dtype == torch.bfloat16 and dz.shape[0] <= 1024
+                    and hip.linear_wgrad_bias(dz, xin_y, P.g(wn), P.g(bn), accumulate)):
+                _wgrad(self.buf, dz, xin_y, P.g(wn), accumulate)
+                _colsum(self.buf, f"{self.tag}.b{i}", dz, P.g(bn), accumulate)
             P.ready(wn)
-            _colsum(self.buf, f"{self.tag}.b{i}", dz, P.g(bn), accumulate)
             P.ready(bn)
             if i > 0:
                 aux = xin[1] if isinstance(xin, tuple) else xin

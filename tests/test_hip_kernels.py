@@ -484,3 +484,27 @@ def test_small_m_forward_and_dgrad_tiles(hip, M, N, K, act):
     a = aux.double()
     fac = {"none": torch.ones_like(a), "sigmoid": a * (1 - a), "elu": torch.where(a > 0, torch.ones_like(a), a + 1)}[act]
     close(dx, (dz.double() @ w2.double()) * fac, TIGHT[bf], "small-M dgrad")
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 512, 1470), (64, 300, 512), (1000, 72, 200), (1, 512, 512), (300, 30, 256)])
+def test_linear_wgrad_bias_one_launch(hip, M, N, K):
+    """short reductions: dW = dz^T x and db = column sums of dz from one launch (ragged 64 x 64 output tiles, more than one
+    256-row LDS chunk, accumulate, strided destination)"""
+    bf = torch.bfloat16
+    dz = rnd((M, N), 1, 1.0, bf).to(DEV)
+    x = rnd((M, K), 2, 1.0, bf).to(DEV)
+    wide = torch.full((N, K + 6), 7.0, dtype=torch.float32, device=DEV)
+    dw = wide[:, :K]                                        # row pitch K + 6
+    db = torch.full((N,), 3.0, dtype=torch.float32, device=DEV)
+    assert hip.linear_wgrad_bias(dz, x, dw, db)
+    ew, eb = dz.double().T @ x.double(), dz.double().sum(0)
+    close(dw, ew, 2e-5, "dW")
+    close(db, eb, 2e-5, "db")
+    assert float((wide[:, K:] - 7.0).abs().max()) == 0.0
+    assert hip.linear_wgrad_bias(dz, x, dw, db, accumulate=True)
+    close(dw, 2 * ew, 2e-5, "dW accumulate")
+    close(db, 2 * eb, 2e-5, "db accumulate")
+    # long reductions and fp32 are refused (the caller falls back), never mis-computed
+    big = torch.zeros(2048, N, dtype=bf, device=DEV)
+    assert not hip.linear_wgrad_bias(big, torch.zeros(2048, K, dtype=bf, device=DEV), dw, db)
+    assert not hip.linear_wgrad_bias(dz.float(), x.float(), dw, db)
