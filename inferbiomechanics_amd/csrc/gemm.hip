@@ -1493,6 +1493,8 @@ __global__ __launch_bounds__(256) void wgrad_smallm_kernel(const bf16_t* __restr
 
 inline bool ok(const void* dz, int64_t lddz, const void* x, int64_t ldx, int64_t M, int dtype) {
   static const int off = []() { const char* e = getenv("IB_NO_SMALLM"); return e ? atoi(e) : 0; }();
+  // M <= 1024: with 2560 rows (Groundlink, F = 10) the ten serial LDS chunks per workgroup lose to the split-M kernels
+  // (step 0.496 -> 0.789 ms when the limit was raised to 4096)
   return !off && dtype == IB_BF16 && M <= 1024 && lddz % 2 == 0 && ldx % 2 == 0 && aligned(dz, 4) && aligned(x, 4);
 }
 }  // namespace wsmall
