@@ -813,6 +813,8 @@ class DenoiserMLPPlan:
         # join costs tens of microseconds (same box: main + 2 branches 0.282 ms, + a head branch 0.308, none 0.320).
         # So: ONE branch for the dependent time-MLP chain; every independent weight-gradient GEMM of the step
         # (head, blocks, time_mlp.2) goes into ONE grouped launch on the main stream.
+        # (issued AFTER the grouped launch instead, the branch's first kernel only started when the grouped launch had
+        # finished -- no overlap at all: 0.232 -> 0.250 ms/step)
         self.branch.run(lambda: self.time.backward_hidden(de32, de_lp, P, accumulate, defer=defer, ready=False))
         grouped = defer is not None and not accumulate
         probs = [(dpred, h[L - 1], P.g("head.weight"), "dm.wsH")]
