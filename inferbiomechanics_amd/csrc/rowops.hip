@@ -106,9 +106,28 @@ __device__ __forceinline__ void store8(T* p, int nv, bool vec, const float (&v)[
       if (e < nv) p[e] = ib_from_f32<T>(v[e]);
   }
 }
+// sum over the LPR lanes that share a matrix row (every one of them gets the total).  The first four steps stay inside a
+// 16-lane DPP row and are DPP adds (no LDS crossbar: a ds_bpermute shuffle costs ~100 cycles of dependent latency each,
+// and the backward needs two such sums per matrix row); rows are combined by one shuffle (LPR = 32) or by reading the
+// four row totals out as scalars (LPR = 64).
+template <int CTRL> __device__ __forceinline__ float gs_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
 template <int LPR> __device__ __forceinline__ float group_sum(float v) {
-#pragma unroll
-  for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  static_assert(LPR == 16 || LPR == 32 || LPR == 64, "lanes per row");
+  v += gs_dpp<0xB1>(v);     // quad_perm [1,0,3,2]
+  v += gs_dpp<0x4E>(v);     // quad_perm [2,3,0,1]
+  v += gs_dpp<0x141>(v);    // row_half_mirror
+  v += gs_dpp<0x140>(v);    // row_mirror
+  if constexpr (LPR == 32) v += __shfl_xor(v, 16, 64);
+  if constexpr (LPR == 64) {
+    const int i = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, 48));
+    v = ((r0 + r1) + r2) + r3;
+  }
   return v;
 }
 
