@@ -129,11 +129,9 @@ def _ints(args):
     return tuple(v for v in args if isinstance(v, int) and not isinstance(v, bool) and 0 <= v < (1 << 31))
 
 
-def roofline_leg(trainer, batches, dtype_name):
-    """Device time of every distinct launch of ONE training step, measured live with HIP events on the launch
-    stream: each distinct C-ABI call of an eager step is re-issued 20x inside a hipGraph (so host launch overhead
-    is not in the number) and replayed 3x between two events.  The dominant entry gets the roofline object:
-    achieved = algorithmic FLOPs per launch / average launch duration (GEMMs), or algorithmic bytes / duration."""
+def record_eager_step(trainer, batches):
+    """one EAGER training step with every C-ABI call recorded.  Under data parallelism the step contains the gradient
+    all-reduce, a collective: EVERY rank must run this (only rank 0 uses the recording)."""
     from inferbiomechanics_amd import hip
     saved = trainer.use_graph, trainer._rec
     trainer.use_graph, trainer._rec = False, None
@@ -141,6 +139,15 @@ def roofline_leg(trainer, batches, dtype_name):
         trainer.step(batches[0])
         torch.cuda.synchronize()
     trainer.use_graph, trainer._rec = saved
+    return rec
+
+
+def roofline_leg(rec, dtype_name):
+    """Device time of every distinct launch of ONE training step, measured live with HIP events on the launch
+    stream: each distinct C-ABI call of the recorded eager step is re-issued 20x inside a hipGraph (so host launch
+    overhead is not in the number) and replayed 3x between two events.  The dominant entry gets the roofline object:
+    achieved = algorithmic FLOPs per launch / average launch duration (GEMMs), or algorithmic bytes / duration."""
+    from inferbiomechanics_amd import hip
     uniq = {}
     for name, args in rec.calls:
         if name in hip._RecordingLib.SKIP:
@@ -272,6 +279,12 @@ def main():
                          f"(WORLD_SIZE={world})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    # IB_BENCH_REHEARSAL=1: the multi-rank control flow on a ONE-GPU box -- every rank on device 0, gloo instead of
+    # RCCL (which refuses two ranks on one device).  Only for checking that no rank waits for a collective another rank
+    # never enters; the numbers of such a run mean nothing.
+    rehearsal = os.environ.get("IB_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     selftest = os.environ.get("IB_DDP_SELFTEST") == "1"      # 1-rank run of the whole RCCL / bucket / segment path
@@ -280,7 +293,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29517")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from inferbiomechanics_amd import hip
     from inferbiomechanics_amd.engine import HipTrainer
@@ -326,6 +342,7 @@ def main():
     dts = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(nq))
     pct = lambda q: round(dts[min(nq - 1, int(q * nq))], 4)
 
+    rec = record_eager_step(trainer, batches)          # all ranks: the step holds the gradient all-reduce
     if rank == 0:
         value = world * B * a.steps / el
         line = {
@@ -342,7 +359,7 @@ def main():
             "final_loss": round(loss, 6),
             "train_tflops": round(value * train_flops_per_window(kind, T, D) / 1e12, 2),
         }
-        rl, breakdown, dev_us = roofline_leg(trainer, batches, a.dtype)
+        rl, breakdown, dev_us = roofline_leg(rec, a.dtype)
         line["roofline"] = rl
         line["step_sum_of_kernel_us"] = round(dev_us, 1)
         line["step_breakdown"] = breakdown
