@@ -255,3 +255,28 @@ def test_bench_data_parallel_launch_sequence_on_one_rank():
     for o in outs:
         assert o["unit"] == "windows/s" and o["n_gpus"] == 1 and o["steps"] == 40 and o["value"] > 0
         assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(o["roofline"])
+
+
+def test_bench_two_rank_control_flow_rehearsal():
+    """bench.py under torch.distributed.run with TWO ranks on this one GPU (IB_BENCH_REHEARSAL=1: gloo instead of RCCL,
+    both ranks on device 0).  Guards the multi-rank control flow -- every collective (parameter broadcast, gradient
+    all-reduce inside every step INCLUDING the recorded eager step of the roofline leg, barriers, the max-reduce of the
+    elapsed time) must be entered by every rank, or the run hangs -- and the one-line stdout contract at n_gpus = 2."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, IB_BENCH_REHEARSAL="1")
+    for k in ("IB_DDP_SELFTEST", "RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29571", os.path.join(root, "bench.py"),
+                        "--gpus", "2", "--steps", "20", "--warmup", "3", "--no-ddim", "--no-cpu-baseline"],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[:1000]
+    o = json.loads(lines[0])
+    assert o["n_gpus"] == 2 and o["config"]["global_batch"] == 512 and o["config"]["parallelism"] == "dp2"
+    assert o["config"]["grad_buckets"] == 1 and o["value"] > 0 and "roofline" in o and "cpu_baseline" not in o
