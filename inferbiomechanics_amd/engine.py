@@ -85,12 +85,16 @@ class GradBuckets:
         with) waits right away.  Two things measured / learnt here: an extra stream of our own around the call added two
         more event hops per bucket (51 us of idle GPU between the backward and the optimizer of a 0.25-ms step); and a
         SYNCHRONOUS collective, which c10d runs on the current stream, leaves its completion event on the very stream
-        the trainer captures its graphs on -- c10d's watchdog thread then queries that event in the middle of a later
-        capture and HIP refuses (the process aborts).  Asynchronous collectives keep their events on c10d's stream."""
+        the trainer launches on -- were the graphs also CAPTURED on that stream, c10d's watchdog thread would query the
+        event in the middle of a later capture and HIP refuses (the process aborts).  HipTrainer therefore captures on a
+        separate stream that never carries real work; the one-bucket policy can then use the synchronous call (no hops)."""
         if not self.active:
             return
         lo, hi = self.ranges[b]
         t = self.flat[lo:hi]
+        if inline and self.on_gpu and not os.environ.get("IB_ASYNC_INLINE"):
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)      # runs on the caller's stream: no event hops
+            return
         w = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         if inline:
             w.wait()
@@ -443,6 +447,7 @@ class HipTrainer:
         return self.step(("windows", cache, idx))
 
     _srcs = None            # this step's {x0, eps, t} tensors behind the pointer slots (chain path), else None
+    _cap_stream = None
     MAX_PINNED_GRAPHS = 32
 
     def _capture(self, st) -> "_Recorder":
@@ -455,9 +460,20 @@ class HipTrainer:
                 rec.cut(self.buckets.finish)
             else:
                 rec.cut(lambda: self.buckets.launch(0, inline=True))
-        rec.begin()
-        self._launches(st, cut=cut if self.ddp else None)
-        rec.end()
+        # Captured on a stream of its own, launched on the trainer's stream.  c10d's watchdog thread polls the completion
+        # events of earlier collectives; an event that sits on a stream WHILE that stream is being captured makes the
+        # poll fail and aborts the process.  The capture stream carries no real work, so no such event ever sits on it.
+        if self._cap_stream is None and self.device.type == "cuda":
+            self._cap_stream = torch.cuda.Stream(device=self.device)
+        if self._cap_stream is not None:
+            with torch.cuda.stream(self._cap_stream):
+                rec.begin()
+                self._launches(st, cut=cut if self.ddp else None)
+                rec.end()
+        else:
+            rec.begin()
+            self._launches(st, cut=cut if self.ddp else None)
+            rec.end()
         return rec
 
     def _step(self, batch) -> torch.Tensor:
