@@ -271,6 +271,9 @@ def main():
     out_fd = os.dup(1)
     os.dup2(2, 1)
 
+    # the host driver of this pool only supports dmabuf IPC; without this RCCL's cross-process buffer registration fails
+    # (hipIpcGetMemHandle: invalid argument).  Must be in the environment before the first HIP call.
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
