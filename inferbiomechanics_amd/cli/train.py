@@ -87,6 +87,7 @@ class TrainCommand(AbstractCommand):
         diffusion = is_diffusion(model_type)
 
         geometry = self.ensure_geometry(args.geometry_folder)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC for RCCL (before the first HIP call)
         device = pick_device(args)
         world_size = int(os.environ.get('WORLD_SIZE', '1'))
         distributed = world_size > 1
