@@ -508,3 +508,34 @@ def test_linear_wgrad_bias_one_launch(hip, M, N, K):
     big = torch.zeros(2048, N, dtype=bf, device=DEV)
     assert not hip.linear_wgrad_bias(big, torch.zeros(2048, K, dtype=bf, device=DEV), dw, db)
     assert not hip.linear_wgrad_bias(dz.float(), x.float(), dw, db)
+
+
+def test_small_m_kernels_seeded_shape_sweep(hip):
+    """40 seeded random shapes through the small-M forward / dgrad / weight+bias-gradient kernels (ragged rows, ragged
+    column tiles, ragged reduction tails, 4-byte-aligned row pitches) against float64"""
+    import random
+    bf = torch.bfloat16
+    rng = random.Random(1234)
+    for case in range(40):
+        M = rng.choice([1, 3, 17, 64, 65, 200, 256, 511, 700])
+        N = rng.choice([16, 30, 48, 128, 300, 512, 600])
+        K = rng.choice([64, 66, 96, 200, 300, 512, 1024, 1470])
+        x = rnd((M, K), 10 + case, 1.0, bf).to(DEV)
+        w = rnd((N, K), 60 + case, K ** -0.5, bf).to(DEV)
+        b = rnd((N,), 110 + case, 0.1).to(DEV)
+        y = torch.full((M, N), 7.0, dtype=bf, device=DEV)
+        hip.linear_fwd(x, w, b, y, act="relu")
+        close(y, torch.relu(x.double() @ w.double().T + b.double()), TIGHT[bf], f"fwd {M}x{N}x{K}")
+        # weight + bias gradient over the M rows
+        dz = rnd((M, N), 160 + case, 1.0, bf).to(DEV)
+        dw = torch.full((N, K), 7.0, dtype=torch.float32, device=DEV)
+        db = torch.full((N,), 7.0, dtype=torch.float32, device=DEV)
+        if hip.linear_wgrad_bias(dz, x, dw, db):
+            close(dw, dz.double().T @ x.double(), 2e-5, f"dW {M}x{N}x{K}")
+            close(db, dz.double().sum(0), 2e-5, f"db {M}x{N}x{K}")
+        # dgrad back to K columns (rounded up to the 16-column tiles the small kernel wants; reduction over N)
+        Kc = (K + 15) // 16 * 16
+        w2 = rnd((N, Kc), 210 + case, N ** -0.5, bf).to(DEV)
+        dx = torch.full((M, Kc), 7.0, dtype=bf, device=DEV)
+        hip.linear_dgrad(dz, w2, dx)
+        close(dx, dz.double() @ w2.double(), TIGHT[bf], f"dgrad {M}x{N}x{Kc}")
