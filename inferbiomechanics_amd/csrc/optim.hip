@@ -130,9 +130,13 @@ __global__ __launch_bounds__(256) void optim_kernel(OptArgs a, OptSources S, int
   const float bc2s = (float)sqrt(1.0 - pow(0.999, (double)step));
   const int64_t n4 = a.n / 4;
   const bool has1 = a.s1 != nullptr, has2 = a.s2 != nullptr;
-  if (SRC && (int)blockIdx.x >= main_blocks) {
+  // the column-sum blocks are long dependent chains (256 strided rows each): they take the FIRST physical block ids so
+  // they start at once and overlap the streaming blocks instead of forming the launch's tail
+  const int ncs = SRC ? (int)gridDim.x - main_blocks : 0;
+  const int lb = SRC ? ((int)blockIdx.x < ncs ? main_blocks + (int)blockIdx.x : (int)blockIdx.x - ncs) : (int)blockIdx.x;
+  if (SRC && lb >= main_blocks) {
     __shared__ float4 red[16][16];
-    int rb = (int)blockIdx.x - main_blocks, j = 0;
+    int rb = lb - main_blocks, j = 0;
     for (; j < S.n; ++j) {                      // which column-sum range, which 64-column chunk of it
       if (S.s[j].kind != 2) continue;
       const int nb = (int)((S.s[j].len + 63) / 64);
@@ -172,7 +176,7 @@ __global__ __launch_bounds__(256) void optim_kernel(OptArgs a, OptSources S, int
     }
   } else {
   const int64_t gstride = (int64_t)(SRC ? main_blocks : (int)gridDim.x) * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gstride) {
+  for (int64_t i = (int64_t)lb * blockDim.x + threadIdx.x; i < n4; i += gstride) {
     float4 p = reinterpret_cast<float4*>(a.p)[i];
     float4 g;
     if constexpr (SRC) {
@@ -197,7 +201,7 @@ __global__ __launch_bounds__(256) void optim_kernel(OptArgs a, OptSources S, int
   }
   // tail (n % 4)
   const int64_t t0 = n4 * 4;
-  for (int64_t i = t0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += gstride) {
+  for (int64_t i = t0 + (int64_t)lb * blockDim.x + threadIdx.x; i < a.n; i += gstride) {
     float s1 = has1 ? a.s1[i] : 0.f, s2 = has2 ? a.s2[i] : 0.f;
     const float p = opt_update(a, a.p[i], a.g[i] * a.gscale, s1, s2, bc1, bc2s);
     a.p[i] = p;
@@ -207,7 +211,7 @@ __global__ __launch_bounds__(256) void optim_kernel(OptArgs a, OptSources S, int
   }
   }   // main blocks
   if constexpr (SRC) {
-    if (S.loss_out && blockIdx.x == 0) {       // the step's loss scalar: one column of the partial rows, fixed order
+    if (S.loss_out && lb == 0) {       // the step's loss scalar: one column of the partial rows, fixed order
       __shared__ float lred[16];
       float v = 0.f;
       const int rg = threadIdx.x >> 4;
