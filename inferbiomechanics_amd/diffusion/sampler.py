@@ -65,7 +65,7 @@ class DDIMSampler:
         plan = m._get_plan(dev)
         if hasattr(plan, "set_inference"):
             plan.set_inference(True)             # weights are frozen for the whole loop
-            plan.prepare_inference(P, x.shape[1], x.shape[2])
+            plan.prepare_inference(P, x.shape[1], x.shape[2], table=tabs.temb)
         try:
             return self._loop(x, t_vec, ctr, tabs, P, steps)
         finally:

@@ -885,16 +885,29 @@ class DenoiserTransformerPlan:
         the frame-embedding projection computed once"""
         self.inference = bool(on)
         self._posproj_T = None
+        self._e_all = None
         for lp in self.layers:
             lp.inference = bool(on)
 
-    def prepare_inference(self, P: ParamSource, T: int, D: int):
-        """once per sampling loop (weights frozen from here on): the frame-embedding half of the input projection"""
+    def prepare_inference(self, P: ParamSource, T: int, D: int, table: Optional[torch.Tensor] = None):
+        """once per sampling loop (weights frozen from here on): the frame-embedding half of the input projection, and --
+        given the sinusoid table -- the time embedding of EVERY timestep (one time-MLP forward over all table rows), so a
+        denoise step only gathers its rows instead of running the time-MLP (15 us of a 0.5 ms step at B = 16)"""
         w_in = P.w("in_proj.weight")
         pos = P.w("temporal_embedding.embedding.weight")[:T]
         posproj = self.buf.get("dt.posproj", (T, self.d), self.dtype)
         hip.linear_fwd(pos, w_in[:, D:], None, posproj)
         self._posproj_T = T
+        self._e_all = None
+        if table is not None and not os.environ.get("IB_NO_TIME_TABLE"):
+            steps = table.shape[0]
+            every_t = torch.arange(steps, dtype=torch.int64, device=table.device)
+            e = self.time.forward(every_t, table, P)                                     # [steps, d] in the compute dtype
+            e_all = self.buf.get("dt.e_all", (steps, self.d), torch.float32)
+            hip.cast2d(e, e_all) if e.dtype != torch.float32 else e_all.copy_(e)
+            self._e_all = e_all
+
+    _e_all = None
 
     inference = False
 
@@ -911,7 +924,11 @@ class DenoiserTransformerPlan:
         M = B * T
         x2 = x3 if x3.dim() == 2 else x3.view(M, D)
         g, dt = self.buf.get, self.dtype
-        e = self.time.forward(t, table, P)                                   # [B, d]
+        if self.inference and self._e_all is not None:
+            e = g("dt.e_rows", (B, self.d), dt)
+            hip.gather_rows(self._e_all, t, e)                               # rows of the per-timestep table
+        else:
+            e = self.time.forward(t, table, P)                               # [B, d]
         w_in = P.w("in_proj.weight")                                         # [d, D + Pd]
         pos = P.w("temporal_embedding.embedding.weight")[:T]                 # [T, Pd]
         posproj = g("dt.posproj", (T, self.d), dt)
