@@ -127,9 +127,20 @@ def _wgrad_group(buf: Buffers, problems, defer: list):
         if K % 4 != 0 or dw.stride(0) % 4 != 0:
             raise hip.HipError("_wgrad_group: gradient rows must be 16-byte aligned")
         items.append((dz, x, buf.bytes(tag, int(hip.lib().ib_linear_wgrad_slabs_workspace(M, N, K)))))
-    ns = hip.linear_wgrad_slabs_multi(items) if 1 < len(items) <= 6 else None
-    if ns is None:
-        ns = [hip.linear_wgrad_slabs(dz, x, ws) for dz, x, ws in items]
+    # only problems whose operand rows are 16-byte aligned qualify for the grouped (ring) launch: the others -- e.g. the
+    # 30-column output gradient of Groundlink's last layer -- are issued on their own instead of dragging the group down
+    def aligned16(t):
+        return t.stride(0) % 8 == 0 and t.data_ptr() % 16 == 0
+    grp = [i for i, (dz, x, ws) in enumerate(items) if aligned16(dz) and aligned16(x) and dz.dtype == torch.bfloat16]
+    ns = [None] * len(items)
+    if 1 < len(grp) <= 6:
+        got = hip.linear_wgrad_slabs_multi([items[i] for i in grp])
+        if got is not None:
+            for i, n in zip(grp, got):
+                ns[i] = n
+    for i, (dz, x, ws) in enumerate(items):
+        if ns[i] is None:
+            ns[i] = hip.linear_wgrad_slabs(dz, x, ws)
     for (dz, x, ws), n, pr in zip(items, ns, problems):
         defer.append((ws, n, pr[2]))
 
