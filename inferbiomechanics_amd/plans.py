@@ -475,6 +475,16 @@ class TransformerLayerPlan:
         g, dt, p, tg = self.buf.get, self.dtype, self.p, self.tag
         lnws = self.buf.bytes("ln.ws", hip.layernorm_bwd_workspace_bytes(M, max(d, 1)))
         defer, later = self.defer, self.later
+        # one GPU (slabs go to the optimizer): the layer's four weight-gradient GEMMs are issued as ONE grouped launch at
+        # the end of the layer (they share a workgroup budget: fewer, longer slices, half the slab traffic)
+        group = [] if (defer is not None and dt == torch.bfloat16 and not os.environ.get("IB_NO_LAYER_GROUP")) else None
+
+        def wgrad(dz_, x_, name, tag):
+            if group is not None:
+                group.append((dz_, x_, P.g(p + name), tag))
+            else:
+                _wgrad(self.buf, dz_, x_, P.g(p + name), accumulate, ws_tag=tag, defer=defer)
+            P.ready(p + name)
 
         def ln_bwd(which, dy, xin, mean, rstd, dxo, res):
             """LayerNorm backward; parameter gradients finished here, or their per-block partial sums left for the optimizer"""
@@ -505,16 +515,14 @@ class TransformerLayerPlan:
         ln_bwd("norm2", dx2.view(M, d), f2, m2, r2, ds2, x1)
 
         def g_ffn2():
-            _wgrad(self.buf, ds2, f1, P.g(p + "feedforward.2.weight"), accumulate, ws_tag=tg + ".ws2", defer=defer)
-            P.ready(p + "feedforward.2.weight")
+            wgrad(ds2, f1, "feedforward.2.weight", tg + ".ws2")
             dbias(tg + ".b2", ds2, "feedforward.2.bias")
         self.branch.run(g_ffn2)
         dz1 = g(tg + ".dz1", (M, self.ffn), dt)
         hip.linear_dgrad(ds2, P.w(p + "feedforward.2.weight"), dz1, act_below="relu", aux=f1)
 
         def g_ffn1():
-            _wgrad(self.buf, dz1, x1, P.g(p + "feedforward.0.weight"), accumulate, ws_tag=tg + ".ws1", defer=defer)
-            P.ready(p + "feedforward.0.weight")
+            wgrad(dz1, x1, "feedforward.0.weight", tg + ".ws1")
             dbias(tg + ".b1", dz1, "feedforward.0.bias")
         self.branch.run(g_ffn1)
         dx1 = g(tg + ".dx1", (M, d), dt)
@@ -524,9 +532,7 @@ class TransformerLayerPlan:
         ln_bwd("norm1", dx1, a, m1, r1, ds1, x)
 
         def g_out():
-            _wgrad(self.buf, ds1, attn.view(M, d), P.g(p + "multihead_attention.out_proj.weight"), accumulate,
-                   ws_tag=tg + ".wso", defer=defer)
-            P.ready(p + "multihead_attention.out_proj.weight")
+            wgrad(ds1, attn.view(M, d), "multihead_attention.out_proj.weight", tg + ".wso")
             dbias(tg + ".bo", ds1, "multihead_attention.out_proj.bias")
         self.branch.run(g_out)
         dattn = g(tg + ".dattn", (B, T, d), dt)
@@ -536,13 +542,13 @@ class TransformerLayerPlan:
         dq2 = dqkv.view(M, 3 * d)
 
         def g_in():
-            _wgrad(self.buf, dq2, x, P.g(p + "multihead_attention.in_proj_weight"), accumulate, ws_tag=tg + ".wsi",
-                   defer=defer)
-            P.ready(p + "multihead_attention.in_proj_weight")
+            wgrad(dq2, x, "multihead_attention.in_proj_weight", tg + ".wsi")
             dbias(tg + ".bi", dq2, "multihead_attention.in_proj_bias")
         self.branch.run(g_in)
         dx = g(tg + ".dx", (B, T, d), dt)
         hip.linear_dgrad(dq2, P.w(p + "multihead_attention.in_proj_weight"), dx.view(M, d), addend=ds1)
+        if group:
+            self.branch.run(lambda: _wgrad_group(self.buf, group, defer))
         if self.join_on_exit or self.flush_on_exit:
             self.branch.join()
         if self.flush_on_exit:
