@@ -73,5 +73,7 @@ def pick_device(args) -> torch.device:
     if not torch.cuda.is_available():
         raise SystemExit("no GPU visible: the HIP path needs an MI355X")
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    if os.environ.get('IB_BENCH_REHEARSAL') == '1':      # several ranks on a one-GPU box (control-flow rehearsal over gloo)
+        local = 0
     torch.cuda.set_device(local)
     return torch.device('cuda', local)

@@ -93,7 +93,10 @@ class TrainCommand(AbstractCommand):
         distributed = world_size > 1
         if distributed:
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-            dist.init_process_group(backend="nccl", timeout=timedelta(hours=1), device_id=device)   # RCCL (train.py:99)
+            if os.environ.get('IB_BENCH_REHEARSAL') == '1':
+                dist.init_process_group(backend="gloo", timeout=timedelta(hours=1))
+            else:
+                dist.init_process_group(backend="nccl", timeout=timedelta(hours=1), device_id=device)   # RCCL (train.py:99)
         rank = dist.get_rank() if distributed else 0
         print(f"Running on {world_size} GPUs.")
         print(f"Current device being used for model training and loss evaluation: {device}.")
