@@ -25,6 +25,7 @@ if ROOT not in sys.path:
 
 PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}     # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
+PEAK_XGMI_GBS = 7 * 153.0                          # per GPU, all seven links
 
 WORKLOADS = {
     # name: (model kind, T, D, per-GPU batch)
@@ -142,25 +143,28 @@ def record_eager_step(trainer, batches):
     return rec
 
 
-def roofline_leg(rec, dtype_name):
+def roofline_leg(rec, dtype_name, gemm_family=False):
     """Device time of every distinct launch of ONE training step, measured live with HIP events on the launch
     stream: each distinct C-ABI call of the recorded eager step is re-issued 20x inside a hipGraph (so host launch
     overhead is not in the number) and replayed 3x between two events.  The dominant entry gets the roofline object:
-    achieved = algorithmic FLOPs per launch / average launch duration (GEMMs), or algorithmic bytes / duration."""
+    achieved = algorithmic FLOPs per launch / average launch duration (GEMMs), or algorithmic bytes / duration.
+    gemm_family: the Linear GEMM entry points (forward, dgrad, weight gradient -- one kernel family, gemm.hip) count as
+    ONE candidate, with every shape listed (the transformer step is 29 GEMM launches of 8 shapes)."""
     from inferbiomechanics_amd import hip
     uniq = {}
-    for name, args in rec.calls:
+    for i, (name, args) in enumerate(rec.calls):
         if name in hip._RecordingLib.SKIP:
             continue
-        key = (name, _ints(args))
+        note = rec.notes.get(i)
+        key = (name, _ints(args), None if note is None else str(note[2]))
         if key not in uniq:
-            uniq[key] = [args, 0]
+            uniq[key] = [args, 0, note]
         uniq[key][1] += 1
     rows = []
-    for (name, ints), (args, count) in uniq.items():
+    for (name, ints, _), (args, count, note) in uniq.items():
         us = hip.time_recorded_call(name, args)
         rows.append({"entry": name, "dims": list(ints), "launches_per_step": count, "avg_launch_us": round(us, 2),
-                     "us_per_step": round(us * count, 2)})
+                     "us_per_step": round(us * count, 2), "_note": note})
     rows.sort(key=lambda r: -r["us_per_step"])
     total = sum(r["us_per_step"] for r in rows)
     es = 2 if dtype_name == "bf16" else 4
@@ -169,6 +173,8 @@ def roofline_leg(rec, dtype_name):
         """(algorithmic flops, algorithmic bytes) of ONE launch; dims = the call's small-integer arguments, which
         for every entry point end with (..., M, N, K, dtype) or (..., M, N, dtype)"""
         d, e = r["dims"], r["entry"]
+        if r["_note"] is not None:                      # grouped launches: shapes sit in arrays, the wrapper noted them
+            return r["_note"][0], r["_note"][1]
         if e == "ib_mlp_chain_train":
             # dims end with (M, T, D, H, L).  FLOPs: the forward GEMMs (D->H, (L-1) x H->H, H->D) and the dgrad chain
             # (D->H transposed head, (L-1) x H->H).  Bytes: what the step needs in HBM given that the weight gradients
@@ -181,27 +187,41 @@ def roofline_leg(rec, dtype_name):
         if e == "ib_linear_wgrad_slabs":
             M, N, K = d[-4], d[-3], d[-2]
             return 2 * M * N * K, (M * K + M * N) * es + N * K * 4
-        if e in ("ib_linear_fwd", "ib_linear_dgrad", "ib_linear_wgrad"):
+        if e in ("ib_linear_fwd", "ib_linear_dgrad", "ib_linear_wgrad", "ib_linear_ln_fwd", "ib_linear_wgrad_bias"):
             M, N, K = d[-4], d[-3], d[-2]
-            return 2 * M * N * K, (M * K + N * K) * es + M * N * (4 if e.endswith("wgrad") else es)
+            return 2 * M * N * K, (M * K + N * K) * es + M * N * (4 if "wgrad" in e else es)
+        if e in ("ib_attention_fwd", "ib_attention_bwd"):
+            B_, T_, H_, dh = d[-5], d[-4], d[-3], d[-2]
+            io = B_ * T_ * H_ * dh * es
+            return (4 if e.endswith("fwd") else 10) * T_ * T_ * dh * B_ * H_, (4 if e.endswith("fwd") else 8) * io
         if e in ("ib_layernorm_fwd", "ib_layernorm_bwd"):
             M, N = d[-3], d[-2]
             return 0, (2 if e.endswith("fwd") else 3) * M * N * es
         return 0, 0
 
-    # the dominant KERNEL = the entry point with the largest share of the step (all its shapes together)
+    # the dominant KERNEL = the entry point (or, with gemm_family, the GEMM kernel family) with the largest share of the
+    # step, all its shapes together
     fam = {}
     for r in rows:
-        f = fam.setdefault(r["entry"], {"us": 0.0, "launches": 0, "flops": 0, "bytes": 0})
         fl, by = work(r)
+        r["tflops"] = round(fl / (r["avg_launch_us"] * 1e-6) / 1e12, 1) if fl and r["avg_launch_us"] > 0 else None
+        name = "linear GEMMs" if (gemm_family and r["entry"] in GEMM_ENTRIES) else r["entry"]
+        f = fam.setdefault(name, {"us": 0.0, "launches": 0, "flops": 0, "bytes": 0, "rows": []})
         f["us"] += r["us_per_step"]; f["launches"] += r["launches_per_step"]
         f["flops"] += fl * r["launches_per_step"]; f["bytes"] += by * r["launches_per_step"]
+        f["rows"].append(r)
     top_e, top = max(fam.items(), key=lambda kv: kv[1]["us"])
     avg_us = top["us"] / top["launches"]
-    out = {"kernel": KERNEL_OF.get(top_e, top_e), "entry": top_e, "launches_per_step": top["launches"],
+    if top_e == "linear GEMMs":
+        kernel = "gemm_ring_kernel / gemm_kernel family (gemm.hip): forward, dgrad and weight-gradient launches"
+        shapes = [{"entry": r["entry"], "MNK": (r["_note"][2] if r["_note"] else r["dims"][-4:-1]),
+                   "launches": r["launches_per_step"], "us": r["avg_launch_us"], "tflops": r["tflops"]} for r in top["rows"]]
+    else:
+        kernel = KERNEL_OF.get(top_e, top_e)
+        shapes = [(r["dims"][-5:] if top_e == "ib_mlp_chain_train" else r["dims"][-4:-1]) for r in top["rows"]]
+    out = {"kernel": kernel, "entry": top_e, "launches_per_step": top["launches"],
            "avg_launch_us": round(avg_us, 2), "share_of_step_device_time": round(top["us"] / total, 3),
-           "shapes": [(r["dims"][-5:] if top_e == "ib_mlp_chain_train" else r["dims"][-4:-1]) for r in rows if r["entry"] == top_e],
-           "traffic": None}
+           "shapes": shapes, "traffic": None}
     if top_e == "ib_mlp_chain_train":
         out["shape_fields"] = ["tokens M = B*T", "T", "D", "H", "blocks L"]
     if top["flops"]:
@@ -216,18 +236,23 @@ def roofline_leg(rec, dtype_name):
                     "frac": round(ach / PEAK_HBM_GBS, 4), "algorithmic_bytes_per_launch": top["bytes"] // top["launches"]})
     else:
         out.update({"bound": "hbm", "achieved": None, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": None})
-    # HBM traffic per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE),
-    # written by tools/summarize_profile.py; null if no profile of this kernel has been summarised
+    # HBM traffic per launch and MFMA utilisation from the committed rocprofv3 --pmc passes of this round's build
+    # (FETCH_SIZE x2 on gfx950 + WRITE_SIZE; SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CU_CYCLES), written by
+    # tools/summarize_profile.py; null if no profile of this kernel has been summarised
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
             t = json.load(open(tpath)).get(top_e)
             if t:                                    # `traffic`: HBM bytes per launch (a number, like `achieved`)
                 out["traffic"] = t["hbm_bytes_per_launch"]
-                out["traffic_source"] = {k: v for k, v in t.items() if k != "hbm_bytes_per_launch"}
+                if "mfma_util" in t:
+                    out["mfma_util"] = t["mfma_util"]
+                out["traffic_source"] = {k: v for k, v in t.items() if k not in ("hbm_bytes_per_launch", "mfma_util")}
         except Exception:
             pass
-    return out, rows[:14], total
+    for r in rows:
+        r.pop("_note", None)
+    return out, rows[:16], total
 
 
 def ddim_leg(dev, dtype, B=16, T=200, D=300, steps=100):
@@ -242,9 +267,129 @@ def ddim_leg(dev, dtype, B=16, T=200, D=300, steps=100):
     sampler.sample(xT)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    # forward FLOPs of one denoise step (the frame-embedding half of the input projection and
+    # the time-MLP are computed once per loop, not per step)
+    d, ffn, L = 512, 2048, 4
+    flops = 2 * (L * (4 * d * d + 2 * d * ffn + 2 * T * d) + D * d + d * D) * T * B
+    ach = flops * steps / el / 1e12
+    dn = "bf16" if dtype == torch.bfloat16 else "f32"
     return {"workload": f"transformer_denoiser_T{T} B={B} {steps}-step DDIM (hipGraph-replayed step)",
             "steps_per_sec": round(steps / el, 1), "window_steps_per_sec": round(B * steps / el, 1),
-            "ms_per_sample_batch": round(el * 1e3, 2)}
+            "ms_per_sample_batch": round(el * 1e3, 2),
+            "roofline": {"bound": "mfma" if B >= 16 else "launch latency (one window: every GEMM is a single wave of "
+                         "workgroups; the figure is reported against the MFMA peak all the same)",
+                         "achieved": round(ach, 2), "peak": PEAK_TFLOPS[dn], "unit": "TFLOP/s",
+                         "frac": round(ach / PEAK_TFLOPS[dn], 4), "algorithmic_flops_per_step": flops,
+                         "scope": "whole denoise step (forward plan + DDIM update), wall clock over the loop"}}
+
+
+GEMM_ENTRIES = ("ib_linear_fwd", "ib_linear_dgrad", "ib_linear_wgrad", "ib_linear_wgrad_slabs", "ib_linear_wgrad_slabs_multi",
+                "ib_linear_wgrad_bias", "ib_linear_ln_fwd")
+
+
+def algorithmic_bytes_per_step(kind, T, D, B, nparams):
+    """compulsory HBM traffic of one training step, SURVEY.md §8d 'Algorithmic bytes': per window x0 + eps read and the
+    saved activations written once / read once; per step the weights read twice (bf16), gradients written, optimizer
+    state read / written (RMSprop: w, g, v = 5 fp32 passes) ~ 7 x 4 bytes per parameter"""
+    if kind == "mlp":
+        per_window = 2 * T * D * 2 + 2 * T * 512 * 2 * 2
+    else:
+        per_window = 2 * T * D * 2 + 2 * 4 * T * (512 * 4 + 1536 + 2048) * 2
+    return B * per_window + 7 * 4 * nparams
+
+
+def train_leg(workload, a, dev, world, rank, steps, warmup, sync, with_roofline=True):
+    """one training workload: W warm-up steps, EXACTLY K timed steps between barriers + synchronisations, max over
+    ranks; then the single-step distribution and (rank 0) the per-launch roofline table."""
+    from inferbiomechanics_amd.engine import HipTrainer
+    kind, T, D, B = WORKLOADS[workload]
+    dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    model = build_model(kind, T, D, dtype, dev)
+    trainer = HipTrainer(model, "diffusion", a.opt_type, 1e-4, use_graph=not a.no_graph, bucket_mb=a.bucket_mb,
+                         overlap_comm={"auto": None, "on": True, "off": False}[a.overlap_comm])
+    batches = make_batches(16, B, T, D, dtype, dev, seed=rank)
+    # priming (not part of W): eager warm-up, the generic graph, and the graph of EVERY batch of the ring -- no capture
+    # may fall into the timed region whatever --steps / --warmup are (round 1: four ~1 ms captures inside 20 timed steps)
+    trainer.pin_batches(batches)
+    for i in range(len(batches)):
+        trainer.step(batches[i])
+    for i in range(warmup):
+        trainer.step(batches[i % len(batches)])
+    cap0 = trainer.captures
+    sync()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        trainer.step(batches[i % len(batches)])
+    sync()
+    el = time.perf_counter() - t0
+    if trainer.captures != cap0:
+        raise SystemExit(f"bench: {trainer.captures - cap0} graph capture(s) inside the timed region")
+    if world > 1:
+        tt = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.cpu())
+    loss = trainer.loss_value()
+
+    # distribution of single-step times (SURVEY.md §8d: median, p10 / p90): one event per step on the caller's stream,
+    # read back after the run -- no host synchronisation inside it
+    nq = max(20, min(steps, 400))
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(nq + 1)]
+    evs[0].record()
+    for i in range(nq):
+        trainer.step(batches[i % len(batches)])
+        evs[i + 1].record()
+    sync()
+    dts = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(nq))
+    pct = lambda q: round(dts[min(nq - 1, int(q * nq))], 4)
+
+    xg = None
+    if world > 1 and trainer.ddp:
+        # the gradient all-reduce alone (same buffer, same communicator): bus bandwidth against the xGMI peak
+        g = trainer.grad
+        for _ in range(3):
+            dist.all_reduce(g)
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(20):
+            dist.all_reduce(g)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t1) / 20
+        busbw = 2 * (world - 1) / world * g.numel() * 4 / dt / 1e9
+        xg = {"allreduce_bytes": g.numel() * 4, "avg_us": round(dt * 1e6, 1), "busbw_GBs": round(busbw, 1),
+              "peak_GBs": PEAK_XGMI_GBS, "frac": round(busbw / PEAK_XGMI_GBS, 4),
+              "note": "peak = 7 xGMI links x 153 GB/s per GPU; busbw = 2(N-1)/N x bytes / time"}
+        g.zero_()
+    rec = record_eager_step(trainer, batches) if with_roofline else None     # all ranks: the step holds the all-reduce
+    out = None
+    if rank == 0:
+        value = world * B * steps / el
+        nparams = sum(p.numel() for p in model.parameters())
+        tfl = value * train_flops_per_window(kind, T, D) / 1e12
+        hbm = algorithmic_bytes_per_step(kind, T, D, B, nparams) * world / (el / steps) / 1e9
+        out = {"workload": f"{workload}_D{D}_B{B}_{a.dtype}", "value": round(value, 1), "unit": "windows/s",
+               "ms_per_step": round(el / steps * 1e3, 4), "steps": steps, "warmup": warmup,
+               "step_ms": {"p10": pct(0.10), "median": pct(0.50), "p90": pct(0.90), "samples": nq},
+               "final_loss": round(loss, 6), "train_tflops": round(tfl, 2),
+               "captures_in_timed_region": trainer.captures - cap0,
+               "config": {"per_gpu_batch": B, "global_batch": B * world, "window": T, "feat": D, "optimizer": a.opt_type,
+                          "hipgraph": not a.no_graph, "parallelism": f"dp{world}",
+                          "grad_buckets": len(trainer.buckets.ranges) if trainer.ddp else 0,
+                          "bucket_bytes": [4 * (hi - lo) for lo, hi in trainer.buckets.ranges] if trainer.ddp else [],
+                          "overlap_comm": bool(trainer.overlap_comm)},
+               # whole-step fractions of the three rooflines SURVEY.md §8d names (per GPU)
+               "step_fractions": {"mfma": round(tfl / world / PEAK_TFLOPS[a.dtype], 4),
+                                  "hbm": round(hbm / world / PEAK_HBM_GBS, 4),
+                                  "xgmi": None if xg is None else xg["frac"]}}
+        if xg is not None:
+            out["xgmi"] = xg
+        if rec is not None:
+            rl, breakdown, dev_us = roofline_leg(rec, a.dtype, gemm_family=(kind != "mlp"))
+            out["roofline"] = rl
+            out["step_sum_of_kernel_us"] = round(dev_us, 1)
+            out["step_breakdown"] = breakdown
+    del trainer, model, batches
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -258,6 +403,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ddim", action="store_true")
+    ap.add_argument("--no-transformer", action="store_true", help="skip the configs[2] / configs[3] transformer leg")
     ap.add_argument("--bucket-mb", type=float, default=13.0,
                     help="gradient bucket size when all-reduces overlap the backward: each bucket boundary cuts the captured "
                          "graph (about 15 us); 13 MiB = one transformer layer of the T=50 denoiser")
@@ -291,6 +437,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     selftest = os.environ.get("IB_DDP_SELFTEST") == "1"      # 1-rank run of the whole RCCL / bucket / segment path
+    backend = None
     if world > 1 or selftest:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
@@ -300,16 +447,10 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+        backend = dist.get_backend()
 
     from inferbiomechanics_amd import hip
-    from inferbiomechanics_amd.engine import HipTrainer
     hip.lib()
-    kind, T, D, B = WORKLOADS[a.workload]
-    dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
-    model = build_model(kind, T, D, dtype, dev)
-    trainer = HipTrainer(model, "diffusion", a.opt_type, 1e-4, use_graph=not a.no_graph, bucket_mb=a.bucket_mb,
-                         overlap_comm={"auto": None, "on": True, "off": False}[a.overlap_comm])
-    batches = make_batches(16, B, T, D, dtype, dev, seed=rank)
 
     def sync():
         torch.cuda.synchronize()
@@ -317,55 +458,32 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for i in range(4):                     # priming: eager warm-up + graph capture (not part of W)
-        trainer.step(batches[i % len(batches)])
-    for i in range(a.warmup):
-        trainer.step(batches[i % len(batches)])
-    sync()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        trainer.step(batches[i % len(batches)])
-    sync()
-    el = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([el], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        el = float(tt.cpu())
-    loss = trainer.loss_value()
-
-    # distribution of single-step times (median, p10 / p90): one event per step on the caller's stream,
-    # read back after the run -- no host synchronisation inside it
-    nq = min(a.steps, 400)
-    evs = [torch.cuda.Event(enable_timing=True) for _ in range(nq + 1)]
-    evs[0].record()
-    for i in range(nq):
-        trainer.step(batches[i % len(batches)])
-        evs[i + 1].record()
-    sync()
-    dts = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(nq))
-    pct = lambda q: round(dts[min(nq - 1, int(q * nq))], 4)
-
-    rec = record_eager_step(trainer, batches)          # all ranks: the step holds the gradient all-reduce
+    kind, T, D, B = WORKLOADS[a.workload]
+    dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    main_leg = train_leg(a.workload, a, dev, world, rank, a.steps, a.warmup, sync)
+    # BASELINE configs[2] (one GPU) / configs[3] (data parallel, per-GPU batch 256): the 4-layer d = 512 transformer
+    # denoiser at T = 50, its own step count (3 ms steps), every rank takes part (the step holds the all-reduces)
+    tr_leg = None
+    if kind == "mlp" and not a.no_transformer:
+        tr_leg = train_leg("transformer_denoiser_T50", a, dev, world, rank, 100, 10, sync)
     if rank == 0:
-        value = world * B * a.steps / el
+        cfg = dict(main_leg["config"])
+        cfg["workload"] = main_leg["workload"] + (" (BASELINE.json configs[1])" if kind == "mlp" else "")
         line = {
-            "metric": "motion-windows/sec training (+ DDIM steps/sec)", "value": round(value, 1), "unit": "windows/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(el / a.steps * 1e3, 4),
+            "metric": "motion-windows/sec training (+ DDIM steps/sec)", "value": main_leg["value"], "unit": "windows/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": main_leg["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": f"{a.workload}_D{D}_B{B}_{a.dtype} (BASELINE.json configs[1])" if kind == "mlp"
-                       else f"{a.workload}_D{D}_B{B}_{a.dtype}",
-                       "per_gpu_batch": B, "global_batch": B * world, "window": T, "feat": D,
-                       "optimizer": a.opt_type, "hipgraph": not a.no_graph, "parallelism": f"dp{world}",
-                       "grad_buckets": len(trainer.buckets.ranges) if trainer.ddp else 0,
-                       "overlap_comm": bool(trainer.overlap_comm)},
-            "step_ms": {"p10": pct(0.10), "median": pct(0.50), "p90": pct(0.90), "samples": nq},
-            "final_loss": round(loss, 6),
-            "train_tflops": round(value * train_flops_per_window(kind, T, D) / 1e12, 2),
+            "config": cfg,
+            # proof that the collective library saw N ranks (a SCALE record must show rccl_world == n_gpus)
+            "rccl_world": dist.get_world_size() if backend else 1, "backend": backend,
         }
-        rl, breakdown, dev_us = roofline_leg(rec, a.dtype)
-        line["roofline"] = rl
-        line["step_sum_of_kernel_us"] = round(dev_us, 1)
-        line["step_breakdown"] = breakdown
+        for k in ("step_ms", "final_loss", "train_tflops", "captures_in_timed_region", "step_fractions", "xgmi", "roofline",
+                  "step_sum_of_kernel_us", "step_breakdown"):
+            if k in main_leg:
+                line[k] = main_leg[k]
+        if tr_leg is not None:
+            tr_leg["workload"] += " (BASELINE.json configs[2]" + ("; configs[3] data-parallel form)" if world > 1 else ")")
+            line["transformer_T50"] = tr_leg
         if not a.no_ddim:
             line["ddim"] = ddim_leg(dev, dtype)                                  # B = 16: the quoted figure
             line["ddim_batches"] = [ddim_leg(dev, dtype, B=b) for b in (1, 256)]   # B in {1,16,256}

@@ -51,7 +51,12 @@ class DDIMSampler:
         tabs = m.tables(dev)
         if tabs.num_sample_steps != self.S:
             tabs.set_sampler(self.S)
-        sig = (tuple(x_T.shape), m.compute_dtype)
+        # the captured step bakes in raw pointers: the model's flat parameter buffer and bf16 shadow (a HipTrainer built
+        # after a first sample() re-packs them), the schedule tables (set_sampler() of another sampler re-creates the DDIM
+        # tables) -- all of them are part of the signature, so a change re-captures instead of replaying stale pointers
+        shadow = m._shadow.data_ptr() if m._shadow is not None else 0
+        sig = (tuple(x_T.shape), m.compute_dtype, m._flat.data_ptr(), shadow, tabs.temb.data_ptr(),
+               tabs.ddim_coef.data_ptr(), tabs.ddim_t.data_ptr(), self.S)
         if sig != self._sig:
             self._sig, self._graph = sig, None
             self._bufs = {"x": torch.empty(x_T.shape, dtype=m.compute_dtype, device=dev),

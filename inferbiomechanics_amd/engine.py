@@ -65,6 +65,9 @@ class GradBuckets:
                 lo, cur = end, []
         self._pending = [len(m) for m in self.members]
         self._works: list = []
+        # raw handles of the streams a collective has been issued from: c10d leaves completion events on them that its
+        # watchdog thread polls -- such a stream must never be put into capture mode (_Recorder.begin refuses it)
+        self.collective_streams: set = set()
 
     def reset(self):
         self._pending = [len(m) for m in self.members]
@@ -92,6 +95,8 @@ class GradBuckets:
             return
         lo, hi = self.ranges[b]
         t = self.flat[lo:hi]
+        if self.on_gpu:
+            self.collective_streams.add(torch.cuda.current_stream().cuda_stream)
         if inline and self.on_gpu and not os.environ.get("IB_ASYNC_INLINE"):
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)      # runs on the caller's stream: no event hops
             return
@@ -118,11 +123,19 @@ class _Recorder:
     """Records a step as segments: hipGraphs (captured launch runs) interleaved with host actions
     (collective launches), then replays them."""
 
-    def __init__(self):
+    def __init__(self, forbidden_streams=()):
         self.actions: List[Tuple[str, object]] = []
         self._g: Optional[hip.Graph] = None
+        self._forbidden = forbidden_streams
 
     def begin(self):
+        # c10d's watchdog polls the completion events of earlier collectives; a poll that lands while the event's stream
+        # is being captured aborts the process (round 1, commits 7ea3d2f / 54e1aa4).  Capture only on a stream that has
+        # never carried a collective.
+        if not hip._dry_run and torch.cuda.is_available() and \
+                torch.cuda.current_stream().cuda_stream in self._forbidden:
+            raise hip.HipError("graph capture refused: this stream has carried collectives (their completion events are "
+                               "polled by c10d's watchdog thread); capture on a dedicated stream")
         self._g = hip.Graph()
         self._g.begin()
 
@@ -450,8 +463,11 @@ class HipTrainer:
     _cap_stream = None
     MAX_PINNED_GRAPHS = 32
 
+    captures = 0            # graphs captured so far (bench.py asserts that none falls inside its timed region)
+
     def _capture(self, st) -> "_Recorder":
-        rec = _Recorder()
+        self.captures += 1
+        rec = _Recorder(self.buckets.collective_streams)
 
         def cut(b: int):
             if b >= 0:
@@ -479,7 +495,8 @@ class HipTrainer:
     def _step(self, batch) -> torch.Tensor:
         self._srcs = None
         st = self._stage(batch)
-        sig = tuple((k, tuple(v.shape)) for k, v in st.items())
+        # model.training is baked into a captured graph (Groundlink / dropout layers choose their launches by it)
+        sig = tuple((k, tuple(v.shape)) for k, v in st.items()) + (("training", bool(self.model.training)),)
         if sig != self._sig:
             self._sig, self._rec, self._warm = sig, None, 0
             self._pinned, self._seen = {}, {}
@@ -496,14 +513,7 @@ class HipTrainer:
                 if len(self._seen) < 4096 or key in self._seen:
                     self._seen[key] = n
                 if n >= 2:
-                    own = torch.zeros(4, dtype=torch.int64, device=self.device)
-                    hip.set_ptrs(own, self._srcs)
-                    generic, self._slots = self._slots, own
-                    try:
-                        pin = (self._capture(st), own)
-                    finally:
-                        self._slots = generic
-                    self._pinned[key] = pin
+                    pin = self._pinned[key] = self._pin(st)
             if pin is not None:
                 pin[0].replay()
             else:
@@ -524,6 +534,40 @@ class HipTrainer:
             self._rec.replay()                  # the capture itself executed nothing
         self.steps_done += 1
         return self.result[0]
+
+    def pin_batches(self, batches) -> int:
+        """Capture AHEAD OF TIME everything a run over `batches` will replay: the generic graph and -- chain path, batches
+        already resident in HBM in the compute dtype -- the graph of every distinct batch-pointer triple (otherwise a
+        triple gets its graph on its second appearance, i.e. ~1 ms of capture in the middle of the run).  A loader that
+        recycles a ring of device buffers calls this once with the ring.  Returns the number of graphs captured here."""
+        if self.stream is None or not self.use_graph:
+            return 0
+        before = self.captures
+        while self._rec is None:                 # two eager warm-up steps, then the generic capture
+            self.step(batches[0])
+        cur = torch.cuda.current_stream()
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            for batch in batches:
+                self._srcs = None
+                st = self._stage(batch)
+                if self._slots is None or self._srcs is None or os.environ.get("IB_NO_PINNED_GRAPHS"):
+                    break
+                key = tuple(t.data_ptr() for t in self._srcs)
+                if key in self._pinned or len(self._pinned) >= self.MAX_PINNED_GRAPHS:
+                    continue
+                self._pinned[key] = self._pin(st)
+        cur.wait_stream(self.stream)
+        return self.captures - before
+
+    def _pin(self, st):
+        own = torch.zeros(4, dtype=torch.int64, device=self.device)
+        hip.set_ptrs(own, self._srcs)
+        generic, self._slots = self._slots, own
+        try:
+            return (self._capture(st), own)
+        finally:
+            self._slots = generic
 
     def loss_value(self) -> float:
         """host readback of the last step's loss (synchronises)"""

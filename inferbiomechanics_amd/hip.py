@@ -194,6 +194,7 @@ class _RecordingLib:
     def __init__(self, real):
         self._real = real
         self.calls = []      # (name, args)
+        self.notes = {}      # index into calls -> (algorithmic flops, algorithmic bytes) for calls whose shapes sit in arrays
 
     def __getattr__(self, name):
         real = getattr(self._real, name)
@@ -202,9 +203,16 @@ class _RecordingLib:
             return real
 
         def call(*a):
+            global _work_note
+            if _work_note is not None:
+                self.notes[len(self.calls)] = _work_note
+                _work_note = None
             self.calls.append((name, a))
             return real(*a)
         return call
+
+
+_work_note = None     # set by a wrapper right before a grouped launch: (flops, bytes) of that launch, for bench.py
 
 
 class _StampLib:
@@ -597,6 +605,12 @@ def linear_wgrad_slabs_multi(problems):
     Ns = (ctypes.c_int64 * n)(*[g_[1] for g_ in geo])
     Ks = (ctypes.c_int64 * n)(*[g_[2] for g_ in geo])
     out = (ctypes.c_int32 * n)()
+    global _work_note
+    es_ = 2 if dt == torch.bfloat16 else 4
+    if isinstance(_lib, _RecordingLib):
+        _work_note = (sum(2 * g_[0] * g_[1] * g_[2] for g_ in geo),
+                      sum((g_[0] * g_[1] + g_[0] * g_[2]) * es_ + g_[1] * g_[2] * 4 for g_ in geo),
+                      [[g_[0], g_[1], g_[2]] for g_ in geo])
     rc = lib().ib_linear_wgrad_slabs_multi(n, cv(A), cv(LA), cv(X), cv(LX), cv(W), cv(WB), cv(out), cv(Ms), cv(Ns), cv(Ks),
                                            dtype_code(dt), stream_ptr())
     if rc == -5:          # IB_E_UNSUPPORTED

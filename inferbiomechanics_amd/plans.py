@@ -85,10 +85,18 @@ class Branch:
         self._join = torch.cuda.Event() if self.on else None
         self._n = 0
 
+    _depth = 0      # class-wide: > 0 while some enabled branch's launches are being issued
+
     def run(self, fn):
         if not self.on:
             fn()
             return
+        if Branch._depth > 0:
+            # a fork nested inside a forked stream crashed hipStreamEndCapture (round 1, gpurun_out/dbg_graph.err):
+            # branches must be SIBLINGS of the main stream.  Refused in eager mode too, so the first warm-up step
+            # already reports it instead of a later capture segfaulting.
+            raise hip.HipError(f"Branch '{self.name}': fork nested inside another forked stream (branches must be "
+                               f"siblings of the main stream; a nested fork crashes hipStreamEndCapture)")
         if self._n == len(self._forks):
             self._forks.append(torch.cuda.Event())
         ev = self._forks[self._n]
@@ -96,7 +104,11 @@ class Branch:
         ev.record(torch.cuda.current_stream())
         with torch.cuda.stream(self.stream):
             self.stream.wait_event(ev)
-            fn()
+            Branch._depth += 1
+            try:
+                fn()
+            finally:
+                Branch._depth -= 1
             self._join.record(self.stream)
 
     def join(self):
