@@ -251,6 +251,10 @@ int ib_col2im_replicate(const void* dcol, int64_t ldcol, const void* aux, int ac
 int ib_dropout(const void* x, void* y, int64_t n, float p, uint32_t seed, int32_t step, const int32_t* step_dev, int dtype,
                ib_stream_t stream);
 int ib_counter_add(int32_t* counter, int32_t delta, ib_stream_t stream);
+/* y[i] *= *scale (fp32 device scalar), in place; y 16-byte aligned.  The loss plugins' autograd bridge: the kernels write
+ * d loss / d outputs in the forward launch, `loss.backward()` (src/cli/train.py:281) later hands the upstream gradient of
+ * the scalar loss over as a device scalar. */
+int ib_scale_by_device_scalar(void* y, const float* scale, int64_t n, int dtype, ib_stream_t stream);
 int ib_fill_i64(int64_t* dst, int64_t value, int64_t n, ib_stream_t stream);
 
 /* ---- fused training chain of the token-wise MLP denoiser (BASELINE.json configs[1]; bf16 only).

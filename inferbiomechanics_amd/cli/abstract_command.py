@@ -28,6 +28,23 @@ def resolve_device(device) -> torch.device:
     return torch.device(d)
 
 
+def flat_to_torch_optimizer_state(sd, model):
+    """HipTrainer.optimizer_state_dict() payload -> torch.optim grammar (parameters in model.parameters() order), so a
+    checkpoint of the fused trainer resumes under `train --eager` (torch.optim over the drop-in modules)"""
+    from ..engine import HipTrainer
+    keys = HipTrainer.TORCH_STATE_KEYS[sd['opt_type']]
+    state = {}
+    for i, (k, p) in enumerate(model.named_parameters()):
+        if not keys or int(sd['step']) == 0:
+            break
+        off, n = sd['layout'][k]
+        st = {'step': torch.tensor(float(sd['step']))}
+        for key, buf in zip(keys, (sd['s1'], sd['s2'])):
+            st[key] = buf[off:off + n].view(p.shape).clone()
+        state[i] = st
+    return {'state': state, 'param_groups': [{'lr': sd['lr'], 'params': list(range(len(list(model.parameters()))))}]}
+
+
 class AbstractCommand:
     def register_subcommand(self, subparsers: argparse._SubParsersAction):
         pass
@@ -53,7 +70,7 @@ class AbstractCommand:
                   root_history_len: int = 10, output_data_format: str = 'all_frames', device: str = 'cpu',
                   compute_dtype: torch.dtype = torch.float32, feat_dim: int = 300, window: int = 50,
                   d_model: int = 512, num_heads: int = 8, dim_feedforward: int = 2048, num_layers: int = 4):
-        dev = resolve_device(device) if device != 'cpu' else 'cpu'
+        dev = self._model_device(device)
         if model_type == 'feedforward':
             from ..models.FeedForwardRegressionBaseline import FeedForwardBaseline
             return FeedForwardBaseline(num_dofs, num_contact_bodies, history_len, output_data_format, activation,
@@ -79,6 +96,22 @@ class AbstractCommand:
         raise NotImplementedError("model type 'analytical' is a nimblephysics CPU heuristic with no parameters "
                                   "(src/models/AnalyticalBaseline.py); it is outside the GPU hot path")
 
+    @staticmethod
+    def _model_device(device):
+        """The reference default is device='cpu' (and analyze / visualize default to --device cpu).  This build has no CPU
+        path, so 'cpu' resolves to the local MI355X (with a log line); without a GPU the construction fails HERE, naming
+        the argument to pass, instead of building a module whose first call raises."""
+        from .. import hip
+        if device != 'cpu':
+            return resolve_device(device)
+        if hip._dry_run:                                   # tests/test_plumbing_cpu.py only
+            return 'cpu'
+        if torch.cuda.is_available():
+            logging.info("get_model(device='cpu'): this build runs on the GPU only -- using the local MI355X")
+            return resolve_device('gpu')
+        raise hip.HipError("get_model(device='cpu'): the HIP path has no CPU fallback and no GPU is visible; "
+                           "pass device='gpu' (CLI: --device gpu) on an MI355X box")
+
     def load_latest_checkpoint(self, model, optimizer=None, checkpoint_dir="../checkpoints"):
         if not os.path.exists(checkpoint_dir):
             print("Checkpoint directory does not exist!")
@@ -96,12 +129,15 @@ class AbstractCommand:
                  for k, v in checkpoint['model_state_dict'].items()}
         target = model.module if hasattr(model, 'module') else model
         target.load_state_dict(state)
-        if optimizer is not None and checkpoint.get('optimizer_state_dict') is not None:
-            if hasattr(optimizer, 'load_optimizer_state_dict'):      # HipTrainer
-                optimizer.load_optimizer_state_dict(checkpoint['optimizer_state_dict'])
-                optimizer.refresh_after_param_load()
-            else:
-                optimizer.load_state_dict(checkpoint['optimizer_state_dict'])
+        osd = checkpoint.get('optimizer_state_dict')
+        if optimizer is not None and hasattr(optimizer, 'load_optimizer_state_dict'):      # HipTrainer
+            if osd is not None:
+                optimizer.load_optimizer_state_dict(osd)     # its own flat payload, or a torch.optim state dict
+            optimizer.refresh_after_param_load()             # always: the parameters changed under the bf16 shadow
+        elif optimizer is not None and osd is not None:
+            if 'layout' in osd and 'state' not in osd:       # written by the fused trainer, loaded under --eager
+                osd = flat_to_torch_optimizer_state(osd, target)
+            optimizer.load_state_dict(osd)
         epoch = checkpoint['epoch']
         batch = key(checkpoints[-1])[1]
         print(f"Loaded checkpoint from epoch {epoch}, batch {batch}")

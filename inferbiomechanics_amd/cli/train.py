@@ -158,13 +158,14 @@ class TrainCommand(AbstractCommand):
         cache = None
         if args.window_cache and trainer is not None and not diffusion:
             from ..data.WindowCache import DeviceWindowCache, PackedWindows
-            if os.path.exists(args.window_cache):
-                pack = PackedWindows.load(args.window_cache)
-            else:
+            # rank 0 packs and writes (atomically: temporary file + rename); the other ranks wait at the barrier and then
+            # memory-map the finished file -- none of them can open a file that is still being written
+            if not os.path.exists(args.window_cache) and rank == 0:
                 print(f"Packing {len(train_dataset)} training windows into {args.window_cache} ...")
-                pack = PackedWindows.from_windows(train_dataset)
-                if rank == 0:
-                    pack.save(args.window_cache)
+                PackedWindows.from_windows(train_dataset).save(args.window_cache)
+            if distributed:
+                dist.barrier()
+            pack = PackedWindows.load(args.window_cache)
             cache = DeviceWindowCache(pack, device)
             print(f"[rank={rank}] window cache: {len(cache)} windows, {cache.table.numel() * 4 / 2**20:.1f} MiB in HBM")
 

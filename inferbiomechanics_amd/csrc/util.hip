@@ -115,3 +115,35 @@ extern "C" int ib_set_ptrs(void* slots, int n, const void* const* ptrs, ib_strea
   IB_CHECK_LAUNCH();
   return IB_OK;
 }
+
+// y[i] *= *scale  (the upstream gradient of a scalar loss arriving in a loss plugin's backward: autograd hands it over as a
+// DEVICE scalar, the kernel that wrote d loss / d outputs ran in the forward).  In place, 16-byte accesses where aligned.
+namespace {
+template <typename T>
+__global__ __launch_bounds__(256) void scale_by_scalar_kernel(T* __restrict__ y, const float* __restrict__ scale, int64_t n) {
+  const float s = *scale;
+  constexpr int V = 16 / sizeof(T);
+  const int64_t nv = n / V;
+  typedef __attribute__((ext_vector_type(V))) T vec_t;
+  vec_t* yv = reinterpret_cast<vec_t*>(y);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (int64_t)gridDim.x * blockDim.x) {
+    vec_t v = yv[i];
+#pragma unroll
+    for (int e = 0; e < V; ++e) v[e] = ib_from_f32<T>(ib_to_f32(v[e]) * s);
+    yv[i] = v;
+  }
+  for (int64_t i = nv * V + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    y[i] = ib_from_f32<T>(ib_to_f32(y[i]) * s);
+}
+}  // namespace
+extern "C" int ib_scale_by_device_scalar(void* y, const float* scale, int64_t n, int dtype, ib_stream_t stream) {
+  if (!y || !scale || n < 0) return IB_E_ARG;
+  if (n == 0) return IB_OK;
+  if ((reinterpret_cast<uintptr_t>(y) & 15) != 0) return IB_E_ARG;
+  const int grid = ib_grid_1d(n, 256 * 8);
+  if (dtype == IB_F32) hipLaunchKernelGGL((scale_by_scalar_kernel<float>), dim3(grid), dim3(256), 0, ib_s(stream), (float*)y, scale, n);
+  else if (dtype == IB_BF16) hipLaunchKernelGGL((scale_by_scalar_kernel<bf16_t>), dim3(grid), dim3(256), 0, ib_s(stream), (bf16_t*)y, scale, n);
+  else return IB_E_DTYPE;
+  IB_CHECK_LAUNCH();
+  return IB_OK;
+}

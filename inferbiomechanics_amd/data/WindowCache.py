@@ -125,11 +125,16 @@ class PackedWindows:
         if len(MAGIC) + len(blob) > HEADER_BYTES:
             raise ValueError("PackedWindows: header too large")
         os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
-        with open(path, "wb") as f:
+        # written under a temporary name and renamed: a reader (another rank, a later run) never sees a partial file
+        tmp = f"{path}.tmp.{os.getpid()}"
+        with open(tmp, "wb") as f:
             f.write((MAGIC + blob).ljust(HEADER_BYTES, b" "))
             np.ascontiguousarray(self.rows, dtype="<f4").tofile(f)
             np.ascontiguousarray(self.subjects, dtype="<i4").tofile(f)
             np.ascontiguousarray(self.trials, dtype="<i4").tofile(f)
+            f.flush()
+            os.fsync(f.fileno())
+        os.replace(tmp, path)
 
     @classmethod
     def load(cls, path: str, mmap: bool = True) -> "PackedWindows":

@@ -574,13 +574,38 @@ class HipTrainer:
         return float(self.result[0].cpu())
 
     # ---- checkpoint payload (grammar of train.py:272-278) ------------------------------------------
+    # torch.optim state names behind the flat (s1, s2) buffers (csrc/optim.hip: the order of its update formulas)
+    TORCH_STATE_KEYS = {"sgd": (), "adam": ("exp_avg", "exp_avg_sq"), "rmsprop": ("square_avg",), "adagrad": ("sum",),
+                        "adadelta": ("square_avg", "acc_delta"), "adamax": ("exp_avg", "exp_inf")}
+
     def optimizer_state_dict(self) -> Dict:
         return {"opt_type": self.opt_type, "lr": self.lr, "step": self.steps_done,
                 "layout": {k: list(v) for k, v in self.layout.items()},
                 "s1": None if self.s1 is None else self.s1.detach().cpu(),
                 "s2": None if self.s2 is None else self.s2.detach().cpu()}
 
+    def torch_optimizer_state_dict(self) -> Dict:
+        """the same state in torch.optim's own grammar ({'state': {i: {...}}, 'param_groups': [...]}, parameters numbered
+        in model.parameters() order as `optim.X(model.parameters(), lr=...)` numbers them, train.py:183-194): what a
+        reference-style (`--eager` / torch.optim) run or the reference itself can load"""
+        names = [k for k, _ in self.model.named_parameters()]
+        keys = self.TORCH_STATE_KEYS[self.opt_type]
+        state = {}
+        if keys and self.steps_done > 0:
+            for i, k in enumerate(names):
+                off, n = self.layout[k]
+                shp = self._params[k].shape
+                st = {"step": torch.tensor(float(self.steps_done))}
+                for key, buf in zip(keys, (self.s1, self.s2)):
+                    st[key] = buf[off:off + n].view(shp).detach().cpu().clone()
+                state[i] = st
+        return {"state": state, "param_groups": [{"lr": self.lr, "params": list(range(len(names)))}]}
+
     def load_optimizer_state_dict(self, sd: Dict):
+        """accepts this trainer's flat payload AND a torch.optim state dict (a checkpoint written by the reference, by
+        `train --eager`, or by torch_optimizer_state_dict())"""
+        if "state" in sd and "param_groups" in sd:
+            return self._load_torch_optimizer_state(sd)
         if sd.get("opt_type") != self.opt_type or {k: list(v) for k, v in self.layout.items()} != sd.get("layout"):
             raise hip.HipError("optimizer state does not match this trainer (optimizer type or parameter layout)")
         if self.s1 is not None:
@@ -589,6 +614,32 @@ class HipTrainer:
             self.s2.copy_(sd["s2"])
         self.steps_done = int(sd["step"])
         self.step_dev.fill_(self.steps_done)
+
+    def _load_torch_optimizer_state(self, sd: Dict):
+        names = [k for k, _ in self.model.named_parameters()]
+        ids = [i for grp in sd["param_groups"] for i in grp["params"]]
+        if len(ids) != len(names):
+            raise hip.HipError(f"torch.optim state covers {len(ids)} parameters, the model has {len(names)}")
+        keys = self.TORCH_STATE_KEYS[self.opt_type]
+        steps = 0
+        for buf in (self.s1, self.s2):
+            if buf is not None:
+                buf.zero_()
+        for pid, k in zip(ids, names):
+            st = sd["state"].get(pid)
+            if not st:
+                continue                      # never stepped (or plain SGD: stateless)
+            missing = [key for key in keys if key not in st]
+            if missing:
+                raise hip.HipError(f"torch.optim state of '{k}' lacks {missing}: not a {self.opt_type} state")
+            off, n = self.layout[k]
+            for key, buf in zip(keys, (self.s1, self.s2)):
+                if tuple(st[key].shape) != tuple(self._params[k].shape):
+                    raise hip.HipError(f"torch.optim state '{key}' of '{k}' has shape {tuple(st[key].shape)}")
+                buf[off:off + n].view(self._params[k].shape).copy_(st[key].to(torch.float32))
+            steps = max(steps, int(float(st.get("step", 0))))
+        self.steps_done = steps
+        self.step_dev.fill_(steps)
 
     def refresh_after_param_load(self):
         """call after model.load_state_dict(): re-cast the bf16 shadow"""

@@ -104,6 +104,7 @@ _SIGS = {
     "ib_q_sample": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _c.c_int, _vp]),
     "ib_ddim_step": (_c.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i64, _i64, _c.c_int, _vp]),
     "ib_counter_add": (_c.c_int, [_vp, _i32, _vp]),
+    "ib_scale_by_device_scalar": (_c.c_int, [_vp, _vp, _i64, _c.c_int, _vp]),
     "ib_fill_i64": (_c.c_int, [_vp, _i64, _i64, _vp]),
     "ib_graph_begin": (_c.c_int, [_vp]),
     "ib_graph_end": (_c.c_int, [_vp, _c.POINTER(_vp)]),
@@ -1360,6 +1361,17 @@ def ddim_step(x, eps, coef, timesteps, step=0, step_dev=None, t_out=None):
     _check(lib().ib_ddim_step(_ptr(x), _ptr(eps), _ptr(coef), _ptr(timesteps), S, int(step), _ptr(step_dev),
                               _ptr(t_out), B, x.numel(), dtype_code(dt), stream_ptr()), "ib_ddim_step")
     return x
+
+
+def scale_by_device_scalar(y: torch.Tensor, scale: torch.Tensor):
+    """y *= scale (a one-element fp32 device tensor), in place; returns y"""
+    _req(y, "y")
+    _req(scale, "scale", torch.float32)
+    if not y.is_contiguous() or scale.numel() != 1:
+        raise HipError("scale_by_device_scalar: y must be contiguous, scale a single fp32 element")
+    _check(lib().ib_scale_by_device_scalar(_ptr(y), _ptr(scale), y.numel(), dtype_code(y.dtype), stream_ptr()),
+           "ib_scale_by_device_scalar")
+    return y
 
 
 def counter_add(counter, delta=1):

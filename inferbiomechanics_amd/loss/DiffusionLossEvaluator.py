@@ -9,6 +9,11 @@ import torch
 from .. import hip
 
 
+def _as_f32_scalar(dloss: torch.Tensor) -> torch.Tensor:
+    """the upstream gradient of the loss as a one-element fp32 tensor (the loss IS fp32 on the device, so this is a view)"""
+    return dloss.detach().reshape(1).to(torch.float32).contiguous()
+
+
 class _MSEFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pred, target):
@@ -24,7 +29,9 @@ class _MSEFn(torch.autograd.Function):
     def backward(ctx, dloss):
         if ctx.dpred is None:
             return None, None
-        return ctx.dpred * dloss.to(ctx.dpred.dtype), None
+        # dpred already holds 2 (pred - target) / n from the forward launch; the upstream gradient of the scalar loss is
+        # a device scalar: one in-place HIP launch, no ATen arithmetic on the backward
+        return hip.scale_by_device_scalar(ctx.dpred, _as_f32_scalar(dloss)), None
 
 
 class DiffusionLossEvaluator:

@@ -62,6 +62,7 @@ class _RegressionLossFn(torch.autograd.Function):
                      G[:, 12 * F:18 * F].view(B, F, 6), G[:, 18 * F:30 * F].view(B, F, 12))
         hip.regression_loss(outs, labels, comp_w, result, ws, grads=grads, threshold=threshold)
         ctx.grads = grads
+        ctx.G = G if need_grad else None
         ctx.mark_non_differentiable(result)
         return result[0], result
 
@@ -69,8 +70,11 @@ class _RegressionLossFn(torch.autograd.Function):
     def backward(ctx, dloss, _dresult):
         if ctx.grads is None:
             return (None,) * 7
-        d = dloss.to(ctx.grads[0].dtype)
-        return tuple(g * d for g in ctx.grads) + (None, None, None)
+        # the four gradients are views of ONE [B, 30 F] buffer the forward launch filled: scale it in place by the
+        # upstream gradient (a device scalar) with one HIP launch -- no ATen arithmetic on the backward
+        from .DiffusionLossEvaluator import _as_f32_scalar
+        hip.scale_by_device_scalar(ctx.G, _as_f32_scalar(dloss))
+        return tuple(ctx.grads) + (None, None, None)
 
 
 class RegressionLossEvaluator:
