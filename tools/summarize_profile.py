@@ -68,6 +68,26 @@ def main():
                 a[(r["Kernel_Name"], r["Grid_Size"])].append(float(r["Counter_Value"]))
         return a
     F, W = counters("pmc_fetch"), counters("pmc_write")
+
+    def counters_by_name(sub):
+        f = first(os.path.join(src, sub, "*", "*counter_collection.csv"))
+        a = collections.defaultdict(lambda: collections.defaultdict(list))
+        if f:
+            for r in csv.DictReader(open(f)):
+                a[(r["Kernel_Name"], r["Grid_Size"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        return a
+    Q = counters_by_name("pmc_mfma")
+
+    def mfma(k):
+        """MFMA utilisation of a kernel = SQ_VALU_MFMA_BUSY_CYCLES (summed over the 1024 SIMDs) / (elapsed cycles x 1024),
+        elapsed cycles = GRBM_GUI_ACTIVE / 8 (rocprofv3 reports the sum over the 8 XCDs) -- the gfx94x `MfmaUtil`
+        expression of rocprofv3's own counter file; executed MFMA FLOPs = SQ_INSTS_VALU_MFMA_MOPS_BF16 x 512"""
+        q = Q.get(k)
+        if not q or not q.get("SQ_VALU_MFMA_BUSY_CYCLES") or not q.get("GRBM_GUI_ACTIVE"):
+            return None, None
+        avg = lambda n: sum(q[n]) / len(q[n]) if q.get(n) else 0.0
+        busy, gui = avg("SQ_VALU_MFMA_BUSY_CYCLES"), avg("GRBM_GUI_ACTIVE")
+        return (busy / (gui / 8.0 * 1024.0) if gui else None), avg("SQ_INSTS_VALU_MFMA_MOPS_BF16") * 512.0
     T = collections.defaultdict(list)
     n = len(trace)
     for r in trace[n // 4:]:                         # skip process start-up / warm-up dispatches
@@ -78,36 +98,52 @@ def main():
         f, w = F.get(k), W.get(k)
         fk = sum(f) / len(f) if f else None
         wk = sum(w) / len(w) if w else None
+        mu, mfl = mfma(k)
         rows.append({"kernel": k[0], "grid_threads": int(k[1]), "dispatches": len(v), "avg_us": sum(v) / len(v) / 1e3,
                      "total_ms": sum(v) / 1e6, "FETCH_SIZE_KiB": fk, "WRITE_SIZE_KiB": wk,
-                     "hbm_bytes": None if fk is None or wk is None else (2 * fk + wk) * 1024})
+                     "hbm_bytes": None if fk is None or wk is None else (2 * fk + wk) * 1024,
+                     "mfma_util": mu, "mfma_flops": mfl})
     rows.sort(key=lambda r: -r["total_ms"])
     with open(os.path.join(dst, f"{tag}_per_kernel.md"), "w") as f:
         f.write(f"# {tag}: per-kernel durations (rocprofv3 --kernel-trace, un-graphed bench.py) joined with HBM counters\n\n"
                 "`hbm MB/launch` = (2 x FETCH_SIZE + WRITE_SIZE) KiB from separate `--pmc` passes (gfx950 FETCH_SIZE correction).\n"
                 "Durations of sub-10 us kernels are inflated in the un-graphed run (the GPU idles between host launches);\n"
                 "tools/kbench.py / bench.py's roofline leg time launches back-to-back inside a hipGraph.\n\n"
-                "| kernel | grid (threads) | dispatches | avg us | total ms | FETCH KiB | WRITE KiB | hbm MB/launch |\n|---|---|---|---|---|---|---|---|\n")
+                "`MFMA util` = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs) from a third `--pmc` pass (busy matrix-pipe\n"
+                "cycles over elapsed SIMD cycles: 100 % = the dense bf16 peak); `MFMA GFLOP` = SQ_INSTS_VALU_MFMA_MOPS_BF16 x 512 = the\n"
+                "FLOPs the matrix pipes EXECUTED per launch (padding rows / columns included).\n\n"
+                "| kernel | grid (threads) | dispatches | avg us | total ms | FETCH KiB | WRITE KiB | hbm MB/launch | MFMA util | MFMA GFLOP |\n|---|---|---|---|---|---|---|---|---|---|\n")
         for r in rows[:40]:
             name = r["kernel"].replace("void ", "").replace("(anonymous namespace)::", "")
             name = name.split("(")[0][-70:] or r["kernel"][:70]
             f.write(f"| `{name}` | {r['grid_threads']} | {r['dispatches']} | {r['avg_us']:.1f} | {r['total_ms']:.2f} | "
                     f"{'' if r['FETCH_SIZE_KiB'] is None else round(r['FETCH_SIZE_KiB'])} | "
                     f"{'' if r['WRITE_SIZE_KiB'] is None else round(r['WRITE_SIZE_KiB'])} | "
-                    f"{'' if r['hbm_bytes'] is None else round(r['hbm_bytes'] / 1e6, 1)} |\n")
-    traffic = {}
-    fam = collections.defaultdict(lambda: {"bytes": 0.0, "n": 0, "us": 0.0})
+                    f"{'' if r['hbm_bytes'] is None else round(r['hbm_bytes'] / 1e6, 1)} | "
+                    f"{'' if r['mfma_util'] is None else format(100 * r['mfma_util'], '.1f') + ' %'} | "
+                    f"{'' if not r['mfma_flops'] else round(r['mfma_flops'] / 1e9, 2)} |\n")
+    tpath = os.path.join(dst, "traffic.json")
+    traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
+    fam = collections.defaultdict(lambda: {"bytes": 0.0, "n": 0, "us": 0.0, "busy": 0.0, "flops": 0.0})
+    GEMM = ("ib_linear_fwd", "ib_linear_dgrad", "ib_linear_wgrad", "ib_linear_wgrad_slabs", "ib_linear_wgrad_slabs_multi")
     for r in rows:
         e = entry_of(r["kernel"])
         if e and r["hbm_bytes"] is not None:
-            fam[e]["bytes"] += r["hbm_bytes"] * r["dispatches"]
-            fam[e]["n"] += r["dispatches"]
-            fam[e]["us"] += r["avg_us"] * r["dispatches"]
+            for name in ([e, "linear GEMMs"] if e in GEMM else [e]):
+                f_ = fam[name]
+                f_["bytes"] += r["hbm_bytes"] * r["dispatches"]
+                f_["n"] += r["dispatches"]
+                f_["us"] += r["avg_us"] * r["dispatches"]
+                if r["mfma_util"] is not None:       # time-weighted utilisation of the family
+                    f_["busy"] += r["mfma_util"] * r["avg_us"] * r["dispatches"]
+                    f_["flops"] += (r["mfma_flops"] or 0.0) * r["dispatches"]
     for e, v in fam.items():
         traffic[e] = {"hbm_bytes_per_launch": round(v["bytes"] / v["n"]), "avg_launch_us_in_profile": round(v["us"] / v["n"], 2),
-                      "dispatches": v["n"], "source": f"profiles/{tag}_per_kernel.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
-                      "separate passes; bytes = (2*FETCH + WRITE) KiB)"}
-    json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
+                      "dispatches": v["n"], "mfma_util": round(v["busy"] / v["us"], 4) if v["busy"] else None,
+                      "mfma_flops_executed_per_launch": round(v["flops"] / v["n"]) if v["flops"] else None,
+                      "source": f"profiles/{tag}_per_kernel.md (rocprofv3 --pmc: FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES in "
+                      "separate passes; bytes = (2*FETCH + WRITE) KiB; mfma_util = busy / (GRBM_GUI_ACTIVE / 8 x 1024))"}
+    json.dump(traffic, open(tpath, "w"), indent=1)
     print(open(os.path.join(dst, f"{tag}_per_kernel.md")).read()[:3000])
     print(json.dumps(traffic, indent=1))
 
