@@ -251,6 +251,22 @@ int ib_col2im_replicate(const void* dcol, int64_t ldcol, const void* aux, int ac
 int ib_dropout(const void* x, void* y, int64_t n, float p, uint32_t seed, int32_t step, const int32_t* step_dev, int dtype,
                ib_stream_t stream);
 int ib_counter_add(int32_t* counter, int32_t delta, ib_stream_t stream);
+
+/* ---- nn.BatchNorm1d over [B, C] rows (the optional layer in front of every Linear of the feedforward model,
+ * src/models/FeedForwardRegressionBaseline.py:71-72; flag --batchnorm, src/cli/train.py:47).  torch defaults: eps 1e-5,
+ * momentum 0.1, affine, track_running_stats.  training != 0: batch statistics normalise, the running statistics and
+ * num_batches_tracked (int64 device scalar, may be NULL) are updated in place (unbiased variance), B >= 2; training == 0:
+ * the running statistics normalise.  save_mean / save_rstd [C] receive what the backward needs.  Fixed summation order.
+ * Backward: dgamma / dbeta [C] (+)=, dx (may be NULL) = d loss / d x, optionally multiplied by the derivative of the
+ * activation below (act_below / aux as in ib_linear_dgrad). */
+int ib_batchnorm_fwd(const void* x, int64_t ldx, const float* gamma, const float* beta, float* running_mean,
+                     float* running_var, int64_t* num_batches_tracked, void* y, int64_t ldy, float* save_mean,
+                     float* save_rstd, int64_t B, int64_t C, float momentum, float eps, int training, int dtype,
+                     ib_stream_t stream);
+int ib_batchnorm_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const float* gamma, const float* save_mean,
+                     const float* save_rstd, void* dx, int64_t lddx, float* dgamma, float* dbeta, int accumulate,
+                     int act_below, const void* aux, int64_t ldaux, int64_t B, int64_t C, int training, int dtype,
+                     ib_stream_t stream);
 /* y[i] *= *scale (fp32 device scalar), in place; y 16-byte aligned.  The loss plugins' autograd bridge: the kernels write
  * d loss / d outputs in the forward launch, `loss.backward()` (src/cli/train.py:281) later hands the upstream gradient of
  * the scalar loss over as a device scalar. */

@@ -365,6 +365,10 @@ class HipTrainer:
                 # Groundlink: [B, F', 30] with the four outputs interleaved per frame; the dropout masks are keyed on
                 # the device-resident step counter, so a replayed graph draws fresh masks every step
                 out = plan.forward(x, P, training=m.training, step_dev=self.step_dev)
+            elif getattr(m, "train_mode_matters", False):
+                # feedforward model with --dropout / --batchnorm: same device-resident step counter for the masks; the
+                # BatchNorm running statistics are updated in place by the captured launches
+                out = plan.forward(x, P, training=m.training, step_dev=self.step_dev)
             else:
                 out = plan.forward(x, P)
             F = self._out_frames(frames_in)

@@ -104,6 +104,10 @@ _SIGS = {
     "ib_q_sample": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _c.c_int, _vp]),
     "ib_ddim_step": (_c.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i64, _i64, _c.c_int, _vp]),
     "ib_counter_add": (_c.c_int, [_vp, _i32, _vp]),
+    "ib_batchnorm_fwd": (_c.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _f32, _f32, _c.c_int,
+                                    _c.c_int, _vp]),
+    "ib_batchnorm_bwd": (_c.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _c.c_int, _c.c_int, _vp, _i64,
+                                    _i64, _i64, _c.c_int, _c.c_int, _vp]),
     "ib_scale_by_device_scalar": (_c.c_int, [_vp, _vp, _i64, _c.c_int, _vp]),
     "ib_fill_i64": (_c.c_int, [_vp, _i64, _i64, _vp]),
     "ib_graph_begin": (_c.c_int, [_vp]),
@@ -1361,6 +1365,61 @@ def ddim_step(x, eps, coef, timesteps, step=0, step_dev=None, t_out=None):
     _check(lib().ib_ddim_step(_ptr(x), _ptr(eps), _ptr(coef), _ptr(timesteps), S, int(step), _ptr(step_dev),
                               _ptr(t_out), B, x.numel(), dtype_code(dt), stream_ptr()), "ib_ddim_step")
     return x
+
+
+def batchnorm_fwd(x, gamma, beta, running_mean, running_var, num_batches_tracked, y, save_mean, save_rstd, training: bool,
+                  momentum: float = 0.1, eps: float = 1e-5):
+    """nn.BatchNorm1d over [B, C] rows (torch defaults); in training mode the running statistics are updated in place"""
+    dt = x.dtype
+    B, C, ldx = _mat(x, "x", dt)
+    By, Cy, ldy = _mat(y, "y", dt)
+    if (By, Cy) != (B, C):
+        raise HipError("batchnorm_fwd: x / y shapes differ")
+    for name, t in (("gamma", gamma), ("beta", beta), ("running_mean", running_mean), ("running_var", running_var),
+                    ("save_mean", save_mean), ("save_rstd", save_rstd)):
+        _req(t, name, torch.float32, 1)
+        if t.numel() != C or not t.is_contiguous():
+            raise HipError(f"batchnorm_fwd: {name} must be a contiguous [{C}] fp32 vector")
+    if num_batches_tracked is not None:
+        _req(num_batches_tracked, "num_batches_tracked", torch.int64)
+    if training and B < 2:
+        raise ValueError("Expected more than 1 value per channel when training, got input size " + str(tuple(x.shape)))
+    _check(lib().ib_batchnorm_fwd(_ptr(x), ldx, _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
+                                  _ptr(num_batches_tracked), _ptr(y), ldy, _ptr(save_mean), _ptr(save_rstd), B, C,
+                                  float(momentum), float(eps), int(bool(training)), dtype_code(dt), stream_ptr()),
+           "ib_batchnorm_fwd")
+
+
+def batchnorm_bwd(dy, x, gamma, save_mean, save_rstd, dx, dgamma, dbeta, training: bool, accumulate=False,
+                  act_below="none", aux=None):
+    dt = dy.dtype
+    B, C, lddy = _mat(dy, "dy", dt)
+    Bx, Cx, ldx = _mat(x, "x", dt)
+    if (Bx, Cx) != (B, C):
+        raise HipError("batchnorm_bwd: dy / x shapes differ")
+    lddx = 0
+    if dx is not None:
+        Bd, Cd, lddx = _mat(dx, "dx", dt)
+        if (Bd, Cd) != (B, C):
+            raise HipError("batchnorm_bwd: dx shape differs")
+    for name, t in (("gamma", gamma), ("save_mean", save_mean), ("save_rstd", save_rstd), ("dgamma", dgamma),
+                    ("dbeta", dbeta)):
+        if t is None and name in ("dgamma", "dbeta"):
+            continue
+        _req(t, name, torch.float32, 1)
+        if t.numel() != C or not t.is_contiguous():
+            raise HipError(f"batchnorm_bwd: {name} must be a contiguous [{C}] fp32 vector")
+    ldaux = 0
+    if ACT[act_below] != 0:
+        if aux is None:
+            raise HipError("batchnorm_bwd: act_below needs aux")
+        Ba, Ca, ldaux = _mat(aux, "aux", dt)
+        if (Ba, Ca) != (B, C):
+            raise HipError("batchnorm_bwd: aux shape differs")
+    _check(lib().ib_batchnorm_bwd(_ptr(dy), lddy, _ptr(x), ldx, _ptr(gamma), _ptr(save_mean), _ptr(save_rstd), _ptr(dx), lddx,
+                                  _ptr(dgamma), _ptr(dbeta), int(accumulate), ACT[act_below],
+                                  _ptr(aux) if ACT[act_below] != 0 else None, ldaux, B, C, int(bool(training)), dtype_code(dt),
+                                  stream_ptr()), "ib_batchnorm_bwd")
 
 
 def scale_by_device_scalar(y: torch.Tensor, scale: torch.Tensor):

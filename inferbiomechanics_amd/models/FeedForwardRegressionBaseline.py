@@ -33,9 +33,8 @@ class FeedForwardBaseline(HipModule):
         super().__init__(compute_dtype)
         if activation not in ACTIVATION_FUNCS:
             raise KeyError(activation)
-        if batchnorm or dropout:
-            # flags default off in every reference command (train.py:43,47); not on the hot path
-            raise NotImplementedError("batchnorm / dropout are not part of the HIP hot path (reference defaults: off)")
+        if dropout and not (0.0 <= dropout_prob < 1.0):
+            raise ValueError(f"dropout probability has to be in [0, 1), but got {dropout_prob}")
         self.stride, self.activation, self.output_data_format = stride, activation, output_data_format
         self.num_dofs, self.num_contact_bodies = num_dofs, num_contact_bodies
         self.history_len, self.root_history_len = history_len, root_history_len
@@ -47,19 +46,40 @@ class FeedForwardBaseline(HipModule):
         dims = [self.input_size] + list(hidden_dims) + [self.output_size]
         logging.info(f"MODEL DIMENSIONS: input size = {self.input_size}, hidden dims = {hidden_dims}, "
                      f"output size = {self.output_size}")
-        # same module indices as the reference Sequential: Linear at 2*i, activation at 2*i+1
+        # same module indices as the reference Sequential (:67-77): per layer [Dropout] [BatchNorm1d(h0)] Linear, then
+        # the activation on all but the last -- so `net.{j}` state-dict keys (Linear weight / bias, BatchNorm weight /
+        # bias / running_mean / running_var / num_batches_tracked) are the reference's with every flag combination
         self.net = nn.ModuleDict()
-        names = []
+        self.dropout_p = float(dropout_prob) if dropout else 0.0
+        names, bns = [], []
+        j = 0
         for i, (h0, h1) in enumerate(zip(dims[:-1], dims[1:])):
-            lin = nn.Linear(h0, h1, dtype=torch.float32, device=device)   # reference init (kaiming-uniform)
-            self.net[str(2 * i)] = lin
-            names.append((f"net.{2 * i}.weight", f"net.{2 * i}.bias"))
-        self._names = names
+            if dropout:
+                j += 1                                                     # nn.Dropout: no state
+            if batchnorm:
+                self.net[str(j)] = nn.BatchNorm1d(h0, device=device)        # parameter / buffer container (torch defaults)
+                bns.append((f"net.{j}.weight", f"net.{j}.bias"))
+                j += 1
+            else:
+                bns.append(None)
+            self.net[str(j)] = nn.Linear(h0, h1, dtype=torch.float32, device=device)   # reference init (kaiming-uniform)
+            names.append((f"net.{j}.weight", f"net.{j}.bias"))
+            j += 1
+            if i < len(dims) - 2:
+                j += 1                                                     # the activation module
+        self._names, self._bn = names, bns
+        self.train_mode_matters = bool(dropout or batchnorm)               # HipTrainer passes training / the step counter
+        self._fwd_calls = 0
         self._plan = None
 
     def _get_plan(self, device) -> DenseStackPlan:
         if self._plan is None or self._plan.buf.device != device or self._plan.dtype != self.compute_dtype:
-            self._plan = DenseStackPlan(self._names, self.activation, self.compute_dtype, device)
+            self._plan = DenseStackPlan(self._names, self.activation, self.compute_dtype, device, bn_names=self._bn,
+                                        dropout_p=self.dropout_p)
+        for bn in self._bn:        # (re)bind the BatchNorm buffers: load_state_dict copies in place, .to() replaces them
+            if bn is not None:
+                m = self.net[bn[0].split(".")[1]]
+                self._plan.bn_buffers[bn[0]] = (m.running_mean, m.running_var, m.num_batches_tracked)
         return self._plan
 
     def pack_inputs(self, input: Dict[str, torch.Tensor], device) -> torch.Tensor:
@@ -83,7 +103,10 @@ class FeedForwardBaseline(HipModule):
 
     def _plan_forward(self, x: torch.Tensor) -> torch.Tensor:
         out = torch.empty((x.shape[0], self.output_size), dtype=self.compute_dtype, device=x.device)
-        return self._get_plan(x.device).forward(x, self.param_source(), out=out)
+        if self.training:
+            self._fwd_calls += 1           # dropout masks are keyed on (seed, step, element): a fresh draw per call
+        return self._get_plan(x.device).forward(x, self.param_source(), out=out, training=self.training,
+                                                step=self._fwd_calls)
 
     def _plan_backward(self, dout, P, accumulate):
         self._plan.backward(dout, P, accumulate)

@@ -183,56 +183,112 @@ def _as_dtype(buf: Buffers, tag: str, t32: torch.Tensor, dtype) -> torch.Tensor:
 
 # ------------------------------------------------------------------------------------------------
 class DenseStackPlan:
-    """[Linear act]* Linear over [M, K0] rows (FeedForwardRegressionBaseline.py:65-77)."""
+    """[Dropout] [BatchNorm1d] Linear act ... [Dropout] [BatchNorm1d] Linear over [M, K0] rows: the reference's layer
+    build, src/models/FeedForwardRegressionBaseline.py:65-77 (`if dropout: Dropout(p)`, `if batchnorm: BatchNorm1d(h0)`,
+    Linear, activation on all but the last).
 
-    def __init__(self, names: Sequence[Tuple[str, str]], activation: str, dtype, device, tag="ff"):
+    Dropout = the counter-hash mask kernel keyed on (seed + layer, step, element), regenerated in the backward instead of
+    stored (as in GroundlinkPlan).  BatchNorm1d = csrc/batchnorm.hip: batch statistics + running-statistics update in
+    train mode, running statistics in eval mode.  With a BatchNorm in front of Linear i the activation derivative of
+    layer i-1 cannot ride in the dgrad epilogue (the normalisation sits between them): it is multiplied in by the
+    BatchNorm backward pass instead; the dropout mask (elementwise, commutes) follows in place."""
+
+    def __init__(self, names: Sequence[Tuple[str, str]], activation: str, dtype, device, tag="ff",
+                 bn_names: Optional[Sequence[Optional[Tuple[str, str]]]] = None, dropout_p: float = 0.0, seed: int = 0x2F1):
         self.names, self.act, self.dtype, self.tag = list(names), activation, dtype, tag
+        self.bn = list(bn_names) if bn_names is not None else [None] * len(self.names)
+        self.p, self.seed = float(dropout_p), seed
+        self.bn_buffers: Dict[str, Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]] = {}   # set by the model
         self.buf = Buffers(device)
-        self.saved: List[torch.Tensor] = []
+        self.saved: List = []
+        self.ctx = (False, 0, None)
 
-    def forward(self, x: torch.Tensor, P: ParamSource, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, P: ParamSource, out: Optional[torch.Tensor] = None, training: bool = False,
+                step: int = 0, step_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
         M = x.shape[0]
         L = len(self.names)
-        self.saved = [x]
+        g, dt, tg = self.buf.get, self.dtype, self.tag
+        drop = training and self.p > 0.0
+        self.saved = []
+        self.ctx = (training, step, step_dev)
         h = x
         for i, (wn, bn) in enumerate(self.names):
             w = P.w(wn)
             last = i == L - 1
-            y = out if (last and out is not None) else self.buf.get(f"{self.tag}.y{i}", (M, w.shape[0]), self.dtype)
+            if drop:
+                d = g(f"{tg}.drop{i}", h.shape, dt)
+                hip.dropout(h, d, self.p, self.seed + i, step, step_dev)
+                h = d
+            bn_in = None
+            if self.bn[i] is not None:
+                gn, btn = self.bn[i]
+                rm, rv, nbt = self.bn_buffers[gn]
+                C = h.shape[1]
+                sm, sr = g(f"{tg}.bnm{i}", (C,), torch.float32), g(f"{tg}.bnr{i}", (C,), torch.float32)
+                yb = g(f"{tg}.bn{i}", h.shape, dt)
+                hip.batchnorm_fwd(h, P.v(gn), P.v(btn), rm, rv, nbt, yb, sm, sr, training)
+                bn_in, h = (h, sm, sr), yb
+            y = out if (last and out is not None) else g(f"{tg}.y{i}", (M, w.shape[0]), dt)
             z = None
             if not last and self.act == "silu":
-                z = self.buf.get(f"{self.tag}.z{i}", (M, w.shape[0]), self.dtype)
+                z = g(f"{tg}.z{i}", (M, w.shape[0]), dt)
             hip.linear_fwd(h, w, P.v(bn), y, act="none" if last else self.act, z=z)
-            self.saved.append(y if z is None else (y, z))
+            self.saved.append((h, bn_in, y, z))          # Linear input, BatchNorm (input, mean, rstd), output, pre-activation
             h = y
         return h
 
     def ready_order(self) -> List[str]:
-        return [n for pair in reversed(self.names) for n in pair]
+        o = []
+        for i in range(len(self.names) - 1, -1, -1):
+            o += list(self.names[i])
+            if self.bn[i] is not None:
+                o += list(self.bn[i])
+        return o
 
     def backward(self, dout: torch.Tensor, P: ParamSource, accumulate=False, need_dx=False):
         L = len(self.names)
+        g, dt, tg = self.buf.get, self.dtype, self.tag
+        training, step, step_dev = self.ctx
+        drop = training and self.p > 0.0
         dz = dout
         dx = None
         for i in range(L - 1, -1, -1):
             wn, bn = self.names[i]
-            xin = self.saved[i]
-            xin_y = xin[0] if isinstance(xin, tuple) else xin
+            lin_in, bn_in, _, _ = self.saved[i]
             # short reductions (a batch of a few hundred rows): weight and bias gradient from one launch
-            if not (self.dtype == torch.bfloat16 and dz.shape[0] <= 1024
-                    and hip.linear_wgrad_bias(dz, xin_y, P.g(wn), P.g(bn), accumulate)):
-                _wgrad(self.buf, dz, xin_y, P.g(wn), accumulate)
-                _colsum(self.buf, f"{self.tag}.b{i}", dz, P.g(bn), accumulate)
+            if not (dt == torch.bfloat16 and dz.shape[0] <= 1024
+                    and hip.linear_wgrad_bias(dz, lin_in, P.g(wn), P.g(bn), accumulate)):
+                _wgrad(self.buf, dz, lin_in, P.g(wn), accumulate)
+                _colsum(self.buf, f"{tg}.b{i}", dz, P.g(bn), accumulate)
             P.ready(wn)
             P.ready(bn)
+            below = i > 0 or need_dx
+            if not below and bn_in is None:
+                continue
+            # derivative of the activation below this layer (layer i-1's), from its output (its pre-activation for silu)
+            act_below, aux = "none", None
             if i > 0:
-                aux = xin[1] if isinstance(xin, tuple) else xin
-                nxt = self.buf.get(f"{self.tag}.dz{i - 1}", xin_y.shape, self.dtype)
-                hip.linear_dgrad(dz, P.w(wn), nxt, act_below=self.act, aux=aux)
-                dz = nxt
-            elif need_dx:
-                dx = self.buf.get(f"{self.tag}.dx", xin_y.shape, self.dtype)
-                hip.linear_dgrad(dz, P.w(wn), dx)
+                _, _, y_prev, z_prev = self.saved[i - 1]
+                act_below, aux = self.act, (z_prev if z_prev is not None else y_prev)
+            if bn_in is not None:
+                xin, sm, sr = bn_in
+                gn, btn = self.bn[i]
+                db = g(f"{tg}.db{i}", lin_in.shape, dt)
+                hip.linear_dgrad(dz, P.w(wn), db)
+                cur = g(f"{tg}.dz{i - 1}" if i > 0 else f"{tg}.dx", lin_in.shape, dt) if below else None
+                hip.batchnorm_bwd(db, xin, P.v(gn), sm, sr, cur, P.g(gn), P.g(btn), training, accumulate=accumulate,
+                                  act_below=act_below if below else "none", aux=aux if below else None)
+                P.ready(gn)
+                P.ready(btn)
+            else:
+                cur = g(f"{tg}.dz{i - 1}" if i > 0 else f"{tg}.dx", lin_in.shape, dt)
+                hip.linear_dgrad(dz, P.w(wn), cur, act_below=act_below, aux=aux)
+            if below and drop:
+                hip.dropout(cur, cur, self.p, self.seed + i, step, step_dev)      # the forward's mask, regenerated
+            if i > 0:
+                dz = cur
+            else:
+                dx = cur
         return dx
 
 

@@ -63,3 +63,31 @@ TL_CASES = [("d512_T50", 512, 8, 2048, 2, 50, torch.float32),
 LOSS_SUBSETS = {"train_default": (list(range(6)), list(range(6)), list(range(6)), list(range(12))),
                 "analyze_default": ([1], [], [], []),
                 "mixed": ([0, 2, 5], [1, 4], [3], [0, 6, 11])}
+
+
+# ---- feedforward model with the optional layers (--batchnorm / --dropout, src/cli/train.py:43-47)
+FF_OPT_HIDDEN = [64, 48]
+FF_OPT_CASES = [("bn_train", True, False, True), ("bn_eval", True, False, False), ("bn_drop_eval", True, True, False),
+                ("drop_eval", False, True, False)]          # (name, batchnorm, dropout, train mode)
+FF_OPT_B, FF_OPT_P = 6, 0.3
+
+
+def ff_opt_state(shapes, seed0=21.0):
+    """deterministic state for a feedforward model with BatchNorm layers: Linear weights / biases as det_state;
+    BatchNorm gamma around 1, running_var positive, num_batches_tracked = 3"""
+    new = {}
+    for i, (k, shp) in enumerate(shapes.items()):
+        shp = tuple(shp)
+        if k.endswith("num_batches_tracked"):
+            new[k] = torch.tensor(3, dtype=torch.int64)
+        elif k.endswith("running_var"):
+            new[k] = 1.0 + 0.3 * det_fill(shp, seed0 + i, 1.0)
+        elif k.endswith("running_mean"):
+            new[k] = det_fill(shp, seed0 + i, 0.2)
+        elif len(shp) >= 2:
+            new[k] = det_fill(shp, seed0 + i, 1.0 / (shp[-1] ** 0.5))
+        elif k.endswith(".weight"):                     # 1-D weight = BatchNorm gamma
+            new[k] = 1.0 + det_fill(shp, seed0 + i, 0.1)
+        else:
+            new[k] = det_fill(shp, seed0 + i, 0.05)
+    return new

@@ -22,8 +22,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 sys.path.insert(0, ROOT)
 from oracle.ref_cpu import K_COP, K_FORCE, K_TORQUE, K_WRENCH, det_fill  # noqa: E402
-from oracle.fixture_inputs import (FF_CASES, GL_CASES, LOSS_SUBSETS, TL_CASES, det_state, ff_inputs,  # noqa: E402
-                                   ff_labels, gl_inputs, loss_case_outputs)
+from oracle.fixture_inputs import (FF_CASES, FF_OPT_B, FF_OPT_CASES, FF_OPT_HIDDEN, FF_OPT_P, GL_CASES,  # noqa: E402
+                                   LOSS_SUBSETS, TL_CASES, det_state, ff_inputs, ff_labels, ff_opt_state, gl_inputs,
+                                   loss_case_outputs)
 
 REF = os.environ.get("IB_REFERENCE", "/root/reference")
 OUT = os.path.join(ROOT, "tests", "golden")
@@ -95,6 +96,47 @@ def gen_feedforward(FF, RLE):
                 d[f"step_{opt_name}/" + k] = np_(p.reshape(-1)[:64])
         np.savez_compressed(os.path.join(OUT, f"ff_{name}.npz"), **d)
         print("ff", name, float(loss.detach()))
+
+
+def gen_feedforward_options(FF, RLE):
+    """the optional layers of the feedforward model (FeedForwardRegressionBaseline.py:68-72; flags --batchnorm / --dropout
+    --dropout-prob, train.py:43-47): state-dict key grammar for every flag combination, BatchNorm in train mode (batch
+    statistics, running-statistics update -- deterministic) and eval mode, Dropout in eval mode (identity; its train-mode
+    masks come from torch's global generator and cannot be pinned)."""
+    dofs, ncb, hist, stride, B = 23, 2, 50, 5, FF_OPT_B
+    F = hist // stride
+    d = {"meta_torch": np.array(torch.__version__)}
+    for bn in (False, True):
+        for dr in (False, True):
+            m = FF(dofs, ncb, hist, "all_frames", "relu", stride, 10, hidden_dims=list(FF_OPT_HIDDEN), batchnorm=bn,
+                   dropout=dr, dropout_prob=FF_OPT_P)
+            d[f"keys/bn{int(bn)}_drop{int(dr)}"] = np.array(list(m.state_dict().keys()))
+    for name, bn, dr, train in FF_OPT_CASES:
+        model = FF(dofs, ncb, hist, "all_frames", "relu", stride, 10, hidden_dims=list(FF_OPT_HIDDEN), batchnorm=bn,
+                   dropout=dr, dropout_prob=FF_OPT_P)
+        sd = model.state_dict()
+        new = ff_opt_state({k: tuple(v.shape) for k, v in sd.items()})
+        model.load_state_dict({k: v.to(sd[k].dtype) for k, v in new.items()})
+        model.train(train)
+        inputs, labels = ff_inputs(B, F, dofs, stride), ff_labels(B, F)
+        out = model({k: v.clone() for k, v in inputs.items()})
+        ev = RLE(dataset=None, split="train")
+        loss = ev({}, dict(out), {k: v.clone() for k, v in labels.items()}, [], [], train_args())
+        loss.backward()
+        d[f"{name}/loss"] = np_(loss)
+        for k, v in out.items():
+            d[f"{name}/out/{k}"] = np_(v)
+        for k, p in model.named_parameters():
+            if p.dim() == 1:
+                d[f"{name}/grad/{k}"] = np_(p.grad)                 # biases, BatchNorm gamma / beta: whole
+            else:
+                d[f"{name}/gnorm/{k}"] = np_(p.grad.norm())
+                d[f"{name}/gslice/{k}"] = np_(p.grad.reshape(-1)[:64])
+        for k, v in model.state_dict().items():
+            if "running" in k or "num_batches" in k:
+                d[f"{name}/after/{k}"] = np_(v)
+        print("ff options", name, float(loss.detach()))
+    np.savez_compressed(os.path.join(OUT, "ff_options.npz"), **d)
 
 
 def gen_transformer_layer(TL):
@@ -194,6 +236,7 @@ def main():
     torch.set_num_threads(4)
     FF, TL, RLE = import_reference()
     gen_feedforward(FF, RLE)
+    gen_feedforward_options(FF, RLE)
     gen_transformer_layer(TL)
     gen_groundlink(RLE)
     gen_loss(RLE)

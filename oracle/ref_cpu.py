@@ -120,6 +120,63 @@ def feedforward_forward(layers: List[Tuple[torch.Tensor, torch.Tensor]],
     }
 
 
+def batchnorm1d(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, running_mean: torch.Tensor,
+                running_var: torch.Tensor, training: bool, momentum: float = 0.1, eps: float = 1e-5):
+    """nn.BatchNorm1d(h0) over [B, C] with torch defaults, as the reference inserts it
+    (FeedForwardRegressionBaseline.py:71-72).  Arithmetic lives in torch (third-party): restated from
+    the published definition -- train: batch mean / BIASED variance normalise, the running statistics
+    move by `momentum` towards the batch mean / UNBIASED variance; eval: running statistics normalise.
+    Returns (y, new_running_mean, new_running_var)."""
+    if training:
+        B = x.shape[0]
+        mean = x.mean(dim=0)
+        var = ((x - mean) ** 2).mean(dim=0)
+        new_rm = (1 - momentum) * running_mean + momentum * mean.detach()
+        new_rv = (1 - momentum) * running_var + momentum * var.detach() * B / (B - 1)
+    else:
+        mean, var = running_mean, running_var
+        new_rm, new_rv = running_mean, running_var
+    y = (x - mean) / torch.sqrt(var + eps) * gamma + beta
+    return y, new_rm, new_rv
+
+
+def feedforward_forward_opts(layers: List[Tuple[torch.Tensor, torch.Tensor]], inputs: Dict[str, torch.Tensor],
+                             activation: str, num_output_frames: int,
+                             bn: Optional[List[Optional[Dict[str, torch.Tensor]]]] = None, training: bool = False,
+                             drop_masks: Optional[List[Optional[torch.Tensor]]] = None):
+    """forward() with the optional layers of FeedForwardRegressionBaseline.py:68-75: per layer
+    ``[Dropout(p)] [BatchNorm1d(h0)] Linear``, activation on all but the last.  ``bn[i]`` = dict(weight, bias,
+    running_mean, running_var) or None; ``drop_masks[i]`` = the SCALED keep mask (0 or 1/(1-p)) of layer i's
+    Dropout, or None (eval mode / no dropout) -- torch draws it from its global generator, so a test
+    recovers the mask the implementation under test drew and hands it over.
+    Returns (outputs, [(new_running_mean, new_running_var) or None per layer])."""
+    x = torch.cat([inputs[k] for k in INPUT_KEY_ORDER], dim=-1)
+    B = x.shape[0]
+    x = x.reshape(B, -1)
+    n = len(layers)
+    stats = []
+    for i, (w, b) in enumerate(layers):
+        if drop_masks is not None and drop_masks[i] is not None:
+            x = x * drop_masks[i]
+        if bn is not None and bn[i] is not None:
+            q = bn[i]
+            x, rm, rv = batchnorm1d(x, q["weight"], q["bias"], q["running_mean"], q["running_var"], training)
+            stats.append((rm, rv))
+        else:
+            stats.append(None)
+        x = linear(x, w, b)
+        if i < n - 1:
+            x = act(activation, x)
+    F = num_output_frames
+    out = {
+        K_COP: x[:, 0 * F:6 * F].reshape(B, F, 6),
+        K_FORCE: x[:, 6 * F:12 * F].reshape(B, F, 6),
+        K_TORQUE: x[:, 12 * F:18 * F].reshape(B, F, 6),
+        K_WRENCH: x[:, 18 * F:30 * F].reshape(B, F, 12),
+    }
+    return out, stats
+
+
 # --------------------------------------------------------------------------
 # Groundlink (src/models/Groundlink.py:19-156)
 # --------------------------------------------------------------------------

@@ -197,3 +197,69 @@ def test_denoisers_run_and_ddim_loop():
     assert y2.shape == x.shape and torch.isfinite(y2).all()
     out = R.ddim_sample(lambda xx, tt: R.denoiser_mlp_forward(p, xx, tt, [16, 24], temb_dim=8), x, 1000, 10)
     assert out.shape == x.shape and torch.isfinite(out).all()
+
+
+# ---- feedforward model with the optional BatchNorm1d / Dropout layers (FeedForwardRegressionBaseline.py:68-72) ----------
+def _ff_opt_oracle(case_bn, train, dt=torch.float64, case_drop=False):
+    from oracle.fixture_inputs import FF_OPT_B, FF_OPT_HIDDEN, ff_opt_state
+    insz, outsz, _ = R.feedforward_sizes(23, 2, 50, 5)
+    dims = [insz] + list(FF_OPT_HIDDEN) + [outsz]
+    shapes, j, lin, bns = {}, 0, [], []
+    for i in range(3):
+        if case_drop:
+            j += 1
+        if case_bn:
+            for nm, shp in (("weight", (dims[i],)), ("bias", (dims[i],)), ("running_mean", (dims[i],)),
+                            ("running_var", (dims[i],)), ("num_batches_tracked", ())):
+                shapes[f"net.{j}.{nm}"] = shp
+            bns.append(j)
+            j += 1
+        shapes[f"net.{j}.weight"] = (dims[i + 1], dims[i])
+        shapes[f"net.{j}.bias"] = (dims[i + 1],)
+        lin.append(j)
+        j += 2
+    sd = {k: (v.to(torch.float32).to(dt).requires_grad_(True) if v.dtype != torch.int64 else v)
+          for k, v in ff_opt_state(shapes).items()}
+    layers = [(sd[f"net.{j}.weight"], sd[f"net.{j}.bias"]) for j in lin]
+    bn = [dict(weight=sd[f"net.{j}.weight"], bias=sd[f"net.{j}.bias"], running_mean=sd[f"net.{j}.running_mean"].detach(),
+               running_var=sd[f"net.{j}.running_var"].detach()) for j in bns] if case_bn else None
+    inputs = {k: v.to(dt) for k, v in ff_inputs(FF_OPT_B, 10, 23, 5).items()}
+    labels = {k: v.to(dt) for k, v in ff_labels(FF_OPT_B, 10).items()}
+    out, stats = R.feedforward_forward_opts(layers, inputs, "relu", 10, bn=bn, training=train)
+    loss, _, _ = R.regression_loss(out, labels, range(6), range(6), range(6), range(12))
+    loss.backward()
+    return sd, out, loss, stats, bns
+
+
+@pytest.mark.parametrize("name,bn,train", [("bn_train", True, True), ("bn_eval", True, False), ("drop_eval", False, False)])
+def test_feedforward_options_match_reference(golden_dir, name, bn, train):
+    """the oracle's BatchNorm1d / optional-layer restatement against the real reference class (train-mode batch
+    statistics + running-statistics update, eval-mode running statistics; Dropout is the identity in eval mode)"""
+    g = load(golden_dir, "ff_options.npz")
+    sd, out, loss, stats, bns = _ff_opt_oracle(bn, train, case_drop=(name == "drop_eval"))
+    for k, v in out.items():
+        close(v.detach(), g[f"{name}/out/{k}"], rtol=1e-4)
+    close(loss.detach(), g[f"{name}/loss"], rtol=3e-5)
+    for k, p in sd.items():
+        if p.dtype == torch.int64 or "running" in k:
+            continue
+        if p.dim() == 1:
+            close(p.grad, g[f"{name}/grad/{k}"], rtol=3e-4, atol=1e-6)
+        else:
+            close(p.grad.norm(), g[f"{name}/gnorm/{k}"], rtol=3e-4)
+            close(p.grad.reshape(-1)[:64], g[f"{name}/gslice/{k}"], rtol=3e-4, atol=1e-6 * float(g[f"{name}/gnorm/{k}"]))
+    if bn:
+        for j, st in zip(bns, stats):
+            close(st[0], g[f"{name}/after/net.{j}.running_mean"], rtol=1e-5, atol=1e-7)
+            close(st[1], g[f"{name}/after/net.{j}.running_var"], rtol=1e-5, atol=1e-7)
+            assert int(g[f"{name}/after/net.{j}.num_batches_tracked"]) == (4 if train else 3)
+
+
+def test_dropout_is_identity_in_eval_mode_of_the_reference(golden_dir):
+    g = load(golden_dir, "ff_options.npz")
+    n = 0
+    for k in g.files:            # parameter indices differ (the Dropout modules shift `net.{j}`): outputs and loss must not
+        if k.startswith("bn_drop_eval/out/") or k == "bn_drop_eval/loss":
+            np.testing.assert_array_equal(g[k], g["bn_eval/" + k.split("/", 1)[1]])
+            n += 1
+    assert n == 5

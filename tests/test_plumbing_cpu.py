@@ -4,6 +4,7 @@ shape/stride checks run, but nothing is launched and nothing is computed).  This
 (wrong arity, shape mismatches between plan steps, missing buffers) without a GPU; numerical parity is
 the job of the -m gpu tests."""
 import argparse
+import os
 
 import pytest
 import torch
@@ -219,3 +220,21 @@ def test_groundlink_plumbing_registry_and_state_dict(dry):
     names = dry.lib().calls
     assert names.count("ib_im2col_replicate") == 4 and names.count("ib_col2im_replicate") == 3
     assert names.count("ib_dropout") == 6 and names[-1].startswith("ib_optim_step")
+
+
+def test_feedforward_state_dict_keys_follow_the_reference_with_every_flag_combination(golden_dir):
+    """`net.{j}` indices shift when --dropout / --batchnorm insert modules (FeedForwardRegressionBaseline.py:67-77): the
+    key lists of the real reference class are in the golden file"""
+    import numpy as np
+    from inferbiomechanics_amd import hip
+    from inferbiomechanics_amd.models.FeedForwardRegressionBaseline import FeedForwardBaseline
+    g = np.load(os.path.join(golden_dir, "ff_options.npz"))
+    hip.set_dry_run(True)
+    try:
+        for bn in (False, True):
+            for dr in (False, True):
+                m = FeedForwardBaseline(23, 2, 50, "all_frames", "relu", 5, 10, hidden_dims=[64, 48], batchnorm=bn, dropout=dr,
+                                        dropout_prob=0.3)
+                assert list(m.state_dict().keys()) == list(g[f"keys/bn{int(bn)}_drop{int(dr)}"])
+    finally:
+        hip.set_dry_run(False)
