@@ -213,6 +213,61 @@ def gen_loss(RLE):
     print("loss ok")
 
 
+def gen_checkpoint_analyze(FF, RLE):
+    """a checkpoint in the REFERENCE's grammar (train.py:272-278: {'epoch', 'model_state_dict' with
+    DDP's `module.` prefix, 'optimizer_state_dict' = torch.optim state}) written from the real class after two RMSprop
+    steps, what `analyze` (analyze.py:139-178,197-238: batch 1, eval mode, --predict-grf-components [1]) reports for it
+    on synthetic windows, and the NEXT training step after a resume (exercises the imported optimizer state)."""
+    from inferbiomechanics_amd.data.AddBiomechanicsDataset import SyntheticWindowDataset
+    hidden, lr = [32, 24], 1e-4
+    model = FF(23, 2, 50, "all_frames", "sigmoid", 5, 10, hidden_dims=hidden)
+    load_det_state(model, seed0=9.0)
+    train_ds = SyntheticWindowDataset(8, 50, 5, seed=0)
+    collate = torch.utils.data.default_collate
+
+    def batch(ds, idx):
+        inputs, labels, _, _ = collate([ds[i] for i in idx])
+        return inputs, labels
+    opt = torch.optim.RMSprop(model.parameters(), lr=lr)
+    model.train()
+    for step in range(2):
+        inputs, labels = batch(train_ds, range(4 * step, 4 * step + 4))
+        opt.zero_grad()
+        loss = RLE(dataset=None, split="train")({}, model(inputs), labels, [], [], train_args())
+        loss.backward()
+        opt.step()
+    ck = os.path.join(OUT, "ref_checkpoint", "feedforward")
+    os.makedirs(ck, exist_ok=True)
+    torch.save({"epoch": 3, "model_state_dict": {"module." + k: v.clone() for k, v in model.state_dict().items()},
+                "optimizer_state_dict": opt.state_dict()}, os.path.join(ck, "epoch_3_batch_7.pt"))
+    d = {"meta_torch": np.array(torch.__version__), "hidden": np.array(hidden)}
+    a1 = train_args([1], [], [], [])                    # analyze defaults (analyze.py:44-47)
+    model.eval()
+    for split, seed in (("dev", 1), ("train", 0)):
+        ds = SyntheticWindowDataset(6, 50, 5, seed=seed)
+        ev = RLE(dataset=None, split=split)
+        losses = []
+        with torch.no_grad():
+            for i in range(6):
+                inputs, labels = batch(ds, [i])
+                losses.append(float(ev({}, model(inputs), labels, [0], [i], a1)))
+        d[f"{split}/losses"] = np.array(losses)
+        d[f"{split}/metrics"] = np.array([np.mean(ev.force_reported_metrics), np.mean(ev.com_acc_reported_metrics),
+                                          np.mean(ev.cop_reported_metrics), np.mean(ev.moment_reported_metrics),
+                                          np.mean(ev.wrench_reported_metrics), np.mean(ev.wrench_moment_reported_metrics)])
+    model.train()
+    inputs, labels = batch(train_ds, range(4))
+    opt.zero_grad()
+    loss = RLE(dataset=None, split="train")({}, model(inputs), labels, [], [], train_args())
+    loss.backward()
+    opt.step()
+    d["resume/loss"] = np_(loss)
+    for k, p in model.named_parameters():
+        d["resume/param/" + k] = np_(p.reshape(-1)[:64])
+    np.savez_compressed(os.path.join(OUT, "ckpt_analyze.npz"), **d)
+    print("checkpoint + analyze ok", float(loss.detach()))
+
+
 def gen_optim():
     d = {"meta_torch": np.array(torch.__version__)}
     ctors = {"sgd": torch.optim.SGD, "adam": torch.optim.Adam, "rmsprop": torch.optim.RMSprop,
@@ -240,6 +295,7 @@ def main():
     gen_transformer_layer(TL)
     gen_groundlink(RLE)
     gen_loss(RLE)
+    gen_checkpoint_analyze(FF, RLE)
     gen_optim()
 
 
