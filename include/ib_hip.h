@@ -59,6 +59,17 @@ int ib_linear_dgrad(const void* dz, int64_t lddz, const void* w, int64_t ldw, in
                     const void* aux, int64_t ldaux, const void* addend, int64_t ldadd, void* dx, int64_t lddx,
                     int64_t M, int64_t N, int64_t K, int dtype, ib_stream_t stream);
 
+/* The same product with the weight handed over TRANSPOSED, wt[K,N] (a bf16 copy the caller refreshes once per step with
+ * ib_transpose_multi): both operands are then contiguous along the reduction and large-M problems (the transformer
+ * denoiser's training shapes) take the 256 x 128 LDS-DMA kernel.  Returns IB_E_UNSUPPORTED -- nothing launched -- when the
+ * problem does not qualify (small M, unaligned operands, fp32, silu): call ib_linear_dgrad then. */
+int ib_linear_dgrad_wt(const void* dz, int64_t lddz, const void* wt, int64_t ldwt, int act_below, const void* aux,
+                       int64_t ldaux, const void* addend, int64_t ldadd, void* dx, int64_t lddx, int64_t M, int64_t N,
+                       int64_t K, int dtype, ib_stream_t stream);
+/* dst_i[c][r] = src_i[r][c] for n <= 32 bf16 matrices in one launch (host arrays of pointers / sizes). */
+int ib_transpose_multi(int n, const void* const* src, const int64_t* lds, void* const* dst, const int64_t* ldd,
+                       const int64_t* rows, const int64_t* cols, int dtype, ib_stream_t stream);
+
 /* The same product for FEW rows and a long reduction (the time-embedding MLP's hidden layer: one row per window of the
  * batch; autograd of `nn.Linear` + activation as in ib_linear_dgrad), plus the bias gradient of the layer below:
  * dbias[K] (fp32, may be NULL) (+)= column sums of the stored dx.  One workgroup per 16 output columns sees every row, so

@@ -19,6 +19,7 @@
 #include <type_traits>
 
 #include "ib_common.h"
+#include "gemm_nt.h"
 
 namespace {
 
@@ -1164,6 +1165,10 @@ extern "C" int ib_linear_fwd(const void* x, int64_t ldx, const void* w, int64_t 
   p.C = y; p.ldc = ldy; p.Z = z; p.ldz = ldz; p.bias = bias;
   p.add_div = add_div; p.ld_add_div = ld_add_div; p.add_mod = add_mod; p.ld_add_mod = ld_add_mod;
   p.seg = (int)(seg > 0 ? seg : 1); p.act = act;
+  if (dtype == IB_BF16 && !add_div && !add_mod && !z) {       // large-M training shapes: the 256 x 128 NT kernel
+    const int rc = ib_gemm_nt_try(x, ldx, w, ldw, y, ldy, bias, act, nullptr, 0, IB_ACT_NONE, nullptr, 0, M, N, K, ib_s(stream));
+    if (rc != IB_E_UNSUPPORTED) return rc;
+  }
   if (dtype == IB_F32) return launch_fwd<float>(p, ib_s(stream));
   if (dtype == IB_BF16) return launch_fwd<bf16_t>(p, ib_s(stream));
   return IB_E_DTYPE;
@@ -1184,6 +1189,21 @@ extern "C" int ib_linear_dgrad(const void* dz, int64_t lddz, const void* w, int6
   if (dtype == IB_F32) return launch_dgrad<float>(p, ib_s(stream));
   if (dtype == IB_BF16) return launch_dgrad<bf16_t>(p, ib_s(stream));
   return IB_E_DTYPE;
+}
+
+// The same product with the weight handed over TRANSPOSED (wt[K,N], k-contiguous along the reduction): both operands are
+// then "NT" and large-M problems take the 256 x 128 kernel of gemm_nt.hip.  IB_E_UNSUPPORTED (nothing launched) when the
+// problem does not qualify -- callers fall back to ib_linear_dgrad with the untransposed weight.
+extern "C" int ib_linear_dgrad_wt(const void* dz, int64_t lddz, const void* wt, int64_t ldwt, int act_below, const void* aux,
+                                  int64_t ldaux, const void* addend, int64_t ldadd, void* dx, int64_t lddx, int64_t M,
+                                  int64_t N, int64_t K, int dtype, ib_stream_t stream) {
+  if (!dz || !wt || !dx || M <= 0 || N <= 0 || K <= 0 || lddz < N || ldwt < N || lddx < K) return IB_E_ARG;
+  if (addend && ldadd < K) return IB_E_ARG;
+  if (act_below != IB_ACT_NONE && (!aux || ldaux < K)) return IB_E_ARG;
+  if (dtype != IB_BF16) return IB_E_UNSUPPORTED;
+  // C[M,K] = sum_n dz[m][n] * wt[k][n]
+  return ib_gemm_nt_try(dz, lddz, wt, ldwt, dx, lddx, nullptr, IB_ACT_NONE, aux, ldaux, act_below, addend, ldadd, M, K, N,
+                        ib_s(stream));
 }
 
 // ---- skinny dgrad: few rows (a batch of time embeddings), long reduction --------------------------------------------

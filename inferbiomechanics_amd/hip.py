@@ -39,6 +39,9 @@ _SIGS = {
                                  _i64, _i64, _i64, _i64, _c.c_int, _vp]),
     "ib_linear_dgrad": (_c.c_int, [_vp, _i64, _vp, _i64, _c.c_int, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64,
                                    _c.c_int, _vp]),
+    "ib_linear_dgrad_wt": (_c.c_int, [_vp, _i64, _vp, _i64, _c.c_int, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64,
+                                      _c.c_int, _vp]),
+    "ib_transpose_multi": (_c.c_int, [_c.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _c.c_int, _vp]),
     "ib_linear_dgrad_skinny": (_c.c_int, [_vp, _i64, _vp, _i64, _c.c_int, _vp, _i64, _vp, _i64, _vp, _c.c_int, _i64, _i64,
                                           _i64, _c.c_int, _vp]),
     "ib_linear_wgrad_bias": (_c.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _c.c_int, _i64, _i64, _i64, _c.c_int, _vp]),
@@ -458,6 +461,59 @@ def linear_dgrad(dz, w, dx, act_below="none", aux=None, addend=None):
     _check(lib().ib_linear_dgrad(_ptr(dz), lddz, _ptr(w), ldw, ACT[act_below], _ptr(aux), ldaux, _ptr(addend), ldadd,
                                  _ptr(dx), lddx, M, N, K, dtype_code(dt), stream_ptr()), "ib_linear_dgrad")
     return dx
+
+
+def linear_dgrad_wt(dz, wt, dx, act_below="none", aux=None, addend=None) -> bool:
+    """dx = (dz . w) * act'(aux) + addend with the weight given TRANSPOSED (wt = w^T [K, N], see transpose_multi): the
+    large-M bf16 path (256 x 128 LDS-DMA kernel).  False = the problem does not qualify, nothing was launched."""
+    dt = dz.dtype
+    if dt != torch.bfloat16:
+        return False
+    M, N, lddz = _mat(dz, "dz", dt)
+    K, Nw, ldwt = _mat(wt, "wt", dt)
+    Mx, Kx, lddx = _mat(dx, "dx", dt)
+    if Nw != N or Mx != M or Kx != K:
+        raise HipError(f"linear_dgrad_wt: shape mismatch dz{tuple(dz.shape)} wt{tuple(wt.shape)} dx{tuple(dx.shape)}")
+    ldaux = ldadd = 0
+    if ACT[act_below] != 0:
+        if aux is None:
+            raise HipError("linear_dgrad_wt: act_below needs aux")
+        Ma, Ka, ldaux = _mat(aux, "aux", dt)
+        if (Ma, Ka) != (M, K):
+            raise HipError("linear_dgrad_wt: aux shape mismatch")
+    if addend is not None:
+        Ma, Ka, ldadd = _mat(addend, "addend", dt)
+        if (Ma, Ka) != (M, K):
+            raise HipError("linear_dgrad_wt: addend shape mismatch")
+    rc = lib().ib_linear_dgrad_wt(_ptr(dz), lddz, _ptr(wt), ldwt, ACT[act_below], _ptr(aux) if ACT[act_below] != 0 else None,
+                                  ldaux, _ptr(addend), ldadd, _ptr(dx), lddx, M, N, K, dtype_code(dt), stream_ptr())
+    if rc == -5:          # IB_E_UNSUPPORTED
+        return False
+    _check(rc, "ib_linear_dgrad_wt")
+    return True
+
+
+def transpose_multi(pairs):
+    """pairs: [(src [R, C], dst [C, R])] bf16 -- every dst = src^T in ONE launch (at most 32 matrices per launch)"""
+    for a in range(0, len(pairs), 32):
+        chunk = pairs[a:a + 32]
+        n = len(chunk)
+        geo = []
+        for src, dst in chunk:
+            R, C, lds = _mat(src, "src", torch.bfloat16)
+            Cd, Rd, ldd = _mat(dst, "dst", torch.bfloat16)
+            if (Cd, Rd) != (C, R):
+                raise HipError(f"transpose_multi: dst must be {C} x {R}, got {tuple(dst.shape)}")
+            geo.append((R, C, lds, ldd))
+        cv = lambda arr: ctypes.cast(arr, ctypes.c_void_p)
+        S = (ctypes.c_void_p * n)(*[p_[0].data_ptr() for p_ in chunk])
+        D = (ctypes.c_void_p * n)(*[p_[1].data_ptr() for p_ in chunk])
+        LS = (ctypes.c_int64 * n)(*[g_[2] for g_ in geo])
+        LD = (ctypes.c_int64 * n)(*[g_[3] for g_ in geo])
+        Rs = (ctypes.c_int64 * n)(*[g_[0] for g_ in geo])
+        Cs = (ctypes.c_int64 * n)(*[g_[1] for g_ in geo])
+        _check(lib().ib_transpose_multi(n, cv(S), cv(LS), cv(D), cv(LD), cv(Rs), cv(Cs), BF16, stream_ptr()),
+               "ib_transpose_multi")
 
 
 def linear_dgrad_skinny(dz, w, dx, act_below="none", aux=None, dbias=None, accumulate=False) -> bool:

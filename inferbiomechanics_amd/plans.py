@@ -474,9 +474,15 @@ class TransformerLayerPlan:
         self.p, self.d, self.h, self.ffn, self.dtype, self.tag = prefix, d_model, num_heads, ffn, dtype, tag
         self.buf = buf if buf is not None else Buffers(device)
         self.ctx = None
-        # the four weight-gradient GEMMs (+ bias sums) hang off the critical dgrad / LayerNorm / attention chain:
-        # they run on this layer's side stream (each with its own slab workspace)
-        self.branch = Branch(device, name="layer")
+        # the four weight-gradient GEMMs (+ bias sums) hang off the critical dgrad / LayerNorm / attention chain.  They CAN
+        # run on a side stream of the layer (IB_LAYER_BRANCH=1), but every one of these launches fills the chip on its own and
+        # each fork / join of the captured graph costs: inline is faster (B = 256, T = 50: 3.059 vs 3.123 ms per step)
+        self.branch = Branch(device, enabled=bool(os.environ.get("IB_LAYER_BRANCH")), name="layer")
+        # transposed bf16 copies of the four weight matrices: the dgrad GEMMs of large batches read them k-contiguously
+        # (ib_linear_dgrad_wt -> the 256 x 128 LDS-DMA kernel of csrc/gemm_nt.hip); refreshed once per forward
+        self._wt: Dict[str, torch.Tensor] = {}
+        self._wt_fresh = False
+        self.own_wt = True           # a parent plan refreshes the copies of all its layers in ONE launch instead
         self.join_on_exit = True     # a parent plan sets this False and joins all layers once at the end
         self.inference = False       # forward only (DDIM sampler): Linear + residual + LayerNorm fused, nothing saved
         # set by a parent plan whose trainer lets the optimizer sum partial gradients (one GPU): weight-gradient slabs go
@@ -489,10 +495,38 @@ class TransformerLayerPlan:
     def branches(self) -> List["Branch"]:
         return [self.branch]
 
+    WT_NAMES = ("feedforward.2.weight", "feedforward.0.weight", "multihead_attention.out_proj.weight",
+                "multihead_attention.in_proj_weight")
+
+    def wt_pairs(self, P: ParamSource, M: int):
+        """[(weight, its transposed copy)] to refresh before a training forward, or [] when the large-M dgrad path does not
+        apply (fp32 parity mode, inference, small token counts)"""
+        self._wt_fresh = False
+        if self.dtype != torch.bfloat16 or self.inference or M < 4096 or os.environ.get("IB_NO_NT"):
+            return []
+        pairs = []
+        for n in self.WT_NAMES:
+            w = P.w(self.p + n)
+            wt = self.buf.get(self.tag + ".wt." + n, (w.shape[1], w.shape[0]), self.dtype)
+            self._wt[n] = wt
+            pairs.append((w, wt))
+        self._wt_fresh = True
+        return pairs
+
+    def _dgrad(self, P: ParamSource, dz, wname: str, dx, act_below="none", aux=None, addend=None):
+        wt = self._wt.get(wname) if self._wt_fresh else None
+        if wt is not None and hip.linear_dgrad_wt(dz, wt, dx, act_below=act_below, aux=aux, addend=addend):
+            return
+        hip.linear_dgrad(dz, P.w(self.p + wname), dx, act_below=act_below, aux=aux, addend=addend)
+
     def forward(self, x3: torch.Tensor, P: ParamSource, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         B, T, d = x3.shape
         M = B * T
         g, dt, p, tg = self.buf.get, self.dtype, self.p, self.tag
+        if self.own_wt:
+            pairs = self.wt_pairs(P, M)
+            if pairs:
+                hip.transpose_multi(pairs)
         x = x3.view(M, d)
         qkv = g(tg + ".qkv", (B, T, 3 * d), dt)
         hip.linear_fwd(x, P.w(p + "multihead_attention.in_proj_weight"), P.v(p + "multihead_attention.in_proj_bias"),
@@ -587,14 +621,14 @@ class TransformerLayerPlan:
             dbias(tg + ".b2", ds2, "feedforward.2.bias")
         self.branch.run(g_ffn2)
         dz1 = g(tg + ".dz1", (M, self.ffn), dt)
-        hip.linear_dgrad(ds2, P.w(p + "feedforward.2.weight"), dz1, act_below="relu", aux=f1)
+        self._dgrad(P, ds2, "feedforward.2.weight", dz1, act_below="relu", aux=f1)
 
         def g_ffn1():
             wgrad(dz1, x1, "feedforward.0.weight", tg + ".ws1")
             dbias(tg + ".b1", dz1, "feedforward.0.bias")
         self.branch.run(g_ffn1)
         dx1 = g(tg + ".dx1", (M, d), dt)
-        hip.linear_dgrad(dz1, P.w(p + "feedforward.0.weight"), dx1, addend=ds2)       # + residual path
+        self._dgrad(P, dz1, "feedforward.0.weight", dx1, addend=ds2)       # + residual path
         # LN1: d(a + x)
         ds1 = g(tg + ".ds1", (M, d), dt)
         ln_bwd("norm1", dx1, a, m1, r1, ds1, x)
@@ -604,7 +638,7 @@ class TransformerLayerPlan:
             dbias(tg + ".bo", ds1, "multihead_attention.out_proj.bias")
         self.branch.run(g_out)
         dattn = g(tg + ".dattn", (B, T, d), dt)
-        hip.linear_dgrad(ds1, P.w(p + "multihead_attention.out_proj.weight"), dattn.view(M, d))
+        self._dgrad(P, ds1, "multihead_attention.out_proj.weight", dattn.view(M, d))
         dqkv = g(tg + ".dqkv", (B, T, 3 * d), dt)
         hip.attention_bwd(qkv, attn, dattn, lse, dqkv, self.h)
         dq2 = dqkv.view(M, 3 * d)
@@ -614,7 +648,7 @@ class TransformerLayerPlan:
             dbias(tg + ".bi", dq2, "multihead_attention.in_proj_bias")
         self.branch.run(g_in)
         dx = g(tg + ".dx", (B, T, d), dt)
-        hip.linear_dgrad(dq2, P.w(p + "multihead_attention.in_proj_weight"), dx.view(M, d), addend=ds1)
+        self._dgrad(P, dq2, "multihead_attention.in_proj_weight", dx.view(M, d), addend=ds1)
         if group:
             self.branch.run(lambda: _wgrad_group(self.buf, group, defer))
         if self.join_on_exit or self.flush_on_exit:
@@ -954,6 +988,7 @@ class DenoiserTransformerPlan:
                                             buf=self.buf, tag=f"tl{l}") for l in range(num_layers)]
         for lp in self.layers:
             lp.join_on_exit = False          # joined once, at the end of the whole backward
+            lp.own_wt = False                # the transposed weight copies of ALL layers are refreshed by one launch
         self.ctx = None
         self._posproj_T = None
         self.fuse_reduce_into_optimizer = False         # set by HipTrainer for single-GPU steps
@@ -1022,6 +1057,9 @@ class DenoiserTransformerPlan:
         h0 = g("dt.h0", (B, T, self.d), dt)
         hip.linear_fwd(x2, w_in[:, :D], P.v("in_proj.bias"), h0.view(M, self.d), add_div=e,
                        add_mod=posproj, seg=T)
+        pairs = [pr for lp in self.layers for pr in lp.wt_pairs(P, M)]
+        if pairs:
+            hip.transpose_multi(pairs)
         h = h0
         for lp in self.layers:
             h = lp.forward(h, P)

@@ -123,7 +123,10 @@ def test_dropout_train_mode_matches_oracle_with_recovered_masks(bn, dtype, rt):
     close(loss, lexp, rt, "loss")
     for k, q in model.named_parameters():
         e = sd[k].grad
-        close(q.grad, e, rt * (1 if dtype == torch.float32 else 2), "grad/" + k, atol=rt * 0.05 * float(e.norm()))
+        # bf16: the BatchNorm / bias gradients are sums of 48 bf16-stored rows of magnitude ~1e-2: absolute slack of
+        # 15 % of rt x the tensor's norm (fp32: 5 %)
+        close(q.grad, e, rt * (1 if dtype == torch.float32 else 2), "grad/" + k,
+              atol=rt * (0.05 if dtype == torch.float32 else 0.15) * float(e.norm()))
     # a second forward draws DIFFERENT masks (keyed on the call counter), eval mode applies none
     d0 = [v for k, v in plan.buf._b.items() if k[0] == "ff.drop1"][0].clone()
     model(inputs)
