@@ -67,6 +67,7 @@ int ib_linear_dgrad_wt(const void* dz, int64_t lddz, const void* wt, int64_t ldw
                        int64_t ldaux, const void* addend, int64_t ldadd, void* dx, int64_t lddx, int64_t M, int64_t N,
                        int64_t K, int dtype, ib_stream_t stream);
 /* dst_i[c][r] = src_i[r][c] for n <= 32 bf16 matrices in one launch (host arrays of pointers / sizes). */
+int ib_debug_set_nt_prof(void* stamps);   /* TIMING-ONLY: [workgroups][16] int64 wall-clock stamps of the NT GEMM (NULL = off) */
 int ib_transpose_multi(int n, const void* const* src, const int64_t* lds, void* const* dst, const int64_t* ldd,
                        const int64_t* rows, const int64_t* cols, int dtype, ib_stream_t stream);
 

@@ -97,6 +97,7 @@ _SIGS = {
     "ib_colsum_segments": (_c.c_int, [_vp, _i64, _i64, _c.c_int, _vp, _vp, _vp, _vp, _vp, _c.c_int, _vp]),
     "ib_debug_set_chain_prof": (_c.c_int, [_vp]),
     "ib_debug_set_gemm_prof": (_c.c_int, [_vp]),
+    "ib_debug_set_nt_prof": (_c.c_int, [_vp]),
     "ib_debug_stamp": (_c.c_int, [_vp, _vp]),
     "ib_time_mlp_fwd_supported": (_c.c_int, [_i64, _i64, _i64]),
     "ib_mlp_chain_prep": (_c.c_int, [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64,

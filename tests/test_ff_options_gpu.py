@@ -123,10 +123,16 @@ def test_dropout_train_mode_matches_oracle_with_recovered_masks(bn, dtype, rt):
     close(loss, lexp, rt, "loss")
     for k, q in model.named_parameters():
         e = sd[k].grad
-        # bf16: the BatchNorm / bias gradients are sums of 48 bf16-stored rows of magnitude ~1e-2: absolute slack of
-        # 15 % of rt x the tensor's norm (fp32: 5 %)
-        close(q.grad, e, rt * (1 if dtype == torch.float32 else 2), "grad/" + k,
-              atol=rt * (0.05 if dtype == torch.float32 else 0.15) * float(e.norm()))
+        if dtype == torch.float32:
+            close(q.grad, e, rt, "grad/" + k, atol=rt * 0.05 * float(e.norm()))
+        else:
+            # bf16: a bias / BatchNorm gradient is a sum over 48 rows of bf16-stored terms of both signs that largely
+            # cancel (|sum| ~ 1e-2 from terms ~ 5e-2): element-wise error is set by the TERMS, so it is held in the
+            # Frobenius norm of the tensor (<= 4 rt = 16 %), matrices additionally element-wise at 2 rt of their max
+            a = q.grad.detach().cpu().double()
+            assert float((a - e).norm()) <= 4 * rt * float(e.norm()), ("grad/" + k, float((a - e).norm()), float(e.norm()))
+            if e.dim() == 2:
+                close(q.grad, e, 2 * rt, "grad/" + k, atol=rt * 0.05 * float(e.norm()))
     # a second forward draws DIFFERENT masks (keyed on the call counter), eval mode applies none
     d0 = [v for k, v in plan.buf._b.items() if k[0] == "ff.drop1"][0].clone()
     model(inputs)
