@@ -95,7 +95,7 @@ class GradBuckets:
             return
         lo, hi = self.ranges[b]
         t = self.flat[lo:hi]
-        if self.on_gpu:
+        if self.on_gpu and not torch.cuda.is_current_stream_capturing():
             self.collective_streams.add(torch.cuda.current_stream().cuda_stream)
         if inline and self.on_gpu and not os.environ.get("IB_ASYNC_INLINE"):
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)      # runs on the caller's stream: no event hops
@@ -472,8 +472,20 @@ class HipTrainer:
     def _capture(self, st) -> "_Recorder":
         self.captures += 1
         rec = _Recorder(self.buckets.collective_streams)
+        # IB_GRAPH_COLLECTIVES=1: the all-reduces are CAPTURED (c10d enqueues the RCCL kernels on its communication stream,
+        # which joins the capture through the event edges it records): one graph per step, no graph cut and no host work per
+        # collective.  Validated on the 1-rank RCCL self-test group only (no multi-GPU box in this build's reach), hence a flag.
+        graph_collectives = self.ddp and os.environ.get("IB_GRAPH_COLLECTIVES") == "1"
 
         def cut(b: int):
+            if graph_collectives:
+                if b >= 0:
+                    self.buckets.launch(b)
+                elif b == -1:
+                    self.buckets.finish()
+                else:
+                    self.buckets.launch(0, inline=True)
+                return
             if b >= 0:
                 rec.cut(lambda: self.buckets.launch(b))
             elif b == -1:

@@ -280,3 +280,32 @@ def test_bench_two_rank_control_flow_rehearsal():
     o = json.loads(lines[0])
     assert o["n_gpus"] == 2 and o["config"]["global_batch"] == 512 and o["config"]["parallelism"] == "dp2"
     assert o["config"]["grad_buckets"] == 1 and o["value"] > 0 and "roofline" in o and "cpu_baseline" not in o
+
+
+def test_captured_collectives_on_one_rank_match_the_cut_graphs():
+    """IB_GRAPH_COLLECTIVES=1: the gradient all-reduce is captured INTO the step's hipGraph (no graph cut, no host work per
+    collective) -- run on the 1-rank RCCL self-test group for the one-bucket policy (MLP denoiser) and the overlapped
+    bucket policy (transformer denoiser); the final loss must equal the cut-graph run bit for bit."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for workload, port in (("mlp_denoiser_T50", "29561"), ("transformer_denoiser_T50", "29563")):
+        outs = []
+        for captured in (False, True):
+            env = dict(os.environ, IB_DDP_SELFTEST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK="0", WORLD_SIZE="1",
+                       LOCAL_RANK="0")
+            env.pop("IB_GRAPH_COLLECTIVES", None)
+            if captured:
+                env["IB_GRAPH_COLLECTIVES"] = "1"
+            r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", workload, "--steps", "30",
+                                "--warmup", "4", "--no-cpu-baseline", "--no-ddim", "--no-transformer", "--overlap-comm",
+                                "on" if "transformer" in workload else "off"],
+                               capture_output=True, text=True, env=env, timeout=600)
+            assert r.returncode == 0, r.stderr[-3000:]
+            outs.append(json.loads([ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")][0]))
+        a, b = outs
+        assert a["final_loss"] == b["final_loss"], (workload, a["final_loss"], b["final_loss"])
+        assert a["config"]["grad_buckets"] == b["config"]["grad_buckets"] >= 1
+        print(workload, "cut graphs", a["ms_per_step"], "ms/step; captured collectives", b["ms_per_step"], "ms/step")
