@@ -115,6 +115,14 @@ int ib_linear_wgrad_slabs_multi(int n, const void* const* dz, const int64_t* ldd
                                 const int64_t* ldx, void* const* workspace, const size_t* workspace_bytes,
                                 int32_t* nslab_out, const int64_t* M, const int64_t* N, const int64_t* K, int dtype,
                                 ib_stream_t stream);
+/* The same launch that ALSO leaves the bias gradients' split-M partial sums: dbias_part[j] (may be NULL per problem) is an
+ * fp32 [32][N_j] array whose rows 0 .. nslab_out[j]-1 receive sum over the slice's rows of dz (one extra MFMA per row tile
+ * against an all-ones fragment in the first column tile's workgroups); the caller's final reduction (ib_colsum_segments /
+ * ib_optim_step_sources) adds the rows up in a fixed order.  Replaces ib_segment_colsum over the whole dz matrix per layer. */
+int ib_linear_wgrad_slabs_multi_bias(int n, const void* const* dz, const int64_t* lddz, const void* const* x,
+                                     const int64_t* ldx, void* const* workspace, const size_t* workspace_bytes,
+                                     float* const* dbias_part, int32_t* nslab_out, const int64_t* M, const int64_t* N,
+                                     const int64_t* K, int dtype, ib_stream_t stream);
 int ib_slab_reduce_multi(int n, const void* const* slabs, const int32_t* nslab, float* const* dw,
                          const int64_t* lddw, const int32_t* N, const int32_t* K, int accumulate,
                          ib_stream_t stream);

@@ -63,6 +63,8 @@ struct GemmParams {
   int accumulate;
   int ablate;
   long long* prof;
+  float* dbias_part;           // wgrad (ring kernel): optional [splits][M] fp32 per-slice row sums of A (= the bias gradient's
+                               // split-M partial sums: sum over the slice's rows of dz), written by the column-tile-0 blocks
 };
 
 template <typename T>
@@ -691,6 +693,19 @@ __device__ __forceinline__ void gemm_ring_body(const GemmParams& p, unsigned cha
   for (int t = 0; t < 4; ++t)
 #pragma unroll
     for (int u = 0; u < 4; ++u) acc[t][u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  // weight gradient: the bias gradient rides along.  sum_k A(i,k) = one more MFMA per row tile against an all-ones
+  // fragment (+25 % matrix work in the blocks of column tile 0, left wave column only): it replaces a column-sum launch
+  // over the whole dz matrix per Linear layer.
+  [[maybe_unused]] f32x4_t accb[4];
+  [[maybe_unused]] bool do_bias = false;
+  [[maybe_unused]] bf16x8_t ones;
+  if constexpr (EPI == EPI_WGRAD) {
+    do_bias = p.dbias_part != nullptr && tj == 0 && wj == 0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) accb[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (bf16_t)1.0f;
+  }
 
 #define RING_STAMP(k) do { if (p.prof && tid == 0) p.prof[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
   RING_STAMP(0);
@@ -724,9 +739,22 @@ __device__ __forceinline__ void gemm_ring_body(const GemmParams& p, unsigned cha
 #pragma unroll
       for (int u = 0; u < 4; ++u)
         acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[u], fa[t], acc[t][u], 0, 0, 0);
+    if constexpr (EPI == EPI_WGRAD) {
+      if (do_bias) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) accb[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[t], accb[t], 0, 0, 0);
+      }
+    }
   }
   RING_STAMP(3);
   if constexpr (EPI == EPI_WGRAD) {
+    if (do_bias && (lane >> 4) == 0) {         // every output column holds the same sum: column 0 of each row tile
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int i = i0 + wi * 64 + 16 * t + (lane & 15);
+        if (i < p.M) p.dbias_part[(int64_t)split_id * p.M + i] = accb[t][0];
+      }
+    }
     epilogue<bf16_t, EPI, IB_ACT_NONE>(p, acc, i0, j0, wi, wj, lane, split_id);
     RING_STAMP(4);
     return;
@@ -1572,6 +1600,14 @@ extern "C" int ib_linear_wgrad_slabs_multi(int n, const void* const* dz, const i
                                            const int64_t* ldx, void* const* workspace, const size_t* workspace_bytes,
                                            int32_t* nslab_out, const int64_t* M, const int64_t* N, const int64_t* K,
                                            int dtype, ib_stream_t stream) {
+  return ib_linear_wgrad_slabs_multi_bias(n, dz, lddz, x, ldx, workspace, workspace_bytes, nullptr, nslab_out, M, N, K, dtype,
+                                          stream);
+}
+
+extern "C" int ib_linear_wgrad_slabs_multi_bias(int n, const void* const* dz, const int64_t* lddz, const void* const* x,
+                                                const int64_t* ldx, void* const* workspace, const size_t* workspace_bytes,
+                                                float* const* dbias_part, int32_t* nslab_out, const int64_t* M,
+                                                const int64_t* N, const int64_t* K, int dtype, ib_stream_t stream) {
   if (n <= 0 || n > WG_MAX || !dz || !lddz || !x || !ldx || !workspace || !workspace_bytes || !nslab_out || !M || !N || !K)
     return IB_E_ARG;
   if (dtype != IB_BF16) return IB_E_UNSUPPORTED;
@@ -1584,6 +1620,7 @@ extern "C" int ib_linear_wgrad_slabs_multi(int n, const void* const* dz, const i
                                 K[j], dtype, true, m.p[j], &split, &tiles, &chunk, n);
     if (rc != IB_OK) return rc;
     if (!ring_ok(m.p[j], IB_BF16, m.p[j].K, chunk)) return IB_E_UNSUPPORTED;   // caller falls back to single launches
+    m.p[j].dbias_part = dbias_part ? dbias_part[j] : nullptr;      // [IB_WGRAD_MAX_SPLIT][N] fp32, rows 0 .. split-1 written
     nslab_out[j] = split;
     m.blk0[j] = blocks;
     blocks += tiles * split;

@@ -53,6 +53,8 @@ _SIGS = {
     "ib_linear_wgrad_slabs_workspace": (_sz, [_i64, _i64, _i64]),
     "ib_linear_wgrad_slabs": (_c.c_int, [_vp, _i64, _vp, _i64, _vp, _sz, _vp, _i64, _i64, _i64, _c.c_int, _vp]),
     "ib_linear_wgrad_slabs_multi": (_c.c_int, [_c.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _c.c_int, _vp]),
+    "ib_linear_wgrad_slabs_multi_bias": (_c.c_int, [_c.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _c.c_int,
+                                                    _vp]),
     "ib_slab_reduce_multi": (_c.c_int, [_c.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _c.c_int, _vp]),
     "ib_step_reduce": (_c.c_int, [_c.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _c.c_int, _vp, _vp, _vp, _vp, _vp,
                                   _c.c_int, _vp]),
@@ -638,10 +640,18 @@ def linear_wgrad_slabs(dz, x, workspace) -> int:
     return n.value if not _dry_run else 1
 
 
-def linear_wgrad_slabs_multi(problems):
+def linear_wgrad_slabs_multi(problems, bias_parts=None):
     """problems: [(dz, x, workspace)] -- split-M slabs of every dW = dz^T x in ONE launch.  Returns the slab counts, or
-    None when the shapes do not all qualify for the ring kernel (issue linear_wgrad_slabs one by one then)."""
+    None when the shapes do not all qualify for the ring kernel (issue linear_wgrad_slabs one by one then).
+    bias_parts: per problem None or an fp32 [32, N] tensor that receives the bias gradient's per-slice partial sums (rows
+    0 .. slab count - 1)."""
     n = len(problems)
+    if bias_parts is not None:
+        for (dz, _, _), bp in zip(problems, bias_parts):
+            if bp is not None:
+                _req(bp, "bias_part", torch.float32, 2)
+                if bp.shape[0] < 32 or bp.shape[1] != dz.shape[1] or not bp.is_contiguous():
+                    raise HipError("linear_wgrad_slabs_multi: bias_part must be a contiguous fp32 [32, N]")
     dt = problems[0][0].dtype
     geo = []
     for dz, x, ws in problems:
@@ -673,8 +683,13 @@ def linear_wgrad_slabs_multi(problems):
         _work_note = (sum(2 * g_[0] * g_[1] * g_[2] for g_ in geo),
                       sum((g_[0] * g_[1] + g_[0] * g_[2]) * es_ + g_[1] * g_[2] * 4 for g_ in geo),
                       [[g_[0], g_[1], g_[2]] for g_ in geo])
-    rc = lib().ib_linear_wgrad_slabs_multi(n, cv(A), cv(LA), cv(X), cv(LX), cv(W), cv(WB), cv(out), cv(Ms), cv(Ns), cv(Ks),
-                                           dtype_code(dt), stream_ptr())
+    if bias_parts is not None and any(b is not None for b in bias_parts):
+        BP = (ctypes.c_void_p * n)(*[(b.data_ptr() if b is not None else None) for b in bias_parts])
+        rc = lib().ib_linear_wgrad_slabs_multi_bias(n, cv(A), cv(LA), cv(X), cv(LX), cv(W), cv(WB), cv(BP), cv(out), cv(Ms),
+                                                    cv(Ns), cv(Ks), dtype_code(dt), stream_ptr())
+    else:
+        rc = lib().ib_linear_wgrad_slabs_multi(n, cv(A), cv(LA), cv(X), cv(LX), cv(W), cv(WB), cv(out), cv(Ms), cv(Ns), cv(Ks),
+                                               dtype_code(dt), stream_ptr())
     if rc == -5:          # IB_E_UNSUPPORTED
         return None
     _check(rc, "ib_linear_wgrad_slabs_multi")

@@ -129,11 +129,15 @@ def _colsum(buf: Buffers, tag: str, x2d: torch.Tensor, out_vec: torch.Tensor, ac
         hip.segment_colsum(part, out_vec.view(1, N), seg=part.shape[0], mode=0, accumulate=accumulate)
 
 
-def _wgrad_group(buf: Buffers, problems, defer: list):
-    """problems: [(dz, x, dw, ws_tag)] -- the slabs of every problem in ONE launch when they all qualify for the ring
-    kernel (one by one otherwise); appends (workspace, nslab, dw) to `defer` for the step's single reduction."""
+def _wgrad_group(buf: Buffers, problems, defer: list, later: Optional[list] = None):
+    """problems: [(dz, x, dw, ws_tag[, dbias])] -- the slabs of every problem in ONE launch when they all qualify for the ring
+    kernel (one by one otherwise); appends (workspace, nslab, dw) to `defer` for the step's single reduction.
+    dbias (optional fp32 [N] gradient of the layer's bias) with `later` given: the same launch leaves the bias gradient's
+    per-slice partial sums (one extra MFMA per row tile, csrc/gemm.hip) and (partial rows, rows, dbias) goes to `later`;
+    returns the problems whose bias gradient still has to be summed by the caller (not in the grouped launch)."""
     items = []
-    for dz, x, dw, tag in problems:
+    for pr in problems:
+        dz, x, dw, tag = pr[:4]
         M, N = dz.shape
         K = x.shape[1]
         if K % 4 != 0 or dw.stride(0) % 4 != 0:
@@ -145,16 +149,31 @@ def _wgrad_group(buf: Buffers, problems, defer: list):
         return t.stride(0) % 8 == 0 and t.data_ptr() % 16 == 0
     grp = [i for i, (dz, x, ws) in enumerate(items) if aligned16(dz) and aligned16(x) and dz.dtype == torch.bfloat16]
     ns = [None] * len(items)
+    parts = [None] * len(items)
     if 1 < len(grp) <= 6:
-        got = hip.linear_wgrad_slabs_multi([items[i] for i in grp])
+        if later is not None and not os.environ.get("IB_NO_WGRAD_BIAS"):
+            for i in grp:
+                if len(problems[i]) > 4 and problems[i][4] is not None:
+                    parts[i] = buf.get(problems[i][3] + ".bpart", (32, items[i][0].shape[1]), torch.float32)
+        got = hip.linear_wgrad_slabs_multi([items[i] for i in grp], bias_parts=[parts[i] for i in grp])
         if got is not None:
             for i, n in zip(grp, got):
                 ns[i] = n
+        else:
+            parts = [None] * len(items)
     for i, (dz, x, ws) in enumerate(items):
         if ns[i] is None:
             ns[i] = hip.linear_wgrad_slabs(dz, x, ws)
-    for (dz, x, ws), n, pr in zip(items, ns, problems):
+            parts[i] = None
+    todo = []
+    for i, ((dz, x, ws), n, pr) in enumerate(zip(items, ns, problems)):
         defer.append((ws, n, pr[2]))
+        if len(pr) > 4 and pr[4] is not None:
+            if parts[i] is not None:
+                later.append((parts[i][:n], n, pr[4]))
+            else:
+                todo.append(pr)
+    return todo
 
 
 def _wgrad(buf: Buffers, dz: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, accumulate: bool, ws_tag: str = "wgrad.ws",
@@ -581,12 +600,20 @@ class TransformerLayerPlan:
         # the end of the layer (they share a workgroup budget: fewer, longer slices, half the slab traffic)
         group = [] if (defer is not None and dt == torch.bfloat16 and not os.environ.get("IB_NO_LAYER_GROUP")) else None
 
-        def wgrad(dz_, x_, name, tag):
+        def wgrad(dz_, x_, name, tag, bias=None):
+            """bias = (workspace tag, bias parameter name): with the grouped launch the bias gradient's partial sums come
+            out of the weight-gradient GEMM itself; otherwise a column-sum launch"""
+            fused_bias = group is not None and later is not None and bias is not None and dz_.shape[0] > 512
             if group is not None:
-                group.append((dz_, x_, P.g(p + name), tag))
+                group.append((dz_, x_, P.g(p + name), tag, P.g(p + bias[1]) if fused_bias else None, bias))
             else:
                 _wgrad(self.buf, dz_, x_, P.g(p + name), accumulate, ws_tag=tag, defer=defer)
             P.ready(p + name)
+            if bias is not None:
+                if fused_bias:
+                    P.ready(p + bias[1])
+                else:
+                    dbias(bias[0], dz_, bias[1])
 
         def ln_bwd(which, dy, xin, mean, rstd, dxo, res):
             """LayerNorm backward; parameter gradients finished here, or their per-block partial sums left for the optimizer"""
@@ -617,15 +644,13 @@ class TransformerLayerPlan:
         ln_bwd("norm2", dx2.view(M, d), f2, m2, r2, ds2, x1)
 
         def g_ffn2():
-            wgrad(ds2, f1, "feedforward.2.weight", tg + ".ws2")
-            dbias(tg + ".b2", ds2, "feedforward.2.bias")
+            wgrad(ds2, f1, "feedforward.2.weight", tg + ".ws2", bias=(tg + ".b2", "feedforward.2.bias"))
         self.branch.run(g_ffn2)
         dz1 = g(tg + ".dz1", (M, self.ffn), dt)
         self._dgrad(P, ds2, "feedforward.2.weight", dz1, act_below="relu", aux=f1)
 
         def g_ffn1():
-            wgrad(dz1, x1, "feedforward.0.weight", tg + ".ws1")
-            dbias(tg + ".b1", dz1, "feedforward.0.bias")
+            wgrad(dz1, x1, "feedforward.0.weight", tg + ".ws1", bias=(tg + ".b1", "feedforward.0.bias"))
         self.branch.run(g_ffn1)
         dx1 = g(tg + ".dx1", (M, d), dt)
         self._dgrad(P, dz1, "feedforward.0.weight", dx1, addend=ds2)       # + residual path
@@ -634,8 +659,8 @@ class TransformerLayerPlan:
         ln_bwd("norm1", dx1, a, m1, r1, ds1, x)
 
         def g_out():
-            wgrad(ds1, attn.view(M, d), "multihead_attention.out_proj.weight", tg + ".wso")
-            dbias(tg + ".bo", ds1, "multihead_attention.out_proj.bias")
+            wgrad(ds1, attn.view(M, d), "multihead_attention.out_proj.weight", tg + ".wso",
+                  bias=(tg + ".bo", "multihead_attention.out_proj.bias"))
         self.branch.run(g_out)
         dattn = g(tg + ".dattn", (B, T, d), dt)
         self._dgrad(P, ds1, "multihead_attention.out_proj.weight", dattn.view(M, d))
@@ -644,13 +669,20 @@ class TransformerLayerPlan:
         dq2 = dqkv.view(M, 3 * d)
 
         def g_in():
-            wgrad(dq2, x, "multihead_attention.in_proj_weight", tg + ".wsi")
-            dbias(tg + ".bi", dq2, "multihead_attention.in_proj_bias")
+            wgrad(dq2, x, "multihead_attention.in_proj_weight", tg + ".wsi",
+                  bias=(tg + ".bi", "multihead_attention.in_proj_bias"))
         self.branch.run(g_in)
         dx = g(tg + ".dx", (B, T, d), dt)
         self._dgrad(P, dq2, "multihead_attention.in_proj_weight", dx.view(M, d), addend=ds1)
         if group:
-            self.branch.run(lambda: _wgrad_group(self.buf, group, defer))
+            def run_group():
+                # problems the grouped launch could not take sum their bias gradient the plain way (P.ready already said)
+                for pr in _wgrad_group(self.buf, group, defer, later):
+                    btag, bname = pr[5]
+                    part = self.buf.get(btag + ".colsum", ((pr[0].shape[0] + 127) // 128, pr[0].shape[1]), torch.float32)
+                    hip.segment_colsum(pr[0], part, seg=128, mode=0)
+                    later.append((part, part.shape[0], P.g(p + bname)))
+            self.branch.run(run_group)
         if self.join_on_exit or self.flush_on_exit:
             self.branch.join()
         if self.flush_on_exit:

@@ -84,8 +84,9 @@ def _worker(rank, world, port, case, q):
             assert tr.plan.chain_ok(D)
         losses = _train(tr, _batches(dtype), slice(rank, None, world))       # DistributedSampler(shuffle=False) striding
         assert tr._rec is not None                                           # the graph segments were captured
-        out = {"flat": tr.flat.detach().cpu(), "losses": losses, "buckets": len(tr.buckets.ranges),
-               "shadow": None if model._shadow is None else model._shadow.detach().cpu().view(torch.int16)}
+        # plain numpy through the queue (torch tensors travel as shared-memory handles that die with this process)
+        out = {"flat": tr.flat.detach().cpu().numpy().copy(), "losses": losses, "buckets": len(tr.buckets.ranges),
+               "shadow": None if model._shadow is None else model._shadow.detach().cpu().view(torch.int16).numpy().copy()}
         dist.barrier()
         dist.destroy_process_group()
         q.put((rank, "ok", out))
@@ -112,9 +113,11 @@ def test_two_ranks_reproduce_the_full_batch_trajectory(case):
         p.join(timeout=120)
     assert all(r[1] == "ok" for r in res), [r[1] for r in res]
     a, b = res[0][2], res[1][2]
+    for r_ in (a, b):
+        r_["flat"] = torch.from_numpy(r_["flat"])
     assert torch.equal(a["flat"], b["flat"]), "the ranks' parameters diverged"
     if a["shadow"] is not None:
-        assert torch.equal(a["shadow"], b["shadow"]), "the ranks' bf16 shadows diverged"
+        assert (a["shadow"] == b["shadow"]).all(), "the ranks' bf16 shadows diverged"
     assert (a["buckets"] > 1) == overlap
     # single process, whole batch, same initialisation as rank 0 (the broadcast source)
     model = _model(kind, dtype, seed=100)
