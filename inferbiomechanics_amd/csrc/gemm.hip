@@ -1574,7 +1574,9 @@ extern "C" int ib_linear_wgrad_bias(const void* dz, int64_t lddz, const void* x,
 
 extern "C" size_t ib_linear_wgrad_slabs_workspace(int64_t M, int64_t N, int64_t K) {
   int chunk;
-  const int split = wgrad_split(M, N, K, 64, &chunk);
+  int split = wgrad_split(M, N, K, 64, &chunk);
+  const int tn = ib_gemm_tn_splits(M, N, K, 1);              // the 256 x 128 kernel (gemm_tn.hip) splits finest when alone
+  if (tn > split) split = tn;
   return (size_t)split * (size_t)N * (size_t)K * sizeof(float);
 }
 
@@ -1591,6 +1593,14 @@ extern "C" int ib_linear_wgrad_slabs(const void* dz, int64_t lddz, const void* x
     IB_CHECK_LAUNCH();
     *nslab_out = 1;
     return IB_OK;
+  }
+  if (dtype == IB_BF16 && dz && x && workspace && lddz >= N && ldx >= K) {      // long reduction: the 256 x 128 kernel
+    const void* dzs[1] = {dz}; const void* xs[1] = {x}; void* wss[1] = {workspace};
+    const int64_t la[1] = {lddz}, lx[1] = {ldx}, Ms[1] = {M}, Ns[1] = {N}, Ks[1] = {K};
+    const size_t wb[1] = {workspace_bytes};
+    int32_t ns = 0;
+    const int rc = ib_gemm_tn_multi(1, dzs, la, xs, lx, wss, wb, nullptr, &ns, Ms, Ns, Ks, ib_s(stream));
+    if (rc != IB_E_UNSUPPORTED) { *nslab_out = ns; return rc; }
   }
   return wgrad_gemm(dz, lddz, x, ldx, nullptr, 0, 0, workspace, workspace_bytes, M, N, K, dtype, ib_s(stream), true,
                     nslab_out);
@@ -1611,6 +1621,11 @@ extern "C" int ib_linear_wgrad_slabs_multi_bias(int n, const void* const* dz, co
   if (n <= 0 || n > WG_MAX || !dz || !lddz || !x || !ldx || !workspace || !workspace_bytes || !nslab_out || !M || !N || !K)
     return IB_E_ARG;
   if (dtype != IB_BF16) return IB_E_UNSUPPORTED;
+  {   // long reductions: the 256 x 128 LDS-DMA kernel (half the operand re-reads of the 128 x 128 tiles)
+    const int rc = ib_gemm_tn_multi(n, dz, lddz, x, ldx, workspace, workspace_bytes, dbias_part, nslab_out, M, N, K,
+                                    ib_s(stream));
+    if (rc != IB_E_UNSUPPORTED) return rc;
+  }
   WgradMulti m{};
   m.n = n;
   int blocks = 0;

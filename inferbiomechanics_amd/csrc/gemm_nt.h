@@ -9,3 +9,11 @@
 int ib_gemm_nt_try(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const float* bias, int fwd_act,
                    const void* aux, int64_t ldaux, int bwd_act, const void* addend, int64_t ldadd, int64_t M, int64_t N,
                    int64_t K, hipStream_t s);
+
+// gemm_tn.hip: weight gradients of long reductions, dW_j[N_j,K_j] = dz_j^T x_j as fp32 split slabs, up to 6 problems per
+// launch.  ib_gemm_tn_splits: slab count the kernel will use (0 = the problem does not qualify); ib_gemm_tn_multi returns
+// IB_E_UNSUPPORTED (nothing launched) unless every problem qualifies.
+int ib_gemm_tn_splits(int64_t M, int64_t N, int64_t K, int group);
+int ib_gemm_tn_multi(int n, const void* const* dz, const int64_t* lddz, const void* const* x, const int64_t* ldx,
+                     void* const* workspace, const size_t* workspace_bytes, float* const* dbias_part, int32_t* nslab_out,
+                     const int64_t* M, const int64_t* N, const int64_t* K, hipStream_t s);

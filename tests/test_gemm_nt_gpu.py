@@ -88,3 +88,71 @@ def test_transpose_multi_many_matrices_and_ragged_edges():
     hip.transpose_multi(pairs)            # 35 matrices: two launches
     for src, dst in pairs:
         assert torch.equal(dst, src.t().contiguous())
+
+
+# ---- weight gradients of long reductions (csrc/gemm_tn.hip: transposing LDS reads, swizzled [m][column] images) -------------
+def _wgrad_ref(dz, x):
+    return dz.float().t() @ x.float()
+
+
+@pytest.mark.parametrize("M,N,K", [(4096, 512, 512), (12800, 2048, 512), (12800, 512, 2048), (12800, 1536, 512),
+                                   (12800, 256, 128), (6400, 320, 200)])
+def test_tn_wgrad_slabs_exact_on_integer_operands(M, N, K):
+    """sum of the split slabs == dz^T x bit for bit (integer operands: every partial sum is exact in fp32)"""
+    from inferbiomechanics_amd import hip
+    dz = ints((M, N), -3, 3, 21).to(DEV, torch.bfloat16)
+    x = ints((M, K), -2, 2, 22).to(DEV, torch.bfloat16)
+    ws = torch.full((int(hip.lib().ib_linear_wgrad_slabs_workspace(M, N, K)),), 0x7F, dtype=torch.uint8, device=DEV)
+    ns = hip.linear_wgrad_slabs(dz, x, ws)
+    slabs = ws[:ns * N * K * 4].view(torch.float32).view(ns, N, K)
+    assert torch.equal(slabs.sum(0), _wgrad_ref(dz, x)), (ns, (slabs.sum(0) - _wgrad_ref(dz, x)).abs().max())
+    dw = torch.empty(N, K, device=DEV)
+    hip.slab_reduce_multi([(ws, ns, dw)])
+    assert torch.equal(dw, _wgrad_ref(dz, x))
+
+
+def test_tn_grouped_launch_with_ragged_widths_and_bias_partials():
+    """the MLP denoiser's problems (D = 300 operands in 304-pitch buffers) and a transformer layer's four problems, each group
+    in ONE launch, with the bias gradients' per-split partial sums"""
+    from inferbiomechanics_amd import hip
+    M = 12800
+    groups = [[(300, 512), (512, 512), (512, 300)], [(512, 2048), (2048, 512), (512, 512), (1536, 512)]]
+    for gi, shapes in enumerate(groups):
+        probs, parts, refs = [], [], []
+        for j, (N, K) in enumerate(shapes):
+            dzb = torch.zeros(M, (N + 7) // 8 * 8, device=DEV, dtype=torch.bfloat16)
+            xb = torch.zeros(M, (K + 7) // 8 * 8, device=DEV, dtype=torch.bfloat16)
+            dzb[:, N:] = 7.0                                   # pad columns hold junk that must never reach an output
+            xb[:, K:] = -5.0
+            dz, x = dzb[:, :N], xb[:, :K]
+            dz.copy_(ints((M, N), -3, 3, 30 + 10 * gi + j).to(DEV, torch.bfloat16))
+            x.copy_(ints((M, K), -2, 2, 40 + 10 * gi + j).to(DEV, torch.bfloat16))
+            ws = torch.full((int(hip.lib().ib_linear_wgrad_slabs_workspace(M, N, K)),), 0x7F, dtype=torch.uint8, device=DEV)
+            probs.append((dz, x, ws))
+            parts.append(torch.full((32, N), float("nan"), device=DEV))
+            refs.append((_wgrad_ref(dz, x), dz.float().sum(0)))
+        ns = hip.linear_wgrad_slabs_multi(probs, bias_parts=parts)
+        assert ns is not None
+        for (dz, x, ws), n, part, (rw, rb) in zip(probs, ns, parts, refs):
+            N, K = dz.shape[1], x.shape[1]
+            slabs = ws[:n * N * K * 4].view(torch.float32).view(n, N, K)
+            assert torch.equal(slabs.sum(0), rw), (N, K, n)
+            assert torch.equal(part[:n].sum(0), rb), (N, K, n)
+
+
+def test_tn_wgrad_is_bitwise_reproducible():
+    from inferbiomechanics_amd import hip
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 12800, 2048, 512
+    dz = torch.randn(M, N, generator=g).to(DEV, torch.bfloat16)
+    x = torch.randn(M, K, generator=g).to(DEV, torch.bfloat16)
+    outs = []
+    for _ in range(2):
+        ws = torch.zeros(int(hip.lib().ib_linear_wgrad_slabs_workspace(M, N, K)), dtype=torch.uint8, device=DEV)
+        ns = hip.linear_wgrad_slabs(dz, x, ws)
+        dw = torch.empty(N, K, device=DEV)
+        hip.slab_reduce_multi([(ws, ns, dw)])
+        outs.append(dw)
+    assert torch.equal(outs[0], outs[1])
+    ref = _wgrad_ref(dz, x)
+    assert (outs[0] - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()      # fp32 summation order only

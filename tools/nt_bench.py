@@ -57,6 +57,19 @@ def main():
     us = timeit(dgrad2, 20)
     print(json.dumps({"kernel": tag, "op": "dgrad*relu'", "MNK": [M, 2048, 512], "us": round(us, 2),
                       "TFLOP/s": round(2 * M * 2048 * 512 / us / 1e6, 1)}), flush=True)
+    for name, shapes in (("transformer layer", [(512, 2048), (2048, 512), (512, 512), (1536, 512)]),
+                         ("mlp denoiser", [(304, 512), (512, 512), (512, 304)])):
+        probs = []
+        for (n, k) in shapes:
+            dz = torch.randn(M, n, device=dev).to(dt)
+            x = torch.randn(M, k, device=dev).to(dt)
+            wsb = torch.empty(int(hip.lib().ib_linear_wgrad_slabs_workspace(M, n, k)), dtype=torch.uint8, device=dev)
+            probs.append((dz, x, wsb))
+        parts = [torch.empty(32, n, device=dev) for (n, k) in shapes]
+        us = timeit(lambda: hip.linear_wgrad_slabs_multi(probs, bias_parts=parts), 10)
+        fl = sum(2 * M * n * k for n, k in shapes)
+        print(json.dumps({"kernel": "tn256" if not os.environ.get("IB_NO_TN") else "ring128", "op": "wgrad group + bias: " + name,
+                          "us": round(us, 2), "TFLOP/s": round(fl / us / 1e6, 1)}), flush=True)
     ws = [(torch.randn(r, c, device=dev).to(dt), torch.empty(c, r, device=dev, dtype=dt))
           for (r, c) in [(512, 2048), (2048, 512), (512, 512), (1536, 512)] * 4]
     us = timeit(lambda: hip.transpose_multi(ws), 20)
