@@ -350,6 +350,11 @@ int ib_step_reduce(int n, const void* const* slabs, const int32_t* nslab, float*
                    const int32_t* N, const int32_t* K, const float* part, int64_t ld, int64_t rows, int nseg,
                    const int32_t* col0, const int32_t* ncols, float* const* dst, float* const* dst2,
                    const float* scale, int accumulate, ib_stream_t stream);
+/* the same with a partial matrix per segment (each left by a different launch): part[j] [rows[j]][ld[j]] fp32 */
+int ib_step_reduce_parts(int n, const void* const* slabs, const int32_t* nslab, float* const* dw, const int64_t* lddw,
+                         const int32_t* N, const int32_t* K, int nseg, const float* const* part, const int64_t* ld,
+                         const int32_t* rows, const int32_t* col0, const int32_t* ncols, float* const* dst,
+                         const float* scale, int accumulate, ib_stream_t stream);
 int ib_debug_stamp(void* slot, ib_stream_t stream);   /* timing-only: *slot = 100 MHz wall clock when the stream gets here */
 int ib_debug_set_gemm_prof(void* stamps);    /* timing-only: [workgroups][8] stamps of the ring GEMM kernel, NULL = off */
 int ib_debug_set_chain_prof(void* stamps);   /* timing-only: [workgroups][16] int64 wall-clock stamps, NULL = off */

@@ -55,6 +55,8 @@ struct ColsumSegs {
   float* dst[CS_MAXSEG]; float* dst2[CS_MAXSEG];
   float scale[CS_MAXSEG];
   int blk0[CS_MAXSEG + 1];       // first block of each segment (64 columns per block)
+  // optional per-segment partial matrices (ib_step_reduce_parts): segment j sums rowsv[j] rows of partv[j] (pitch ldv[j])
+  const float* partv[CS_MAXSEG]; int64_t ldv[CS_MAXSEG]; int rowsv[CS_MAXSEG];
 };
 __device__ __forceinline__ void colsum_segs_body(const ColsumSegs& p, int bid, float4 (&red)[16][16]) {
   int sgi = 0;
@@ -65,15 +67,18 @@ __device__ __forceinline__ void colsum_segs_body(const ColsumSegs& p, int bid, f
   const int nc = p.ncols[sgi];
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   if (c < nc) {
-    const float* base = p.part + p.col0[sgi] + c;
+    const bool own = p.partv[sgi] != nullptr;
+    const float* base = (own ? p.partv[sgi] : p.part) + p.col0[sgi] + c;
+    const int64_t ld = own ? p.ldv[sgi] : p.ld;
+    const int rows = own ? p.rowsv[sgi] : p.rows;
     if (c + 4 <= nc) {
-      for (int r = rg; r < p.rows; r += 16) {
-        const float4 v = *reinterpret_cast<const float4*>(base + (int64_t)r * p.ld);
+      for (int r = rg; r < rows; r += 16) {
+        const float4 v = *reinterpret_cast<const float4*>(base + (int64_t)r * ld);
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
       }
     } else {
-      for (int r = rg; r < p.rows; r += 16) {
-        const float* q = base + (int64_t)r * p.ld;
+      for (int r = rg; r < rows; r += 16) {
+        const float* q = base + (int64_t)r * ld;
         s.x += q[0];
         if (c + 1 < nc) s.y += q[1];
         if (c + 2 < nc) s.z += q[2];
@@ -186,6 +191,41 @@ extern "C" int ib_step_reduce(int n, const void* const* slabs, const int32_t* ns
   if (rc != IB_OK) return rc;
   rc = build_colsum_segs(part, ld, rows, nseg, col0, ncols, dst, dst2, scale, accumulate, cp, &cb);
   if (rc != IB_OK) return rc;
+  hipLaunchKernelGGL(step_reduce_kernel, dim3(sb + cb), dim3(256), 0, ib_s(stream), sp, cp, sb);
+  IB_CHECK_LAUNCH();
+  return IB_OK;
+}
+
+// ib_step_reduce with a partial matrix PER SEGMENT (a transformer layer's gradients under data parallelism: the split-M
+// slabs of its four weight gradients + the bias / LayerNorm partial sums, each left by a different launch, finished by ONE
+// launch right before the layer's bucket is all-reduced).  nseg <= 24; every part[j] 16-byte aligned, ld[j] % 4 == 0.
+extern "C" int ib_step_reduce_parts(int n, const void* const* slabs, const int32_t* nslab, float* const* dw,
+                                    const int64_t* lddw, const int32_t* N, const int32_t* K, int nseg,
+                                    const float* const* part, const int64_t* ld, const int32_t* rows, const int32_t* col0,
+                                    const int32_t* ncols, float* const* dst, const float* scale, int accumulate,
+                                    ib_stream_t stream) {
+  if (nseg < 0 || nseg > CS_MAXSEG || (nseg > 0 && (!part || !ld || !rows || !col0 || !ncols || !dst))) return IB_E_ARG;
+  SlabMulti sp{};
+  int sb = 0;
+  if (n > 0) {
+    const int rc = build_slab_multi(n, slabs, nslab, dw, lddw, N, K, accumulate, sp, &sb);
+    if (rc != IB_OK) return rc;
+  }
+  ColsumSegs cp{};
+  cp.nseg = nseg; cp.accumulate = accumulate;
+  int cb = 0;
+  for (int j = 0; j < nseg; ++j) {
+    if (!part[j] || !dst[j] || rows[j] <= 0 || ncols[j] <= 0 || col0[j] < 0 || col0[j] % 4 != 0 || ld[j] % 4 != 0 ||
+        col0[j] + ncols[j] > ld[j] || (reinterpret_cast<uintptr_t>(part[j]) % 16) != 0)
+      return IB_E_ARG;
+    cp.partv[j] = part[j]; cp.ldv[j] = ld[j]; cp.rowsv[j] = rows[j];
+    cp.col0[j] = col0[j]; cp.ncols[j] = ncols[j]; cp.dst[j] = dst[j]; cp.dst2[j] = nullptr;
+    cp.scale[j] = scale ? scale[j] : 1.f;
+    cp.blk0[j] = cb;
+    cb += (ncols[j] + 63) / 64;
+  }
+  cp.blk0[nseg] = cb;
+  if (sb + cb == 0) return IB_OK;
   hipLaunchKernelGGL(step_reduce_kernel, dim3(sb + cb), dim3(256), 0, ib_s(stream), sp, cp, sb);
   IB_CHECK_LAUNCH();
   return IB_OK;

@@ -58,6 +58,8 @@ _SIGS = {
     "ib_slab_reduce_multi": (_c.c_int, [_c.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _c.c_int, _vp]),
     "ib_step_reduce": (_c.c_int, [_c.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _c.c_int, _vp, _vp, _vp, _vp, _vp,
                                   _c.c_int, _vp]),
+    "ib_step_reduce_parts": (_c.c_int, [_c.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _c.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                        _c.c_int, _vp]),
     "ib_segment_colsum": (_c.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _c.c_int, _c.c_int, _c.c_int, _vp]),
     "ib_layernorm_bwd_reduce": (_c.c_int, [_vp, _sz, _vp, _vp, _c.c_int, _i64, _i64, _vp]),
     "ib_layernorm_fwd": (_c.c_int, [_vp, _vp, _c.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _f32,
@@ -742,6 +744,38 @@ def step_reduce(items, part, rows: int, segs, accumulate=False):
     _check(lib().ib_step_reduce(n, cv(slabs), cv(nslab), cv(dws), cv(ldd), cv(Ns), cv(Ks), _ptr(part), ld, rows, m,
                                 cv(col0), cv(ncols), cv(dst), cv(dst2), cv(scale), int(accumulate), stream_ptr()),
            "ib_step_reduce")
+
+
+def step_reduce_parts(items, segs, accumulate=False):
+    """ONE launch that finishes a group of gradients: items = [(slab workspace, nslab, dw fp32 [N, K])] (split-M slabs of
+    weight gradients, at most 8), segs = [(part fp32 [rows_total, ld], rows, dst fp32 [ncols])] -- dst = column sums over
+    part[:rows, :ncols] (bias / LayerNorm partial sums, each matrix left by a different launch; at most 24)"""
+    n = len(items)
+    for ws, ns, dw in items:
+        _req(ws, "workspace")
+        _mat(dw, "dw", torch.float32)
+    cv = lambda a: ctypes.cast(a, ctypes.c_void_p)
+    slabs = (ctypes.c_void_p * max(n, 1))(*[it[0].data_ptr() for it in items])
+    nslab = (ctypes.c_int32 * max(n, 1))(*[int(it[1]) for it in items])
+    dws = (ctypes.c_void_p * max(n, 1))(*[it[2].data_ptr() for it in items])
+    ldd = (ctypes.c_int64 * max(n, 1))(*[it[2].stride(0) for it in items])
+    Ns = (ctypes.c_int32 * max(n, 1))(*[it[2].shape[0] for it in items])
+    Ks = (ctypes.c_int32 * max(n, 1))(*[it[2].shape[1] for it in items])
+    m = len(segs)
+    for part, rows, dst in segs:
+        pr, pc, ld = _mat(part, "part", torch.float32)
+        _req(dst, "dst", torch.float32)
+        if rows > pr or dst.numel() != pc or not dst.is_contiguous():
+            raise HipError("step_reduce_parts: segment does not fit its partial matrix")
+    parts = (ctypes.c_void_p * max(m, 1))(*[s_[0].data_ptr() for s_ in segs])
+    lds = (ctypes.c_int64 * max(m, 1))(*[(s_[0].stride(0) if s_[0].shape[0] > 1 else s_[0].shape[1]) for s_ in segs])
+    rows = (ctypes.c_int32 * max(m, 1))(*[int(s_[1]) for s_ in segs])
+    col0 = (ctypes.c_int32 * max(m, 1))(*[0 for _ in segs])
+    ncols = (ctypes.c_int32 * max(m, 1))(*[s_[0].shape[1] for s_ in segs])
+    dst = (ctypes.c_void_p * max(m, 1))(*[s_[2].data_ptr() for s_ in segs])
+    _check(lib().ib_step_reduce_parts(n, cv(slabs), cv(nslab), cv(dws), cv(ldd), cv(Ns), cv(Ks), m, cv(parts), cv(lds), cv(rows),
+                                      cv(col0), cv(ncols), cv(dst), None, int(accumulate), stream_ptr()),
+           "ib_step_reduce_parts")
 
 
 def segment_colsum(x, out, seg, mode=0, accumulate=False, out_bf16=None):

@@ -598,6 +598,13 @@ class TransformerLayerPlan:
         defer, later = self.defer, self.later
         # one GPU (slabs go to the optimizer): the layer's four weight-gradient GEMMs are issued as ONE grouped launch at
         # the end of the layer (they share a workgroup budget: fewer, longer slices, half the slab traffic)
+        # data parallel / drop-in autograd tier with large batches: the same grouped launch, its slabs and every partial-sum
+        # matrix of the layer finished by ONE reduction launch at the end of the layer (before the layer's bucket is
+        # all-reduced) instead of a slab reduction per weight and two column-sum launches per bias
+        local = defer is None and dt == torch.bfloat16 and M >= 4096 and not accumulate \
+            and not os.environ.get("IB_NO_LAYER_GROUP")
+        if local:
+            defer, later = [], []
         group = [] if (defer is not None and dt == torch.bfloat16 and not os.environ.get("IB_NO_LAYER_GROUP")) else None
 
         def wgrad(dz_, x_, name, tag, bias=None):
@@ -683,6 +690,8 @@ class TransformerLayerPlan:
                     hip.segment_colsum(pr[0], part, seg=128, mode=0)
                     later.append((part, part.shape[0], P.g(p + bname)))
             self.branch.run(run_group)
+        if local:
+            hip.step_reduce_parts(defer, [(part, rows, dst) for part, rows, dst in later])
         if self.join_on_exit or self.flush_on_exit:
             self.branch.join()
         if self.flush_on_exit:
