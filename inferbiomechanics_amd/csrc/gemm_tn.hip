@@ -289,15 +289,22 @@ inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 // problem does not qualify).  Splits divide M / 64 exactly (every work item has the same number of K steps, >= 4).
 int ib_gemm_tn_splits(int64_t M, int64_t N, int64_t K, int group) {
   static const int off = []() { const char* e = getenv("IB_NO_TN"); return e ? atoi(e) : 0; }();
-  if (off || M < 4096 || M % 64 != 0 || N < 64 || K < 64 || K % 4 != 0) return 0;
+  // work items per launch the split selection aims at (256 = one per CU).  More items fill the tail rounds better but every
+  // split is one more fp32 slab of the gradient for the step's final reduction to read (measured, B = 256, T = 50: MLP denoiser
+  // step 0.227 / 0.214 / 0.227 / 0.227 ms and transformer step 2.81 / 2.50 / 2.69 / 2.55 ms at 192 / 256 / 384 / 512).
+  // IB_TN_TARGET: tuning override.
+  static const int total = []() { const char* e = getenv("IB_TN_TARGET"); return e ? atoi(e) : 256; }();
+  // a lone problem must be long (short reductions have their own one-pass kernel); inside a group a short one rides along
+  if (off || M % 64 != 0 || M < 256 || (group <= 1 && M < 4096) || N < 64 || K < 64 || K % 4 != 0) return 0;
   const int64_t steps = M / 64;
   const int64_t tiles = ((N + TM - 1) / TM) * ((K + TK - 1) / TK);
-  const int64_t target = group <= 1 ? 512 : (512 + group - 1) / group;      // ~2 work items per CU over the whole launch
+  const int64_t target = group <= 1 ? total : (total + group - 1) / group;
   int best = 0;
-  for (int64_t s = 1; s <= 32 && s <= steps / 4; ++s) {
+  int64_t best_d = 0;
+  for (int64_t s = 1; s <= 32 && s <= steps / 4; ++s) {          // splits divide the K steps exactly, >= 4 steps each
     if (steps % s) continue;
-    best = (int)s;
-    if (tiles * s >= target) break;
+    const int64_t d = tiles * s > target ? tiles * s - target : target - tiles * s;
+    if (best == 0 || d < best_d) { best = (int)s; best_d = d; }
   }
   return best;
 }

@@ -981,13 +981,7 @@ class DenoiserMLPPlan:
         for i in range(L - 1, -1, -1):
             probs.append((dz[i], h[i - 1] if i > 0 else xt, P.g(f"blocks.{i}.linear.weight"), f"dm.ws{i}"))
         s_, u_, zu_ = self.time.ctx
-        # time_mlp.2's weight gradient reduces over B rows only (one per window): grouped with the token-row problems it
-        # would keep the whole launch off the long-reduction kernel (csrc/gemm_tn.hip), so it rides on the time-MLP branch
-        tprob = (de_lp, u_, P.g("time_mlp.2.weight"), self.time.tag + ".ws2")
-        if grouped and B * T >= 4096 and not os.environ.get("IB_NO_TN"):
-            self.branch.run(lambda: _wgrad(self.buf, tprob[0], tprob[1], tprob[2], accumulate, ws_tag=tprob[3], defer=defer))
-        else:
-            probs.append(tprob)
+        probs.append((de_lp, u_, P.g("time_mlp.2.weight"), self.time.tag + ".ws2"))     # B rows only: rides along
         if grouped and len(probs) <= 6:
             _wgrad_group(self.buf, probs, defer)
         else:
