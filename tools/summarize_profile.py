@@ -17,7 +17,10 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ENTRY_OF = [("mlp_chain_kernel", "", "ib_mlp_chain_train"), ("gemm_ring_wgrad_multi_kernel", "", "ib_linear_wgrad_slabs_multi"),
+ENTRY_OF = [("gemm_tn_kernel", "", "ib_linear_wgrad_slabs_multi"), ("gemm_nt_kernel<0, 0, false", "", "ib_linear_fwd"),
+            ("gemm_nt_kernel<1, 0", "", "ib_linear_fwd"), ("gemm_nt_kernel<0, 1", "", "ib_linear_dgrad"),
+            ("gemm_nt_kernel<0, 0, true", "", "ib_linear_dgrad"), ("gemm_nt_kernel", "", "ib_linear_fwd"),
+            ("mlp_chain_kernel", "", "ib_mlp_chain_train"), ("gemm_ring_wgrad_multi_kernel", "", "ib_linear_wgrad_slabs_multi"),
             ("optim_kernel<true>", "", "ib_optim_step_sources"), ("optim_kernelILb1", "", "ib_optim_step_sources"),
             ("step_reduce_kernel", "", "ib_step_reduce"), ("time_mlp_fwd_kernel", "", "ib_mlp_chain_prep"),
             ("gemm_ring_kernel", "Lb0ELb0ELi2", "ib_linear_wgrad_slabs"), ("gemm_ring_kernel", "Lb1ELb1ELi0", "ib_linear_fwd"),
@@ -47,8 +50,9 @@ def entry_of(name):
 
 
 def first(pattern):
+    """the NEWEST match: gpurun merges every call's files into gpurun_out/, so earlier collections of the same tag linger"""
     g = glob.glob(pattern)
-    return g[0] if g else None
+    return max(g, key=os.path.getmtime) if g else None
 
 
 def main():
