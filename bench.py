@@ -115,7 +115,9 @@ def cpu_baseline(kind, T, D, B, budget_s=15.0):
 KERNEL_OF = {   # C-ABI entry -> device kernel it launches (names as rocprofv3 --kernel-trace reports them)
     "ib_mlp_chain_train": "mlp_chain_kernel<4, 3, 10>", "ib_mlp_chain_prep": "time_mlp_fwd_kernel<4, 4> (+ weight packing blocks)",
     "ib_linear_wgrad_slabs": "gemm_ring_kernel<false, false, EPI_WGRAD>", "ib_slab_reduce_multi": "slab_reduce_multi_kernel",
-    "ib_linear_wgrad_slabs_multi": "gemm_ring_wgrad_multi_kernel", "ib_optim_step_sources": "optim_kernel<true>",
+    "ib_linear_wgrad_slabs_multi": "gemm_tn_kernel<false> (gemm_ring_wgrad_multi_kernel for short reductions)",
+    "ib_linear_wgrad_slabs_multi_bias": "gemm_tn_kernel<true>", "ib_linear_dgrad_wt": "gemm_nt_kernel",
+    "ib_optim_step_sources": "optim_kernel<true>",
     "ib_step_reduce": "step_reduce_kernel",
     "ib_colsum_segments": "colsum_segments_kernel",
     "ib_linear_fwd": "gemm_kernel<T, true, true, EPI_FWD>", "ib_linear_dgrad": "gemm_kernel<T, true, false, EPI_DGRAD>",
@@ -187,7 +189,8 @@ def roofline_leg(rec, dtype_name, gemm_family=False):
         if e == "ib_linear_wgrad_slabs":
             M, N, K = d[-4], d[-3], d[-2]
             return 2 * M * N * K, (M * K + M * N) * es + N * K * 4
-        if e in ("ib_linear_fwd", "ib_linear_dgrad", "ib_linear_wgrad", "ib_linear_ln_fwd", "ib_linear_wgrad_bias"):
+        if e in ("ib_linear_fwd", "ib_linear_dgrad", "ib_linear_dgrad_wt", "ib_linear_wgrad", "ib_linear_ln_fwd",
+                 "ib_linear_wgrad_bias"):
             M, N, K = d[-4], d[-3], d[-2]
             return 2 * M * N * K, (M * K + N * K) * es + M * N * (4 if "wgrad" in e else es)
         if e in ("ib_attention_fwd", "ib_attention_bwd"):
@@ -213,7 +216,8 @@ def roofline_leg(rec, dtype_name, gemm_family=False):
     top_e, top = max(fam.items(), key=lambda kv: kv[1]["us"])
     avg_us = top["us"] / top["launches"]
     if top_e == "linear GEMMs":
-        kernel = "gemm_ring_kernel / gemm_kernel family (gemm.hip): forward, dgrad and weight-gradient launches"
+        kernel = ("Linear GEMM family: gemm_nt_kernel (forward, dgrad; gemm_nt.hip), gemm_tn_kernel (weight gradients; "
+                  "gemm_tn.hip), gemm_ring_kernel / gemm_kernel (the remaining shapes; gemm.hip)")
         shapes = [{"entry": r["entry"], "MNK": (r["_note"][2] if r["_note"] else r["dims"][-4:-1]),
                    "launches": r["launches_per_step"], "us": r["avg_launch_us"], "tflops": r["tflops"]} for r in top["rows"]]
     else:
@@ -283,8 +287,8 @@ def ddim_leg(dev, dtype, B=16, T=200, D=300, steps=100):
                          "scope": "whole denoise step (forward plan + DDIM update), wall clock over the loop"}}
 
 
-GEMM_ENTRIES = ("ib_linear_fwd", "ib_linear_dgrad", "ib_linear_wgrad", "ib_linear_wgrad_slabs", "ib_linear_wgrad_slabs_multi",
-                "ib_linear_wgrad_bias", "ib_linear_ln_fwd")
+GEMM_ENTRIES = ("ib_linear_fwd", "ib_linear_dgrad", "ib_linear_dgrad_wt", "ib_linear_wgrad", "ib_linear_wgrad_slabs",
+                "ib_linear_wgrad_slabs_multi", "ib_linear_wgrad_slabs_multi_bias", "ib_linear_wgrad_bias", "ib_linear_ln_fwd")
 
 
 def algorithmic_bytes_per_step(kind, T, D, B, nparams):
