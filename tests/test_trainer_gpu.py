@@ -309,3 +309,31 @@ def test_captured_collectives_on_one_rank_match_the_cut_graphs():
         assert a["final_loss"] == b["final_loss"], (workload, a["final_loss"], b["final_loss"])
         assert a["config"]["grad_buckets"] == b["config"]["grad_buckets"] >= 1
         print(workload, "cut graphs", a["ms_per_step"], "ms/step; captured collectives", b["ms_per_step"], "ms/step")
+
+
+def test_large_batch_kernel_paths_agree():
+    """the fused transformer step at M = 6400 token rows through (a) the 256 x 128 NT / TN kernels with the bias partial sums
+    (default), (b) the 128 x 128 ring kernels with column-sum launches (IB_NO_NT / IB_NO_TN / IB_NO_WGRAD_BIAS) and (c) the
+    data-parallel launch sequence on a 1-rank RCCL group: same losses up to bf16 summation order (5e-3), four steps"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    arms = {"default": {}, "ring": {"IB_NO_NT": "1", "IB_NO_TN": "1", "IB_NO_WGRAD_BIAS": "1"},
+            "ddp": {"IB_DDP_SELFTEST": "1", "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"}}
+    out = {}
+    for name, extra in arms.items():
+        env = dict(os.environ)
+        for k in ("IB_NO_NT", "IB_NO_TN", "IB_NO_WGRAD_BIAS", "IB_DDP_SELFTEST", "IB_GRAPH_COLLECTIVES"):
+            env.pop(k, None)
+        env.update(extra)
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "path_ab.py")], capture_output=True, text=True, env=env,
+                           timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        out[name] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    ref = out["ring"]["losses"]
+    for name in ("default", "ddp"):
+        for a, e in zip(out[name]["losses"], ref):
+            assert abs(a - e) <= 5e-3 * abs(e), (name, out[name]["losses"], ref)
+        assert abs(out[name]["psum"] - out["ring"]["psum"]) <= 1e-5 * out["ring"]["psum"], name
