@@ -161,6 +161,20 @@ int ib_attention_fwd(const void* qkv, void* out, float* lse, int64_t B, int64_t 
                      int64_t dh, int dtype, ib_stream_t stream);
 int ib_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
                      int64_t B, int64_t T, int64_t H, int64_t dh, int dtype, ib_stream_t stream);
+/* the same with nn.MultiheadAttention(dropout = p)'s dropout on the softmax probabilities (TransformerBaseline.py:12-13;
+ * train mode only -- the caller passes p = 0 in eval mode): out = (softmax(..) x mask / (1 - p)) v.  The mask of
+ * (window, head, query, key) is a counter-based hash of (seed, step or *step_dev, indices): the backward regenerates the
+ * forward's draw from the same (seed, step), nothing T x T is stored.  p in [0, 1); p = 0 is ib_attention_fwd / _bwd.
+ * ib_attention_drop_mask writes the multipliers (0 or 1 / (1 - p)) of one draw as fp32 [B, H, T, T] (tests: a float64
+ * restatement of a train-mode layer needs the masks the kernels used). */
+int ib_attention_fwd_drop(const void* qkv, void* out, float* lse, int64_t B, int64_t T, int64_t H, int64_t dh,
+                          float p, uint32_t seed, int32_t step, const int32_t* step_dev, int dtype,
+                          ib_stream_t stream);
+int ib_attention_bwd_drop(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
+                          int64_t B, int64_t T, int64_t H, int64_t dh, float p, uint32_t seed, int32_t step,
+                          const int32_t* step_dev, int dtype, ib_stream_t stream);
+int ib_attention_drop_mask(float* mask, int64_t B, int64_t T, int64_t H, float p, uint32_t seed, int32_t step,
+                           const int32_t* step_dev, ib_stream_t stream);
 
 /* ---- input packing: torch.concat x10 + reshape, FeedForwardRegressionBaseline.py:97-108.
  * out[b, f, off_k + c] = cast(in_k[b, f, c]); inputs fp32 contiguous [B*F, width_k]. */

@@ -14,7 +14,8 @@
 //     phase 1 per 16-query block: S^T, dP^T = V . dO^T, dS = P (dP - D), dQ^T = K^T . dS^T
 //     phase 2 per 16-key block  : S = Q . K^T, dP = dO . V^T, dS, dV^T = dO^T . P, dK^T = Q^T . dS
 //   (S / dP are recomputed in phase 2 instead of being exchanged: 7 instead of 5 products, but nothing T x T
-//   ever leaves registers).  D[q] = rowsum(dO * O) is computed while staging.
+//   ever leaves registers).  D[q] = sum_key P dP is summed in phase 1 from the row's P and dP registers (fp32) and
+//   passed to phase 2 through LDS; the saved output O is not read.
 //
 // Lane maps used (same as gemm.hip, verified on hardware by tests/test_hip_kernels.py::test_tr16...):
 //   mfma(A, B, C): A[row = lane%16][k = 8*(lane/16)+j], B[k = 8*(lane/16)+j][col = lane%16],
@@ -69,9 +70,11 @@ __device__ __forceinline__ void stage_image(bf16_t* img, const bf16_t* __restric
   }
 }
 
-template <int NT>
+// DROP: nn.MultiheadAttention's dropout on the probabilities -- the multiplier (0 or 1 / (1 - p)) of (query, key) is a hash
+// (ib_common.h) applied to the P registers after the row sum; the backward regenerates it
+template <int NT, bool DROP>
 __global__ __launch_bounds__(256) void attn_fwd_mfma(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                     float* __restrict__ lse, int T, int H, float scale) {
+                                                     float* __restrict__ lse, int T, int H, float scale, IbAttnDrop drop) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr int Tp = NT * 16;
   bf16_t* Qs = reinterpret_cast<bf16_t*>(smem_raw);
@@ -84,6 +87,8 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(const bf16_t* __restrict__ 
   stage_image(Qs, base, 3 * d, T, Tp);
   stage_image(Ks, base + d, 3 * d, T, Tp);
   stage_image(Vs, base + 2 * d, 3 * d, T, Tp);
+  uint32_t dkey = 0;
+  if constexpr (DROP) dkey = ib_attn_drop_key(drop, blockIdx.x);
   __syncthreads();
   const int nqb = (T + 15) >> 4;
   for (int qb = wave; qb < nqb; qb += 4) {
@@ -111,8 +116,9 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(const bf16_t* __restrict__ 
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float pv = __expf(s[kt][r] - m);     // -inf -> 0
-        s[kt][r] = pv;
         l += pv;
+        if constexpr (DROP) s[kt][r] = pv * ib_attn_drop_mult(drop, dkey, q, kt * 16 + 4 * g + r);
+        else s[kt][r] = pv;
       }
     l = group4_sum(l);
     f32x4_t o[4];
@@ -140,10 +146,10 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(const bf16_t* __restrict__ 
   }
 }
 
-template <int NT>
+template <int NT, bool DROP>
 __global__ __launch_bounds__(256) void attn_bwd_mfma(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
                                                      const bf16_t* __restrict__ dout, const float* __restrict__ lse,
-                                                     bf16_t* __restrict__ dqkv, int T, int H, float scale) {
+                                                     bf16_t* __restrict__ dqkv, int T, int H, float scale, IbAttnDrop drop) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr int Tp = NT * 16;
   bf16_t* Qs = reinterpret_cast<bf16_t*>(smem_raw);
@@ -157,30 +163,18 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma(const bf16_t* __restrict__ 
   const int d = H * 64;
   const bf16_t* base = qkv + (int64_t)b * T * 3 * d + h * 64;
   bf16_t* dbase = dqkv + (int64_t)b * T * 3 * d + h * 64;
-  const bf16_t* obase = out + (int64_t)b * T * d + h * 64;
+  (void)out;      // D = rowsum(dP x P) is summed from the recomputed probabilities (phase 1), not from the rounded output
   const bf16_t* gbase = dout + (int64_t)b * T * d + h * 64;
   stage_image(Qs, base, 3 * d, T, Tp);
   stage_image(Ks, base + d, 3 * d, T, Tp);
   stage_image(Vs, base + 2 * d, 3 * d, T, Tp);
-  // dO image + D = rowsum(dO * O): 8 consecutive threads own one row (blockDim = 256 is a multiple of 8)
-  for (int i = threadIdx.x; i < Tp * 8; i += blockDim.x) {
-    const int r = i >> 3, c = i & 7;
-    uint4 gv = make_uint4(0u, 0u, 0u, 0u), ov = gv;
-    if (r < T) {
-      gv = *reinterpret_cast<const uint4*>(gbase + (int64_t)r * d + c * 8);
-      ov = *reinterpret_cast<const uint4*>(obase + (int64_t)r * d + c * 8);
-    }
-    *reinterpret_cast<uint4*>(Gs + r * LDR + c * 8) = gv;
-    const bf16x8_t g8 = __builtin_bit_cast(bf16x8_t, gv), o8 = __builtin_bit_cast(bf16x8_t, ov);
-    float part = 0.f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) part += (float)g8[e] * (float)o8[e];
-    part += __shfl_xor(part, 1, 64);
-    part += __shfl_xor(part, 2, 64);
-    part += __shfl_xor(part, 4, 64);
-    if (c == 0) Dl[r] = part;
+  stage_image(Gs, gbase, d, T, Tp);
+  for (int t = threadIdx.x; t < Tp; t += blockDim.x) {
+    Ll[t] = t < T ? lse[((int64_t)b * H + h) * T + t] : 0.f;
+    Dl[t] = 0.f;                                               // rows beyond the last query block stay 0
   }
-  for (int t = threadIdx.x; t < Tp; t += blockDim.x) Ll[t] = t < T ? lse[((int64_t)b * H + h) * T + t] : 0.f;
+  uint32_t dkey = 0;
+  if constexpr (DROP) dkey = ib_attn_drop_key(drop, blockIdx.x);
   __syncthreads();
 
   // ---------------- phase 1: dQ, one 16-query block per wave iteration (lane owns query q)
@@ -189,9 +183,34 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma(const bf16_t* __restrict__ 
     const int q = qb * 16 + (lane & 15);
     const bf16x8_t qf[2] = {row_frag(Qs, q, 0, lane), row_frag(Qs, q, 1, lane)};
     const bf16x8_t gf[2] = {row_frag(Gs, q, 0, lane), row_frag(Gs, q, 1, lane)};
-    const float Lq = Ll[q], Dq = Dl[q];
-    // stream over pairs of key tiles: the lse is known, so dS of a pair is final as soon as it is computed and
-    // goes straight into the dQ products (only two S/dP tiles are live at a time)
+    const float Lq = Ll[q];
+    // pass 1 over the key tiles: P and (masked) dP of the whole row stay in registers, and D[q] = sum_key P dP is summed
+    // from them in fp32 -- exact for the values the products see.  (rowsum(dO x O) of the SAVED output is the same number
+    // only up to O's bf16 rounding, and dS = P (dP - D) cancels: with a peaked softmax that rounding was the whole dQ / dK
+    // error of the bf16 path.)
+    f32x4_t pr[NT], dpr[NT];
+    float Dq = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+      const int krow = kt * 16 + (lane & 15);
+      f32x4_t a = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+      a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Ks, krow, 0, lane), qf[0], a, 0, 0, 0);
+      a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Ks, krow, 1, lane), qf[1], a, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Vs, krow, 0, lane), gf[0], dp, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Vs, krow, 1, lane), gf[1], dp, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = kt * 16 + 4 * g + r;
+        const float pv = key < T ? __expf(a[r] * scale - Lq) : 0.f;
+        if constexpr (DROP) dp[r] *= ib_attn_drop_mult(drop, dkey, q, key);
+        Dq += pv * dp[r];
+        a[r] = pv;
+      }
+      pr[kt] = a;
+      dpr[kt] = dp;
+    }
+    Dq = group4_sum(Dq);
+    if (g == 0) Dl[q] = Dq;                                    // phase 2 reads it (after the barrier below)
     f32x4_t dq[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -199,22 +218,9 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma(const bf16_t* __restrict__ 
     for (int kp = 0; kp < NT / 2; ++kp) {
       f32x4_t ds2[2];
 #pragma unroll
-      for (int hh = 0; hh < 2; ++hh) {
-        const int kt = 2 * kp + hh;
-        const int krow = kt * 16 + (lane & 15);
-        f32x4_t a = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Ks, krow, 0, lane), qf[0], a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Ks, krow, 1, lane), qf[1], a, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Vs, krow, 0, lane), gf[0], dp, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Vs, krow, 1, lane), gf[1], dp, 0, 0, 0);
+      for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = kt * 16 + 4 * g + r;
-          const float pv = key < T ? __expf(a[r] * scale - Lq) : 0.f;
-          a[r] = pv * (dp[r] - Dq);
-        }
-        ds2[hh] = a;
-      }
+        for (int r = 0; r < 4; ++r) ds2[hh][r] = pr[2 * kp + hh][r] * (dpr[2 * kp + hh][r] - Dq);
       const bf16x8_t sf = acc_frag(ds2[0], ds2[1]);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt)
@@ -232,6 +238,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma(const bf16_t* __restrict__ 
     }
   }
 
+  __syncthreads();                                             // D of every query is in LDS
   // ---------------- phase 2: dK, dV, one 16-key block per wave iteration (lane owns key)
   for (int kb = wave; kb < nb; kb += 4) {
     const int key = kb * 16 + (lane & 15);
@@ -256,8 +263,10 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma(const bf16_t* __restrict__ 
         for (int r = 0; r < 4; ++r) {
           const int qq = qt * 16 + 4 * g + r;                  // this register's query
           const float pv = qq < T ? __expf(a[r] * scale - Ll[qq]) : 0.f;
-          a[r] = pv;
-          dp[r] = pv * (dp[r] - Dl[qq]);
+          float mk = 1.f;
+          if constexpr (DROP) mk = ib_attn_drop_mult(drop, dkey, qq, key);
+          a[r] = pv * mk;                                      // dV sums the dropped probabilities
+          dp[r] = pv * (mk * dp[r] - Dl[qq]);
         }
         pp2[hh] = a;
         ds2[hh] = dp;
@@ -292,30 +301,42 @@ template <typename K> int ensure_lds(K k, size_t need, int& cur) {
   cur = 160 * 1024;
   return IB_OK;
 }
-int g_lds_f[4] = {48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024};
-int g_lds_b[4] = {48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024};
+int g_lds_f[2][4] = {{48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024}, {48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024}};
+int g_lds_b[2][4] = {{48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024}, {48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024}};
 
+template <int NT, bool DROP>
+int launch_fwd2(const void* qkv, void* out, float* lse, int64_t B, int64_t T, int64_t H, float scale, int slot,
+                const IbAttnDrop& a, hipStream_t s) {
+  const size_t lds = (size_t)3 * NT * 16 * LDR * 2;
+  auto k = attn_fwd_mfma<NT, DROP>;
+  if (ensure_lds(k, lds, g_lds_f[DROP][slot]) != IB_OK) return IB_E_LAUNCH;
+  hipLaunchKernelGGL(k, dim3((unsigned)(B * H)), dim3(256), lds, s, (const bf16_t*)qkv, (bf16_t*)out, lse, (int)T, (int)H,
+                     scale, a);
+  IB_CHECK_LAUNCH();
+  return IB_OK;
+}
 template <int NT>
 int launch_fwd(const void* qkv, void* out, float* lse, int64_t B, int64_t T, int64_t H, float scale, int slot,
-               hipStream_t s) {
-  const size_t lds = (size_t)3 * NT * 16 * LDR * 2;
-  auto k = attn_fwd_mfma<NT>;
-  if (ensure_lds(k, lds, g_lds_f[slot]) != IB_OK) return IB_E_LAUNCH;
-  hipLaunchKernelGGL(k, dim3((unsigned)(B * H)), dim3(256), lds, s, (const bf16_t*)qkv, (bf16_t*)out, lse, (int)T, (int)H,
-                     scale);
+               const IbAttnDrop* drop, hipStream_t s) {
+  return drop ? launch_fwd2<NT, true>(qkv, out, lse, B, T, H, scale, slot, *drop, s)
+              : launch_fwd2<NT, false>(qkv, out, lse, B, T, H, scale, slot, IbAttnDrop{}, s);
+}
+template <int NT, bool DROP>
+int launch_bwd2(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int64_t B, int64_t T,
+                int64_t H, float scale, int slot, const IbAttnDrop& a, hipStream_t s) {
+  const size_t lds = (size_t)4 * NT * 16 * LDR * 2 + (size_t)2 * NT * 16 * 4;
+  auto k = attn_bwd_mfma<NT, DROP>;
+  if (ensure_lds(k, lds, g_lds_b[DROP][slot]) != IB_OK) return IB_E_LAUNCH;
+  hipLaunchKernelGGL(k, dim3((unsigned)(B * H)), dim3(256), lds, s, (const bf16_t*)qkv, (const bf16_t*)out,
+                     (const bf16_t*)dout, lse, (bf16_t*)dqkv, (int)T, (int)H, scale, a);
   IB_CHECK_LAUNCH();
   return IB_OK;
 }
 template <int NT>
 int launch_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int64_t B, int64_t T,
-               int64_t H, float scale, int slot, hipStream_t s) {
-  const size_t lds = (size_t)4 * NT * 16 * LDR * 2 + (size_t)2 * NT * 16 * 4;
-  auto k = attn_bwd_mfma<NT>;
-  if (ensure_lds(k, lds, g_lds_b[slot]) != IB_OK) return IB_E_LAUNCH;
-  hipLaunchKernelGGL(k, dim3((unsigned)(B * H)), dim3(256), lds, s, (const bf16_t*)qkv, (const bf16_t*)out,
-                     (const bf16_t*)dout, lse, (bf16_t*)dqkv, (int)T, (int)H, scale);
-  IB_CHECK_LAUNCH();
-  return IB_OK;
+               int64_t H, float scale, int slot, const IbAttnDrop* drop, hipStream_t s) {
+  return drop ? launch_bwd2<NT, true>(qkv, out, dout, lse, dqkv, B, T, H, scale, slot, *drop, s)
+              : launch_bwd2<NT, false>(qkv, out, dout, lse, dqkv, B, T, H, scale, slot, IbAttnDrop{}, s);
 }
 
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) % 16) == 0; }
@@ -325,21 +346,21 @@ inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) % 16) =
 // Internal entry points used by attention.hip's dispatcher (not part of the public C-ABI).
 // Return IB_E_UNSUPPORTED when the shape / alignment is outside this kernel's domain.
 int ib_attention_fwd_mfma_bf16(const void* qkv, void* out, float* lse, int64_t B, int64_t T, int64_t H, int64_t dh,
-                               hipStream_t s) {
+                               const IbAttnDrop* drop, hipStream_t s) {
   if (dh != 64 || T > 256 || !al16(qkv) || !al16(out)) return IB_E_UNSUPPORTED;
   const float scale = 0.125f;
-  if (T <= 64) return launch_fwd<4>(qkv, out, lse, B, T, H, scale, 0, s);
-  if (T <= 128) return launch_fwd<8>(qkv, out, lse, B, T, H, scale, 1, s);
-  if (T <= 224) return launch_fwd<14>(qkv, out, lse, B, T, H, scale, 2, s);
-  return launch_fwd<16>(qkv, out, lse, B, T, H, scale, 3, s);
+  if (T <= 64) return launch_fwd<4>(qkv, out, lse, B, T, H, scale, 0, drop, s);
+  if (T <= 128) return launch_fwd<8>(qkv, out, lse, B, T, H, scale, 1, drop, s);
+  if (T <= 224) return launch_fwd<14>(qkv, out, lse, B, T, H, scale, 2, drop, s);
+  return launch_fwd<16>(qkv, out, lse, B, T, H, scale, 3, drop, s);
 }
 
 int ib_attention_bwd_mfma_bf16(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
-                               int64_t B, int64_t T, int64_t H, int64_t dh, hipStream_t s) {
+                               int64_t B, int64_t T, int64_t H, int64_t dh, const IbAttnDrop* drop, hipStream_t s) {
   if (dh != 64 || T > 256 || !al16(qkv) || !al16(out) || !al16(dout) || !al16(dqkv)) return IB_E_UNSUPPORTED;
   const float scale = 0.125f;
-  if (T <= 64) return launch_bwd<4>(qkv, out, dout, lse, dqkv, B, T, H, scale, 0, s);
-  if (T <= 128) return launch_bwd<8>(qkv, out, dout, lse, dqkv, B, T, H, scale, 1, s);
-  if (T <= 224) return launch_bwd<14>(qkv, out, dout, lse, dqkv, B, T, H, scale, 2, s);
-  return launch_bwd<16>(qkv, out, dout, lse, dqkv, B, T, H, scale, 3, s);
+  if (T <= 64) return launch_bwd<4>(qkv, out, dout, lse, dqkv, B, T, H, scale, 0, drop, s);
+  if (T <= 128) return launch_bwd<8>(qkv, out, dout, lse, dqkv, B, T, H, scale, 1, drop, s);
+  if (T <= 224) return launch_bwd<14>(qkv, out, dout, lse, dqkv, B, T, H, scale, 2, drop, s);
+  return launch_bwd<16>(qkv, out, dout, lse, dqkv, B, T, H, scale, 3, drop, s);
 }

@@ -81,22 +81,16 @@ __global__ __launch_bounds__(256) void col2im_kernel(const T* __restrict__ dcol,
   }
 }
 
-__device__ __forceinline__ uint32_t mix32(uint32_t v) {      // lowbias32 (Wellons): a full-avalanche 32-bit mixer
-  v ^= v >> 16; v *= 0x21f0aaadu;
-  v ^= v >> 15; v *= 0x735a2d97u;
-  v ^= v >> 15;
-  return v;
-}
 
 template <typename T>
 __global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n, float p,
                                                        uint32_t seed, int step, const int32_t* __restrict__ step_dev) {
   const uint32_t st = (uint32_t)(step_dev ? *step_dev : step);
-  const uint32_t key = mix32(seed ^ mix32(st + 0x9e3779b9u));
+  const uint32_t key = ib_mix32(seed ^ ib_mix32(st + 0x9e3779b9u));
   const float keep = 1.f / (1.f - p);
   const uint32_t thr = (uint32_t)(p * 4294967296.0);          // drop when the 32-bit draw is below p * 2^32
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const uint32_t r = mix32((uint32_t)i ^ key) ^ mix32((uint32_t)(i >> 32) + key);
+    const uint32_t r = ib_mix32((uint32_t)i ^ key) ^ ib_mix32((uint32_t)(i >> 32) + key);
     y[i] = r < thr ? ib_from_f32<T>(0.f) : ib_from_f32<T>(ib_to_f32(x[i]) * keep);
   }
 }
@@ -106,16 +100,16 @@ __global__ __launch_bounds__(256) void dropout_vec8_kernel(const bf16_t* __restr
                                                             float p, uint32_t seed, int step,
                                                             const int32_t* __restrict__ step_dev) {
   const uint32_t st = (uint32_t)(step_dev ? *step_dev : step);
-  const uint32_t key = mix32(seed ^ mix32(st + 0x9e3779b9u));
+  const uint32_t key = ib_mix32(seed ^ ib_mix32(st + 0x9e3779b9u));
   const float keep = 1.f / (1.f - p);
   const uint32_t thr = (uint32_t)(p * 4294967296.0);
   for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n8; g += (int64_t)gridDim.x * blockDim.x) {
     bf16x8_t v;
     __builtin_memcpy(&v, __builtin_assume_aligned(x + 8 * g, 16), 16);
-    const uint32_t hi = mix32((uint32_t)((8 * g) >> 32) + key);
+    const uint32_t hi = ib_mix32((uint32_t)((8 * g) >> 32) + key);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const uint32_t r = mix32((uint32_t)(8 * g + e) ^ key) ^ hi;       // (8g + e) >> 32 is the same for all 8
+      const uint32_t r = ib_mix32((uint32_t)(8 * g + e) ^ key) ^ hi;       // (8g + e) >> 32 is the same for all 8
       v[e] = r < thr ? (bf16_t)0.f : (bf16_t)((float)v[e] * keep);
     }
     __builtin_memcpy(__builtin_assume_aligned(y + 8 * g, 16), &v, 16);

@@ -65,6 +65,30 @@ __device__ __forceinline__ float ib_wave_max(float v) {
   return v;
 }
 
+// lowbias32 (Wellons): a full-avalanche 32-bit mixer -- the counter-based dropout masks are hashes of (seed, step, element)
+__device__ __forceinline__ uint32_t ib_mix32(uint32_t v) {
+  v ^= v >> 16; v *= 0x21f0aaadu;
+  v ^= v >> 15; v *= 0x735a2d97u;
+  v ^= v >> 15;
+  return v;
+}
+// attention-probability dropout (nn.MultiheadAttention(dropout=p), TransformerBaseline.py:12-13): the mask of probability
+// (window b, head h, query q, key j) is a hash of (seed, step, b*H+h, q, j), so the backward regenerates the forward's draw
+struct IbAttnDrop {
+  uint32_t thr;            // drop when the 32-bit draw is below p * 2^32
+  float keep;              // 1 / (1 - p)
+  uint32_t seed;
+  int32_t step;
+  const int32_t* step_dev; // device-resident step counter (graph replay), or null
+};
+__device__ __forceinline__ uint32_t ib_attn_drop_key(const IbAttnDrop& a, int bh) {
+  const uint32_t st = (uint32_t)(a.step_dev ? *a.step_dev : a.step);
+  return ib_mix32(ib_mix32(a.seed ^ ib_mix32(st + 0x9e3779b9u)) + (uint32_t)bh * 0x85ebca6bu);
+}
+__device__ __forceinline__ float ib_attn_drop_mult(const IbAttnDrop& a, uint32_t key, int q, int j) {   // q, j < 2^16
+  return ib_mix32((((uint32_t)q << 16) | (uint32_t)j) ^ key) < a.thr ? 0.f : a.keep;
+}
+
 // XCD-aware bijective remap of a 1-D block id: blocks b and b+8 share an XCD (round-robin
 // dispatch), so give each XCD a contiguous chunk of the logical grid -> neighbouring tiles that
 // share an operand panel hit the same L2.  Speed only, never correctness.

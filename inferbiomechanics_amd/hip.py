@@ -69,6 +69,11 @@ _SIGS = {
                                     _vp, _i64, _i64, _i64, _i64, _c.c_int, _vp]),
     "ib_attention_fwd": (_c.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _c.c_int, _vp]),
     "ib_attention_bwd": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _c.c_int, _vp]),
+    "ib_attention_fwd_drop": (_c.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _c.c_float, _c.c_uint32, _c.c_int32, _vp,
+                                         _c.c_int, _vp]),
+    "ib_attention_bwd_drop": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _c.c_float, _c.c_uint32, _c.c_int32,
+                                         _vp, _c.c_int, _vp]),
+    "ib_attention_drop_mask": (_c.c_int, [_vp, _i64, _i64, _i64, _c.c_float, _c.c_uint32, _c.c_int32, _vp, _vp]),
     "ib_concat_keys": (_c.c_int, [_vp, _vp, _i32, _vp, _i64, _c.c_int, _vp]),
     "ib_cast": (_c.c_int, [_vp, _c.c_int, _vp, _c.c_int, _i64, _vp]),
     "ib_cast2d": (_c.c_int, [_vp, _i64, _c.c_int, _vp, _i64, _c.c_int, _i64, _i64, _vp]),
@@ -881,7 +886,20 @@ def layernorm_bwd_reduce(workspace, dgamma, dbeta, M, N, accumulate=False):
 # --------------------------------------------------------------------------------------------
 # attention
 # --------------------------------------------------------------------------------------------
-def attention_fwd(qkv, out, lse, num_heads):
+def _drop_args(drop):
+    """drop = (p, seed, step, step_dev) of a train-mode call, or None"""
+    if drop is None:
+        return None
+    p, seed, step, step_dev = drop
+    if not 0.0 <= p < 1.0:
+        raise HipError(f"dropout probability has to be in [0, 1), but got {p}")
+    if step_dev is not None:
+        _req(step_dev, "step_dev", torch.int32)
+    return float(p), int(seed) & 0xFFFFFFFF, int(step), _ptr(step_dev)
+
+
+def attention_fwd(qkv, out, lse, num_heads, drop=None):
+    """drop = (p, seed, step, step_dev): dropout on the softmax probabilities (nn.MultiheadAttention(dropout=p), train mode)"""
     dt = qkv.dtype
     _req(qkv, "qkv", dt, 3)
     B, T, d3 = qkv.shape
@@ -894,12 +912,25 @@ def attention_fwd(qkv, out, lse, num_heads):
     _req(lse, "lse", torch.float32)
     if lse.numel() != B * num_heads * T or not lse.is_contiguous():
         raise HipError("lse must be contiguous fp32 [B,H,T]")
+    da = _drop_args(drop)
+    if da is not None:
+        _check(lib().ib_attention_fwd_drop(_ptr(qkv), _ptr(out), _ptr(lse), B, T, num_heads, d // num_heads, *da,
+                                           dtype_code(dt), stream_ptr()), "ib_attention_fwd_drop")
+        return out
     _check(lib().ib_attention_fwd(_ptr(qkv), _ptr(out), _ptr(lse), B, T, num_heads, d // num_heads, dtype_code(dt),
                                   stream_ptr()), "ib_attention_fwd")
     return out
 
 
-def attention_bwd(qkv, out, dout, lse, dqkv, num_heads):
+def attention_drop_mask(B, T, num_heads, drop, device):
+    """the multipliers (0 or 1 / (1 - p)) attention_fwd(..., drop=drop) applies, fp32 [B, H, T, T] (tests)"""
+    mask = torch.empty(B, num_heads, T, T, dtype=torch.float32, device=device)
+    _check(lib().ib_attention_drop_mask(_ptr(mask), B, T, num_heads, *_drop_args(drop), stream_ptr()),
+           "ib_attention_drop_mask")
+    return mask
+
+
+def attention_bwd(qkv, out, dout, lse, dqkv, num_heads, drop=None):
     dt = qkv.dtype
     B, T, d3 = qkv.shape
     d = d3 // 3
@@ -911,6 +942,11 @@ def attention_bwd(qkv, out, dout, lse, dqkv, num_heads):
     _req(lse, "lse", torch.float32)
     if lse.numel() != B * num_heads * T:
         raise HipError("lse must be fp32 [B,H,T]")
+    da = _drop_args(drop)
+    if da is not None:
+        _check(lib().ib_attention_bwd_drop(_ptr(qkv), _ptr(out), _ptr(dout), _ptr(lse), _ptr(dqkv), B, T, num_heads,
+                                           d // num_heads, *da, dtype_code(dt), stream_ptr()), "ib_attention_bwd_drop")
+        return dqkv
     _check(lib().ib_attention_bwd(_ptr(qkv), _ptr(out), _ptr(dout), _ptr(lse), _ptr(dqkv), B, T, num_heads,
                                   d // num_heads, dtype_code(dt), stream_ptr()), "ib_attention_bwd")
     return dqkv

@@ -4,7 +4,10 @@ Same constructor and state_dict names as the reference layer (``multihead_attent
 ``...out_proj.weight``, ``feedforward.{0,2}.*``, ``norm{1,2}.*``).  The reference's whole-model
 ``TransformerBaseline.forward`` is dead code (it needs data keys that no longer exist, SURVEY.md §8a6);
 its layer arithmetic is what the transformer denoiser is built from.
-dropout must be 0 (the only value the reference model passes, TransformerBaseline.py:79).
+dropout (the reference model passes 0.0, TransformerBaseline.py:79) acts in train mode exactly where the reference layer has
+it: on the attention probabilities inside nn.MultiheadAttention(dropout=p) (:12-13), dropout1 (:30) and dropout2 (:35); the
+masks are counter-based hashes regenerated in the backward (the draws differ from torch's generator, the arithmetic given a
+mask does not: tests/test_transformer_dropout_gpu.py).
 """
 import math
 
@@ -41,8 +44,8 @@ class TransformerLayer(HipModule):
     def __init__(self, timestep_vector_dim: int, num_heads: int, dim_feedforward: int, dropout: float = 0.0,
                  dtype=torch.float32, device=None):
         super().__init__(torch.bfloat16 if dtype == torch.bfloat16 else torch.float32)
-        if dropout != 0.0:
-            raise NotImplementedError("dropout != 0 is not on the HIP hot path (reference passes 0.0)")
+        if not 0.0 <= dropout < 1.0:
+            raise ValueError(f"dropout probability has to be in [0, 1), but got {dropout}")
         if timestep_vector_dim % num_heads:
             raise AssertionError("embed_dim must be divisible by num_heads")
         self.d, self.h, self.ffn = timestep_vector_dim, num_heads, dim_feedforward
@@ -50,16 +53,23 @@ class TransformerLayer(HipModule):
         self.multihead_attention = sub["multihead_attention"]
         self.feedforward = sub["feedforward"]
         self.norm1, self.norm2 = sub["norm1"], sub["norm2"]
+        self.dropout_p = float(dropout)
+        self.train_mode_matters = self.dropout_p > 0.0
+        self._fwd_calls = 0
         self._plan = None
 
     def _get_plan(self, device):
         if self._plan is None or self._plan.buf.device != device or self._plan.dtype != self.compute_dtype:
-            self._plan = TransformerLayerPlan("", self.d, self.h, self.ffn, self.compute_dtype, device)
+            self._plan = TransformerLayerPlan("", self.d, self.h, self.ffn, self.compute_dtype, device,
+                                              dropout_p=self.dropout_p)
         return self._plan
 
     def _plan_forward(self, x):
         out = torch.empty_like(x)
-        return self._get_plan(x.device).forward(x, self.param_source(), out=out)
+        if self.training:
+            self._fwd_calls += 1           # the masks are keyed on (seed, step, element): a fresh draw per call
+        return self._get_plan(x.device).forward(x, self.param_source(), out=out, training=self.training,
+                                                step=self._fwd_calls)
 
     def _plan_backward(self, dout, P, accumulate):
         return {0: self._plan.backward(dout, P, accumulate).clone()}

@@ -486,11 +486,16 @@ class GroundlinkPlan:
 
 # ------------------------------------------------------------------------------------------------
 class TransformerLayerPlan:
-    """Post-norm encoder layer (TransformerBaseline.py:24-38): x=LN1(x+MHA(x)); x=LN2(x+W2 relu(W1 x))."""
+    """Post-norm encoder layer (TransformerBaseline.py:24-38): x=LN1(x+Drop(MHA(x))); x=LN2(x+Drop(W2 relu(W1 x))).
+
+    dropout_p (train mode only): the layer's three dropouts -- on the attention probabilities inside the attention kernels
+    (nn.MultiheadAttention(dropout=p), :12-13), dropout1 on the attention block's output (:30), dropout2 on the feedforward
+    output (:35).  All masks are counter-based hashes of (seed + site, step, element), regenerated in the backward."""
 
     def __init__(self, prefix: str, d_model: int, num_heads: int, ffn: int, dtype, device, buf: Optional[Buffers] = None,
-                 tag="tl"):
+                 tag="tl", dropout_p: float = 0.0, seed: int = 0x3A7):
         self.p, self.d, self.h, self.ffn, self.dtype, self.tag = prefix, d_model, num_heads, ffn, dtype, tag
+        self.drop_p, self.seed = float(dropout_p), int(seed)
         self.buf = buf if buf is not None else Buffers(device)
         self.ctx = None
         # the four weight-gradient GEMMs (+ bias sums) hang off the critical dgrad / LayerNorm / attention chain.  They CAN
@@ -538,10 +543,16 @@ class TransformerLayerPlan:
             return
         hip.linear_dgrad(dz, P.w(self.p + wname), dx, act_below=act_below, aux=aux, addend=addend)
 
-    def forward(self, x3: torch.Tensor, P: ParamSource, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def forward(self, x3: torch.Tensor, P: ParamSource, out: Optional[torch.Tensor] = None, training: bool = False,
+                step: int = 0, step_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
         B, T, d = x3.shape
         M = B * T
         g, dt, p, tg = self.buf.get, self.dtype, self.p, self.tag
+        drop = None
+        if training and self.drop_p > 0.0:
+            if self.inference:
+                raise hip.HipError("TransformerLayerPlan: inference mode with training=True")
+            drop = (self.drop_p, self.seed, step, step_dev)
         if self.own_wt:
             pairs = self.wt_pairs(P, M)
             if pairs:
@@ -552,7 +563,7 @@ class TransformerLayerPlan:
                        qkv.view(M, 3 * d))
         attn = g(tg + ".attn", (B, T, d), dt)
         lse = g(tg + ".lse", (B, self.h, T), torch.float32)
-        hip.attention_fwd(qkv, attn, lse, self.h)
+        hip.attention_fwd(qkv, attn, lse, self.h, drop=drop)
         x1 = g(tg + ".x1", (M, d), dt)
         x2 = out if out is not None else g(tg + ".x2", (B, T, d), dt)
         f1 = g(tg + ".f1", (M, self.ffn), dt)
@@ -572,15 +583,19 @@ class TransformerLayerPlan:
             a = g(tg + ".a", (M, d), dt)
             hip.linear_fwd(attn.view(M, d), P.w(p + "multihead_attention.out_proj.weight"),
                            P.v(p + "multihead_attention.out_proj.bias"), a)
+            if drop:           # dropout1, in place: only the dropped block output is read again (LayerNorm input)
+                hip.dropout(a, a, self.drop_p, self.seed + 1, step, step_dev)
             m1, r1 = g(tg + ".m1", (M,), torch.float32), g(tg + ".r1", (M,), torch.float32)
             hip.layernorm_fwd(a, P.v(p + "norm1.weight"), P.v(p + "norm1.bias"), x1, m1, r1, res=x)
         hip.linear_fwd(x1, P.w(p + "feedforward.0.weight"), P.v(p + "feedforward.0.bias"), f1, act="relu")
         if not (fuse and lin_ln(f1, "feedforward.2.weight", "feedforward.2.bias", "norm2", x1, x2.view(M, d), ".lnws2")):
             f2 = g(tg + ".f2", (M, d), dt)
             hip.linear_fwd(f1, P.w(p + "feedforward.2.weight"), P.v(p + "feedforward.2.bias"), f2)
+            if drop:           # dropout2
+                hip.dropout(f2, f2, self.drop_p, self.seed + 2, step, step_dev)
             m2, r2 = g(tg + ".m2", (M,), torch.float32), g(tg + ".r2", (M,), torch.float32)
             hip.layernorm_fwd(f2, P.v(p + "norm2.weight"), P.v(p + "norm2.bias"), x2.view(M, d), m2, r2, res=x1)
-        self.ctx = (x, qkv, attn, lse, a, x1, m1, r1, f1, f2, m2, r2, B, T)
+        self.ctx = (x, qkv, attn, lse, a, x1, m1, r1, f1, f2, m2, r2, B, T, drop)
         return x2
 
     def ready_order(self) -> List[str]:
@@ -591,7 +606,7 @@ class TransformerLayerPlan:
                                 "multihead_attention.in_proj_weight", "multihead_attention.in_proj_bias")]
 
     def backward(self, dx2: torch.Tensor, P: ParamSource, accumulate=False) -> torch.Tensor:
-        x, qkv, attn, lse, a, x1, m1, r1, f1, f2, m2, r2, B, T = self.ctx
+        x, qkv, attn, lse, a, x1, m1, r1, f1, f2, m2, r2, B, T, drop = self.ctx
         M, d = x.shape
         g, dt, p, tg = self.buf.get, self.dtype, self.p, self.tag
         lnws = self.buf.bytes("ln.ws", hip.layernorm_bwd_workspace_bytes(M, max(d, 1)))
@@ -649,12 +664,17 @@ class TransformerLayerPlan:
         # LN2: d(f2 + x1)
         ds2 = g(tg + ".ds2", (M, d), dt)
         ln_bwd("norm2", dx2.view(M, d), f2, m2, r2, ds2, x1)
+        # ds2 = d(x1 + Drop(f2)): the residual path takes it as is, the feedforward path through dropout2's mask
+        df2 = ds2
+        if drop:
+            df2 = g(tg + ".df2", (M, d), dt)
+            hip.dropout(ds2, df2, drop[0], self.seed + 2, drop[2], drop[3])
 
         def g_ffn2():
-            wgrad(ds2, f1, "feedforward.2.weight", tg + ".ws2", bias=(tg + ".b2", "feedforward.2.bias"))
+            wgrad(df2, f1, "feedforward.2.weight", tg + ".ws2", bias=(tg + ".b2", "feedforward.2.bias"))
         self.branch.run(g_ffn2)
         dz1 = g(tg + ".dz1", (M, self.ffn), dt)
-        self._dgrad(P, ds2, "feedforward.2.weight", dz1, act_below="relu", aux=f1)
+        self._dgrad(P, df2, "feedforward.2.weight", dz1, act_below="relu", aux=f1)
 
         def g_ffn1():
             wgrad(dz1, x1, "feedforward.0.weight", tg + ".ws1", bias=(tg + ".b1", "feedforward.0.bias"))
@@ -664,15 +684,19 @@ class TransformerLayerPlan:
         # LN1: d(a + x)
         ds1 = g(tg + ".ds1", (M, d), dt)
         ln_bwd("norm1", dx1, a, m1, r1, ds1, x)
+        da = ds1                       # d(x + Drop(a)): dropout1's mask on the attention path only
+        if drop:
+            da = g(tg + ".da", (M, d), dt)
+            hip.dropout(ds1, da, drop[0], self.seed + 1, drop[2], drop[3])
 
         def g_out():
-            wgrad(ds1, attn.view(M, d), "multihead_attention.out_proj.weight", tg + ".wso",
+            wgrad(da, attn.view(M, d), "multihead_attention.out_proj.weight", tg + ".wso",
                   bias=(tg + ".bo", "multihead_attention.out_proj.bias"))
         self.branch.run(g_out)
         dattn = g(tg + ".dattn", (B, T, d), dt)
-        self._dgrad(P, ds1, "multihead_attention.out_proj.weight", dattn.view(M, d))
+        self._dgrad(P, da, "multihead_attention.out_proj.weight", dattn.view(M, d))
         dqkv = g(tg + ".dqkv", (B, T, 3 * d), dt)
-        hip.attention_bwd(qkv, attn, dattn, lse, dqkv, self.h)
+        hip.attention_bwd(qkv, attn, dattn, lse, dqkv, self.h, drop=drop)
         dq2 = dqkv.view(M, 3 * d)
 
         def g_in():

@@ -160,6 +160,53 @@ def gen_transformer_layer(TL):
         print("tl", name, float(y.sum()))
 
 
+def gen_transformer_layer_dropout(TL):
+    """TransformerLayer(dropout=0.25) in TRAIN mode (TransformerBaseline.py:8-38): torch's generator draws the masks, hooks
+    record them -- nn.MultiheadAttention is asked for its per-head weights (they are returned AFTER its dropout, so
+    weights / eval-mode probabilities = the multipliers), dropout1 / dropout2 by output / input.  Saved: input, masks, output,
+    all gradients.  Pins WHERE the three dropouts act (oracle/ref_cpu.py::transformer_layer_forward(masks=...))."""
+    d, h, ffn, B, T, p = 32, 4, 64, 2, 9, 0.25
+    layer = TL(d, h, ffn, p, dtype=torch.float64)
+    load_det_state(layer)
+    layer.train()
+    rec = {}
+    layer.multihead_attention.register_forward_pre_hook(
+        lambda m, a, kw: (a, dict(kw, average_attn_weights=False)), with_kwargs=True)
+    layer.multihead_attention.register_forward_hook(lambda m, a, out: rec.__setitem__("w", out[1].detach().clone()))
+    for nm in ("dropout1", "dropout2"):
+        getattr(layer, nm).register_forward_hook(
+            lambda m, a, out, nm=nm: rec.__setitem__(nm, (a[0].detach().clone(), out.detach().clone())))
+    torch.manual_seed(1234)
+    x = det_fill((B, T, d), 7, 1.0, torch.float64).requires_grad_(True)
+    wout = det_fill((B, T, d), 8, 1.0, torch.float64)
+    y = layer(x)
+    (y * wout).sum().backward()
+    # eval-mode probabilities of the same input (no dropout) -> the attention multipliers
+    layer.eval()
+    with torch.no_grad():
+        layer(x)
+    probs = rec["w"].clone()                       # eval pass overwrote rec["w"] with the undropped probabilities
+    layer.train()
+    torch.manual_seed(1234)
+    layer(x)                                       # same seed: the train pass's dropped weights again
+    attn_mult = torch.where(probs > 0, rec["w"] / probs, torch.zeros_like(probs))
+    keep = 1.0 / (1.0 - p)
+    assert ((attn_mult - 0).abs() < 1e-9).logical_or((attn_mult - keep).abs() < 1e-9).all()
+    attn_mult = torch.where(attn_mult > keep / 2, torch.full_like(probs, keep), torch.zeros_like(probs))   # exact values
+    dd = {"meta_torch": np.array(torch.__version__), "p": np.array(p), "x": np_(x), "wout": np_(wout), "y": np_(y),
+          "dx": np_(x.grad), "mask/attn": np_(attn_mult)}
+    for nm, key in (("dropout1", "drop1"), ("dropout2", "drop2")):
+        i, o = rec[nm]
+        m = torch.where(o != 0, torch.full_like(o, keep), torch.zeros_like(o))
+        assert torch.allclose(i * m, o, atol=1e-12)
+        dd["mask/" + key] = np_(m)
+    for k, q in layer.named_parameters():
+        dd["param/" + k] = np_(q)
+        dd["grad/" + k] = np_(q.grad)
+    np.savez_compressed(os.path.join(OUT, "tl_dropout_train.npz"), **dd)
+    print("tl dropout train", float(y.sum()), float(attn_mult.mean()))
+
+
 def gen_groundlink(RLE):
     """Groundlink (src/models/Groundlink.py:19-156) in eval mode (its fc Dropout(0.2) draws from torch's generator in
     train mode and cannot be pinned); outputs, loss through the reference evaluator, gradient norms + slices."""
@@ -293,6 +340,7 @@ def main():
     gen_feedforward(FF, RLE)
     gen_feedforward_options(FF, RLE)
     gen_transformer_layer(TL)
+    gen_transformer_layer_dropout(TL)
     gen_groundlink(RLE)
     gen_loss(RLE)
     gen_checkpoint_analyze(FF, RLE)

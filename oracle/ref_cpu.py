@@ -238,10 +238,12 @@ def layer_norm(x: torch.Tensor, g: torch.Tensor, b: torch.Tensor, eps: float = 1
 
 
 def mha_forward(x: torch.Tensor, in_w: torch.Tensor, in_b: torch.Tensor,
-                out_w: torch.Tensor, out_b: torch.Tensor, num_heads: int) -> torch.Tensor:
-    """nn.MultiheadAttention(batch_first=True) self-attention, no mask, dropout 0
+                out_w: torch.Tensor, out_b: torch.Tensor, num_heads: int,
+                prob_mult: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """nn.MultiheadAttention(batch_first=True) self-attention, no mask
     (TransformerBaseline.py:12-13,29): packed in-proj [3d,d], per-head
-    softmax(QK^T/sqrt(d_h))V, out-proj."""
+    softmax(QK^T/sqrt(d_h))V, out-proj.  prob_mult [B,H,T,T] (train mode, dropout=p at :13): the
+    dropout multipliers (0 or 1/(1-p)) applied to the NORMALISED probabilities before P.V."""
     B, T, d = x.shape
     dh = d // num_heads
     qkv = linear(x, in_w, in_b)                                        # [B,T,3d]
@@ -253,6 +255,8 @@ def mha_forward(x: torch.Tensor, in_w: torch.Tensor, in_b: torch.Tensor,
     s = s - s.max(dim=-1, keepdim=True).values
     p = torch.exp(s)
     p = p / p.sum(dim=-1, keepdim=True)
+    if prob_mult is not None:
+        p = p * prob_mult
     o = (p @ v).transpose(1, 2).reshape(B, T, d)
     return linear(o, out_w, out_b)
 
@@ -266,15 +270,23 @@ TL_KEYS = [  # state_dict names of the reference TransformerLayer
 
 
 def transformer_layer_forward(p: Dict[str, torch.Tensor], x: torch.Tensor, num_heads: int,
-                              prefix: str = "") -> torch.Tensor:
-    """TransformerLayer.forward: TransformerBaseline.py:24-38 (post-norm, ReLU FFN, dropout 0)."""
+                              prefix: str = "", masks: Optional[Dict[str, torch.Tensor]] = None) -> torch.Tensor:
+    """TransformerLayer.forward: TransformerBaseline.py:24-38 (post-norm, ReLU FFN).  masks (train mode with
+    dropout != 0): the multipliers (0 or 1/(1-p)) of the three dropouts -- "attn" [B,H,T,T] on the attention
+    probabilities (:12-13), "drop1" [B,T,d] on the attention block's output (:30), "drop2" [B,T,d] on the
+    feedforward output (:35); None = eval mode / dropout 0."""
     g = lambda k: p[prefix + k]
+    masks = masks or {}
     a = mha_forward(x, g("multihead_attention.in_proj_weight"), g("multihead_attention.in_proj_bias"),
                     g("multihead_attention.out_proj.weight"), g("multihead_attention.out_proj.bias"),
-                    num_heads)
+                    num_heads, prob_mult=masks.get("attn"))
+    if "drop1" in masks:
+        a = a * masks["drop1"]
     x = layer_norm(x + a, g("norm1.weight"), g("norm1.bias"))
     f = linear(act("relu", linear(x, g("feedforward.0.weight"), g("feedforward.0.bias"))),
                g("feedforward.2.weight"), g("feedforward.2.bias"))
+    if "drop2" in masks:
+        f = f * masks["drop2"]
     return layer_norm(x + f, g("norm2.weight"), g("norm2.bias"))
 
 

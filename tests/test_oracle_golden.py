@@ -112,6 +112,30 @@ def test_transformer_layer_matches_reference(golden_dir, name, d, h, ffn, B, T, 
         close(p.grad.reshape(-1)[:64], g["gslice/" + k], rtol=rt * 30, atol=rt * 30 * float(g["gnorm/" + k]))
 
 
+def test_transformer_layer_train_mode_dropout_matches_reference(golden_dir):
+    """TransformerLayer(dropout=0.25).train() of the REAL class with the masks torch drew (recorded by hooks,
+    oracle/make_golden.py::gen_transformer_layer_dropout): the restatement applies the three multipliers where the
+    reference does -- on the normalised attention probabilities, on the attention block's output, on the feedforward
+    output -- so output and every gradient agree to float64 rounding"""
+    g = {k: torch.from_numpy(np.asarray(v)) for k, v in load(golden_dir, "tl_dropout_train.npz").items() if k != "meta_torch"}
+    p = float(g["p"])
+    masks = {k: g["mask/" + k] for k in ("attn", "drop1", "drop2")}
+    for m in masks.values():
+        vals = torch.unique(m)
+        assert len(vals) == 2 and vals[0] == 0 and abs(float(vals[1]) - 1 / (1 - p)) < 1e-12
+        assert 0.6 < float((m != 0).double().mean()) < 0.9
+    sd = {k: g["param/" + k].clone().requires_grad_(True) for k in R.TL_KEYS}
+    x = g["x"].clone().requires_grad_(True)
+    y = R.transformer_layer_forward(sd, x, 4, masks=masks)
+    close(y.detach(), g["y"], rtol=1e-10)
+    (y * g["wout"]).sum().backward()
+    close(x.grad, g["dx"], rtol=1e-9)
+    for k, q in sd.items():
+        close(q.grad, g["grad/" + k], rtol=1e-9, atol=1e-11 * float(g["grad/" + k].norm()))
+    # and the masks matter: eval-mode arithmetic is a different function
+    assert (R.transformer_layer_forward(sd, x, 4).detach() - g["y"]).abs().max() > 1e-2
+
+
 @pytest.mark.parametrize("subset", list(LOSS_SUBSETS))
 def test_loss_evaluator_matches_reference(golden_dir, subset):
     g = load(golden_dir, "loss_cases.npz")
