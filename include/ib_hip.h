@@ -246,6 +246,15 @@ int ib_optim_step_sources(int opt, float* p, const float* g, float* s1, float* s
  * COMPLETED steps, the kernel uses *step_dev + 1 and its last-exiting block publishes it (no separate counter launch). */
 
 /* ---- diffusion wrapper [BUILD-DEFINED]: DDPM q_sample, DDIM eta=0 update, table gathers ----- */
+/* ---- tiny matrix products: C[M,N] (+)= sum_k A(m,k) B(k,n), A(m,k) = A[m*sam + k*sak], B(k,n) = B[k*sbk + n*sbn], each
+ * operand with its own storage dtype (IB_F32 / IB_BF16), fp32 accumulation in a fixed order.  The frame-embedding
+ * projection of the transformer denoiser and its two gradients (nn.Embedding(window, 30) concatenated on the feature
+ * dim, TransformerBaseline.py:41-48,119-126, then the input Linear): [50,30] x [30,512] problems on an unaligned column
+ * slice of in_proj.weight.  M*N <= 2^22, K <= 2^16, M*N*K <= 2^28; IB_E_UNSUPPORTED beyond. */
+int ib_tiny_matmul(const void* A, int a_dtype, int64_t sam, int64_t sak, const void* B, int b_dtype, int64_t sbk,
+                   int64_t sbn, void* C, int c_dtype, int64_t ldc, int accumulate, int64_t M, int64_t N, int64_t K,
+                   ib_stream_t stream);
+
 /* out[b, :] = table[idx[b], :]  (timestep-embedding rows; table computed in float64 on the host,
  * cast once).  idx int64. */
 int ib_gather_rows(const float* table, const int64_t* idx, void* out, int64_t B, int64_t dim,

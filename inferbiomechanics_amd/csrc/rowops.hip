@@ -618,3 +618,67 @@ extern "C" int ib_cast2d(const void* src, int64_t lds, int src_dtype, void* dst,
 extern "C" int ib_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, ib_stream_t stream) {
   return ib_cast2d(src, n, src_dtype, dst, n, dst_dtype, 1, n, stream);
 }
+
+// ---- tiny matrix products ------------------------------------------------------------------------------------------
+// C[M,N] (+)= sum_k A(m,k) B(k,n) with every operand addressed by two strides (so transposes and column slices of a
+// weight matrix are views) and its own storage type.  For the frame-embedding projection of the transformer denoiser and
+// its two gradients (TransformerBaseline.py:41-48,119-126 pattern: [T=50, 30] x [30, 512]): far below one MFMA tile
+// pair, and the 30-column slice of in_proj.weight is not 16-byte aligned, so the tiled kernels took 20 - 58 us of
+// scalar loads for 1.5 MFLOP.  K >= 64: one wave per output element (lanes stride the reduction, butterfly sum);
+// shorter reductions: one thread per output element.  fp32 accumulation in a fixed order (bitwise reproducible).
+namespace {
+__device__ __forceinline__ float tiny_ld(const void* p, int dtype, int64_t i) {
+  return dtype == IB_F32 ? static_cast<const float*>(p)[i] : static_cast<float>(static_cast<const bf16_t*>(p)[i]);
+}
+__device__ __forceinline__ void tiny_st(void* p, int dtype, int64_t i, float v, int accumulate) {
+  if (dtype == IB_F32) {
+    float* q = static_cast<float*>(p) + i;
+    *q = accumulate ? *q + v : v;
+  } else {
+    bf16_t* q = static_cast<bf16_t*>(p) + i;
+    *q = static_cast<bf16_t>(accumulate ? static_cast<float>(*q) + v : v);
+  }
+}
+template <bool WAVE>
+__global__ __launch_bounds__(256) void tiny_matmul_kernel(const void* __restrict__ A, int ad, int64_t sam, int64_t sak,
+                                                          const void* __restrict__ B, int bd, int64_t sbk, int64_t sbn,
+                                                          void* __restrict__ C, int cd, int64_t ldc, int accumulate, int M,
+                                                          int N, int K) {
+  const int total = M * N;
+  if (WAVE) {
+    const int lane = threadIdx.x & 63;
+    for (int o = blockIdx.x * 4 + (threadIdx.x >> 6); o < total; o += gridDim.x * 4) {
+      const int m = o / N, n = o - m * N;
+      float acc = 0.f;
+      for (int k = lane; k < K; k += 64) acc += tiny_ld(A, ad, m * sam + k * sak) * tiny_ld(B, bd, k * sbk + n * sbn);
+      acc = ib_wave_sum(acc);
+      if (lane == 0) tiny_st(C, cd, (int64_t)m * ldc + n, acc, accumulate);
+    }
+  } else {
+    for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < total; o += gridDim.x * blockDim.x) {
+      const int m = o / N, n = o - m * N;
+      float acc = 0.f;
+      for (int k = 0; k < K; ++k) acc += tiny_ld(A, ad, m * sam + k * sak) * tiny_ld(B, bd, k * sbk + n * sbn);
+      tiny_st(C, cd, (int64_t)m * ldc + n, acc, accumulate);
+    }
+  }
+}
+}  // namespace
+
+extern "C" int ib_tiny_matmul(const void* A, int a_dtype, int64_t sam, int64_t sak, const void* B, int b_dtype, int64_t sbk,
+                              int64_t sbn, void* C, int c_dtype, int64_t ldc, int accumulate, int64_t M, int64_t N, int64_t K,
+                              ib_stream_t stream) {
+  if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || ldc < N) return IB_E_ARG;
+  for (int d : {a_dtype, b_dtype, c_dtype})
+    if (d != IB_F32 && d != IB_BF16) return IB_E_DTYPE;
+  if (M * N > (1 << 22) || K > (1 << 16) || M * N * K > ((int64_t)1 << 28)) return IB_E_UNSUPPORTED;   // "tiny" only
+  hipStream_t s = ib_s(stream);
+  if (K >= 64)
+    hipLaunchKernelGGL((tiny_matmul_kernel<true>), dim3(ib_grid_1d(M * N, 4, 256 * 16)), dim3(256), 0, s, A, a_dtype, sam, sak, B,
+                       b_dtype, sbk, sbn, C, c_dtype, ldc, accumulate, (int)M, (int)N, (int)K);
+  else
+    hipLaunchKernelGGL((tiny_matmul_kernel<false>), dim3(ib_grid_1d(M * N, 256, 256 * 16)), dim3(256), 0, s, A, a_dtype, sam, sak,
+                       B, b_dtype, sbk, sbn, C, c_dtype, ldc, accumulate, (int)M, (int)N, (int)K);
+  IB_CHECK_LAUNCH();
+  return IB_OK;
+}

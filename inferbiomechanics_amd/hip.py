@@ -69,6 +69,8 @@ _SIGS = {
                                     _vp, _i64, _i64, _i64, _i64, _c.c_int, _vp]),
     "ib_attention_fwd": (_c.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _c.c_int, _vp]),
     "ib_attention_bwd": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _c.c_int, _vp]),
+    "ib_tiny_matmul": (_c.c_int, [_vp, _c.c_int, _i64, _i64, _vp, _c.c_int, _i64, _i64, _vp, _c.c_int, _i64, _c.c_int, _i64, _i64,
+                                  _i64, _vp]),
     "ib_attention_fwd_drop": (_c.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _c.c_float, _c.c_uint32, _c.c_int32, _vp,
                                          _c.c_int, _vp]),
     "ib_attention_bwd_drop": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _c.c_float, _c.c_uint32, _c.c_int32,
@@ -881,6 +883,23 @@ def layernorm_bwd_reduce(workspace, dgamma, dbeta, M, N, accumulate=False):
     wsb = workspace.numel() * workspace.element_size()
     _check(lib().ib_layernorm_bwd_reduce(_ptr(workspace), wsb, _ptr(dgamma), _ptr(dbeta), int(accumulate), int(M), int(N),
                                          stream_ptr()), "ib_layernorm_bwd_reduce")
+
+
+def tiny_matmul(A, B, C, accumulate=False):
+    """C[M,N] (+)= A[M,K] . B[K,N] for problems far below a GEMM tile; A, B, C are 2-D views with ANY strides for A and B
+    (transposes, column slices) and a unit column stride for C, each fp32 or bf16"""
+    for t, n in ((A, "A"), (B, "B"), (C, "C")):
+        _req(t, n, None, 2)
+        if t.dtype not in (torch.float32, torch.bfloat16):
+            raise HipError(f"tiny_matmul: {n} must be fp32 or bf16")
+    M, K = A.shape
+    K2, N = B.shape
+    if K2 != K or tuple(C.shape) != (M, N) or C.stride(1) != 1:
+        raise HipError(f"tiny_matmul: shapes {tuple(A.shape)} x {tuple(B.shape)} -> {tuple(C.shape)} (C rows contiguous)")
+    _check(lib().ib_tiny_matmul(_ptr(A), dtype_code(A.dtype), A.stride(0), A.stride(1), _ptr(B), dtype_code(B.dtype),
+                                B.stride(0), B.stride(1), _ptr(C), dtype_code(C.dtype), C.stride(0), int(accumulate), M, N, K,
+                                stream_ptr()), "ib_tiny_matmul")
+    return C
 
 
 # --------------------------------------------------------------------------------------------

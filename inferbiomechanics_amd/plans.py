@@ -1058,6 +1058,13 @@ class DenoiserTransformerPlan:
         self._posproj_T = None
         self.fuse_reduce_into_optimizer = False         # set by HipTrainer for single-GPU steps
         self.pending_sources = None
+        # the step's head and tail are chains of SMALL launches (time-MLP, frame-embedding projection, weight transposes;
+        # their gradients): latency-bound and mutually independent, so they run as sibling branches of the main stream
+        # (parallel branches of the captured graph).  The trainer switches them off under data parallelism.
+        self.br_time = Branch(device, name="tr_time")
+        self.br_thid = Branch(device, name="tr_thid")
+        self.br_pos = Branch(device, name="tr_pos")
+        self.br_wt = Branch(device, name="tr_wt")
 
     def flush_each_layer(self, on: bool):
         """overlapped data-parallel steps: keep the layers' side streams, hand completed gradient buckets to the trainer at
@@ -1081,7 +1088,7 @@ class DenoiserTransformerPlan:
         w_in = P.w("in_proj.weight")
         pos = P.w("temporal_embedding.embedding.weight")[:T]
         posproj = self.buf.get("dt.posproj", (T, self.d), self.dtype)
-        hip.linear_fwd(pos, w_in[:, D:], None, posproj)
+        hip.tiny_matmul(pos, w_in[:, D:].t(), posproj)
         self._posproj_T = T
         self._e_all = None
         if table is not None and not os.environ.get("IB_NO_TIME_TABLE"):
@@ -1097,7 +1104,7 @@ class DenoiserTransformerPlan:
     inference = False
 
     def branches(self) -> List[Branch]:
-        return [lp.branch for lp in self.layers]
+        return [lp.branch for lp in self.layers] + [self.br_time, self.br_thid, self.br_pos, self.br_wt]
 
     def forward(self, x3: torch.Tensor, t: torch.Tensor, table: torch.Tensor, P: ParamSource,
                 out: Optional[torch.Tensor] = None, BT: Optional[Tuple[int, int]] = None) -> torch.Tensor:
@@ -1109,28 +1116,35 @@ class DenoiserTransformerPlan:
         M = B * T
         x2 = x3 if x3.dim() == 2 else x3.view(M, D)
         g, dt = self.buf.get, self.dtype
-        if self.inference and self._e_all is not None:
-            e = g("dt.e_rows", (B, self.d), dt)
-            hip.gather_rows(self._e_all, t, e)                               # rows of the per-timestep table
-        else:
-            e = self.time.forward(t, table, P)                               # [B, d]
         w_in = P.w("in_proj.weight")                                         # [d, D + Pd]
         pos = P.w("temporal_embedding.embedding.weight")[:T]                 # [T, Pd]
         posproj = g("dt.posproj", (T, self.d), dt)
+        pairs = [pr for lp in self.layers for pr in lp.wt_pairs(P, M)]
+        if self.inference and self._e_all is not None:
+            e = g("dt.e_rows", (B, self.d), dt)
+            hip.gather_rows(self._e_all, t, e)                               # rows of the per-timestep table
+        elif self.inference:
+            e = self.time.forward(t, table, P)                               # [B, d]
+        else:
+            # training: the time-MLP and the weight transposes (read by the backward only) beside the projection below
+            box = []
+            self.br_time.run(lambda: box.append(self.time.forward(t, table, P)))
+            e = box[0]
+            if pairs:
+                self.br_wt.run(lambda: hip.transpose_multi(pairs))
         if not (self.inference and self._posproj_T == T):    # frozen weights (sampling): projected once per sample()
-            hip.linear_fwd(pos, w_in[:, D:], None, posproj)
+            hip.tiny_matmul(pos, w_in[:, D:].t(), posproj)
+        self.br_time.join()
         h0 = g("dt.h0", (B, T, self.d), dt)
         hip.linear_fwd(x2, w_in[:, :D], P.v("in_proj.bias"), h0.view(M, self.d), add_div=e,
                        add_mod=posproj, seg=T)
-        pairs = [pr for lp in self.layers for pr in lp.wt_pairs(P, M)]
-        if pairs:
-            hip.transpose_multi(pairs)
         h = h0
         for lp in self.layers:
             h = lp.forward(h, P)
         out = out if out is not None else g("dt.out", (B, T, D), dt)
         hip.linear_fwd(h.view(M, self.d), P.w("out_proj.weight"), P.v("out_proj.bias"),
                        out if out.dim() == 2 else out.view(M, D))
+        self.br_wt.join()
         self.ctx = (x2, pos, h, B, T)
         return out
 
@@ -1138,7 +1152,7 @@ class DenoiserTransformerPlan:
         o = ["out_proj.weight", "out_proj.bias"]
         for lp in reversed(self.layers):
             o += lp.ready_order()
-        return o + ["in_proj.bias", "in_proj.weight", "temporal_embedding.embedding.weight"] + TimeMLPPlan.ready_order()
+        return o + ["in_proj.bias"] + TimeMLPPlan.ready_order() + ["temporal_embedding.embedding.weight", "in_proj.weight"]
 
     def backward(self, dout3: torch.Tensor, P: ParamSource, accumulate=False):
         x, pos, hlast, B, T = self.ctx
@@ -1164,29 +1178,33 @@ class DenoiserTransformerPlan:
             dh = lp.backward(dh, P, accumulate)
         dz0 = dh.view(M, self.d)
         w_in, gw_in = P.w("in_proj.weight"), P.g("in_proj.weight")
-        _wgrad(self.buf, dz0, x, gw_in[:, :D], accumulate)
+        # tail: three chains of small launches hang off dz0 -- the time-MLP's two halves and the frame-embedding gradients
+        # -- beside the one real GEMM (the input projection's weight gradient): sibling branches
         de32 = g("dt.de32", (B, self.d), torch.float32)
-        hip.segment_colsum(dz0, de32, seg=T, mode=0)                          # d e[window]
-        _colsum(self.buf, "dt.bi", de32, P.g("in_proj.bias"), accumulate)
-        P.ready("in_proj.bias")
-        dpp32 = g("dt.dpp32", (T, self.d), torch.float32)
-        hip.segment_colsum(dz0, dpp32, seg=T, mode=1)                         # d posproj[frame]
-        dpp = _as_dtype(self.buf, "dt.dpp", dpp32, dt)
-        _wgrad(self.buf, dpp, pos, gw_in[:, D:], accumulate)
-        P.ready("in_proj.weight")
-        # d embedding table rows [:T] = dposproj . W_p   (fp32 result via a cast of the compute-dtype GEMM)
-        dpos = g("dt.dpos", (T, self.Pd), dt)
-        hip.linear_dgrad(dpp, w_in[:, D:], dpos)
+        de_lp = g("dt.de_lp", (B, self.d), dt) if dt == torch.bfloat16 else None
+        hip.segment_colsum(dz0, de32, seg=T, mode=0, out_bf16=de_lp)          # d e[window]
+
+        def t_out():
+            _colsum(self.buf, "dt.bi", de32, P.g("in_proj.bias"), accumulate)
+            P.ready("in_proj.bias")
+            self.time.backward_out_layer(de32, de_lp, P, accumulate)
+        self.br_time.run(t_out)
+        self.br_thid.run(lambda: self.time.backward_hidden(de32, de_lp, P, accumulate))
         gpos = P.g("temporal_embedding.embedding.weight")
         if gpos.shape[0] != T:
             raise hip.HipError(f"window length {T} != frame-embedding table rows {gpos.shape[0]}")
-        dpos32 = dpos
-        if dt != torch.float32:
-            dpos32 = g("dt.dpos32", (T, self.Pd), torch.float32)
-            hip.cast2d(dpos, dpos32)
-        hip.segment_colsum(dpos32, gpos, seg=1, mode=0, accumulate=accumulate)   # row-wise copy / accumulate
-        P.ready("temporal_embedding.embedding.weight")
-        self.time.backward(de32, P, accumulate)
+
+        def t_pos():
+            dpp32 = g("dt.dpp32", (T, self.d), torch.float32)
+            hip.segment_colsum(dz0, dpp32, seg=T, mode=1)                     # d posproj[frame], fp32
+            # d in_proj.weight[:, D:] = dposproj^T . pos and d embedding rows = dposproj . W_p: [T, 30]-sized products
+            hip.tiny_matmul(dpp32.t(), pos, gw_in[:, D:], accumulate=accumulate)
+            hip.tiny_matmul(dpp32, w_in[:, D:], gpos, accumulate=accumulate)
+            P.ready("temporal_embedding.embedding.weight")
+        self.br_pos.run(t_pos)
+        _wgrad(self.buf, dz0, x, gw_in[:, :D], accumulate)
+        self.br_time.join(); self.br_thid.join(); self.br_pos.join()
+        P.ready("in_proj.weight")
         for lp in self.layers:
             lp.branch.join()
         P.flush()

@@ -539,3 +539,31 @@ def test_small_m_kernels_seeded_shape_sweep(hip):
         dx = torch.full((M, Kc), 7.0, dtype=bf, device=DEV)
         hip.linear_dgrad(dz, w2, dx)
         close(dx, dz.double() @ w2.double(), TIGHT[bf], f"dgrad {M}x{N}x{Kc}")
+
+
+@pytest.mark.parametrize("M,N,K", [(50, 512, 30), (50, 30, 512), (512, 30, 50), (1, 1, 1), (7, 3, 64), (3, 5, 63), (200, 30, 1000)])
+def test_tiny_matmul_strided_views(M, N, K):
+    """C (+)= A . B with A, B any 2-D views (transposes, unaligned column slices of a wider matrix), mixed fp32 / bf16 storage:
+    the frame-embedding projection of the transformer denoiser and its two gradients"""
+    from inferbiomechanics_amd import hip
+    g = torch.Generator().manual_seed(M * 131 + N * 7 + K)
+    wide = torch.randn(N, 300 + K, generator=g).to(torch.bfloat16).cuda()        # B = a column slice, transposed
+    Bv = wide[:, 300:].t()                                                        # [K, N], strides (1, 300 + K)
+    A32 = torch.randn(K, M, generator=g).cuda().t()                               # [M, K] transposed view, fp32
+    for A in (A32, A32.to(torch.bfloat16)):
+        for cdt in (torch.float32, torch.bfloat16):
+            big = torch.randn(M, N + 5, generator=g).to(cdt).cuda()
+            C = big[:, 2:2 + N]                                                   # rows of a wider matrix
+            before = big.clone()
+            exp = A.double().cpu() @ Bv.double().cpu()
+            hip.tiny_matmul(A, Bv, C)
+            tol = 1e-5 if cdt == torch.float32 else 1e-2
+            assert (C.double().cpu() - exp).abs().max() <= tol * max(1.0, exp.abs().max())
+            hip.tiny_matmul(A, Bv, C, accumulate=True)
+            assert (C.double().cpu() - 2 * exp).abs().max() <= 2 * tol * max(1.0, exp.abs().max())
+            assert torch.equal(big[:, :2], before[:, :2]) and torch.equal(big[:, 2 + N:], before[:, 2 + N:])
+    again = torch.empty(M, N, device="cuda")
+    first = hip.tiny_matmul(A32, Bv, torch.empty(M, N, device="cuda")).clone()
+    assert torch.equal(hip.tiny_matmul(A32, Bv, again), first)                    # fixed summation order
+    with pytest.raises(hip.HipError):
+        hip.tiny_matmul(A32, Bv[:, :1].expand(K, N) if N > 1 else Bv, torch.empty(M + 1, N, device="cuda"))
