@@ -498,10 +498,14 @@ class TransformerLayerPlan:
         self.drop_p, self.seed = float(dropout_p), int(seed)
         self.buf = buf if buf is not None else Buffers(device)
         self.ctx = None
-        # the four weight-gradient GEMMs (+ bias sums) hang off the critical dgrad / LayerNorm / attention chain.  They CAN
-        # run on a side stream of the layer (IB_LAYER_BRANCH=1), but every one of these launches fills the chip on its own and
-        # each fork / join of the captured graph costs: inline is faster (B = 256, T = 50: 3.059 vs 3.123 ms per step)
-        self.branch = Branch(device, enabled=bool(os.environ.get("IB_LAYER_BRANCH")), name="layer")
+        # the four weight-gradient GEMMs (+ bias sums) hang off the critical dgrad / LayerNorm / attention chain.  One GPU,
+        # large batches: they are ONE grouped launch per layer (csrc/gemm_tn.hip), issued on a side stream of the layer so the
+        # next layer's chain starts beside it (B = 256, T = 50, same box: 2.45 ms inline, 2.41 ms forked; joined once at the
+        # end of the whole backward).  Everything else runs them inline: as separate launches on a side stream they were
+        # slower (3.059 vs 3.123 ms with the round-1 kernels), and a data-parallel layer joins right away for its bucket.
+        # IB_LAYER_BRANCH=1 forces the side stream for every shape, IB_NO_LAYER_BRANCH=1 forces inline.
+        self.branch = Branch(device, enabled=not os.environ.get("IB_NO_LAYER_BRANCH"), name="layer")
+        self._always_fork = bool(os.environ.get("IB_LAYER_BRANCH"))
         # transposed bf16 copies of the four weight matrices: the dgrad GEMMs of large batches read them k-contiguously
         # (ib_linear_dgrad_wt -> the 256 x 128 LDS-DMA kernel of csrc/gemm_nt.hip); refreshed once per forward
         self._wt: Dict[str, torch.Tensor] = {}
@@ -621,6 +625,8 @@ class TransformerLayerPlan:
         if local:
             defer, later = [], []
         group = [] if (defer is not None and dt == torch.bfloat16 and not os.environ.get("IB_NO_LAYER_GROUP")) else None
+        fork = self._always_fork or (group is not None and not local and not self.flush_on_exit and M >= 4096)
+        side = self.branch.run if fork else (lambda fn: fn())
 
         def wgrad(dz_, x_, name, tag, bias=None):
             """bias = (workspace tag, bias parameter name): with the grouped launch the bias gradient's partial sums come
@@ -672,13 +678,13 @@ class TransformerLayerPlan:
 
         def g_ffn2():
             wgrad(df2, f1, "feedforward.2.weight", tg + ".ws2", bias=(tg + ".b2", "feedforward.2.bias"))
-        self.branch.run(g_ffn2)
+        side(g_ffn2)
         dz1 = g(tg + ".dz1", (M, self.ffn), dt)
         self._dgrad(P, df2, "feedforward.2.weight", dz1, act_below="relu", aux=f1)
 
         def g_ffn1():
             wgrad(dz1, x1, "feedforward.0.weight", tg + ".ws1", bias=(tg + ".b1", "feedforward.0.bias"))
-        self.branch.run(g_ffn1)
+        side(g_ffn1)
         dx1 = g(tg + ".dx1", (M, d), dt)
         self._dgrad(P, dz1, "feedforward.0.weight", dx1, addend=ds2)       # + residual path
         # LN1: d(a + x)
@@ -692,7 +698,7 @@ class TransformerLayerPlan:
         def g_out():
             wgrad(da, attn.view(M, d), "multihead_attention.out_proj.weight", tg + ".wso",
                   bias=(tg + ".bo", "multihead_attention.out_proj.bias"))
-        self.branch.run(g_out)
+        side(g_out)
         dattn = g(tg + ".dattn", (B, T, d), dt)
         self._dgrad(P, da, "multihead_attention.out_proj.weight", dattn.view(M, d))
         dqkv = g(tg + ".dqkv", (B, T, 3 * d), dt)
@@ -702,7 +708,7 @@ class TransformerLayerPlan:
         def g_in():
             wgrad(dq2, x, "multihead_attention.in_proj_weight", tg + ".wsi",
                   bias=(tg + ".bi", "multihead_attention.in_proj_bias"))
-        self.branch.run(g_in)
+        side(g_in)
         dx = g(tg + ".dx", (B, T, d), dt)
         self._dgrad(P, dq2, "multihead_attention.in_proj_weight", dx.view(M, d), addend=ds1)
         if group:
@@ -713,8 +719,10 @@ class TransformerLayerPlan:
                     part = self.buf.get(btag + ".colsum", ((pr[0].shape[0] + 127) // 128, pr[0].shape[1]), torch.float32)
                     hip.segment_colsum(pr[0], part, seg=128, mode=0)
                     later.append((part, part.shape[0], P.g(p + bname)))
-            self.branch.run(run_group)
-        if local:
+                if local:     # reads the slabs of the launch above: same stream
+                    hip.step_reduce_parts(defer, [(part, rows, dst) for part, rows, dst in later])
+            side(run_group)
+        elif local:
             hip.step_reduce_parts(defer, [(part, rows, dst) for part, rows, dst in later])
         if self.join_on_exit or self.flush_on_exit:
             self.branch.join()
