@@ -542,10 +542,9 @@ def test_small_m_kernels_seeded_shape_sweep(hip):
 
 
 @pytest.mark.parametrize("M,N,K", [(50, 512, 30), (50, 30, 512), (512, 30, 50), (1, 1, 1), (7, 3, 64), (3, 5, 63), (200, 30, 1000)])
-def test_tiny_matmul_strided_views(M, N, K):
+def test_tiny_matmul_strided_views(hip, M, N, K):
     """C (+)= A . B with A, B any 2-D views (transposes, unaligned column slices of a wider matrix), mixed fp32 / bf16 storage:
     the frame-embedding projection of the transformer denoiser and its two gradients"""
-    from inferbiomechanics_amd import hip
     g = torch.Generator().manual_seed(M * 131 + N * 7 + K)
     wide = torch.randn(N, 300 + K, generator=g).to(torch.bfloat16).cuda()        # B = a column slice, transposed
     Bv = wide[:, 300:].t()                                                        # [K, N], strides (1, 300 + K)

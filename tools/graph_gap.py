@@ -39,6 +39,31 @@ def main():
             g.replay()
         torch.cuda.synchronize()
         out[name] = (time.perf_counter() - t0) / reps / n * 1e6
+    # fork / join: N x [main kernel; fork a side stream with one kernel beside one main kernel; join]
+    side = torch.cuda.Stream()
+    ev_f, ev_j = [torch.cuda.Event() for _ in range(n)], [torch.cuda.Event() for _ in range(n)]
+    a2, b2 = torch.zeros(64, device=dev), torch.zeros(64, dtype=torch.bfloat16, device=dev)
+    s = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            for i in range(n):
+                hip.cast(a, b)
+                ev_f[i].record(s)
+                with torch.cuda.stream(side):
+                    side.wait_event(ev_f[i])
+                    hip.cast(a2, b2)
+                    ev_j[i].record(side)
+                hip.cast(a, b)
+                s.wait_event(ev_j[i])
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        g.replay()
+    torch.cuda.synchronize()
+    out["fork_join(3 casts)"] = (time.perf_counter() - t0) / 20 / n * 1e6
     keys = ("HIP_FORCE_DEV_KERNARG", "DEBUG_CLR_GRAPH_PACKET_CAPTURE", "AMD_OPT_FLUSH", "DEBUG_HIP_GRAPH_BATCH_SIZE",
             "DEBUG_HIP_FORCE_GRAPH_QUEUES", "GPU_FLUSH_ON_EXECUTION", "DEBUG_CLR_KERNARG_HDP_FLUSH_WA")
     env = {k: os.environ[k] for k in keys if k in os.environ}
