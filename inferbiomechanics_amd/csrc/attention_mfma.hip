@@ -21,6 +21,7 @@
 //   mfma(A, B, C): A[row = lane%16][k = 8*(lane/16)+j], B[k = 8*(lane/16)+j][col = lane%16],
 //   D[row = 4*(lane/16)+r][col = lane%16].
 #include "ib_common.h"
+#include <algorithm>
 
 namespace {
 
@@ -74,24 +75,28 @@ __device__ __forceinline__ void stage_image(bf16_t* img, const bf16_t* __restric
 // (ib_common.h) applied to the P registers after the row sum; the backward regenerates it
 template <int NT, bool DROP>
 __global__ __launch_bounds__(256) void attn_fwd_mfma(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                     float* __restrict__ lse, int T, int H, float scale, IbAttnDrop drop) {
+                                                     float* __restrict__ lse, int T, int H, float scale, IbAttnDrop drop,
+                                                     int qsplit) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr int Tp = NT * 16;
   bf16_t* Qs = reinterpret_cast<bf16_t*>(smem_raw);
   bf16_t* Ks = Qs + Tp * LDR;
   bf16_t* Vs = Ks + Tp * LDR;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
-  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  // qsplit > 1 (few windows: the sampler at B = 1 / 16 is 8 / 128 (window, head) pairs on 256 CUs): `qsplit` workgroups
+  // share one (window, head), each stages K and V and takes every qsplit-th group of four query blocks
+  const int bh = (int)blockIdx.x / qsplit, part = (int)blockIdx.x % qsplit;
+  const int b = bh / H, h = bh % H;
   const int d = H * 64;
   const bf16_t* base = qkv + (int64_t)b * T * 3 * d + h * 64;
   stage_image(Qs, base, 3 * d, T, Tp);
   stage_image(Ks, base + d, 3 * d, T, Tp);
   stage_image(Vs, base + 2 * d, 3 * d, T, Tp);
   uint32_t dkey = 0;
-  if constexpr (DROP) dkey = ib_attn_drop_key(drop, blockIdx.x);
+  if constexpr (DROP) dkey = ib_attn_drop_key(drop, bh);
   __syncthreads();
   const int nqb = (T + 15) >> 4;
-  for (int qb = wave; qb < nqb; qb += 4) {
+  for (int qb = part * 4 + wave; qb < nqb; qb += 4 * qsplit) {
     const int q = qb * 16 + (lane & 15);
     bf16x8_t qf[2] = {row_frag(Qs, q, 0, lane), row_frag(Qs, q, 1, lane)};
     f32x4_t s[NT];
@@ -310,8 +315,12 @@ int launch_fwd2(const void* qkv, void* out, float* lse, int64_t B, int64_t T, in
   const size_t lds = (size_t)3 * NT * 16 * LDR * 2;
   auto k = attn_fwd_mfma<NT, DROP>;
   if (ensure_lds(k, lds, g_lds_f[DROP][slot]) != IB_OK) return IB_E_LAUNCH;
-  hipLaunchKernelGGL(k, dim3((unsigned)(B * H)), dim3(256), lds, s, (const bf16_t*)qkv, (bf16_t*)out, lse, (int)T, (int)H,
-                     scale, a);
+  // fewer (window, head) pairs than CUs: split the query blocks of a pair over several workgroups
+  const int groups = (int)((T + 63) / 64);                     // groups of four query blocks (one per wave)
+  int qsplit = 1;
+  if (B * H < 256) qsplit = (int)std::min<int64_t>(groups, std::max<int64_t>(1, 256 / (B * H)));
+  hipLaunchKernelGGL(k, dim3((unsigned)(B * H * qsplit)), dim3(256), lds, s, (const bf16_t*)qkv, (bf16_t*)out, lse, (int)T,
+                     (int)H, scale, a, qsplit);
   IB_CHECK_LAUNCH();
   return IB_OK;
 }
