@@ -578,6 +578,9 @@ class TransformerLayerPlan:
             w = P.w(p + wname)
             if w.shape[1] < 1024:      # measured at M = 3200: K = 2048 43.6 -> 30.5 us fused, K = 512 20.4 -> 26.2 (two
                 return False           # short kernels instead of two short kernels: nothing to split)
+            if M >= int(os.environ.get("IB_LINLN_MAX_M", "4096")) and not os.environ.get("IB_NO_NT"):
+                return False           # large batches fill the chip without a K split: the 256 x 128 NT kernel + LayerNorm
+                                       # (M = 51200: 120 + 30 us against 235 us fused)
             ws = self.buf.bytes(tg + wtag, int(hip.lib().ib_linear_ln_fwd_workspace(M, w.shape[0], w.shape[1])))
             return hip.linear_ln_fwd(inp, w, P.v(p + bname), res, P.v(p + nname + ".weight"), P.v(p + nname + ".bias"), y, ws)
 
