@@ -62,12 +62,23 @@ __device__ __forceinline__ float group4_sum(float v) {
 }
 
 // stage one [T][64] slice (row stride `ld` elements in global memory) into a [Tp][LDR] LDS image
+// Eight pieces per thread are requested before the first is stored: as a rolled loop (one load, one LDS store per trip) the
+// staging of a 200-frame head was 14 dependent memory round trips per image -- most of the kernel's time at T = 200.
 __device__ __forceinline__ void stage_image(bf16_t* img, const bf16_t* __restrict__ src, int64_t ld, int T, int Tp) {
-  for (int i = threadIdx.x; i < Tp * 8; i += blockDim.x) {
-    const int r = i >> 3, c = i & 7;
-    uint4 v = make_uint4(0u, 0u, 0u, 0u);
-    if (r < T) v = *reinterpret_cast<const uint4*>(src + (int64_t)r * ld + c * 8);
-    *reinterpret_cast<uint4*>(img + r * LDR + c * 8) = v;
+  constexpr int U = 8;
+  for (int i0 = threadIdx.x; i0 < Tp * 8; i0 += 256 * U) {
+    uint4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = i0 + 256 * u, r = i >> 3, c = i & 7;
+      v[u] = make_uint4(0u, 0u, 0u, 0u);
+      if (r < T) v[u] = *reinterpret_cast<const uint4*>(src + (int64_t)r * ld + c * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = i0 + 256 * u, r = i >> 3, c = i & 7;
+      if (i < Tp * 8) *reinterpret_cast<uint4*>(img + r * LDR + c * 8) = v[u];
+    }
   }
 }
 
@@ -79,9 +90,8 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(const bf16_t* __restrict__ 
                                                      int qsplit) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr int Tp = NT * 16;
-  bf16_t* Qs = reinterpret_cast<bf16_t*>(smem_raw);
-  bf16_t* Ks = Qs + Tp * LDR;
-  bf16_t* Vs = Ks + Tp * LDR;
+  bf16_t* Ks = reinterpret_cast<bf16_t*>(smem_raw);           // only K and V are staged: a query row is read once, by the
+  bf16_t* Vs = Ks + Tp * LDR;                                  // one lane group that owns it, straight into its fragments
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
   // qsplit > 1 (few windows: the sampler at B = 1 / 16 is 8 / 128 (window, head) pairs on 256 CUs): `qsplit` workgroups
   // share one (window, head), each stages K and V and takes every qsplit-th group of four query blocks
@@ -89,7 +99,6 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(const bf16_t* __restrict__ 
   const int b = bh / H, h = bh % H;
   const int d = H * 64;
   const bf16_t* base = qkv + (int64_t)b * T * 3 * d + h * 64;
-  stage_image(Qs, base, 3 * d, T, Tp);
   stage_image(Ks, base + d, 3 * d, T, Tp);
   stage_image(Vs, base + 2 * d, 3 * d, T, Tp);
   uint32_t dkey = 0;
@@ -98,7 +107,12 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(const bf16_t* __restrict__ 
   const int nqb = (T + 15) >> 4;
   for (int qb = part * 4 + wave; qb < nqb; qb += 4 * qsplit) {
     const int q = qb * 16 + (lane & 15);
-    bf16x8_t qf[2] = {row_frag(Qs, q, 0, lane), row_frag(Qs, q, 1, lane)};
+    bf16x8_t qf[2];
+    {
+      const bf16_t* qrow = base + (int64_t)min(q, T - 1) * 3 * d + 8 * g;     // rows beyond T: finite duplicates, never stored
+      __builtin_memcpy(&qf[0], __builtin_assume_aligned(qrow, 16), 16);
+      __builtin_memcpy(&qf[1], __builtin_assume_aligned(qrow + 32, 16), 16);
+    }
     f32x4_t s[NT];
     float m = -INFINITY;
 #pragma unroll
@@ -312,7 +326,7 @@ int g_lds_b[2][4] = {{48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024}, {48 * 1024, 4
 template <int NT, bool DROP>
 int launch_fwd2(const void* qkv, void* out, float* lse, int64_t B, int64_t T, int64_t H, float scale, int slot,
                 const IbAttnDrop& a, hipStream_t s) {
-  const size_t lds = (size_t)3 * NT * 16 * LDR * 2;
+  const size_t lds = (size_t)2 * NT * 16 * LDR * 2;
   auto k = attn_fwd_mfma<NT, DROP>;
   if (ensure_lds(k, lds, g_lds_f[DROP][slot]) != IB_OK) return IB_E_LAUNCH;
   // fewer (window, head) pairs than CUs: split the query blocks of a pair over several workgroups
