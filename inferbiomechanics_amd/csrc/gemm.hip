@@ -1255,12 +1255,22 @@ __global__ __launch_bounds__(256) void dgrad_skinny_kernel(const bf16_t* __restr
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c0 = blockIdx.x * 16;
   // w[:, c0 .. c0+16) -> wimg[col][k]: one 16-byte piece = 8 columns of one reduction row
-  for (int pce = tid; pce < N * 2; pce += 256) {
-    const int k = pce >> 1, half = pce & 1;
-    bf16x8_t v;
-    __builtin_memcpy(&v, __builtin_assume_aligned(w + (int64_t)k * ldw + c0 + 8 * half, 16), 16);
+  // (four pieces per thread requested before the first is scattered: a rolled loop was N/128 dependent round trips)
+  for (int p0 = tid; p0 < N * 2; p0 += 256 * 4) {
+    bf16x8_t v[4];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) wimg[(8 * half + e) * WS + k] = v[e];
+    for (int u = 0; u < 4; ++u) {
+      const int pce = min(p0 + 256 * u, N * 2 - 1), k = pce >> 1, half = pce & 1;
+      __builtin_memcpy(&v[u], __builtin_assume_aligned(w + (int64_t)k * ldw + c0 + 8 * half, 16), 16);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int pce = p0 + 256 * u, k = pce >> 1, half = pce & 1;
+      if (pce < N * 2) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) wimg[(8 * half + e) * WS + k] = v[u][e];
+      }
+    }
   }
   __syncthreads();
   const int mt_total = (M + 15) / 16;
