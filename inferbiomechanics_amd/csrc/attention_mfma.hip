@@ -22,6 +22,7 @@
 //   D[row = 4*(lane/16)+r][col = lane%16].
 #include "ib_common.h"
 #include <algorithm>
+#include <cstdlib>
 
 namespace {
 
@@ -64,19 +65,20 @@ __device__ __forceinline__ float group4_sum(float v) {
 // stage one [T][64] slice (row stride `ld` elements in global memory) into a [Tp][LDR] LDS image
 // Eight pieces per thread are requested before the first is stored: as a rolled loop (one load, one LDS store per trip) the
 // staging of a 200-frame head was 14 dependent memory round trips per image -- most of the kernel's time at T = 200.
+template <int NTHR = 256>
 __device__ __forceinline__ void stage_image(bf16_t* img, const bf16_t* __restrict__ src, int64_t ld, int T, int Tp) {
   constexpr int U = 8;
-  for (int i0 = threadIdx.x; i0 < Tp * 8; i0 += 256 * U) {
+  for (int i0 = threadIdx.x; i0 < Tp * 8; i0 += NTHR * U) {
     uint4 v[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int i = i0 + 256 * u, r = i >> 3, c = i & 7;
+      const int i = i0 + NTHR * u, r = i >> 3, c = i & 7;
       v[u] = make_uint4(0u, 0u, 0u, 0u);
       if (r < T) v[u] = *reinterpret_cast<const uint4*>(src + (int64_t)r * ld + c * 8);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int i = i0 + 256 * u, r = i >> 3, c = i & 7;
+      const int i = i0 + NTHR * u, r = i >> 3, c = i & 7;
       if (i < Tp * 8) *reinterpret_cast<uint4*>(img + r * LDR + c * 8) = v[u];
     }
   }
@@ -150,6 +152,96 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(const bf16_t* __restrict__ 
       for (int dt = 0; dt < 4; ++dt)
         o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(Vs, 32 * kp, 32 * kp + 16, dt, lane), pf, o[dt], 0, 0, 0);
     }
+    if (q < T) {
+      const float inv = 1.f / l;
+      bf16_t* orow = out + ((int64_t)b * T + q) * d + h * 64;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        bf16x4_t w;
+        w[0] = (bf16_t)(o[dt][0] * inv); w[1] = (bf16_t)(o[dt][1] * inv);
+        w[2] = (bf16_t)(o[dt][2] * inv); w[3] = (bf16_t)(o[dt][3] * inv);
+        *reinterpret_cast<bf16x4_t*>(orow + dt * 16 + 4 * g) = w;
+      }
+      if (g == 0 && lse) lse[((int64_t)b * H + h) * T + q] = m + logf(l);
+    }
+  }
+}
+
+// Long windows (T > 64: the T = 200 sampler and training configs).  The kernel above keeps a whole score row in registers
+// (NT = 14: 203 VGPRs -> two waves per SIMD, and with ~100 KB of K / V images per workgroup little else to overlap with:
+// it ran at a third of its memory floor).  Here the row is walked TWICE -- pass A finds the row maximum, pass B recomputes
+// each pair of score tiles, exponentiates and feeds P.V at once (two more QK^T MFMAs per tile: nothing next to the exp
+// chain they unblock) -- so only one tile pair is live (< 128 VGPRs), and eight waves share one pair of K / V images:
+// four waves per SIMD with two workgroups per CU.  Same arithmetic per element as the one-pass kernel.
+template <int NT, bool DROP>
+__global__ __launch_bounds__(512, 4) void attn_fwd_mfma_2p(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                        float* __restrict__ lse, int T, int H, float scale, IbAttnDrop drop,
+                                                        int qsplit) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  constexpr int Tp = NT * 16;
+  bf16_t* Ks = reinterpret_cast<bf16_t*>(smem_raw);
+  bf16_t* Vs = Ks + Tp * LDR;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
+  const int bh = (int)blockIdx.x / qsplit, part = (int)blockIdx.x % qsplit;
+  const int b = bh / H, h = bh % H;
+  const int d = H * 64;
+  const bf16_t* base = qkv + (int64_t)b * T * 3 * d + h * 64;
+  stage_image<512>(Ks, base + d, 3 * d, T, Tp);
+  stage_image<512>(Vs, base + 2 * d, 3 * d, T, Tp);
+  uint32_t dkey = 0;
+  if constexpr (DROP) dkey = ib_attn_drop_key(drop, bh);
+  __syncthreads();
+  const int nqb = (T + 15) >> 4;
+  for (int qb = part * 8 + wave; qb < nqb; qb += 8 * qsplit) {
+    const int q = qb * 16 + (lane & 15);
+    bf16x8_t qf[2];
+    {
+      const bf16_t* qrow = base + (int64_t)min(q, T - 1) * 3 * d + 8 * g;
+      __builtin_memcpy(&qf[0], __builtin_assume_aligned(qrow, 16), 16);
+      __builtin_memcpy(&qf[1], __builtin_assume_aligned(qrow + 32, 16), 16);
+    }
+    // pass A: row maximum
+    float m = -INFINITY;
+#pragma unroll 2                       // (a fully unrolled walk lets the scheduler hoist every tile's fragment reads: spills)
+    for (int kt = 0; kt < NT; ++kt) {
+      f32x4_t a = {0.f, 0.f, 0.f, 0.f};
+      a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Ks, kt * 16 + (lane & 15), 0, lane), qf[0], a, 0, 0, 0);
+      a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Ks, kt * 16 + (lane & 15), 1, lane), qf[1], a, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (kt * 16 + 4 * g + r < T) m = fmaxf(m, a[r] * scale);
+    }
+    m = group4_max(m);
+    // pass B: probabilities of a tile pair -> P.V
+    float l = 0.f;
+    f32x4_t o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int kp = 0; kp < NT / 2; ++kp) {
+      f32x4_t s2[2];
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int kt = 2 * kp + hh;
+        f32x4_t a = {0.f, 0.f, 0.f, 0.f};
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Ks, kt * 16 + (lane & 15), 0, lane), qf[0], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Ks, kt * 16 + (lane & 15), 1, lane), qf[1], a, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = kt * 16 + 4 * g + r;
+          const float pv = key < T ? __expf(a[r] * scale - m) : 0.f;
+          l += pv;
+          if constexpr (DROP) a[r] = pv * ib_attn_drop_mult(drop, dkey, q, key);
+          else a[r] = pv;
+        }
+        s2[hh] = a;
+      }
+      const bf16x8_t pf = acc_frag(s2[0], s2[1]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag(Vs, 32 * kp, 32 * kp + 16, dt, lane), pf, o[dt], 0, 0, 0);
+    }
+    l = group4_sum(l);
     if (q < T) {
       const float inv = 1.f / l;
       bf16_t* orow = out + ((int64_t)b * T + q) * d + h * 64;
@@ -321,12 +413,27 @@ template <typename K> int ensure_lds(K k, size_t need, int& cur) {
   return IB_OK;
 }
 int g_lds_f[2][4] = {{48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024}, {48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024}};
+int g_lds_f2[2][4] = {{48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024}, {48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024}};
 int g_lds_b[2][4] = {{48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024}, {48 * 1024, 48 * 1024, 48 * 1024, 48 * 1024}};
 
 template <int NT, bool DROP>
 int launch_fwd2(const void* qkv, void* out, float* lse, int64_t B, int64_t T, int64_t H, float scale, int slot,
                 const IbAttnDrop& a, hipStream_t s) {
   const size_t lds = (size_t)2 * NT * 16 * LDR * 2;
+  static const bool one_pass = getenv("IB_ATTN_ONE_PASS") != nullptr;
+  // long windows: two-pass kernel, eight waves per workgroup -- when that still fills the chip (a single window is better
+  // off with four query-block groups per head on the one-pass kernel: 5.5 against 7.9 us at B = 1, T = 200)
+  if (NT > 4 && !one_pass && B * H * ((T + 127) / 128) >= 256) {
+    auto k2 = attn_fwd_mfma_2p<NT, DROP>;
+    if (ensure_lds(k2, lds, g_lds_f2[DROP][slot]) != IB_OK) return IB_E_LAUNCH;
+    const int groups8 = (int)((T + 127) / 128);                // groups of eight query blocks (one per wave)
+    int qs = 1;
+    if (B * H < 256) qs = (int)std::min<int64_t>(groups8, std::max<int64_t>(1, 256 / (B * H)));
+    hipLaunchKernelGGL(k2, dim3((unsigned)(B * H * qs)), dim3(512), lds, s, (const bf16_t*)qkv, (bf16_t*)out, lse, (int)T,
+                       (int)H, scale, a, qs);
+    IB_CHECK_LAUNCH();
+    return IB_OK;
+  }
   auto k = attn_fwd_mfma<NT, DROP>;
   if (ensure_lds(k, lds, g_lds_f[DROP][slot]) != IB_OK) return IB_E_LAUNCH;
   // fewer (window, head) pairs than CUs: split the query blocks of a pair over several workgroups

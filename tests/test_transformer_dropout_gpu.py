@@ -56,6 +56,10 @@ CASES = [  # name, dtype, B, T, H, dh, tolerance
     ("mfma_bf16_T50", torch.bfloat16, 3, 50, 8, 64, 2e-2),
     ("mfma_bf16_T200", torch.bfloat16, 2, 200, 2, 64, 2e-2),
     ("mfma_bf16_T256", torch.bfloat16, 1, 256, 2, 64, 2e-2),
+    # enough (window, head) pairs to fill the chip with 8-wave workgroups: the two-pass long-window forward kernel
+    ("mfma2p_bf16_T200", torch.bfloat16, 16, 200, 8, 64, 2e-2),
+    ("mfma2p_bf16_T100", torch.bfloat16, 32, 100, 8, 64, 2e-2),
+    ("mfma2p_bf16_T250", torch.bfloat16, 32, 250, 4, 64, 2e-2),
 ]
 
 
@@ -91,6 +95,7 @@ def test_attention_probability_dropout_matches_oracle(name, dt, B, T, H, dh, tol
     hip.attention_fwd(qkv, plain, lse, H)
     hip.attention_fwd(qkv, plain0, lse, H, drop=(0.0, 1, 2, None))
     assert torch.equal(plain, plain0) and rel(out, plain) > 0.05
+    assert rel(plain, attn_oracle(qkv.cpu().double(), H, None)) <= tol            # and the plain kernel of this shape
 
 
 def test_attention_dropout_draws():
