@@ -383,7 +383,7 @@ int ib_gemm_nt_try(const void* A, int64_t lda, const void* B, int64_t ldb, void*
                    const void* aux, int64_t ldaux, int bwd_act, const void* addend, int64_t ldadd, int64_t M, int64_t N,
                    int64_t K, hipStream_t s) {
   static const int off = []() { const char* e = getenv("IB_NO_NT"); return e ? atoi(e) : 0; }();
-  static const int min_m = []() { const char* e = getenv("IB_NT_MIN_M"); return e ? atoi(e) : 4096; }();
+  static const int min_m = []() { const char* e = getenv("IB_NT_MIN_M"); return e ? atoi(e) : 640; }();
   if (off || M < min_m || N < 128 || N % 8 != 0 || K < 4 * BK || K % BK != 0) return IB_E_UNSUPPORTED;
   if (!al16(A) || !al16(B) || !al16(C) || lda % 8 || ldb % 8 || ldc % 8) return IB_E_UNSUPPORTED;
   if (M * lda >= (int64_t(1) << 31) || N * ldb >= (int64_t(1) << 31)) return IB_E_UNSUPPORTED;     // 32-bit element offsets
