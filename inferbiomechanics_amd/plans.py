@@ -576,8 +576,11 @@ class TransformerLayerPlan:
         def lin_ln(inp, wname, bname, nname, res, y, wtag):
             """Linear -> +res -> LayerNorm as one K-split GEMM + fused reduction (small M); False = not applicable"""
             w = P.w(p + wname)
-            if w.shape[1] < 1024:      # measured at M = 3200: K = 2048 43.6 -> 30.5 us fused, K = 512 20.4 -> 26.2 (two
-                return False           # short kernels instead of two short kernels: nothing to split)
+            # swept on the sampler (T = 200): K = 2048 fused wins up to the NT kernel's territory (M = 3200: 43.6 -> 30.5 us);
+            # K = 512 (two short kernels either way) wins only while the GEMM is far from filling the chip (M <= 2048:
+            # B = 2 / 4 / 8 +4 / +6 / +2 % steps/s; M = 3200: -6 %)
+            if w.shape[1] < 512 or (w.shape[1] < 1024 and M > int(os.environ.get("IB_LINLN_K512_MAX_M", "2048"))):
+                return False
             if M >= int(os.environ.get("IB_LINLN_MAX_M", "4096")) and not os.environ.get("IB_NO_NT"):
                 return False           # large batches fill the chip without a K split: the 256 x 128 NT kernel + LayerNorm
                                        # (M = 51200: 120 + 30 us against 235 us fused)
