@@ -312,6 +312,9 @@ def train_leg(workload, a, dev, world, rank, steps, warmup, sync, with_roofline=
     trainer = HipTrainer(model, "diffusion", a.opt_type, 1e-4, use_graph=not a.no_graph, bucket_mb=a.bucket_mb,
                          overlap_comm={"auto": None, "on": True, "off": False}[a.overlap_comm])
     batches = make_batches(16, B, T, D, dtype, dev, seed=rank)
+    # the whole leg runs ON the trainer's stream, as cli/train.py's loop does: a step() called from another stream hands
+    # over through two cross-queue events per step (25 us of the 0.218 ms MLP step)
+    prev_stream = trainer.adopt_stream()
     # priming (not part of W): eager warm-up, the generic graph, and the graph of EVERY batch of the ring -- no capture
     # may fall into the timed region whatever --steps / --warmup are (round 1: four ~1 ms captures inside 20 timed steps)
     trainer.pin_batches(batches)
@@ -366,6 +369,9 @@ def train_leg(workload, a, dev, world, rank, steps, warmup, sync, with_roofline=
               "note": "peak = 7 xGMI links x 153 GB/s per GPU; busbw = 2(N-1)/N x bytes / time"}
         g.zero_()
     rec = record_eager_step(trainer, batches) if with_roofline else None     # all ranks: the step holds the all-reduce
+    if prev_stream is not None:
+        torch.cuda.synchronize()
+        torch.cuda.set_stream(prev_stream)
     out = None
     if rank == 0:
         value = world * B * steps / el

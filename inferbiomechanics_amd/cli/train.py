@@ -179,6 +179,7 @@ class TrainCommand(AbstractCommand):
             eps = torch.randn(x0.shape, generator=gen)
             return x0, t, eps
 
+        adopted = False
         for epoch in range(epoch_checkpoint + 1, args.epochs):
             dev_dataloader.sampler.set_epoch(epoch)
             train_dataloader.sampler.set_epoch(epoch)
@@ -206,6 +207,9 @@ class TrainCommand(AbstractCommand):
                 dist.barrier()
             print(f'[rank={rank}] Running Training Epoch {epoch}')
             model.train()
+            if trainer is not None and not adopted:
+                trainer.adopt_stream()      # the loop's device work runs on the trainer's stream: no per-step hand-over
+                adopted = True
             if cache is not None:
                 train_batches = list(cache.batches(args.batch_size, rank=rank, world=world_size))
             else:
