@@ -35,6 +35,7 @@ def main():
             m = Groundlink(23, 12, 10, "all_frames", device=dev, compute_dtype=dt)
             m.train()
             tr = HipTrainer(m, "regression", "adam", 1e-4, args=targs, use_graph=not a.no_graph)
+            tr.adopt_stream()             # as cli/train.py does: the loop's device work on the trainer's stream
             B = a.batch
             inputs = {k: torch.randn(B, F, w, device=dev) for k, w in zip(INPUT_KEY_ORDER, input_key_widths(23, 30))}
             labels = {k: torch.randn(B, F, c, device=dev) for k, c in zip(LOSS_KEY_ORDER, LOSS_KEY_WIDTHS)}

@@ -34,7 +34,9 @@ def main():
 
     def trainer():
         m = FeedForwardBaseline(23, 2, 50, "all_frames", "sigmoid", 5, 10, device=dev, compute_dtype=torch.bfloat16)
-        return HipTrainer(m, "regression", "rmsprop", 1e-4, args=args)
+        t = HipTrainer(m, "regression", "rmsprop", 1e-4, args=args)
+        t.adopt_stream()                  # as cli/train.py does: the loop's device work on the trainer's stream
+        return t
 
     for workers in (0, 4):
         tr = trainer()
