@@ -337,3 +337,32 @@ def test_large_batch_kernel_paths_agree():
         for a, e in zip(out[name]["losses"], ref):
             assert abs(a - e) <= 5e-3 * abs(e), (name, out[name]["losses"], ref)
         assert abs(out[name]["psum"] - out["ring"]["psum"]) <= 1e-5 * out["ring"]["psum"], name
+
+
+def test_adopt_stream_same_trajectory_no_handover():
+    """a loop that works on the trainer's stream (HipTrainer.adopt_stream(), as cli/train.py and bench.py do) takes the same
+    steps as one that calls step() from the default stream -- bitwise the same losses and parameters -- and the values read
+    back afterwards on the adopted stream are ordered after the last step"""
+    import bench
+    from inferbiomechanics_amd.engine import HipTrainer
+    dev = torch.device("cuda", 0)
+    outs = []
+    for adopt in (False, True):
+        model = bench.build_model("mlp", 50, 300, torch.bfloat16, dev)
+        tr = HipTrainer(model, "diffusion", "rmsprop", 1e-3)
+        batches = bench.make_batches(4, 32, 50, 300, torch.bfloat16, dev, seed=5)
+        prev = tr.adopt_stream() if adopt else None
+        if adopt:
+            assert torch.cuda.current_stream() == tr.stream and prev is not None
+        losses = []
+        for i in range(12):
+            tr.step(batches[i % 4])
+            losses.append(tr.loss_value())
+        flat = tr.flat.detach().clone()
+        torch.cuda.synchronize()
+        if adopt:
+            torch.cuda.set_stream(prev)
+            assert torch.cuda.current_stream() == prev
+        outs.append((losses, flat.cpu()))
+    assert outs[0][0] == outs[1][0], (outs[0][0], outs[1][0])
+    assert torch.equal(outs[0][1], outs[1][1])
