@@ -387,7 +387,9 @@ def train_leg(workload, a, dev, world, rank, steps, warmup, sync, with_roofline=
                           "hipgraph": not a.no_graph, "parallelism": f"dp{world}",
                           "grad_buckets": len(trainer.buckets.ranges) if trainer.ddp else 0,
                           "bucket_bytes": [4 * (hi - lo) for lo, hi in trainer.buckets.ranges] if trainer.ddp else [],
-                          "overlap_comm": bool(trainer.overlap_comm)},
+                          "overlap_comm": bool(trainer.overlap_comm),
+                          "loop_stream": "trainer (HipTrainer.adopt_stream, as cli/train.py)" if prev_stream is not None
+                          else "caller"},
                # whole-step fractions of the three rooflines SURVEY.md §8d names (per GPU)
                "step_fractions": {"mfma": round(tfl / world / PEAK_TFLOPS[a.dtype], 4),
                                   "hbm": round(hbm / world / PEAK_HBM_GBS, 4),
