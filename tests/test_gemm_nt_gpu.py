@@ -24,7 +24,10 @@ def ints(shape, lo, hi, seed):
 
 
 SHAPES = [(4096, 512, 512), (4100, 128, 128), (5000, 200, 192), (12800, 2048, 512), (12800, 512, 2048), (4352, 1536, 512),
-          (70000, 128, 128)]
+          (70000, 128, 128),
+          # the NT kernel takes over from 640 rows (IB_NT_MIN_M): fewer tiles than workgroups, ragged last row panel,
+          # N not a multiple of the 128-column tile, K = 256 (the shortest stage stream) and K = 320
+          (640, 512, 512), (641, 136, 256), (700, 304, 320), (1000, 2048, 512), (3200, 1536, 512), (1023, 128, 1024)]
 
 
 @pytest.mark.parametrize("M,N,K", SHAPES)
