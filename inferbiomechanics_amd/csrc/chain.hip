@@ -150,8 +150,11 @@ __device__ __forceinline__ void row_reduce2(float (&a)[NM], float (&b)[NM], floa
 
 // NTH: n-tiles per wave for the hidden width (H = 128 * NTH);  NTD / KBD: n-tiles per wave and k-blocks for the
 // feature width (D <= 128 * NTD, D <= 32 * KBD).
+// IB_CHAIN_NHF: the backward epilogue walks the panel's four m-tiles in NHF groups; the fewer m-tiles are live at once, the
+// fewer registers spill -- and a spill reload is a vector-memory operation that retires in order behind the weight
+// prefetch.  Measured (B = 256, T = 50): NHF = 1 736 B of scratch per lane; NHF = 2 208 B, 97-101 us; NHF = 4 72 B, 88 us.
 #ifndef IB_CHAIN_NHF
-#define IB_CHAIN_NHF 2
+#define IB_CHAIN_NHF 4
 #endif
 constexpr int CH_NWIN = 8;                                 // windows whose time embedding is staged per panel
 template <int NTH, int NTD, int KBD>
@@ -340,7 +343,7 @@ __global__ __launch_bounds__(CH_THREADS) void mlp_chain_kernel(ChainParams p) {
       auto side = [&](int kb, auto) {
         if (kb == 0) er = in_piece16(esrc, p.ld_e, min(nwin, CH_NWIN), PPR, TIDV);
       };
-      chain_gemm<NTH, KBD>(p.wf[0], wave * NTH, cur, RS, lane, acc, side);
+      chain_gemm<NTH, KBD>(p.wf[0], wave_s * NTH, cur, RS, lane_id_now(), acc, side);
     } else {
       bf16_t* hprev = p.h[i - 1] + (int64_t)r0 * H;
       auto side = [&](int kb, auto kbc) {
@@ -350,7 +353,7 @@ __global__ __launch_bounds__(CH_THREADS) void mlp_chain_kernel(ChainParams p) {
         for (int j = 0; j < NPH; ++j)
           if (j % KB == kb) out_piece16(cur, RS, hprev, H, nrows, PPR, TIDV + j * CH_THREADS);
       };
-      chain_gemm<NTH, C::KBH>(p.wf[i], wave * NTH, cur, RS, lane, acc, side);
+      chain_gemm<NTH, C::KBH>(p.wf[i], wave_s * NTH, cur, RS, lane_id_now(), acc, side);
     }
     if (tid < CH_NWIN * PPR) *reinterpret_cast<uint4*>(eimg + tid * 16) = er;
     CH_STAMP(2 + 4 * i);
@@ -447,7 +450,7 @@ __global__ __launch_bounds__(CH_THREADS) void mlp_chain_kernel(ChainParams p) {
       for (int j = 0; j < KBD; ++j)
         if (j % KB == kb) re[j] = in_piece8(epsg, D, nrows, ppr, TIDV + j * CH_THREADS);
     };
-    chain_gemm<NTD, C::KBH>(p.wf[p.L], wave * NTD, cur, RS, lane, acc, side);
+    chain_gemm<NTD, C::KBH>(p.wf[p.L], wave_s * NTD, cur, RS, lane_id_now(), acc, side);
     CH_STAMP(2 + 4 * p.L);
     store_rows8<KBD>(nxt, RS, ppr, TIDV, re);     // eps image; dpred overwrites it in place
     __syncthreads();
@@ -526,7 +529,7 @@ __global__ __launch_bounds__(CH_THREADS) void mlp_chain_kernel(ChainParams p) {
               *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(dpg + (int64_t)row * p.ld_dpred) + pc * 16) = v;
             }
         };
-        chain_gemm<NTH, KBD>(p.wb[p.L], wave * NTH, cur, RS, lane, acc, side);
+        chain_gemm<NTH, KBD>(p.wb[p.L], wave_s * NTH, cur, RS, lane_id_now(), acc, side);
       } else {
         auto side = [&](int kb, auto kbc) {
           constexpr int KB = decltype(kbc)::value;
@@ -542,7 +545,7 @@ __global__ __launch_bounds__(CH_THREADS) void mlp_chain_kernel(ChainParams p) {
               *reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(dpg + (int64_t)row * p.ld_dpred) + pc * 8) = v;
             }
         };
-        chain_gemm<NTH, KBD>(p.wb[p.L], wave * NTH, cur, RS, lane, acc, side);
+        chain_gemm<NTH, KBD>(p.wb[p.L], wave_s * NTH, cur, RS, lane_id_now(), acc, side);
       }
     } else {
       bf16_t* dzg = p.dz[i + 1] + (int64_t)r0 * H;
@@ -555,7 +558,7 @@ __global__ __launch_bounds__(CH_THREADS) void mlp_chain_kernel(ChainParams p) {
             out_piece16(cur, RS, dzg, H, nrows, PPR, TIDV + j * CH_THREADS);
           }
       };
-      chain_gemm<NTH, C::KBH>(p.wb[i + 1], wave * NTH, cur, RS, lane, acc, side);
+      chain_gemm<NTH, C::KBH>(p.wb[i + 1], wave_s * NTH, cur, RS, lane_id_now(), acc, side);
     }
     CH_STAMP(4 + 4 * p.L + 9 * (p.L - 1 - i));
     store_rows16<NPH>(nxt, RS, PPR, TIDV, ru);
