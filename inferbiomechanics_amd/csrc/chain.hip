@@ -88,7 +88,10 @@ template <int V> struct IntC { static constexpr int value = V; };
 template <int NT, int KB, class Side>
 __device__ __forceinline__ void chain_gemm(const bf16_t* __restrict__ wp, int nt0, const unsigned char* abuf, int rs,
                                            int lane, f32x4_t (&acc)[4][NT], Side&& side) {
-  constexpr int RING = 3, PD = 2;
+#ifndef IB_CHAIN_RING
+#define IB_CHAIN_RING 3
+#endif
+  constexpr int RING = IB_CHAIN_RING, PD = RING - 1;
   const bf16x8_t* wl = reinterpret_cast<const bf16x8_t*>(wp) + ((int64_t)nt0 * KB) * 64 + lane;
   const unsigned char* arow = abuf + (lane & 15) * rs + 16 * (lane >> 4);
   bf16x8_t wr[RING][NT];

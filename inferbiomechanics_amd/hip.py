@@ -15,7 +15,8 @@ from typing import Dict, List, Optional, Sequence
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libib_hip.so")
+# IB_HIP_LIB: another build of the same library (A/B runs of kernel variants inside one gpurun call); never a fallback
+LIB_PATH = os.environ.get("IB_HIP_LIB") or os.path.join(_HERE, "lib", "libib_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "ib_hip.h")
 
 F32, BF16 = 0, 1
