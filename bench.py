@@ -112,6 +112,85 @@ def cpu_baseline(kind, T, D, B, budget_s=15.0):
             "sample": f"{n} training steps of batch {B} ({kind} denoiser, T={T}, D={D}, fp32, RMSprop) in {el:.1f} s"}
 
 
+def regression_ref_shape_leg(dev, B, gpu_steps=400, cpu_budget_s=4.0):
+    """BASELINE.json configs[0] / SURVEY.md §8d "Config 1": the reference's own model shape -- FeedForwardBaseline([512, 512],
+    sigmoid), history 50 / stride 5 => 1470 -> 512 -> 512 -> 300 (src/models/FeedForwardRegressionBaseline.py:52,63), fp32,
+    RMSprop lr 1e-4 (src/cli/train.py:41,190), the reference loss with every component (RegressionLossEvaluator.__call__) --
+    one training step of the loop body src/cli/train.py:240-284: HipTrainer (fused, hipGraph-replayed, fp32 kernels) next to
+    the oracle's CPU step, timed in the same run on the same batch from the same initial weights; the losses of both after
+    the same number of steps are reported side by side ("matched loss trajectory")."""
+    import argparse as _ap
+    from inferbiomechanics_amd.data.AddBiomechanicsDataset import INPUT_KEY_ORDER, LOSS_KEY_ORDER, LOSS_KEY_WIDTHS, input_key_widths
+    from inferbiomechanics_amd.engine import HipTrainer
+    from inferbiomechanics_amd.models.FeedForwardRegressionBaseline import FeedForwardBaseline
+    from oracle import ref_cpu as R
+    F = 10
+    targs = _ap.Namespace(predict_grf_components=list(range(6)), predict_cop_components=list(range(6)),
+                          predict_moment_components=list(range(6)), predict_wrench_components=list(range(12)))
+    torch.manual_seed(0)
+    m = FeedForwardBaseline(23, 2, 50, "all_frames", "sigmoid", 5, 10, hidden_dims=[512, 512], device=dev,
+                            compute_dtype=torch.float32)
+    m.train()
+    w0 = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(1)
+    inputs = {k: torch.randn(B, F, w, generator=g) for k, w in zip(INPUT_KEY_ORDER, input_key_widths(23, 15))}
+    labels = {k: torch.randn(B, F, c, generator=g) * (10.0 if "Force" in k or "FORCE" in k.upper() else 1.0)
+              for k, c in zip(LOSS_KEY_ORDER, LOSS_KEY_WIDTHS)}          # force ~ 10 N(0,1): the CoP mask (> 10.0) is exercised
+    din = {k: v.to(dev) for k, v in inputs.items()}
+    dlab = {k: v.to(dev) for k, v in labels.items()}
+    tr = HipTrainer(m, "regression", "rmsprop", 1e-4, args=targs, use_graph=True)
+    prev = tr.adopt_stream()
+    ncmp = 20
+    for _ in range(ncmp):
+        tr.step((din, dlab))
+    gpu_loss = tr.loss_value()                       # loss of step `ncmp` (computed before that step's update)
+    for _ in range(30):
+        tr.step((din, dlab))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(gpu_steps):
+        tr.step((din, dlab))
+    torch.cuda.synchronize()
+    gpu_ms = (time.perf_counter() - t0) / gpu_steps * 1e3
+    if prev is not None:
+        torch.cuda.set_stream(prev)
+    # the oracle's CPU step: same weights, same batch, same optimizer arithmetic
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    params = {k: v.clone().requires_grad_(True) for k, v in w0.items()}
+    layers = [(params[f"net.{2 * i}.weight"], params[f"net.{2 * i}.bias"]) for i in range(3)]
+    state = {k: R.optim_init_state("rmsprop", v.detach()) for k, v in params.items()}
+
+    def cpu_step(i):
+        for v in params.values():
+            v.grad = None
+        out = R.feedforward_forward(layers, inputs, "sigmoid", F)
+        loss, _, _ = R.regression_loss(out, labels, range(6), range(6), range(6), range(12))
+        loss.backward()
+        with torch.no_grad():
+            for k, v in params.items():
+                v.copy_(R.optim_step("rmsprop", v, v.grad, state[k], 1e-4, i + 1))
+        return float(loss)
+
+    cpu_loss = None
+    for i in range(ncmp):
+        cpu_loss = cpu_step(i)
+    n, t1 = 0, time.perf_counter()
+    while True:
+        cpu_step(ncmp + n)
+        n += 1
+        el = time.perf_counter() - t1
+        if el > cpu_budget_s or n >= 2000:
+            break
+    cpu_ms = el / n * 1e3
+    del tr, m
+    return {"batch": B, "gpu_ms_per_step": round(gpu_ms, 4), "gpu_windows_per_s": round(B / gpu_ms * 1e3, 1),
+            "cpu_ms_per_step": round(cpu_ms, 3), "cpu_windows_per_s": round(B / cpu_ms * 1e3, 1),
+            "cpu_cores": torch.get_num_threads(), "cpu_steps_timed": n, "gpu_steps_timed": gpu_steps,
+            "speedup": round(cpu_ms / gpu_ms, 1),
+            "loss_at_step_%d" % ncmp: {"gpu": round(gpu_loss, 6), "cpu_oracle": round(cpu_loss, 6),
+                                       "rel_diff": round(abs(gpu_loss - cpu_loss) / max(abs(cpu_loss), 1e-30), 8)}}
+
+
 KERNEL_OF = {   # C-ABI entry -> device kernel it launches (names as rocprofv3 --kernel-trace reports them)
     "ib_mlp_chain_train": "mlp_chain_kernel<4, 3, 10>", "ib_mlp_chain_prep": "time_mlp_fwd_kernel<4, 4> (+ weight packing blocks)",
     "ib_linear_wgrad_slabs": "gemm_ring_kernel<false, false, EPI_WGRAD>", "ib_slab_reduce_multi": "slab_reduce_multi_kernel",
@@ -145,7 +224,7 @@ def record_eager_step(trainer, batches):
     return rec
 
 
-def roofline_leg(rec, dtype_name, gemm_family=False):
+def roofline_leg(rec, dtype_name, gemm_family=False, workload=None):
     """Device time of every distinct launch of ONE training step, measured live with HIP events on the launch
     stream: each distinct C-ABI call of the recorded eager step is re-issued 20x inside a hipGraph (so host launch
     overhead is not in the number) and replayed 3x between two events.  The dominant entry gets the roofline object:
@@ -240,18 +319,28 @@ def roofline_leg(rec, dtype_name, gemm_family=False):
                     "frac": round(ach / PEAK_HBM_GBS, 4), "algorithmic_bytes_per_launch": top["bytes"] // top["launches"]})
     else:
         out.update({"bound": "hbm", "achieved": None, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": None})
-    # HBM traffic per launch and MFMA utilisation from the committed rocprofv3 --pmc passes of this round's build
-    # (FETCH_SIZE x2 on gfx950 + WRITE_SIZE; SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CU_CYCLES), written by
-    # tools/summarize_profile.py; null if no profile of this kernel has been summarised
+    # HBM traffic per launch and MFMA utilisation: STORED figures from the committed rocprofv3 --pmc passes (counters cannot
+    # be collected inside this run), keyed by WORKLOAD and entry (tools/summarize_profile.py); FETCH_SIZE x2 on gfx950 +
+    # WRITE_SIZE; SQ_VALU_MFMA_BUSY_CYCLES / elapsed SIMD cycles.  The line says that they are stored, which build they
+    # were collected on, and whether the kernel sources have changed since (`traffic_stale`).  null if no profile of this
+    # workload's dominant kernel has been summarised.
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
+    if os.path.exists(tpath) and workload is not None:
         try:
-            t = json.load(open(tpath)).get(top_e)
+            from tools.csrc_hash import csrc_hash
+            tj = json.load(open(tpath))
+            t = tj.get(workload, {}).get(top_e)
+            meta = tj.get("_meta", {}).get(workload, {})
             if t:                                    # `traffic`: HBM bytes per launch (a number, like `achieved`)
                 out["traffic"] = t["hbm_bytes_per_launch"]
                 if "mfma_util" in t:
                     out["mfma_util"] = t["mfma_util"]
-                out["traffic_source"] = {k: v for k, v in t.items() if k not in ("hbm_bytes_per_launch", "mfma_util")}
+                here = csrc_hash()
+                out["traffic_measured"] = "stored"
+                out["traffic_stale"] = meta.get("csrc_hash") != here
+                out["traffic_source"] = dict({k: v for k, v in t.items() if k not in ("hbm_bytes_per_launch", "mfma_util")},
+                                             profiled_csrc_hash=meta.get("csrc_hash"), this_csrc_hash=here,
+                                             profiled_git=meta.get("git_head_when_summarised"), tag=meta.get("tag"))
         except Exception:
             pass
     for r in rows:
@@ -311,7 +400,9 @@ def train_leg(workload, a, dev, world, rank, steps, warmup, sync, with_roofline=
     model = build_model(kind, T, D, dtype, dev)
     trainer = HipTrainer(model, "diffusion", a.opt_type, 1e-4, use_graph=not a.no_graph, bucket_mb=a.bucket_mb,
                          overlap_comm={"auto": None, "on": True, "off": False}[a.overlap_comm])
-    batches = make_batches(16, B, T, D, dtype, dev, seed=rank)
+    # >= 64 pre-generated batches.  64 x 15.4 MB (x0 + eps, bf16) = 983 MB, four times the 256-MiB Infinity
+    # Cache, so the timed loop reads its inputs from HBM (16 batches = 246 MB could have been cache hits)
+    batches = make_batches(a.batches, B, T, D, dtype, dev, seed=rank)
     # the whole leg runs ON the trainer's stream, as cli/train.py's loop does: a step() called from another stream hands
     # over through two cross-queue events per step (25 us of the 0.218 ms MLP step)
     prev_stream = trainer.adopt_stream()
@@ -384,7 +475,7 @@ def train_leg(workload, a, dev, world, rank, steps, warmup, sync, with_roofline=
                "final_loss": round(loss, 6), "train_tflops": round(tfl, 2),
                "captures_in_timed_region": trainer.captures - cap0,
                "config": {"per_gpu_batch": B, "global_batch": B * world, "window": T, "feat": D, "optimizer": a.opt_type,
-                          "hipgraph": not a.no_graph, "parallelism": f"dp{world}",
+                          "hipgraph": not a.no_graph, "parallelism": f"dp{world}", "pregenerated_batches": len(batches),
                           "grad_buckets": len(trainer.buckets.ranges) if trainer.ddp else 0,
                           "bucket_bytes": [4 * (hi - lo) for lo, hi in trainer.buckets.ranges] if trainer.ddp else [],
                           "overlap_comm": bool(trainer.overlap_comm),
@@ -397,13 +488,47 @@ def train_leg(workload, a, dev, world, rank, steps, warmup, sync, with_roofline=
         if xg is not None:
             out["xgmi"] = xg
         if rec is not None:
-            rl, breakdown, dev_us = roofline_leg(rec, a.dtype, gemm_family=(kind != "mlp"))
+            rl, breakdown, dev_us = roofline_leg(rec, a.dtype, gemm_family=(kind != "mlp"), workload=workload)
             out["roofline"] = rl
             out["step_sum_of_kernel_us"] = round(dev_us, 1)
             out["step_breakdown"] = breakdown
     del trainer, model, batches
     torch.cuda.empty_cache()
     return out
+
+
+def self_launch(n):
+    """Run this very command line as n ranks of one node: `python -m torch.distributed.run --nnodes=1 --nproc-per-node n
+    --master-addr 127.0.0.1 --master-port <free port> bench.py <same arguments>` as a child process (the reference
+    expects an env:// launcher too: src/cli/train.py:99-102, src/.gitignore:10-11).  Returns the child's return code
+    after printing rank 0's JSON line (the last stdout line that parses as the result object)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+    line = None
+    for ln in p.stdout.decode(errors="replace").splitlines():
+        ln = ln.strip()
+        if ln.startswith("{") and '"metric"' in ln:
+            try:
+                json.loads(ln)
+                line = ln
+            except ValueError:
+                pass
+    if line is not None:
+        sys.stdout.write(line + "\n")
+        sys.stdout.flush()
+    elif p.returncode == 0:
+        sys.stderr.write("bench: the launched ranks printed no result line\n")
+        return 1
+    return p.returncode
 
 
 def main():
@@ -415,6 +540,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--opt-type", default="rmsprop")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--batches", type=int, default=64, help="pre-generated synthetic batches resident in HBM (SURVEY §8d: >= 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ddim", action="store_true")
     ap.add_argument("--no-transformer", action="store_true", help="skip the configs[2] / configs[3] transformer leg")
@@ -437,9 +563,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves.  This process has made no GPU / HIP
+        # call yet (and never will): the ranks are FRESH child processes under torch.distributed.run (subprocess, never
+        # os.exec*); rank 0's single JSON line and the launcher's return code are relayed.
+        os.dup2(out_fd, 1)
+        raise SystemExit(self_launch(a.gpus))
     if a.gpus > 1 and world != a.gpus:
-        raise SystemExit(f"--gpus {a.gpus} needs `python -m torch.distributed.run --nproc-per-node {a.gpus} bench.py ...` "
-                         f"(WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {a.gpus} (or without a launcher)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     # IB_BENCH_REHEARSAL=1: the multi-rank control flow on a ONE-GPU box -- every rank on device 0, gloo instead of
@@ -506,6 +637,12 @@ def main():
             line["ddim_batches"] = [ddim_leg(dev, dtype, B=b) for b in (1, 256)]   # B in {1,16,256}
         if not a.no_cpu_baseline and world == 1:            # rank 0 at N=1 only (the other ranks wait at the barrier)
             line["cpu_baseline"] = cpu_baseline(kind, T, D, B)
+            # BASELINE.json configs[0]: the reference's own CPU-runnable case (plumbing; launch-latency bound on the GPU)
+            line["regression_ref_shape"] = {
+                "workload": "FeedForwardBaseline([512,512], sigmoid) 1470->300, fp32, RMSprop 1e-4, reference loss "
+                            "(BASELINE.json configs[0]; SURVEY.md 8d Config 1; src/cli/train.py:240-284)",
+                "bound": "launch latency (11 dependent launches of a few us each; 7 MFLOP per window)",
+                "legs": [regression_ref_shape_leg(dev, b) for b in (4, 64)]}
         sys.stdout.flush()
         os.write(out_fd, (json.dumps(line) + "\n").encode())
     if world > 1 or selftest:

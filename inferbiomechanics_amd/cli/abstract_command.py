@@ -31,18 +31,11 @@ def resolve_device(device) -> torch.device:
 def flat_to_torch_optimizer_state(sd, model):
     """HipTrainer.optimizer_state_dict() payload -> torch.optim grammar (parameters in model.parameters() order), so a
     checkpoint of the fused trainer resumes under `train --eager` (torch.optim over the drop-in modules)"""
-    from ..engine import HipTrainer
-    keys = HipTrainer.TORCH_STATE_KEYS[sd['opt_type']]
-    state = {}
-    for i, (k, p) in enumerate(model.named_parameters()):
-        if not keys or int(sd['step']) == 0:
-            break
-        off, n = sd['layout'][k]
-        st = {'step': torch.tensor(float(sd['step']))}
-        for key, buf in zip(keys, (sd['s1'], sd['s2'])):
-            st[key] = buf[off:off + n].view(p.shape).clone()
-        state[i] = st
-    return {'state': state, 'param_groups': [{'lr': sd['lr'], 'params': list(range(len(list(model.parameters()))))}]}
+    from ..engine import torch_param_groups, torch_state_from_flat
+    shapes = {k: p.shape for k, p in model.named_parameters()}
+    names = list(shapes)
+    state = torch_state_from_flat(sd['opt_type'], int(sd['step']), names, lambda k: shapes[k], sd['layout'], sd['s1'], sd['s2'])
+    return {'state': state, 'param_groups': torch_param_groups(sd['opt_type'], sd['lr'], len(names))}
 
 
 class AbstractCommand:

@@ -35,6 +35,38 @@ from .module import HipModule, flat_layout
 from .plans import ParamSource
 
 
+TORCH_OPTIM_CLASS = {"sgd": "SGD", "adam": "Adam", "rmsprop": "RMSprop", "adagrad": "Adagrad", "adadelta": "Adadelta",
+                     "adamax": "Adamax"}
+
+
+def torch_param_groups(opt_type: str, lr: float, nparams: int) -> List[Dict]:
+    """The `param_groups` list torch.optim's `optim.X(params, lr=lr)` (train.py:183-194: only lr is set) writes into its
+    state dict: EVERY hyper-parameter of the class (alpha / eps / betas / momentum / weight_decay / foreach ...), taken from
+    the class of the running torch, not only lr.  `Optimizer.load_state_dict` REPLACES the live groups by the saved ones,
+    so a group without them makes the first `optimizer.step()` raise KeyError('alpha')."""
+    cls = getattr(torch.optim, TORCH_OPTIM_CLASS[opt_type])
+    g = dict(cls([torch.zeros(1)], lr=lr).state_dict()["param_groups"][0])
+    g["lr"] = lr
+    g["params"] = list(range(nparams))
+    return [g]
+
+
+def torch_state_from_flat(opt_type: str, steps: int, names, shape_of, layout, s1, s2) -> Dict:
+    """per-parameter torch.optim state (`state[i] = {"step", <buffers>}`) from the flat (s1, s2) buffers.  Before the
+    first step torch.optim holds NO per-parameter state (it is created lazily inside step()) -- except Adagrad, whose
+    constructor creates {"step": 0, "sum": 0} and whose step() expects it."""
+    keys = HipTrainer.TORCH_STATE_KEYS[opt_type]
+    state = {}
+    if keys and (steps > 0 or opt_type == "adagrad"):
+        for i, k in enumerate(names):
+            off, n = layout[k]
+            st = {"step": torch.tensor(float(steps))}
+            for key, buf in zip(keys, (s1, s2)):
+                st[key] = buf[off:off + n].view(shape_of(k)).detach().cpu().clone()
+            state[i] = st
+    return state
+
+
 class GradBuckets:
     """Contiguous slices of the flat gradient buffer, all-reduced (SUM) as soon as every gradient inside a
     slice has been produced.  The division by world_size is folded into the optimizer kernel."""
@@ -480,7 +512,7 @@ class HipTrainer:
 
     _srcs = None            # this step's {x0, eps, t} tensors behind the pointer slots (chain path), else None
     _cap_stream = None
-    MAX_PINNED_GRAPHS = 32
+    MAX_PINNED_GRAPHS = 128
 
     captures = 0            # graphs captured so far (bench.py asserts that none falls inside its timed region)
 
@@ -620,17 +652,9 @@ class HipTrainer:
         in model.parameters() order as `optim.X(model.parameters(), lr=...)` numbers them, train.py:183-194): what a
         reference-style (`--eager` / torch.optim) run or the reference itself can load"""
         names = [k for k, _ in self.model.named_parameters()]
-        keys = self.TORCH_STATE_KEYS[self.opt_type]
-        state = {}
-        if keys and self.steps_done > 0:
-            for i, k in enumerate(names):
-                off, n = self.layout[k]
-                shp = self._params[k].shape
-                st = {"step": torch.tensor(float(self.steps_done))}
-                for key, buf in zip(keys, (self.s1, self.s2)):
-                    st[key] = buf[off:off + n].view(shp).detach().cpu().clone()
-                state[i] = st
-        return {"state": state, "param_groups": [{"lr": self.lr, "params": list(range(len(names)))}]}
+        state = torch_state_from_flat(self.opt_type, self.steps_done, names, lambda k: self._params[k].shape, self.layout,
+                                      self.s1, self.s2)
+        return {"state": state, "param_groups": torch_param_groups(self.opt_type, self.lr, len(names))}
 
     def load_optimizer_state_dict(self, sd: Dict):
         """accepts this trainer's flat payload AND a torch.optim state dict (a checkpoint written by the reference, by

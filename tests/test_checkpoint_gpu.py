@@ -98,3 +98,18 @@ def test_resuming_the_fused_trainer_from_a_reference_checkpoint_continues_its_tr
     opt = torch.optim.RMSprop(model.parameters(), lr=1e-4)
     opt.load_state_dict(tsd)
     assert float(opt.state_dict()["state"][0]["step"]) == 3.0
+    # ... and torch.optim STEPS from it (load_state_dict replaces the live param_groups: they must carry alpha / eps / ...,
+    # not only lr) exactly as the fused trainer's next step does: same gradient, same parameters before
+    before = {k: p.detach().clone() for k, p in model.named_parameters()}
+    tr.step(({k: v.to(DEV) for k, v in inputs.items()}, {k: v.to(DEV) for k, v in labels.items()}))
+    torch.cuda.synchronize()
+    q = {k: before[k].clone().requires_grad_(True) for k in before}
+    for k, p in model.named_parameters():
+        q[k].grad = p.grad.detach().clone()              # the gradient step 4 used (taken at `before`)
+    opt2 = torch.optim.RMSprop(list(q.values()), lr=1e-4)
+    opt2.load_state_dict(tsd)
+    opt2.step()
+    for k, p in model.named_parameters():
+        upd = (p.detach() - before[k]).abs().max().item()
+        err = (p.detach() - q[k].detach()).abs().max().item()
+        assert err <= 1e-3 * upd + 1e-9, (k, err, upd)

@@ -238,3 +238,22 @@ def test_feedforward_state_dict_keys_follow_the_reference_with_every_flag_combin
                 assert list(m.state_dict().keys()) == list(g[f"keys/bn{int(bn)}_drop{int(dr)}"])
     finally:
         hip.set_dry_run(False)
+
+
+def test_bench_self_launch_relays_the_ranks_return_code():
+    """`python bench.py --gpus 2` without a launcher starts its own ranks (torch.distributed.run as a child process, before
+    any GPU call) and relays their return code.  Without a GPU every rank exits with "bench.py needs a GPU": the relayed
+    code is non-zero and stdout carries no result line."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if torch.cuda.is_available():
+        pytest.skip("CPU-only check (on a GPU box tests/test_trainer_gpu.py runs the real two-rank rehearsal)")
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0
+    assert r.stdout.strip() == ""
+    assert "needs a GPU" in r.stderr

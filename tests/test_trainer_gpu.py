@@ -258,28 +258,109 @@ def test_bench_data_parallel_launch_sequence_on_one_rank():
 
 
 def test_bench_two_rank_control_flow_rehearsal():
-    """bench.py under torch.distributed.run with TWO ranks on this one GPU (IB_BENCH_REHEARSAL=1: gloo instead of RCCL,
-    both ranks on device 0).  Guards the multi-rank control flow -- every collective (parameter broadcast, gradient
-    all-reduce inside every step INCLUDING the recorded eager step of the roofline leg, barriers, the max-reduce of the
-    elapsed time) must be entered by every rank, or the run hangs -- and the one-line stdout contract at n_gpus = 2."""
+    """`python bench.py --gpus 2` BARE (no launcher, WORLD_SIZE unset): bench.py starts its own two ranks under
+    torch.distributed.run as a fresh child process and relays rank 0's line.  Here on ONE GPU (IB_BENCH_REHEARSAL=1: gloo
+    instead of RCCL, both ranks on device 0).  Guards the multi-rank control flow -- every collective (parameter broadcast,
+    gradient all-reduce inside every step INCLUDING the recorded eager step of the roofline leg, barriers, the max-reduce
+    of the elapsed time) must be entered by every rank, or the run hangs -- and the one-line stdout contract at n_gpus = 2."""
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, IB_BENCH_REHEARSAL="1")
-    for k in ("IB_DDP_SELFTEST", "RANK", "WORLD_SIZE", "LOCAL_RANK"):
+    for k in ("IB_DDP_SELFTEST", "RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29571", os.path.join(root, "bench.py"),
-                        "--gpus", "2", "--steps", "20", "--warmup", "3", "--no-ddim", "--no-cpu-baseline"],
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "3",
+                        "--no-ddim", "--no-cpu-baseline", "--batches", "16"],
                        capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
-    assert len(lines) == 1, r.stdout[:1000]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[:1000]
     o = json.loads(lines[0])
-    assert o["n_gpus"] == 2 and o["config"]["global_batch"] == 512 and o["config"]["parallelism"] == "dp2"
+    assert o["n_gpus"] == 2 and o["rccl_world"] == 2 and o["backend"] == "gloo"
+    assert o["config"]["global_batch"] == 512 and o["config"]["parallelism"] == "dp2"
     assert o["config"]["grad_buckets"] == 1 and o["value"] > 0 and "roofline" in o and "cpu_baseline" not in o
+    assert o["transformer_T50"]["config"]["parallelism"] == "dp2"
+
+
+def test_nested_branch_fork_is_refused():
+    """plans.Branch: a fork issued while another enabled branch's launches are being issued (a fork nested inside a forked
+    stream) crashed hipStreamEndCapture in round 1; it is refused with HipError in eager mode already.  Sibling forks and
+    disabled (inline) branches nest freely."""
+    from inferbiomechanics_amd import hip
+    from inferbiomechanics_amd.plans import Branch
+    a, b = Branch(DEV, name="outer"), Branch(DEV, name="inner")
+    assert a.on and b.on
+    x = torch.zeros(8, device=DEV)
+    with pytest.raises(hip.HipError, match="nested"):
+        a.run(lambda: b.run(lambda: x.add_(1)))
+    assert Branch._depth == 0                       # the guard leaves the class-wide depth balanced
+    a.join()
+    # siblings: fine
+    a.run(lambda: x.add_(1))
+    b.run(lambda: x.add_(1))
+    a.join()
+    b.join()
+    # a disabled branch runs inline, also inside an enabled one
+    c = Branch(DEV, enabled=False, name="inline")
+    a.run(lambda: c.run(lambda: x.add_(1)))
+    a.join()
+    torch.cuda.synchronize()
+    assert Branch._depth == 0
+
+
+_CAPTURE_GUARD = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", device_id=dev)
+from collections import OrderedDict
+from inferbiomechanics_amd import hip
+from inferbiomechanics_amd.engine import GradBuckets, _Recorder
+flat = torch.ones(1024, device=dev)
+bk = GradBuckets(flat, OrderedDict(w=(0, 1024)), 1 << 62, active=True)
+side, clean = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+with torch.cuda.stream(side):
+    bk.launch(0, inline=True)                 # a synchronous c10d collective: its completion event sits on `side`
+torch.cuda.synchronize()
+assert side.cuda_stream in bk.collective_streams and clean.cuda_stream not in bk.collective_streams
+refused = False
+with torch.cuda.stream(side):
+    try:
+        _Recorder(bk.collective_streams).begin()
+    except hip.HipError as e:
+        refused = "carried collectives" in str(e)
+assert refused, "capture on a stream that carried a collective was not refused"
+with torch.cuda.stream(clean):                # a stream that never carried one captures fine
+    slots = torch.zeros(4, dtype=torch.int64, device=dev)
+    rec = _Recorder(bk.collective_streams)
+    rec.begin()
+    hip.set_ptrs(slots, [flat])
+    rec.end()
+    torch.cuda.synchronize()
+    assert int(slots[0]) == 0                 # the capture executed nothing
+    rec.replay()
+torch.cuda.synchronize()
+assert int(slots[0]) == flat.data_ptr(), int(slots[0])
+dist.destroy_process_group()
+print("capture-guard ok")
+"""
+
+
+def test_capture_on_a_stream_that_carried_a_collective_is_refused():
+    """engine._Recorder.begin(): c10d's watchdog polls the completion events of earlier collectives; a poll that lands while
+    the event's stream is being captured aborts the process (round 1).  A 1-rank RCCL collective is issued on a stream, then
+    capture on THAT stream must raise HipError; capture on a clean stream works.  Child process: own process group."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29583", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, "-c", _CAPTURE_GUARD, root], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0 and "capture-guard ok" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
 
 
 def test_captured_collectives_on_one_rank_match_the_cut_graphs():

@@ -11,6 +11,7 @@ TAG=${1:-r02}
 WL=${2:-mlp_denoiser_T50}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
+python3 $GRAFT_REPO_ROOT/tools/csrc_hash.py > $OUT/csrc_hash.txt     # the build these counters belong to
 cd /tmp && export TMPDIR=/tmp
 ARGS="--workload $WL --steps 40 --warmup 5 --no-cpu-baseline --no-ddim --no-transformer --no-graph"
 timeout -k 10 280 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $GRAFT_REPO_ROOT/bench.py $ARGS > $OUT/trace.log 2>&1; echo trace_rc=$?

@@ -3,7 +3,13 @@
 
   profiles/<tag>_kernel_stats.csv     rocprofv3 --kernel-trace --stats summary (verbatim)
   profiles/<tag>_per_kernel.md        per (kernel, grid) average duration joined with the HBM counters
-  profiles/traffic.json               {C-ABI entry: {"hbm_bytes_per_launch": ..., ...}} read by bench.py's roofline leg
+  profiles/traffic.json               {workload: {C-ABI entry: {"hbm_bytes_per_launch": ..., ...}}, "_meta": {workload: {...}}}
+                                      read by bench.py's roofline leg.  Keyed by WORKLOAD: the same entry point (and the
+                                      "linear GEMMs" family) runs different kernels / shapes in the MLP and the transformer
+                                      step.  _meta carries the hash of the kernel sources the counters were collected on
+                                      (tools/csrc_hash.py, written on the GPU box by tools/profile_round.sh) and the git commit.
+
+usage: tools/summarize_profile.py <tag> <workload>     e.g. r03_mlp mlp_denoiser_T50 / r03_tr transformer_denoiser_T50
 
 HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024: FETCH_SIZE / WRITE_SIZE are in KiB and come from SEPARATE
 --pmc passes; on gfx950 FETCH_SIZE reports half of the bytes of a wide coalesced read stream (MI355X_MICROARCH.md §HBM).
@@ -57,6 +63,7 @@ def first(pattern):
 
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    workload = sys.argv[2] if len(sys.argv) > 2 else ("transformer_denoiser_T50" if "_tr" in tag else "mlp_denoiser_T50")
     src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
@@ -128,6 +135,9 @@ def main():
                     f"{'' if not r['mfma_flops'] else round(r['mfma_flops'] / 1e9, 2)} |\n")
     tpath = os.path.join(dst, "traffic.json")
     traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
+    if any(isinstance(v, dict) and "hbm_bytes_per_launch" in v for v in traffic.values()):
+        traffic = {}                                 # round-2 layout (keyed by entry only): discard, it mixed workloads
+    per = {}
     fam = collections.defaultdict(lambda: {"bytes": 0.0, "n": 0, "us": 0.0, "busy": 0.0, "flops": 0.0})
     GEMM = ("ib_linear_fwd", "ib_linear_dgrad", "ib_linear_wgrad", "ib_linear_wgrad_slabs", "ib_linear_wgrad_slabs_multi")
     for r in rows:
@@ -142,11 +152,18 @@ def main():
                     f_["busy"] += r["mfma_util"] * r["avg_us"] * r["dispatches"]
                     f_["flops"] += (r["mfma_flops"] or 0.0) * r["dispatches"]
     for e, v in fam.items():
-        traffic[e] = {"hbm_bytes_per_launch": round(v["bytes"] / v["n"]), "avg_launch_us_in_profile": round(v["us"] / v["n"], 2),
+        per[e] = {"hbm_bytes_per_launch": round(v["bytes"] / v["n"]), "avg_launch_us_in_profile": round(v["us"] / v["n"], 2),
                       "dispatches": v["n"], "mfma_util": round(v["busy"] / v["us"], 4) if v["busy"] else None,
                       "mfma_flops_executed_per_launch": round(v["flops"] / v["n"]) if v["flops"] else None,
                       "source": f"profiles/{tag}_per_kernel.md (rocprofv3 --pmc: FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES in "
                       "separate passes; bytes = (2*FETCH + WRITE) KiB; mfma_util = busy / (GRBM_GUI_ACTIVE / 8 x 1024))"}
+    traffic[workload] = per
+    hfile = os.path.join(src, "csrc_hash.txt")
+    ghash = os.popen(f"git -C {ROOT} rev-parse --short HEAD 2>/dev/null").read().strip()
+    traffic.setdefault("_meta", {})[workload] = {
+        "tag": tag, "csrc_hash": open(hfile).read().strip() if os.path.exists(hfile) else None,
+        "git_head_when_summarised": ghash,
+        "collected": "rocprofv3 --pmc passes of tools/profile_round.sh on an MI355X (stored, not measured by bench.py)"}
     json.dump(traffic, open(tpath, "w"), indent=1)
     print(open(os.path.join(dst, f"{tag}_per_kernel.md")).read()[:3000])
     print(json.dumps(traffic, indent=1))
