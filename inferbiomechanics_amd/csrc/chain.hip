@@ -17,6 +17,7 @@
 // row, so bias / embedding / gamma loads and every store are 8- or 16-byte pieces.
 // LayerNorm row statistics: 16-lane-group shuffles + one cross-wave exchange through LDS, fixed order (deterministic).
 #include "ib_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -78,7 +79,13 @@ __device__ __forceinline__ bf16x4_t pack4(float a, float b, float c, float d) {
 }
 
 // acc[mt][u] += W_eff[16*(nt0+u) .. +15][:] . A[16*mt .. +15][:]^T over KB k-blocks of 32.
-// Packed weights: block (nt, kb) is 1 KiB at ((nt * KB + kb) * 64 + lane) * 16 bytes.
+// Packed weights: block (nt, kb) is 1 KiB at ((kb * NTOT + nt) * 64 + lane) * 16 bytes, NTOT = 8 * NT n-tiles: the 32 blocks
+// the eight waves of a workgroup request at one k-step are 32 KiB CONTIGUOUS (k-block-major).  (n-tile-major, block
+// (nt, kb) at nt * KB + kb, put those 32 requests 16 KiB apart -- a power-of-two stride that lands them on the same few
+// L2 channels; IB_CHAIN_KBMAJOR=0 builds that layout for the A/B.)
+#ifndef IB_CHAIN_KBMAJOR
+#define IB_CHAIN_KBMAJOR 1
+#endif
 // Prefetch ring of 3 k-blocks (2 in flight while one is consumed); the loop is fully unrolled so ring slots are
 // static registers.  `side(kb)` is called once per k-block: the row copies of the neighbouring phases (stores of the
 // previous output image, loads of the next epilogue's operands) are issued a piece per k-block BEHIND the first weight
@@ -92,18 +99,24 @@ __device__ __forceinline__ void chain_gemm(const bf16_t* __restrict__ wp, int nt
 #define IB_CHAIN_RING 3
 #endif
   constexpr int RING = IB_CHAIN_RING, PD = RING - 1;
+#if IB_CHAIN_KBMAJOR
+  constexpr int SU = 1, SK = CH_WAVES * NT;       // block strides of the n-tile / k-block index
+  const bf16x8_t* wl = reinterpret_cast<const bf16x8_t*>(wp) + (int64_t)nt0 * 64 + lane;
+#else
+  constexpr int SU = KB, SK = 1;
   const bf16x8_t* wl = reinterpret_cast<const bf16x8_t*>(wp) + ((int64_t)nt0 * KB) * 64 + lane;
+#endif
   const unsigned char* arow = abuf + (lane & 15) * rs + 16 * (lane >> 4);
   bf16x8_t wr[RING][NT];
 #pragma unroll
   for (int s = 0; s < PD && s < KB; ++s)
 #pragma unroll
-    for (int u = 0; u < NT; ++u) wr[s][u] = wl[(u * KB + s) * 64];
+    for (int u = 0; u < NT; ++u) wr[s][u] = wl[(u * SU + s * SK) * 64];
 #pragma unroll
   for (int kb = 0; kb < KB; ++kb) {
     if (kb + PD < KB) {
 #pragma unroll
-      for (int u = 0; u < NT; ++u) wr[(kb + PD) % RING][u] = wl[(u * KB + kb + PD) * 64];
+      for (int u = 0; u < NT; ++u) wr[(kb + PD) % RING][u] = wl[(u * SU + (kb + PD) * SK) * 64];
     }
     side(kb, IntC<KB>{});      // piece j of a side job runs at k-block j % KB
     // pin the issue point of this k-block's prefetch: at the register limit hipcc otherwise sinks every weight load
@@ -679,6 +692,545 @@ __global__ __launch_bounds__(CH_THREADS) void mlp_chain_kernel(ChainParams p) {
 
 #undef TIDV
 
+// =====================================================================================================================
+// v2 (round 3): the same chain with ROW-WISE epilogues.
+//
+// What the phase stamps of v1 said: the five GEMM phases take 24 of 74 us; the rest is epilogue time in which each wave
+// owns 64 COLUMNS of all 64 rows -- every LayerNorm statistic is then a cross-wave exchange behind a workgroup barrier
+// (the barrier waits for the SIMD's younger wave: 2-3 us each), every HBM row copy is a separate "piece mover" pass over
+// the LDS image with runtime index arithmetic (divisions by the row width), rows 50..63 of a 50-token panel are computed
+// and stored like real ones, and the pre-activation u makes an HBM round trip (26 MB written, 26 MB read per launch)
+// only to be re-read by the workgroup that wrote it.
+//
+// v2 keeps the GEMM phases (a wave owns output columns, weights stream L2 -> VGPR) and turns the tile through LDS once per
+// layer so that the epilogue owns whole ROWS: wave w takes rows w, w + 8, ... and a lane 8 consecutive columns of the row
+// (H = 512: 64 lanes x 8 columns = one row per wave-instruction).
+//   forward:  GEMM -> column owners write u = bf16(z + bias + e) into the second image -> barrier -> per row: SiLU, the two
+//             row sums by a 64-lane butterfly (no LDS, no barrier), normalise, h row -> first image (next GEMM's input) and
+//             -> HBM as one coalesced 1-KiB store from registers.  u stays IN REGISTERS (8 rows x 16 bytes per lane and
+//             layer) until the backward of the same layer -- no HBM round trip, no LDS image (KEEP: up to 2 blocks).
+//   backward: GEMM -> column owners write dh (fp32, two halves of 32 rows: 66 KB) -> barrier -> per row: LayerNorm / SiLU
+//             backward entirely in registers, dz row -> image + HBM; dgamma / dbeta / dbias accumulate per lane over the
+//             wave's rows and are summed across waves once per layer, in wave order (deterministic).
+// Rows beyond the panel are skipped (wave-uniform test), not computed and clamped.  Same parameters, same outputs, same
+// partial-sum layout as v1; u[i] may be NULL (then it is not stored at all) when the blocks fit the register plan.
+// Sum of a per-lane value over the LPR lanes that hold one row (LPR = 16, 32, 64); every lane of the group gets the total.
+// DPP only (ds_bpermute / __shfl_xor cross the LDS crossbar: ~100+ cycles of latency per step on the row's critical path):
+// the 16 lanes of a DPP row first, then row_bcast15 (lane 15 of rows 0 / 2 added into rows 1 / 3), row_bcast31 (lane 31
+// into rows 2 / 3); the total ends in the group's last lane and comes back through a scalar register.
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ float dpp_bcast_add(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROWMASK, 0xF, false));
+}
+template <int LPR>
+__device__ __forceinline__ float group_sum(float a, int lane) {
+  a = row16_sum(a);
+  if constexpr (LPR >= 32) a = dpp_bcast_add<0x142, 0xA>(a);
+  if constexpr (LPR == 64) {
+    a = dpp_bcast_add<0x143, 0xC>(a);
+    a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a), 63));
+  } else if constexpr (LPR == 32) {
+    const float lo = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a), 31));
+    const float hi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a), 63));
+    a = lane < 32 ? lo : hi;
+  }
+  return a;
+}
+__device__ __forceinline__ void unpack8(const uint4& q, float (&x)[8]) {
+  const bf16x8_t v = __builtin_bit_cast(bf16x8_t, q);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) x[k] = (float)v[k];
+}
+__device__ __forceinline__ uint4 pack8(const float (&x)[8]) {
+  bf16x8_t o;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) o[k] = (bf16_t)x[k];
+  return __builtin_bit_cast(uint4, o);
+}
+__device__ __forceinline__ void load8f(const float* p, float (&x)[8]) {
+  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
+}
+
+template <int NTH, int NTD, int KBD, bool KEEP>
+__global__ __launch_bounds__(CH_THREADS) void mlp_chain2_kernel(ChainParams p) {
+  using C = ChainCfg<NTH, NTD, KBD>;
+  constexpr int H = C::H, RS = C::RS, PPR = H / 8;
+  constexpr int LPR = H / 8;                       // lanes per row in the row-wise passes (8 columns per lane)
+  constexpr int RPW = 64 / LPR;                    // rows per wave-instruction (1 at H = 512)
+  constexpr int RSTEP = CH_WAVES * RPW;            // row stride between a lane's successive rows
+  constexpr int NJ = CH_ROWS / RSTEP, NJH = NJ / 2;
+  constexpr int RSX = H * 4 + 16;                  // fp32 exchange image: 32 rows
+  static_assert(32 * RSX <= C::BUF, "fp32 half-panel exchange must fit one image buffer");
+  static_assert(3 * CH_WAVES * H * 4 <= C::BUF, "column-sum exchange must fit one image buffer");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[C::LDS];
+  unsigned char* imgA = smem;                       // GEMM input of the forward; fp32 exchange / column sums in the backward
+  unsigned char* imgB = smem + C::BUF;              // u exchange (forward), eps / dpred, GEMM input of the backward
+  float2* coef = reinterpret_cast<float2*>(smem + 2 * C::BUF);
+  float* stats = reinterpret_cast<float*>(coef + 2 * CH_ROWS * CH_WAVES);   // [L][64][2] mean, rstd
+  unsigned char* eimg = reinterpret_cast<unsigned char*>(stats + CH_MAXL * CH_ROWS * 2);   // [CH_NWIN][H] bf16
+  float* lossred = reinterpret_cast<float*>(eimg + C::EIMG);            // [8]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+#define TIDV ((wave_s << 6) | lane_id_now())
+  const int g = lane >> 4, l16 = lane & 15;
+  const int r0 = blockIdx.x * p.P;
+  const int D = p.D, M = p.M;
+  const bf16_t* in_x0 = p.slots ? reinterpret_cast<const bf16_t*>(p.slots[0]) : p.x0;
+  const bf16_t* in_eps = p.slots ? reinterpret_cast<const bf16_t*>(p.slots[1]) : p.eps;
+  const int64_t* in_t = p.slots ? reinterpret_cast<const int64_t*>(p.slots[2]) : p.t;
+  const int nrows = min(p.P, M - r0);
+  const float invH = 1.f / (float)H;
+  // row-wise ownership
+  const int sub = lane / LPR, c8 = (lane % LPR) * 8;
+  const int wrow = wave_s * RPW + sub;              // this lane's row of iteration 0 (wave-uniform at H = 512)
+  CH_STAMP(0);
+
+  int rowg[4]; bool valid[4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const int lr = 16 * mt + l16;
+    valid[mt] = lr < nrows;
+    rowg[mt] = min(r0 + lr, M - 1);
+  }
+  const int w0 = r0 / p.T;
+  const int nwin = (r0 + nrows - 1) / p.T - w0 + 1;
+  const bool estage = nwin <= CH_NWIN;
+  int ewl[4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) ewl[mt] = min(rowg[mt] / p.T - w0, CH_NWIN - 1);
+
+  // ---- q_sample, row-wise: wave w takes rows w, w + 8, ...; a row is D / 4 pieces of 8 bytes (<= 128: two per lane).
+  // xt -> HBM and -> image A, whose columns D .. DP-1 are zeroed (the packed weights there are zero, but 0 x garbage is not)
+  {
+    const int ppr = D >> 2;
+    uint2 rx[CH_ROWS / CH_WAVES][2], re[CH_ROWS / CH_WAVES][2];
+#pragma unroll
+    for (int j = 0; j < CH_ROWS / CH_WAVES; ++j) {
+      const int rc = min(wave_s + CH_WAVES * j, nrows - 1);
+      const bf16_t* xr = in_x0 + (int64_t)(r0 + rc) * D;
+      const bf16_t* er_ = in_eps + (int64_t)(r0 + rc) * D;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int pc = min(lane + 64 * q, ppr - 1);
+        rx[j][q] = *reinterpret_cast<const uint2*>(xr + pc * 4);
+        re[j][q] = *reinterpret_cast<const uint2*>(er_ + pc * 4);
+      }
+    }
+    // the per-row coefficients (three dependent loads: timestep, two table entries) BEHIND the row loads: the wave that
+    // fetches them would otherwise stall on them before it has requested its rows
+    if (tid < CH_ROWS) {
+      float2 c = make_float2(0.f, 0.f);
+      if (tid < nrows) {
+        int64_t k = in_t[(r0 + tid) / p.T];
+        k = k < 0 ? 0 : (k >= p.table_rows ? p.table_rows - 1 : k);
+        c = make_float2(p.sqrt_ab[k], p.sqrt_1mab[k]);
+      }
+      coef[tid] = c;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < CH_ROWS / CH_WAVES; ++j) {
+      const int r = wave_s + CH_WAVES * j;
+      if (r < nrows) {
+        const float2 c = coef[r];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int pc = lane + 64 * q;
+          const bf16x4_t xv = __builtin_bit_cast(bf16x4_t, rx[j][q]), ev = __builtin_bit_cast(bf16x4_t, re[j][q]);
+          bf16x4_t o = pack4(c.x * (float)xv[0] + c.y * (float)ev[0], c.x * (float)xv[1] + c.y * (float)ev[1],
+                             c.x * (float)xv[2] + c.y * (float)ev[2], c.x * (float)xv[3] + c.y * (float)ev[3]);
+          if (pc < ppr) *reinterpret_cast<bf16x4_t*>(p.xt + (int64_t)(r0 + r) * p.ld_xt + pc * 4) = o;
+          else o = pack4(0.f, 0.f, 0.f, 0.f);
+          if (pc < C::DP / 4) *reinterpret_cast<bf16x4_t*>(imgA + r * RS + pc * 8) = o;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  CH_STAMP(1);
+
+  uint4 ukeep[KEEP ? 2 : 1][NJ];
+
+  // ---- forward block i (I = i as a compile-time index of the kept registers)
+  auto fwd_layer = [&](auto ic, const int i) {
+    constexpr int I = decltype(ic)::value;
+    f32x4_t acc[4][NTH];
+    zero_acc<NTH>(acc);
+    uint4 er = make_uint4(0u, 0u, 0u, 0u);
+    const bf16_t* esrc = p.e + (int64_t)w0 * p.ld_e + (int64_t)i * H;
+    const int colb = wave * 16 * NTH + 4 * g;
+    // The panel's time-embedding rows.  One window per panel (the headline shape): every row adds the SAME e row, each
+    // lane fetches its 4 x NTH columns of it straight into registers -- no LDS staging, no barrier.  Several windows: the
+    // rows are staged in LDS (e image).  Both requests are issued unconditionally BEHIND the first weight loads (a branch
+    // around a load makes hipcc drain the prefetch ring at the join); which one is used is a wave-uniform choice afterwards.
+    bf16x4_t e1[NTH];
+    float4 b4[NTH];
+    float gm[8], bt[8];                    // LayerNorm gain / bias of this lane's 8 columns (row-wise pass)
+    // (requested late in the k-loop: 44 registers that would otherwise be live through the whole GEMM phase, on top of the
+    // accumulators, the prefetch ring and the kept pre-activations -- the first version of this spilled)
+    auto side = [&](int kb, auto kbc) {
+      constexpr int KB = decltype(kbc)::value;
+      if (kb == KB - 1) {                  // the ring's other slots are dead by now
+        load8f(p.gamma[i] + c8, gm);
+        load8f(p.beta[i] + c8, bt);
+      }
+      if (kb == KB - 1) {
+        er = in_piece16(esrc, p.ld_e, min(nwin, CH_NWIN), PPR, TIDV);
+#pragma unroll
+        for (int u = 0; u < NTH; ++u) {
+          e1[u] = *reinterpret_cast<const bf16x4_t*>(esrc + colb + 16 * u);
+          b4[u] = *reinterpret_cast<const float4*>(p.bias[i] + colb + 16 * u);
+        }
+      }
+    };
+    if (i == 0) chain_gemm<NTH, KBD>(p.wf[0], wave_s * NTH, imgA, RS, lane_id_now(), acc, side);
+    else chain_gemm<NTH, C::KBH>(p.wf[i], wave_s * NTH, imgA, RS, lane_id_now(), acc, side);
+    CH_STAMP(2 + 3 * i);
+    if (nwin == 1) {
+      // column owners: u = bf16(z + bias + e) -> image B
+#pragma unroll
+      for (int u = 0; u < NTH; ++u) {
+        const float ee[4] = {(float)e1[u][0], (float)e1[u][1], (float)e1[u][2], (float)e1[u][3]};
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)       // (z + bias) + e: the same order as the staged path
+          *reinterpret_cast<bf16x4_t*>(imgB + (16 * mt + l16) * RS + (colb + 16 * u) * 2) =
+              pack4(acc[mt][u][0] + b4[u].x + ee[0], acc[mt][u][1] + b4[u].y + ee[1], acc[mt][u][2] + b4[u].z + ee[2],
+                    acc[mt][u][3] + b4[u].w + ee[3]);
+      }
+    } else {
+      if (tid < CH_NWIN * PPR) *reinterpret_cast<uint4*>(eimg + tid * 16) = er;
+      __syncthreads();                     // e image complete
+      auto pre = [&](auto stagedc) {
+        constexpr bool STAGED = decltype(stagedc)::value != 0;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          const bf16_t* erow = p.e + (int64_t)(rowg[mt] / p.T) * p.ld_e + (int64_t)i * H;
+          const unsigned char* el = eimg + ewl[mt] * (H * 2);
+#pragma unroll
+          for (int u = 0; u < NTH; ++u) {
+            const int col = colb + 16 * u;
+            bf16x4_t e4;
+            if constexpr (STAGED) e4 = *reinterpret_cast<const bf16x4_t*>(el + col * 2);
+            else e4 = *reinterpret_cast<const bf16x4_t*>(erow + col);
+            *reinterpret_cast<bf16x4_t*>(imgB + (16 * mt + l16) * RS + col * 2) =
+                pack4(acc[mt][u][0] + b4[u].x + (float)e4[0], acc[mt][u][1] + b4[u].y + (float)e4[1],
+                      acc[mt][u][2] + b4[u].z + (float)e4[2], acc[mt][u][3] + b4[u].w + (float)e4[3]);
+          }
+        }
+      };
+      if (estage) pre(IntC<1>{});
+      else pre(IntC<0>{});
+    }
+    __syncthreads();                       // u image complete; every wave is done reading image A
+    CH_STAMP(3 + 3 * i);
+    {
+      bf16_t* ug = p.u[i];
+      bf16_t* hg = p.h[i] + (int64_t)r0 * H;
+      // G rows at a time, stage by stage (the rows of a group are independent: their latency chains -- LDS read, exp / rcp,
+      // the row reductions -- overlap); a group whose first row lies beyond the panel ends the loop (wave-uniform at
+      // H = 512; a lane's rows ascend).  Stores of single rows beyond the panel are predicated.
+      constexpr int G = 2;
+#pragma unroll
+      for (int j0 = 0; j0 < NJ; j0 += G) {
+        if (RPW == 1 && wave_s + RSTEP * j0 >= nrows) break;
+        uint4 q[G];
+        float v[G][8], s1[G], s2[G];
+#pragma unroll
+        for (int gi = 0; gi < G; ++gi) {
+          const int r = wrow + RSTEP * (j0 + gi);
+          q[gi] = *reinterpret_cast<const uint4*>(imgB + r * RS + c8 * 2);
+          if constexpr (KEEP) ukeep[I][j0 + gi] = q[gi];
+        }
+#pragma unroll
+        for (int gi = 0; gi < G; ++gi) {
+          float x[8];
+          unpack8(q[gi], x);
+          // pairwise partial sums (even / odd columns): the compiler packs them into v_pk_add / v_pk_fma
+          float a0 = 0.f, a1 = 0.f, q0 = 0.f, q1 = 0.f;
+#pragma unroll
+          for (int k = 0; k < 8; k += 2) {
+            v[gi][k] = x[k] * fast_sigmoid(x[k]);
+            v[gi][k + 1] = x[k + 1] * fast_sigmoid(x[k + 1]);
+            a0 += v[gi][k]; a1 += v[gi][k + 1];
+            q0 += v[gi][k] * v[gi][k]; q1 += v[gi][k + 1] * v[gi][k + 1];
+          }
+          s1[gi] = a0 + a1; s2[gi] = q0 + q1;
+        }
+#pragma unroll
+        for (int gi = 0; gi < G; ++gi) {
+          s1[gi] = group_sum<LPR>(s1[gi], lane);
+          s2[gi] = group_sum<LPR>(s2[gi], lane);
+        }
+#pragma unroll
+        for (int gi = 0; gi < G; ++gi) {
+          const int r = wrow + RSTEP * (j0 + gi);
+          const bool ok = r < nrows;
+          const float mean = s1[gi] * invH;
+          const float rstd = __builtin_amdgcn_rsqf(fmaxf(s2[gi] * invH - mean * mean, 0.f) + p.ln_eps);
+          float hv[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) hv[k] = (v[gi][k] - mean) * rstd * gm[k] + bt[k];
+          const uint4 hq = pack8(hv);
+          if (ok) {
+            if (ug != nullptr) *reinterpret_cast<uint4*>(ug + (int64_t)(r0 + r) * H + c8) = q[gi];
+            *reinterpret_cast<uint4*>(imgA + r * RS + c8 * 2) = hq;
+            *reinterpret_cast<uint4*>(hg + (int64_t)r * H + c8) = hq;
+            if (c8 == 0) *reinterpret_cast<float2*>(stats + (i * CH_ROWS + r) * 2) = make_float2(mean, rstd);
+          }
+        }
+      }
+    }
+    __syncthreads();                       // image A = h_i complete
+    CH_STAMP(4 + 3 * i);
+  };
+  if constexpr (KEEP) {
+    fwd_layer(IntC<0>{}, 0);
+    if (p.L > 1) fwd_layer(IntC<1>{}, 1);
+  } else {
+    for (int i = 0; i < p.L; ++i) fwd_layer(IntC<0>{}, i);
+  }
+
+  // ---- head + loss + dL/dpred (column owners; eps rows staged row-wise into image B, dpred written over them)
+  const bool dp16 = (p.ld_dpred & 7) == 0 && (reinterpret_cast<uintptr_t>(p.dpred) & 15) == 0;
+  {
+    const int ppr = D >> 2;
+    uint2 re[CH_ROWS / CH_WAVES][2];
+#pragma unroll
+    for (int j = 0; j < CH_ROWS / CH_WAVES; ++j) {
+      const int rc = min(wave_s + CH_WAVES * j, nrows - 1);
+      const bf16_t* er_ = in_eps + (int64_t)(r0 + rc) * D;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) re[j][q] = *reinterpret_cast<const uint2*>(er_ + min(lane + 64 * q, ppr - 1) * 4);
+    }
+    f32x4_t acc[4][NTD];
+    zero_acc<NTD>(acc);
+    auto side = [&](int, auto) {};
+    chain_gemm<NTD, C::KBH>(p.wf[p.L], wave_s * NTD, imgA, RS, lane_id_now(), acc, side);
+    CH_STAMP(2 + 3 * p.L);
+#pragma unroll
+    for (int j = 0; j < CH_ROWS / CH_WAVES; ++j) {
+      const int r = wave_s + CH_WAVES * j;
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+        if (lane + 64 * q < ppr) *reinterpret_cast<uint2*>(imgB + r * RS + (lane + 64 * q) * 8) = re[j][q];
+    }
+    __syncthreads();
+    const int colb = wave * 16 * NTD + 4 * g;
+    float lsum = 0.f;
+    float* prow = p.partial + (int64_t)blockIdx.x * p.ld_part;
+#pragma unroll
+    for (int u = 0; u < NTD; ++u) {
+      const int col = colb + 16 * u;
+      const bool cin = col < D;
+      float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (cin) b4 = *reinterpret_cast<const float4*>(p.bias[p.L] + col);
+      const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+      float cs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        bf16x4_t* slot = reinterpret_cast<bf16x4_t*>(imgB + (16 * mt + l16) * RS + col * 2);
+        bf16x4_t dp = pack4(0.f, 0.f, 0.f, 0.f);
+        if (cin && valid[mt]) {
+          const bf16x4_t e4 = *slot;
+          float d[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float pr = (float)(bf16_t)(acc[mt][u][r] + bb[r]);
+            d[r] = pr - (float)e4[r];
+            lsum += d[r] * d[r];
+          }
+          dp = pack4(d[0] * p.gscale, d[1] * p.gscale, d[2] * p.gscale, d[3] * p.gscale);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) cs[r] += (float)dp[r];
+        }
+        *slot = dp;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cs[r] = row16_sum(cs[r]);
+      if (l16 == 0) *reinterpret_cast<float4*>(prow + 3 * p.L * H + col) = make_float4(cs[0], cs[1], cs[2], cs[3]);
+    }
+    lsum = ib_wave_sum(lsum);
+    if (lane == 0) lossred[wave] = lsum;
+    __syncthreads();                       // dpred image complete
+    if (tid == 0) {
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < CH_WAVES; ++w) s += lossred[w];
+      prow[3 * p.L * H + C::DN] = s;
+    }
+    // dpred rows -> HBM, row-wise (pad columns of a 16-byte row pitch receive the image's zeros)
+    bf16_t* dpg = p.dpred + (int64_t)r0 * p.ld_dpred;
+#pragma unroll
+    for (int j = 0; j < CH_ROWS / CH_WAVES; ++j) {
+      const int r = wave_s + CH_WAVES * j;
+      if (r < nrows) {
+        if (dp16) {
+          if (lane < ((D + 7) >> 3))
+            *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(dpg + (int64_t)r * p.ld_dpred) + lane * 16) =
+                *reinterpret_cast<const uint4*>(imgB + r * RS + lane * 16);
+        } else {
+#pragma unroll
+          for (int q = 0; q < 2; ++q)
+            if (lane + 64 * q < ppr)
+              *reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(dpg + (int64_t)r * p.ld_dpred) + (lane + 64 * q) * 8) =
+                  *reinterpret_cast<const uint2*>(imgB + r * RS + (lane + 64 * q) * 8);
+        }
+      }
+    }
+    CH_STAMP(3 + 3 * p.L);
+  }
+
+  // ---- backward of block i: dh = (dz_{i+1} or dpred) . W^T (GEMM input = image B) -> LayerNorm / SiLU backward -> dz_i
+  auto bwd_layer = [&](auto ic, const int i) {
+    constexpr int I = decltype(ic)::value;
+    const int sb0 = 4 + 3 * p.L + 6 * (p.L - 1 - i);
+    uint4 ur[NJ];
+    if constexpr (KEEP) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) ur[j] = ukeep[I][j];
+    } else {
+      const bf16_t* ug = p.u[i] + (int64_t)r0 * H;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        ur[j] = *reinterpret_cast<const uint4*>(ug + (int64_t)min(wrow + RSTEP * j, nrows - 1) * H + c8);
+    }
+    f32x4_t acc[4][NTH];
+    zero_acc<NTH>(acc);
+    float gm[8];
+    auto side = [&](int kb, auto kbc) {
+      constexpr int KB = decltype(kbc)::value;
+      if (kb == KB - 1) load8f(p.gamma[i] + c8, gm);
+    };
+    if (i == p.L - 1) chain_gemm<NTH, KBD>(p.wb[p.L], wave_s * NTH, imgB, RS, lane_id_now(), acc, side);
+    else chain_gemm<NTH, C::KBH>(p.wb[i + 1], wave_s * NTH, imgB, RS, lane_id_now(), acc, side);
+    CH_STAMP(sb0);
+    float dgam[8], dbet[8], dbs[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { dgam[k] = 0.f; dbet[k] = 0.f; dbs[k] = 0.f; }
+    bf16_t* dzg = p.dz[i] + (int64_t)r0 * H;
+    const int colb = wave * 16 * NTH + 4 * g;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      // column owners: dh of rows 32 half .. 32 half + 31 -> fp32 exchange image (image A's storage)
+#pragma unroll
+      for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+        for (int u = 0; u < NTH; ++u)
+          *reinterpret_cast<f32x4_t*>(imgA + (16 * m2 + l16) * RSX + (colb + 16 * u) * 4) = acc[2 * half + m2][u];
+      __syncthreads();
+      CH_STAMP(sb0 + 1 + 2 * half);
+      constexpr int G = NJH >= 2 ? 2 : 1;
+#pragma unroll
+      for (int jj0 = 0; jj0 < NJH; jj0 += G) {
+        if (RPW == 1 && wave_s + RSTEP * (half * NJH + jj0) >= nrows) break;
+        float dxh[G][8], xh[G][8], ds[G][8], sa[G], sb[G];
+        float2 st[G];
+#pragma unroll
+        for (int gi = 0; gi < G; ++gi) {
+          const int j = half * NJH + jj0 + gi;
+          const int r = wrow + RSTEP * j;
+          const bool ok = r < nrows;
+          float dh[8], x[8];
+          load8f(reinterpret_cast<const float*>(imgA + (r - 32 * half) * RSX) + c8, dh);
+          unpack8(ur[j], x);
+          st[gi] = *reinterpret_cast<const float2*>(stats + (i * CH_ROWS + min(r, nrows - 1)) * 2);
+          sa[gi] = 0.f; sb[gi] = 0.f;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const float xx = ok ? x[k] : 0.f;          // rows beyond the panel hold garbage: keep the sums finite
+            const float sg = fast_sigmoid(xx);
+            const float v = xx * sg;
+            ds[gi][k] = sg * (1.f + xx * (1.f - sg));
+            xh[gi][k] = (v - st[gi].x) * st[gi].y;
+            const float d = ok ? dh[k] : 0.f;
+            dgam[k] += d * xh[gi][k];
+            dbet[k] += d;
+            dxh[gi][k] = d * gm[k];
+            sa[gi] += dxh[gi][k];
+            sb[gi] += dxh[gi][k] * xh[gi][k];
+          }
+        }
+#pragma unroll
+        for (int gi = 0; gi < G; ++gi) {
+          sa[gi] = group_sum<LPR>(sa[gi], lane);
+          sb[gi] = group_sum<LPR>(sb[gi], lane);
+        }
+#pragma unroll
+        for (int gi = 0; gi < G; ++gi) {
+          const int r = wrow + RSTEP * (half * NJH + jj0 + gi);
+          const bool ok = r < nrows;
+          const float ma = sa[gi] * invH, mb = sb[gi] * invH;
+          float dzv[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) dzv[k] = st[gi].y * (dxh[gi][k] - ma - xh[gi][k] * mb) * ds[gi][k];
+          const uint4 zq = pack8(dzv);
+          if (ok) {
+            float zr[8];
+            unpack8(zq, zr);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) dbs[k] += zr[k];
+            *reinterpret_cast<uint4*>(imgB + r * RS + c8 * 2) = zq;
+            *reinterpret_cast<uint4*>(dzg + (int64_t)r * H + c8) = zq;
+          }
+        }
+      }
+      __syncthreads();                     // exchange image free again; after the second half image B = dz_i
+      CH_STAMP(sb0 + 2 + 2 * half);
+    }
+    {
+      // dgamma | dbeta | dbias of this panel: the waves' per-lane sums over their rows, added in row-group order
+      if constexpr (RPW > 1) {             // several row groups per wave: add them first (fixed order)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          if constexpr (LPR == 16) {
+            dgam[k] += __shfl_xor(dgam[k], 16, 64); dbet[k] += __shfl_xor(dbet[k], 16, 64); dbs[k] += __shfl_xor(dbs[k], 16, 64);
+          }
+          dgam[k] += __shfl_xor(dgam[k], 32, 64); dbet[k] += __shfl_xor(dbet[k], 32, 64); dbs[k] += __shfl_xor(dbs[k], 32, 64);
+        }
+      }
+      float* cr = reinterpret_cast<float*>(imgA);
+      if (sub == 0) {
+        float* c0 = cr + ((0 * CH_WAVES + wave) * H + c8);
+        float* c1 = cr + ((1 * CH_WAVES + wave) * H + c8);
+        float* c2 = cr + ((2 * CH_WAVES + wave) * H + c8);
+        *reinterpret_cast<float4*>(c0) = make_float4(dgam[0], dgam[1], dgam[2], dgam[3]);
+        *reinterpret_cast<float4*>(c0 + 4) = make_float4(dgam[4], dgam[5], dgam[6], dgam[7]);
+        *reinterpret_cast<float4*>(c1) = make_float4(dbet[0], dbet[1], dbet[2], dbet[3]);
+        *reinterpret_cast<float4*>(c1 + 4) = make_float4(dbet[4], dbet[5], dbet[6], dbet[7]);
+        *reinterpret_cast<float4*>(c2) = make_float4(dbs[0], dbs[1], dbs[2], dbs[3]);
+        *reinterpret_cast<float4*>(c2 + 4) = make_float4(dbs[4], dbs[5], dbs[6], dbs[7]);
+      }
+      __syncthreads();
+      if (tid < H) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < CH_WAVES; ++w) {
+          s0 += cr[(0 * CH_WAVES + w) * H + tid];
+          s1 += cr[(1 * CH_WAVES + w) * H + tid];
+          s2 += cr[(2 * CH_WAVES + w) * H + tid];
+        }
+        float* pg = p.partial + (int64_t)blockIdx.x * p.ld_part + 3 * i * H;
+        pg[tid] = s0;
+        pg[H + tid] = s1;
+        pg[2 * H + tid] = s2;
+        if (p.de_lp) p.de_lp[(int64_t)blockIdx.x * p.ld_de + i * H + tid] = (bf16_t)s2;
+      }
+      __syncthreads();                     // the next block's exchange writes reuse this storage
+    }
+    CH_STAMP(sb0 + 5);
+  };
+  if constexpr (KEEP) {
+    if (p.L > 1) bwd_layer(IntC<1>{}, 1);
+    bwd_layer(IntC<0>{}, 0);
+  } else {
+    for (int i = p.L - 1; i >= 0; --i) bwd_layer(IntC<0>{}, i);
+  }
+}
+
+#undef TIDV
+
 // ---- weight packing: bf16 row-major [N_out, K_in] -> fragment-major blocks, zero padded
 struct PackDesc {
   const bf16_t* src; int64_t ld;
@@ -698,7 +1250,11 @@ __device__ __forceinline__ void pack_blocks(const PackParams& p, int first, int 
       if (blk >= p.d[j].block0) di = j;
     const PackDesc& d = p.d[di];
     const int local = blk - d.block0;
+#if IB_CHAIN_KBMAJOR
+    const int nt = local % d.n_tiles, kb = local / d.n_tiles;
+#else
     const int nt = local / d.KB, kb = local % d.KB;
+#endif
     const int n = 16 * nt + (lane & 15), k0 = 32 * kb + 8 * (lane >> 4);
     bf16x8_t v;
 #pragma unroll
@@ -855,8 +1411,8 @@ extern "C" int ib_mlp_chain_train(const void* x0, const void* eps, const int64_t
     p.bias[i] = bias[i];
   }
   for (int i = 0; i < L; ++i) {
-    if (!gamma[i] || !beta[i] || !u[i] || !h[i] || !dz[i]) return IB_E_ARG;
-    if (!al16(gamma[i]) || !al16(beta[i]) || !al16(u[i]) || !al16(h[i]) || !al16(dz[i])) return IB_E_ARG;
+    if (!gamma[i] || !beta[i] || !h[i] || !dz[i]) return IB_E_ARG;
+    if (!al16(gamma[i]) || !al16(beta[i]) || (u[i] && !al16(u[i])) || !al16(h[i]) || !al16(dz[i])) return IB_E_ARG;
     p.gamma[i] = gamma[i]; p.beta[i] = beta[i];
     p.u[i] = (bf16_t*)u[i]; p.h[i] = (bf16_t*)h[i]; p.dz[i] = (bf16_t*)dz[i];
   }
@@ -865,8 +1421,18 @@ extern "C" int ib_mlp_chain_train(const void* x0, const void* eps, const int64_t
   p.gscale = 2.f / ((float)M * (float)D); p.ln_eps = ln_eps;
   p.prof = g_chain_prof;
   hipStream_t st = ib_s(stream);
-#define IB_CHAIN_LAUNCH(NTH, NTD, KBD) \
-  hipLaunchKernelGGL((mlp_chain_kernel<NTH, NTD, KBD>), dim3(nwg), dim3(CH_THREADS), 0, st, p)
+  // v2 (row-wise epilogues) is the kernel; IB_CHAIN_V1=1 selects the round-2 kernel for A/B measurements.  v2 keeps u in
+  // registers for L <= 2 (u[i] may then be NULL: nothing is stored); deeper stacks pass u through HBM as v1 does.
+  static const bool use_v1 = getenv("IB_CHAIN_V1") != nullptr;
+  const bool keep = L <= 2;
+  for (int i = 0; i < L; ++i)
+    if (!u[i] && (use_v1 || !keep)) return IB_E_ARG;
+#define IB_CHAIN_LAUNCH(NTH, NTD, KBD)                                                                                  \
+  do {                                                                                                                  \
+    if (use_v1) hipLaunchKernelGGL((mlp_chain_kernel<NTH, NTD, KBD>), dim3(nwg), dim3(CH_THREADS), 0, st, p);           \
+    else if (keep) hipLaunchKernelGGL((mlp_chain2_kernel<NTH, NTD, KBD, true>), dim3(nwg), dim3(CH_THREADS), 0, st, p); \
+    else hipLaunchKernelGGL((mlp_chain2_kernel<NTH, NTD, KBD, false>), dim3(nwg), dim3(CH_THREADS), 0, st, p);          \
+  } while (0)
   if (s.nth == 4 && s.ntd == 3 && s.kbd == 10) IB_CHAIN_LAUNCH(4, 3, 10);
   else if (s.nth == 4 && s.ntd == 1 && s.kbd == 2) IB_CHAIN_LAUNCH(4, 1, 2);
   else if (s.nth == 4 && s.ntd == 1 && s.kbd == 4) IB_CHAIN_LAUNCH(4, 1, 4);

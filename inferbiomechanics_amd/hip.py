@@ -1367,7 +1367,7 @@ def time_mlp_fwd(table, t, w1, b1, w2, b2, s, zu, u, e, pack=None, slots=None):
 
 
 def _ptr_array(tensors):
-    arr = (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    arr = (ctypes.c_void_p * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])
     return arr, ctypes.cast(arr, ctypes.c_void_p)
 
 
@@ -1421,7 +1421,9 @@ def set_ptrs(slots, tensors):
 def mlp_chain_train(x0, eps, t, sqrt_ab, sqrt_1mab, e, packed, bias, gamma, beta, xt, u, h, dz, dpred, partial,
                     T: int, de_lp=None, ln_eps: float = 1e-5, slots=None):
     """x0 / eps: contiguous bf16 [B,T,D]; e: bf16 [B, L*H]; xt / dpred: bf16 2-D [B*T, D] (row pitch % 4 == 0);
-    u / h / dz: L contiguous bf16 [B*T, H]; bias: L+1 fp32 vectors; gamma / beta: L fp32 vectors;
+    h / dz: L contiguous bf16 [B*T, H]; u: the same, or None / None entries -- the kernel keeps the pre-activations in
+    registers and stores them only into the buffers it is given (L <= 2; deeper stacks need every u buffer);
+    bias: L+1 fp32 vectors; gamma / beta: L fp32 vectors;
     partial: fp32 [workgroups, >= mlp_chain_partial_width] (column layout: include/ib_hip.h);
     de_lp: optional bf16 [B, L*H], legal only when mlp_chain_rows_per_workgroup(B*T) == T"""
     bt = torch.bfloat16
@@ -1431,8 +1433,11 @@ def mlp_chain_train(x0, eps, t, sqrt_ab, sqrt_1mab, e, packed, bias, gamma, beta
     B, T_, D = x0.shape
     if T_ != T:
         raise HipError("mlp_chain_train: T mismatch")
-    M, L = B * T, len(u)
-    H = u[0].shape[1]
+    M, L = B * T, len(h)
+    H = h[0].shape[1]
+    u = [None] * L if u is None else list(u)
+    if any(a is None for a in u) and (L > 2 or os.environ.get("IB_CHAIN_V1")):
+        raise HipError("mlp_chain_train: u buffers are optional only for L <= 2 (pre-activations kept in registers)")
     _req(t, "t", torch.int64, 1); _req(sqrt_ab, "sqrt_ab", torch.float32, 1); _req(sqrt_1mab, "sqrt_1mab", torch.float32, 1)
     er, ec, lde = _mat(e, "e", bt)
     if (er, ec) != (B, L * H) or t.numel() != B:
@@ -1446,6 +1451,8 @@ def mlp_chain_train(x0, eps, t, sqrt_ab, sqrt_1mab, e, packed, bias, gamma, beta
         if len(lst) != L:
             raise HipError(f"mlp_chain_train: {name} needs {L} entries")
         for a in lst:
+            if a is None and name == "u":
+                continue
             _req(a, name, dt)
             if tuple(a.shape) != shape or not a.is_contiguous():
                 raise HipError(f"mlp_chain_train: {name} must be contiguous {shape}")

@@ -983,7 +983,8 @@ class DenoiserMLPPlan:
         Dp = (D + 7) // 8 * 8
         xt = g("ch.xt", (M, Dp), dt)[:, :D]
         dpred = g("ch.dpred", (M, Dp), dt)[:, :D]
-        u = [g(f"ch.u{i}", (M, H), dt) for i in range(L)]
+        # the pre-activations stay in the chain kernel's registers (L <= 2); deeper stacks pass them through HBM
+        u = None if (L <= 2 and not os.environ.get("IB_CHAIN_V1")) else [g(f"ch.u{i}", (M, H), dt) for i in range(L)]
         h = [g(f"ch.h{i}", (M, H), dt) for i in range(L)]
         dz = [g(f"ch.dz{i}", (M, H), dt) for i in range(L)]
         nwg = hip.mlp_chain_workgroups(M)

@@ -132,6 +132,17 @@ def test_chain_matches_float64_restatement(hip, B, T, D, H, L):
     for i in range(L):
         close(u_k[i], us[i], tol, f"u{i}")
         close(h_k[i], hs[i], tol, f"h{i}")
+    if L <= 2:
+        # the product path hands over NO u buffers (the pre-activations never leave the kernel's registers): every
+        # output must be bitwise what the launch with u buffers produced
+        outs = [xt.clone(), dpred.clone(), part.clone()] + [a.clone() for a in h_k + dz_k]
+        for a in [xt, dpred, part] + h_k + dz_k:
+            a.zero_()
+        hip.mlp_chain_train(d(x0), d(eps), d(t), d(sab), d(s1m), d(e), packed, [d(b) for b in bias], [d(g) for g in gamma],
+                            [d(b) for b in beta], xt, None, h_k, dz_k, dpred, part, T, de_lp=de_lp)
+        torch.cuda.synchronize()
+        for a, b_ in zip([xt, dpred, part] + h_k + dz_k, outs):
+            assert torch.equal(a, b_)
     assert abs(out.item() - loss.item()) <= 1e-2 * abs(loss.item()), (out.item(), loss.item())
     close(dpred, pred.grad, tol, "dpred")
     for i in range(L - 1, -1, -1):

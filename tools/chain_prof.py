@@ -44,14 +44,36 @@ def main():
     for _ in range(5):
         launch()
     torch.cuda.synchronize()
+    # un-instrumented launch time: 200 back-to-back launches between two events, best of 5
+    best = 1e9
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(200):
+            launch()
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) / 200 * 1e3)
+    print(f"launch (no stamps, back to back): {best:.2f} us   lib={hip.LIB_PATH.split('/')[-1]}")
+    if "--no-phases" in sys.argv:
+        return
     hip.lib().ib_debug_set_chain_prof(ctypes.c_void_p(stamps.data_ptr()))
+    import os
     names = ["q_sample"]
-    for i in range(L):
-        names += [f"fwd{i}.gemm", f"fwd{i}.epi.sync+u+silu", f"fwd{i}.epi.reduce", f"fwd{i}.epi.copy_u+h+sync"]
-    names += ["head.gemm", "head.epi"]
-    for i in range(L - 1, -1, -1):
-        names += [f"bwd{i}.gemm", f"bwd{i}.u_image+sync", f"bwd{i}.pass1a", f"bwd{i}.reduce_a", f"bwd{i}.pass2a+pass1b",
-                  f"bwd{i}.reduce_b", f"bwd{i}.pass2b", f"bwd{i}.colsums", f"bwd{i}.sync(+copy_dz0)"]
+    if os.environ.get("IB_CHAIN_V1"):
+        for i in range(L):
+            names += [f"fwd{i}.gemm", f"fwd{i}.epi.sync+u+silu", f"fwd{i}.epi.reduce", f"fwd{i}.epi.copy_u+h+sync"]
+        names += ["head.gemm", "head.epi"]
+        for i in range(L - 1, -1, -1):
+            names += [f"bwd{i}.gemm", f"bwd{i}.u_image+sync", f"bwd{i}.pass1a", f"bwd{i}.reduce_a", f"bwd{i}.pass2a+pass1b",
+                      f"bwd{i}.reduce_b", f"bwd{i}.pass2b", f"bwd{i}.colsums", f"bwd{i}.sync(+copy_dz0)"]
+    else:                                # v2: row-wise epilogues
+        for i in range(L):
+            names += [f"fwd{i}.gemm", f"fwd{i}.sync+u_exchange+sync", f"fwd{i}.rows(silu,LN,h)+sync"]
+        names += ["head.gemm", "head.epi+dpred_rows"]
+        for i in range(L - 1, -1, -1):
+            names += [f"bwd{i}.gemm", f"bwd{i}.dh_half0+sync", f"bwd{i}.rows_half0+sync", f"bwd{i}.dh_half1+sync",
+                      f"bwd{i}.rows_half1+sync", f"bwd{i}.colsums"]
     n = len(names)
     acc = None
     reps = 8
