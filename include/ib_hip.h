@@ -398,6 +398,24 @@ int ib_event_destroy(void* ev);
 /* ---- device self-tests of instruction-layout assumptions (tests only) ----------------------- */
 /* timing-only: bit mask of GEMM phases to skip (results are WRONG when non-zero; tools/kbench.py only) */
 int ib_debug_set_ablate(int mask);
+/* Which kernel family the LAST dispatching entry point of this thread's process launched (tests/test_dispatch_gpu.py holds
+ * every BASELINE shape to its family, so that a threshold edit cannot silently move a benchmarked shape to another kernel).
+ * Not part of the reference-facing surface; a plain global, read (and cleared) right after the call it describes. */
+enum {
+  IB_PATH_NONE = 0,
+  IB_PATH_NT = 1,           /* gemm_nt.hip: 256 x 128 LDS-DMA kernel (forward / dgrad with a transposed weight) */
+  IB_PATH_TN = 2,           /* gemm_tn.hip: 256 x 128 weight-gradient kernel, grouped */
+  IB_PATH_RING = 3,         /* gemm.hip: 128 x 128 LDS-DMA ring kernel */
+  IB_PATH_GENERIC = 4,      /* gemm.hip: register-staged kernel (fp32 exact MFMA, or unaligned / ragged bf16 operands) */
+  IB_PATH_SMALLM = 5,       /* gemm.hip: 64 x 16 tiles for batches of a few hundred rows (forward / dgrad) */
+  IB_PATH_SKINNY = 6,       /* gemm.hip: few-row dgrad (one workgroup per 16 output columns) */
+  IB_PATH_WGRAD_SMALL = 7,  /* gemm.hip: direct weight gradient of a short reduction */
+  IB_PATH_RING_MULTI = 8,   /* gemm.hip: grouped ring weight-gradient launch */
+  IB_PATH_LINLN = 9,        /* gemm.hip: K-split Linear + residual + LayerNorm (sampler) */
+  IB_PATH_CHAIN2 = 10,      /* chain.hip: fused MLP-denoiser chain, row-wise epilogues */
+  IB_PATH_CHAIN1 = 11       /* chain.hip: the round-2 chain kernel (IB_CHAIN_V1=1) */
+};
+int ib_debug_last_path(void);
 int ib_selftest_tr16(const void* in_bf16_64x16, void* out_bf16_64x4, ib_stream_t stream);
 
 #ifdef __cplusplus

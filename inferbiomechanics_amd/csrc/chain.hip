@@ -1433,6 +1433,7 @@ extern "C" int ib_mlp_chain_train(const void* x0, const void* eps, const int64_t
     else if (keep) hipLaunchKernelGGL((mlp_chain2_kernel<NTH, NTD, KBD, true>), dim3(nwg), dim3(CH_THREADS), 0, st, p); \
     else hipLaunchKernelGGL((mlp_chain2_kernel<NTH, NTD, KBD, false>), dim3(nwg), dim3(CH_THREADS), 0, st, p);          \
   } while (0)
+  IB_PATH(use_v1 ? IB_PATH_CHAIN1 : IB_PATH_CHAIN2);
   if (s.nth == 4 && s.ntd == 3 && s.kbd == 10) IB_CHAIN_LAUNCH(4, 3, 10);
   else if (s.nth == 4 && s.ntd == 1 && s.kbd == 2) IB_CHAIN_LAUNCH(4, 1, 2);
   else if (s.nth == 4 && s.ntd == 1 && s.kbd == 4) IB_CHAIN_LAUNCH(4, 1, 4);

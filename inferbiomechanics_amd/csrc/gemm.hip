@@ -1141,12 +1141,14 @@ int launch_fwd(GemmParams& p, hipStream_t s) {
   p.tiles_n = (p.N + BN - 1) / BN; p.tiles_m = (p.M + BM - 1) / BM;
   p.k_chunk = p.K; p.slab_stride = 0; p.xcd_group = 1;
   const int tiles = p.tiles_m * p.tiles_n;
-  if (sizeof(T) == 2 && smallm::ok(p)) return smallm::launch<1>(p, s);
+  if (sizeof(T) == 2 && smallm::ok(p)) { IB_PATH(IB_PATH_SMALLM); return smallm::launch<1>(p, s); }
   if (sizeof(T) == 2 && ring_ok(p, IB_BF16, p.K, p.K)) {
+    IB_PATH(IB_PATH_RING);
     hipLaunchKernelGGL((gemm_ring_kernel<true, true, EPI_FWD>), dim3(tiles, 1), dim3(NTHREADS), 0, s, p);
     IB_CHECK_LAUNCH();
     return IB_OK;
   }
+  IB_PATH(IB_PATH_GENERIC);
   hipLaunchKernelGGL((gemm_kernel<T, true, true, EPI_FWD>), dim3(tiles, 1), dim3(NTHREADS), 0, s, p);
   IB_CHECK_LAUNCH();
   return IB_OK;
@@ -1164,12 +1166,14 @@ int launch_dgrad(GemmParams& p, hipStream_t s) {
   p.tiles_n = (p.N + BN - 1) / BN; p.tiles_m = (p.M + BM - 1) / BM;
   p.k_chunk = p.K; p.slab_stride = 0; p.xcd_group = 1;
   const int tiles = p.tiles_m * p.tiles_n;
-  if (sizeof(T) == 2 && smallm::dgrad_ok(p)) return smallm::launch_dgrad(p, s);
+  if (sizeof(T) == 2 && smallm::dgrad_ok(p)) { IB_PATH(IB_PATH_SMALLM); return smallm::launch_dgrad(p, s); }
   if (sizeof(T) == 2 && ring_ok(p, IB_BF16, p.K, p.K)) {
+    IB_PATH(IB_PATH_RING);
     hipLaunchKernelGGL((gemm_ring_kernel<true, false, EPI_DGRAD>), dim3(tiles, 1), dim3(NTHREADS), 0, s, p);
     IB_CHECK_LAUNCH();
     return IB_OK;
   }
+  IB_PATH(IB_PATH_GENERIC);
   hipLaunchKernelGGL((gemm_kernel<T, true, false, EPI_DGRAD>), dim3(tiles, 1), dim3(NTHREADS), 0, s, p);
   IB_CHECK_LAUNCH();
   return IB_OK;
@@ -1353,6 +1357,7 @@ extern "C" int ib_linear_dgrad_skinny(const void* dz, int64_t lddz, const void* 
     return IB_E_UNSUPPORTED;
   const dim3 grid((unsigned)(K / 16)), block(256);
   hipStream_t s = ib_s(stream);
+  IB_PATH(IB_PATH_SKINNY);
 #define IB_SKINNY(ACT)                                                                                                  \
   hipLaunchKernelGGL((skinny::dgrad_skinny_kernel<ACT>), grid, block, 0, s, (const bf16_t*)dz, lddz, (const bf16_t*)w, ldw, \
                      (const bf16_t*)aux, ldaux, (bf16_t*)dx, lddx, dbias, accumulate, (int)M, (int)N)
@@ -1427,8 +1432,10 @@ int wgrad_gemm(const void* dz, int64_t lddz, const void* x, int64_t ldx, float* 
                               slabs_only, p, &split, &tiles, &chunk);
   if (rc != IB_OK) return rc;
   if (dtype == IB_F32) {
+    IB_PATH(IB_PATH_GENERIC);
     hipLaunchKernelGGL((gemm_kernel<float, false, false, EPI_WGRAD>), dim3(tiles * split), dim3(NTHREADS), 0, s, p);
   } else {
+    IB_PATH(ring_ok(p, IB_BF16, p.K, chunk) ? IB_PATH_RING : IB_PATH_GENERIC);
     if (ring_ok(p, IB_BF16, p.K, chunk))
       hipLaunchKernelGGL((gemm_ring_kernel<false, false, EPI_WGRAD>), dim3(tiles * split), dim3(NTHREADS), 0, s, p);
     else
@@ -1561,6 +1568,7 @@ extern "C" int ib_linear_wgrad(const void* dz, int64_t lddz, const void* x, int6
                                int64_t lddw, int accumulate, void* workspace, size_t workspace_bytes,
                                int64_t M, int64_t N, int64_t K, int dtype, ib_stream_t stream) {
   if (dz && x && dw && M > 0 && N > 0 && K > 0 && lddz >= N && ldx >= K && lddw >= K && wsmall::ok(dz, lddz, x, ldx, M, dtype)) {
+    IB_PATH(IB_PATH_WGRAD_SMALL);
     hipLaunchKernelGGL(wsmall::wgrad_smallm_kernel, dim3((unsigned)((K + 63) / 64), (unsigned)((N + 63) / 64)), dim3(256), 0,
                        ib_s(stream), (const bf16_t*)dz, lddz, (const bf16_t*)x, ldx, dw, lddw, nullptr, accumulate, (int)M, (int)N, (int)K);
     IB_CHECK_LAUNCH();
@@ -1575,6 +1583,7 @@ extern "C" int ib_linear_wgrad_bias(const void* dz, int64_t lddz, const void* x,
                                     ib_stream_t stream) {
   if (!dz || !x || !dw || !dbias || M <= 0 || N <= 0 || K <= 0 || lddz < N || ldx < K || lddw < K) return IB_E_ARG;
   if (!wsmall::ok(dz, lddz, x, ldx, M, dtype)) return IB_E_UNSUPPORTED;
+  IB_PATH(IB_PATH_WGRAD_SMALL);
   hipLaunchKernelGGL(wsmall::wgrad_smallm_kernel, dim3((unsigned)((K + 63) / 64), (unsigned)((N + 63) / 64)), dim3(256), 0,
                      ib_s(stream), (const bf16_t*)dz, lddz, (const bf16_t*)x, ldx, dw, lddw, dbias, accumulate, (int)M, (int)N,
                      (int)K);
@@ -1597,6 +1606,7 @@ extern "C" int ib_linear_wgrad_slabs(const void* dz, int64_t lddz, const void* x
   if (dz && x && workspace && M > 0 && N > 0 && K > 0 && lddz >= N && ldx >= K && K % 4 == 0 &&
       workspace_bytes >= (size_t)N * K * sizeof(float) && aligned(workspace, 16) && wsmall::ok(dz, lddz, x, ldx, M, dtype)) {
     // short reduction: the one-pass kernel writes the whole gradient as a single "slab"
+    IB_PATH(IB_PATH_WGRAD_SMALL);
     hipLaunchKernelGGL(wsmall::wgrad_smallm_kernel, dim3((unsigned)((K + 63) / 64), (unsigned)((N + 63) / 64)), dim3(256), 0,
                        ib_s(stream), (const bf16_t*)dz, lddz, (const bf16_t*)x, ldx, reinterpret_cast<float*>(workspace), K,
                        nullptr, 0, (int)M, (int)N, (int)K);
@@ -1651,6 +1661,7 @@ extern "C" int ib_linear_wgrad_slabs_multi_bias(int n, const void* const* dz, co
     blocks += tiles * split;
   }
   m.blk0[n] = blocks;
+  IB_PATH(IB_PATH_RING_MULTI);
   hipLaunchKernelGGL(gemm_ring_wgrad_multi_kernel, dim3(blocks), dim3(NTHREADS), 0, ib_s(stream), m);
   IB_CHECK_LAUNCH();
   return IB_OK;
@@ -1771,6 +1782,7 @@ extern "C" int ib_linear_ln_fwd(const void* x, int64_t ldx, const void* w, int64
   p.C = workspace; p.ldc = N; p.slab_stride = (int64_t)M * N; p.accumulate = 0; p.vecC = 1;
   if (!ring_ok(p, IB_BF16, p.K, chunk)) return IB_E_UNSUPPORTED;
   hipStream_t s = ib_s(stream);
+  IB_PATH(IB_PATH_LINLN);
   hipLaunchKernelGGL((gemm_ring_kernel<true, true, EPI_WGRAD>), dim3(p.tiles_m * p.tiles_n * split), dim3(NTHREADS), 0, s, p);
   IB_CHECK_LAUNCH();
 #define IB_SLAB_LN(LPR, NCH)                                                                                            \

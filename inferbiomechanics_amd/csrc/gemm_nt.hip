@@ -391,6 +391,7 @@ int ib_gemm_nt_try(const void* A, int64_t lda, const void* B, int64_t ldb, void*
   if (aux && (!al16(aux) || ldaux % 8)) return IB_E_UNSUPPORTED;
   if (addend && (!al16(addend) || ldadd % 8)) return IB_E_UNSUPPORTED;
   if (bwd_act != IB_ACT_NONE && (bwd_act == IB_ACT_SILU || !aux || fwd_act != IB_ACT_NONE)) return IB_E_UNSUPPORTED;
+  IB_PATH(IB_PATH_NT);
   NtParams p{};
   p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.lda = lda; p.ldb = ldb; p.M = (int)M; p.N = (int)N; p.K = (int)K;
   p.C = (bf16_t*)C; p.ldc = ldc; p.bias = bias; p.aux = (const bf16_t*)aux; p.ldaux = ldaux;

@@ -338,6 +338,7 @@ int ib_gemm_tn_multi(int n, const void* const* dz, const int64_t* lddz, const vo
   const int grid = items < 256 ? items : 256;
   bool any_bias = false;
   for (int j = 0; j < n; ++j) any_bias = any_bias || P.pr[j].dbias != nullptr;
+  IB_PATH(IB_PATH_TN);
   if (any_bias) hipLaunchKernelGGL(gemm_tn_kernel<true>, dim3(grid), dim3(TN_THREADS), 0, s, P);
   else hipLaunchKernelGGL(gemm_tn_kernel<false>, dim3(grid), dim3(TN_THREADS), 0, s, P);
   IB_CHECK_LAUNCH();

@@ -19,6 +19,9 @@ typedef __attribute__((ext_vector_type(4))) short s16x4_t;
     if (e__ != hipSuccess) return IB_E_LAUNCH;               \
   } while (0)
 
+extern int g_ib_last_path;                       // util.hip; see ib_debug_last_path()
+#define IB_PATH(code) (g_ib_last_path = (code))
+
 static inline hipStream_t ib_s(ib_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
 __device__ __forceinline__ float ib_to_f32(float v) { return v; }

@@ -125,9 +125,13 @@ __global__ __launch_bounds__(256) void optim_kernel(OptArgs a, OptSources S, int
   // entry, and the block that draws the last exit ticket publishes step and resets the ticket -- it exits after
   // every other block has entered (and therefore read the old value), so no block can see the new count.
   const int step = a.step_dev ? (a.ticket ? *(volatile int32_t*)a.step_dev + 1 : *a.step_dev) : a.step;
-  // bias corrections in double (torch computes them as Python floats)
-  const float bc1 = (float)(1.0 - pow(0.9, (double)step));
-  const float bc2s = (float)sqrt(1.0 - pow(0.999, (double)step));
+  // bias corrections in double (torch computes them as Python floats) -- Adam / Adamax only: two double-precision pow()
+  // are several hundred instructions at the head of every thread, ahead of its first load
+  float bc1 = 1.f, bc2s = 1.f;
+  if (a.opt == IB_OPT_ADAM || a.opt == IB_OPT_ADAMAX) {
+    bc1 = (float)(1.0 - pow(0.9, (double)step));
+    bc2s = (float)sqrt(1.0 - pow(0.999, (double)step));
+  }
   const int64_t n4 = a.n / 4;
   const bool has1 = a.s1 != nullptr, has2 = a.s2 != nullptr;
   // the column-sum blocks are long dependent chains (256 strided rows each): they take the FIRST physical block ids so

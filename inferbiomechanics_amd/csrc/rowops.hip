@@ -3,6 +3,7 @@
 // One wave (64 lanes) owns one row; a lane holds CH chunks of 4 consecutive elements in registers
 // (8- or 16-byte loads), so every tensor crosses HBM exactly once per kernel.
 #include "ib_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -318,6 +319,141 @@ __global__ __launch_bounds__(LN_BWD_WPB * 64) void layernorm_bwd_kernel(const T*
   }
 }
 
+// ---- LayerNorm backward, the transformer denoiser's shape (bf16, N = 512, whole 16-byte pieces, no activation, no
+// per-window addend): one row per wave-instruction (64 lanes x 8 columns), and EVERY row of a wave requested before the
+// first is used.  The generic kernel above walks its rows one at a time (load -> two row reductions -> store, 6 times per
+// wave at M = 12800): replayed back to back its inputs come from L2 / MALL and it takes 13.5 us, but inside the training
+// step (inputs cold: dy from the previous GEMM, x and the residual from the forward pass) every trip pays an HBM round trip
+// and it takes 30 us for 52 MB = 1.8 TB/s.  Here a 16-wave workgroup per CU keeps 4 rows x 3 KiB per wave in flight.
+constexpr int LNF_WAVES = 16, LNF_ROWS = 4, LNF_N = 512;
+__global__ __launch_bounds__(LNF_WAVES * 64) void layernorm_bwd512_kernel(const bf16_t* __restrict__ dy,
+                                                                          const bf16_t* __restrict__ x,
+                                                                          const bf16_t* __restrict__ res,
+                                                                          const float* __restrict__ gamma,
+                                                                          const float* __restrict__ mean,
+                                                                          const float* __restrict__ rstd,
+                                                                          bf16_t* __restrict__ dx, float* __restrict__ partial,
+                                                                          int M) {
+  __shared__ float red[LNF_WAVES][2][LNF_N];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = lane * 8;
+  const int wstride = gridDim.x * LNF_WAVES;
+  float gm[8], ag[8], ab[8];
+  {
+    const float4 a = *reinterpret_cast<const float4*>(gamma + col), b = *reinterpret_cast<const float4*>(gamma + col + 4);
+    gm[0] = a.x; gm[1] = a.y; gm[2] = a.z; gm[3] = a.w; gm[4] = b.x; gm[5] = b.y; gm[6] = b.z; gm[7] = b.w;
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { ag[e] = 0.f; ab[e] = 0.f; }
+  for (int rb = blockIdx.x * LNF_WAVES + wave; rb < M; rb += wstride * LNF_ROWS) {
+    bf16x8_t xv[LNF_ROWS], dv[LNF_ROWS], rv[LNF_ROWS];
+    float mu[LNF_ROWS], rs[LNF_ROWS];
+#pragma unroll
+    for (int j = 0; j < LNF_ROWS; ++j) {              // every request of this trip first
+      const int row = min(rb + j * wstride, M - 1);
+      const int64_t ro = (int64_t)row * LNF_N + col;
+      xv[j] = *reinterpret_cast<const bf16x8_t*>(x + ro);
+      dv[j] = *reinterpret_cast<const bf16x8_t*>(dy + ro);
+      if (res) rv[j] = *reinterpret_cast<const bf16x8_t*>(res + ro);
+      mu[j] = mean[row];
+      rs[j] = rstd[row];
+    }
+#pragma unroll
+    for (int j = 0; j < LNF_ROWS; ++j) {
+      const int row = rb + j * wstride;
+      const bool live = row < M;                       // wave-uniform
+      float h[8], gg[8];
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float xe = (float)xv[j][e];
+        if (res) xe += (float)rv[j][e];
+        const float d = live ? (float)dv[j][e] : 0.f;
+        h[e] = (xe - mu[j]) * rs[j];
+        gg[e] = d * gm[e];
+        s1 += gg[e]; s2 += gg[e] * h[e];
+        ag[e] += d * h[e];
+        ab[e] += d;
+      }
+      const float c1 = group_sum<64>(s1) * (1.f / LNF_N);
+      const float c2 = group_sum<64>(s2) * (1.f / LNF_N);
+      if (live) {
+        bf16x8_t o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16_t)((gg[e] - c1 - h[e] * c2) * rs[j]);
+        *reinterpret_cast<bf16x8_t*>(dx + (int64_t)row * LNF_N + col) = o;
+      }
+    }
+  }
+  {
+    float4* r0 = reinterpret_cast<float4*>(&red[wave][0][col]);
+    float4* r1 = reinterpret_cast<float4*>(&red[wave][1][col]);
+    r0[0] = make_float4(ag[0], ag[1], ag[2], ag[3]); r0[1] = make_float4(ag[4], ag[5], ag[6], ag[7]);
+    r1[0] = make_float4(ab[0], ab[1], ab[2], ab[3]); r1[1] = make_float4(ab[4], ab[5], ab[6], ab[7]);
+  }
+  __syncthreads();
+  if (threadIdx.x < LNF_N) {
+    float sg = 0.f, sb = 0.f;
+#pragma unroll
+    for (int w = 0; w < LNF_WAVES; ++w) { sg += red[w][0][threadIdx.x]; sb += red[w][1][threadIdx.x]; }
+    partial[(int64_t)blockIdx.x * LNF_N + threadIdx.x] = sg;
+    partial[((int64_t)gridDim.x + blockIdx.x) * LNF_N + threadIdx.x] = sb;
+  }
+}
+
+// LayerNorm forward at the same shape: y = LN(x + res), four rows per wave requested together (the generic kernel has one
+// row per wave in flight; in the step its 40 MB take 12.4 us = 3.2 TB/s)
+__global__ __launch_bounds__(256) void layernorm_fwd512_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ res,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               bf16_t* __restrict__ y, float* __restrict__ mean,
+                                                               float* __restrict__ rstd, int M, float eps) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = lane * 8;
+  const int rb = (blockIdx.x * 4 + wave) * LNF_ROWS;
+  if (rb >= M) return;
+  bf16x8_t xv[LNF_ROWS], rv[LNF_ROWS];
+#pragma unroll
+  for (int j = 0; j < LNF_ROWS; ++j) {
+    const int64_t ro = (int64_t)min(rb + j, M - 1) * LNF_N + col;
+    xv[j] = *reinterpret_cast<const bf16x8_t*>(x + ro);
+    if (res) rv[j] = *reinterpret_cast<const bf16x8_t*>(res + ro);
+  }
+  float gm[8], bt[8];
+  {
+    const float4 a = *reinterpret_cast<const float4*>(gamma + col), b = *reinterpret_cast<const float4*>(gamma + col + 4);
+    const float4 c = *reinterpret_cast<const float4*>(beta + col), d = *reinterpret_cast<const float4*>(beta + col + 4);
+    gm[0] = a.x; gm[1] = a.y; gm[2] = a.z; gm[3] = a.w; gm[4] = b.x; gm[5] = b.y; gm[6] = b.z; gm[7] = b.w;
+    bt[0] = c.x; bt[1] = c.y; bt[2] = c.z; bt[3] = c.w; bt[4] = d.x; bt[5] = d.y; bt[6] = d.z; bt[7] = d.w;
+  }
+#pragma unroll
+  for (int j = 0; j < LNF_ROWS; ++j) {
+    const int row = rb + j;
+    float v[8];
+    float sm = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      v[e] = (float)xv[j][e];
+      if (res) v[e] += (float)rv[j][e];
+      sm += v[e];
+    }
+    const float mu = group_sum<64>(sm) * (1.f / LNF_N);
+    float q = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const float d = v[e] - mu; q += d * d; }
+    const float rs = 1.f / sqrtf(group_sum<64>(q) * (1.f / LNF_N) + eps);       // the generic kernel's two-pass arithmetic
+    if (row < M) {
+      if (lane == 0) {
+        if (mean) mean[row] = mu;
+        if (rstd) rstd[row] = rs;
+      }
+      bf16x8_t o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (bf16_t)((v[e] - mu) * rs * gm[e] + bt[e]);
+      *reinterpret_cast<bf16x8_t*>(y + (int64_t)row * LNF_N + col) = o;
+    }
+  }
+}
+
 // ---------------------------------------------------------------- segmented column sum
 // rows of segment s: m = s*a + r*b, r in [0, cnt).  A 256-thread block = (256/RL) column groups of 4
 // consecutive columns x RL row lanes; the row lanes' partial sums are combined through LDS in a fixed
@@ -492,6 +628,13 @@ extern "C" int ib_layernorm_fwd(const void* x, const void* res, int act, const f
   }
   if (dtype == IB_BF16) {
     const int vec = (N % 8 == 0) && al(x, 16) && al(res, 16) && al(y, 16) && al(add_div, 16) && (ld_add % 8 == 0);
+    static const bool no_fast = getenv("IB_NO_LN_FAST") != nullptr;
+    if (!no_fast && N == LNF_N && vec && vecp && act == IB_ACT_NONE && !add_div && M >= 4096) {
+      hipLaunchKernelGGL(layernorm_fwd512_kernel, dim3((unsigned)((M + 4 * LNF_ROWS - 1) / (4 * LNF_ROWS))), dim3(256), 0, s,
+                         (const bf16_t*)x, (const bf16_t*)res, gamma, beta, (bf16_t*)y, mean, rstd, (int)M, eps);
+      IB_CHECK_LAUNCH();
+      return IB_OK;
+    }
     return LN_DISPATCH(launch_ln_fwd, bf16_t, x, res, act, gamma, beta, y, mean, rstd, M, N, eps, vec, vecp, add_div,
                        ld_add, (int)seg, s);
   }
@@ -525,6 +668,13 @@ extern "C" int ib_layernorm_bwd(const void* dy, const void* x, const void* res, 
   } else if (dtype == IB_BF16) {
     const int vec = (N % 8 == 0) && al(x, 16) && al(res, 16) && al(dy, 16) && al(dx, 16) && al(dres, 16) &&
                     al(add_div, 16) && (ld_add % 8 == 0);
+    static const bool no_fast = getenv("IB_NO_LN_FAST") != nullptr;
+    if (!no_fast && N == LNF_N && vec && vecp && act == IB_ACT_NONE && !add_div && !dres && M >= 4096) {
+      hipLaunchKernelGGL(layernorm_bwd512_kernel, dim3(parts), dim3(LNF_WAVES * 64), 0, s, (const bf16_t*)dy, (const bf16_t*)x,
+                         (const bf16_t*)res, gamma, mean, rstd, (bf16_t*)dx, partial, (int)M);
+      IB_CHECK_LAUNCH();
+      rc = IB_OK;
+    } else
     rc = LN_DISPATCH_BWD(launch_ln_bwd, bf16_t, dy, x, res, act, gamma, mean, rstd, dx, dres, partial, M, N, vec, vecp,
                      parts, add_div, ld_add, (int)seg, s);
   } else {

@@ -136,6 +136,7 @@ _SIGS = {
     "ib_event_destroy": (_c.c_int, [_vp]),
     "ib_selftest_tr16": (_c.c_int, [_vp, _vp, _vp]),
     "ib_debug_set_ablate": (_c.c_int, [_c.c_int]),
+    "ib_debug_last_path": (_c.c_int, []),
 }
 
 
@@ -146,7 +147,7 @@ def declared_symbols() -> List[str]:
     return sorted(set(re.findall(r"\b(ib_[a-z0-9_]+)\s*\(", src)))
 
 
-_HOST_ONLY = ("_workspace", "_supported", "_workgroups", "_packed_elems", "_partial_width")   # pure host queries: no launch, no stream
+_HOST_ONLY = ("_workspace", "_supported", "_workgroups", "_packed_elems", "_partial_width", "_last_path")   # pure host queries: no launch, no stream
 
 
 class _DryRunLib:
@@ -215,6 +216,7 @@ class _RecordingLib:
     def __init__(self, real):
         self._real = real
         self.calls = []      # (name, args)
+        self.paths = []      # per call: the kernel family the entry point dispatched to (IB_PATH_*, 0 = no dispatch)
         self.notes = {}      # index into calls -> (algorithmic flops, algorithmic bytes) for calls whose shapes sit in arrays
 
     def __getattr__(self, name):
@@ -229,10 +231,15 @@ class _RecordingLib:
                 self.notes[len(self.calls)] = _work_note
                 _work_note = None
             self.calls.append((name, a))
-            return real(*a)
+            self._real.ib_debug_last_path()            # clear
+            rc = real(*a)
+            self.paths.append(int(self._real.ib_debug_last_path()))
+            return rc
         return call
 
 
+PATH_NAMES = {0: "-", 1: "nt256x128", 2: "tn256x128", 3: "ring128", 4: "generic", 5: "smallm", 6: "skinny", 7: "wgrad_small",
+              8: "ring_multi", 9: "linear_ln", 10: "chain_v2", 11: "chain_v1"}
 _work_note = None     # set by a wrapper right before a grouped launch: (flops, bytes) of that launch, for bench.py
 
 

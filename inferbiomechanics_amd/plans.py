@@ -1014,7 +1014,14 @@ class DenoiserMLPPlan:
         # (head, blocks, time_mlp.2) goes into ONE grouped launch on the main stream.
         # (issued AFTER the grouped launch instead, the branch's first kernel only started when the grouped launch had
         # finished -- no overlap at all: 0.232 -> 0.250 ms/step)
-        self.branch.run(lambda: self.time.backward_hidden(de32, de_lp, P, accumulate, defer=defer, ready=False))
+        if os.environ.get("IB_SKIP_TIME_BWD"):       # TIMING-ONLY: an upper bound of what the branch costs (wrong gradients)
+            if defer is not None and getattr(self, "_tb_defer", None):
+                defer.extend(self._tb_defer)
+        else:
+            n0 = len(defer) if defer is not None else 0
+            self.branch.run(lambda: self.time.backward_hidden(de32, de_lp, P, accumulate, defer=defer, ready=False))
+            if defer is not None:
+                self._tb_defer = defer[n0:]
         grouped = defer is not None and not accumulate
         probs = [(dpred, h[L - 1], P.g("head.weight"), "dm.wsH")]
         for i in range(L - 1, -1, -1):

@@ -283,7 +283,11 @@ def transformer_layer_forward(p: Dict[str, torch.Tensor], x: torch.Tensor, num_h
     if "drop1" in masks:
         a = a * masks["drop1"]
     x = layer_norm(x + a, g("norm1.weight"), g("norm1.bias"))
-    f = linear(act("relu", linear(x, g("feedforward.0.weight"), g("feedforward.0.bias"))),
+    z1 = linear(x, g("feedforward.0.weight"), g("feedforward.0.bias"))
+    # masks["relu"] (0 / 1, [B,T,ffn]): the ReLU gate taken from somewhere else (a test hands over the gate the bf16
+    # KERNEL used: where a pre-activation lies within bf16 rounding of zero the two gates differ, and with them whole
+    # (token, unit) contributions of the FFN input layer's gradient); None = the reference's own ReLU (:17-20)
+    f = linear(z1 * masks["relu"] if "relu" in masks else act("relu", z1),
                g("feedforward.2.weight"), g("feedforward.2.bias"))
     if "drop2" in masks:
         f = f * masks["drop2"]
@@ -506,7 +510,8 @@ def denoiser_mlp_forward(p: Dict[str, torch.Tensor], x_t: torch.Tensor, t: torch
 
 
 def denoiser_transformer_forward(p: Dict[str, torch.Tensor], x_t: torch.Tensor, t: torch.Tensor,
-                                 num_layers: int, num_heads: int, temb_dim: int = 128) -> torch.Tensor:
+                                 num_layers: int, num_heads: int, temb_dim: int = 128,
+                                 layer_masks: Optional[List[Dict[str, torch.Tensor]]] = None) -> torch.Tensor:
     """Transformer denoiser (BASELINE configs 3-5): in-proj over concat(x, pos_emb[frame]) (the
     reference concatenates a learned per-frame embedding, TransformerBaseline.py:119-126) plus the
     time embedding, `num_layers` reference TransformerLayers, out-proj."""
@@ -516,7 +521,8 @@ def denoiser_transformer_forward(p: Dict[str, torch.Tensor], x_t: torch.Tensor, 
     xin = torch.cat([x_t, pos.unsqueeze(0).expand(B, -1, -1)], dim=-1)
     h = linear(xin, p["in_proj.weight"], p["in_proj.bias"]) + e[:, None, :]
     for l in range(num_layers):
-        h = transformer_layer_forward(p, h, num_heads, prefix=f"transformer_layers.{l}.")
+        h = transformer_layer_forward(p, h, num_heads, prefix=f"transformer_layers.{l}.",
+                                      masks=None if layer_masks is None else layer_masks[l])
     return linear(h, p["out_proj.weight"], p["out_proj.bias"])
 
 

@@ -1,0 +1,11 @@
+# A/B of the transformer T50 step with environment switches: tools/ab_tr.sh "" "IB_NO_LN_FAST=1" ...
+for v in "$@"; do
+  echo "== $v"
+  env $v python bench.py --workload transformer_denoiser_T50 --steps 100 --warmup 10 --no-cpu-baseline --no-ddim --no-transformer 2>/dev/null | python -c "
+import json,sys
+o=json.loads(sys.stdin.read())
+print(o['ms_per_step'], o['step_ms'], o['final_loss'])
+for b in o['step_breakdown'][:18]: print('   ', b['entry'], b['dims'][-4:], b['launches_per_step'], b['avg_launch_us'])
+print('   sum', o['step_sum_of_kernel_us'])
+"
+done
