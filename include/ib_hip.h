@@ -362,6 +362,17 @@ int ib_time_mlp_fwd(const float* table, int64_t table_rows, const int64_t* t, co
                     const float* b1, const void* w2, int64_t ldw2, const float* b2, void* s, void* zu, void* u,
                     void* e, int64_t ld_e, int64_t B, int64_t temb, int64_t hidden, int64_t out,
                     ib_stream_t stream);
+/* Backward of the time-embedding MLP's hidden layer in ONE launch of independent workgroups (bf16):
+ *   dzu = (de w2) * silu'(zu)   [B, hidden];   dW1 = dzu^T s   [hidden, temb];   db1 = column sums of dzu (as stored in bf16)
+ * de [B, out] = d loss / d e (the chain kernel's per-window sums), w2 [out, hidden], zu / s: what ib_time_mlp_fwd saved.
+ * The results are left as ib_time_mlp_bwd_slab_count(B) fp32 partial slabs (one per 64 windows, summed in slab order by
+ * ib_optim_step_sources / ib_step_reduce like every split weight gradient): dw1_slabs [slabs][hidden][temb],
+ * db1_slabs [slabs][hidden].  Replaces ib_linear_dgrad_skinny + ib_linear_wgrad_slabs of time_mlp.0 on a forked stream. */
+int ib_time_mlp_bwd_supported(int64_t temb, int64_t hidden, int64_t out);
+int ib_time_mlp_bwd_slab_count(int64_t B);
+int ib_time_mlp_bwd(const void* de, int64_t ld_de, const void* w2, int64_t ldw2, const void* zu, int64_t ldzu,
+                    const void* s, int64_t lds, float* dw1_slabs, float* db1_slabs, int64_t B, int64_t temb,
+                    int64_t hidden, int64_t out, ib_stream_t stream);
 /* ib_time_mlp_fwd + ib_mlp_chain_pack as ONE launch (both are independent and tiny; saves a kernel boundary) */
 int ib_mlp_chain_prep(const float* table, int64_t table_rows, const int64_t* t, const void* w1, int64_t ldw1,
                       const float* b1, const void* w2, int64_t ldw2, const float* b2, void* s, void* zu, void* u,

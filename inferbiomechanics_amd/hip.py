@@ -116,6 +116,9 @@ _SIGS = {
                                      _i64, _i64, _vp, _vp, _vp, _i64, _i64, _c.c_int, _vp, _vp]),
     "ib_time_mlp_fwd": (_c.c_int, [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64,
                                    _i64, _i64, _vp]),
+    "ib_time_mlp_bwd_supported": (_c.c_int, [_i64, _i64, _i64]),
+    "ib_time_mlp_bwd_slab_count": (_c.c_int, [_i64]),
+    "ib_time_mlp_bwd": (_c.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _vp]),
     "ib_sum_partials": (_c.c_int, [_vp, _i64, _f32, _vp, _vp]),
     "ib_q_sample": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _c.c_int, _vp]),
     "ib_ddim_step": (_c.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _i64, _i64, _c.c_int, _vp]),
@@ -147,7 +150,7 @@ def declared_symbols() -> List[str]:
     return sorted(set(re.findall(r"\b(ib_[a-z0-9_]+)\s*\(", src)))
 
 
-_HOST_ONLY = ("_workspace", "_supported", "_workgroups", "_packed_elems", "_partial_width", "_last_path")   # pure host queries: no launch, no stream
+_HOST_ONLY = ("_workspace", "_supported", "_workgroups", "_packed_elems", "_partial_width", "_last_path", "_slab_count")   # pure host queries: no launch, no stream
 
 
 class _DryRunLib:
@@ -1371,6 +1374,35 @@ def time_mlp_fwd(table, t, w1, b1, w2, b2, s, zu, u, e, pack=None, slots=None):
                                  _ptr(s), _ptr(zu), _ptr(u), _ptr(e), lde, B, temb, hid, out, stream_ptr()),
            "ib_time_mlp_fwd")
     return e
+
+
+def time_mlp_bwd_supported(temb: int, hidden: int, out: int) -> bool:
+    return bool(lib().ib_time_mlp_bwd_supported(temb, hidden, out))
+
+
+def time_mlp_bwd_slab_count(B: int) -> int:
+    return int(lib().ib_time_mlp_bwd_slab_count(B))
+
+
+def time_mlp_bwd(de, w2, zu, s, dw1_slabs, db1_slabs) -> int:
+    """backward of the time-embedding MLP's hidden layer in one launch (bf16): de [B, out], w2 [out, hidden], zu [B, hidden],
+    s [B, temb] -> fp32 partial slabs dw1_slabs [slabs, hidden, temb], db1_slabs [slabs, hidden] (slabs =
+    time_mlp_bwd_slab_count(B); summed in order by optim_step(sources=...) / step_reduce).  Returns the slab count."""
+    bt = torch.bfloat16
+    B, out, ld_de = _mat(de, "de", bt)
+    o2, hid, ldw2 = _mat(w2, "w2", bt)
+    Bz, hz, ldzu = _mat(zu, "zu", bt)
+    Bs, temb, lds = _mat(s, "s", bt)
+    if o2 != out or hz != hid or Bz != B or Bs != B:
+        raise HipError("time_mlp_bwd: operand shapes do not chain")
+    n = time_mlp_bwd_slab_count(B)
+    _req(dw1_slabs, "dw1_slabs", torch.float32); _req(db1_slabs, "db1_slabs", torch.float32)
+    if tuple(dw1_slabs.shape) != (n, hid, temb) or tuple(db1_slabs.shape) != (n, hid) or not dw1_slabs.is_contiguous() \
+            or not db1_slabs.is_contiguous():
+        raise HipError(f"time_mlp_bwd: slabs must be contiguous [{n}, {hid}, {temb}] and [{n}, {hid}]")
+    _check(lib().ib_time_mlp_bwd(_ptr(de), ld_de, _ptr(w2), ldw2, _ptr(zu), ldzu, _ptr(s), lds, _ptr(dw1_slabs),
+                                 _ptr(db1_slabs), B, temb, hid, out, stream_ptr()), "ib_time_mlp_bwd")
+    return n
 
 
 def _ptr_array(tensors):

@@ -794,9 +794,29 @@ class TimeMLPPlan:
             if ready:
                 P.ready("time_mlp.2.bias")
 
+    def fused_bwd_ok(self, P: ParamSource, defer, accumulate) -> bool:
+        """the one-launch backward of the hidden layer (csrc/chain.hip: ib_time_mlp_bwd) leaves fp32 partial slabs, so it
+        needs a deferred reduction to hand them to (the step's optimizer / ib_step_reduce)"""
+        if self.dtype != torch.bfloat16 or defer is None or accumulate or os.environ.get("IB_NO_TIME_BWD_FUSE"):
+            return False
+        w1, w2 = P.w("time_mlp.0.weight"), P.w("time_mlp.2.weight")
+        return hip.time_mlp_bwd_supported(w1.shape[1], w1.shape[0], w2.shape[0])
+
     def backward_hidden(self, de32, de_lp, P: ParamSource, accumulate=False, defer=None, ready=True):
         s, u, zu = self.ctx
         tg = self.tag
+        if self.fused_bwd_ok(P, defer, accumulate):
+            de = self._de(de32, de_lp)
+            hid, temb = P.w("time_mlp.0.weight").shape
+            nsl = hip.time_mlp_bwd_slab_count(de.shape[0])
+            wsw = self.buf.get(tg + ".bww", (nsl, hid, temb), torch.float32)
+            wsb = self.buf.get(tg + ".bwb", (nsl, hid), torch.float32)
+            hip.time_mlp_bwd(de, P.w("time_mlp.2.weight"), zu, s, wsw, wsb)
+            defer.append((wsw, nsl, P.g("time_mlp.0.weight")))
+            defer.append((wsb, nsl, P.g("time_mlp.0.bias").view(1, hid)))
+            if ready:
+                P.ready("time_mlp.0.weight"); P.ready("time_mlp.0.bias")
+            return
         du = self.buf.get(tg + ".du", u.shape, self.dtype)
         de = self._de(de32, de_lp)
         # one row per window: the few-row kernel (16 output columns per workgroup, the bias sums in the same launch);
@@ -1014,12 +1034,17 @@ class DenoiserMLPPlan:
         # (head, blocks, time_mlp.2) goes into ONE grouped launch on the main stream.
         # (issued AFTER the grouped launch instead, the branch's first kernel only started when the grouped launch had
         # finished -- no overlap at all: 0.232 -> 0.250 ms/step)
-        if os.environ.get("IB_SKIP_TIME_BWD"):       # TIMING-ONLY: an upper bound of what the branch costs (wrong gradients)
+        if os.environ.get("IB_SKIP_TIME_BWD"):       # TIMING-ONLY: an upper bound of what the time-MLP backward costs (wrong gradients)
             if defer is not None and getattr(self, "_tb_defer", None):
                 defer.extend(self._tb_defer)
         else:
             n0 = len(defer) if defer is not None else 0
-            self.branch.run(lambda: self.time.backward_hidden(de32, de_lp, P, accumulate, defer=defer, ready=False))
+            if self.time.fused_bwd_ok(P, defer, accumulate):
+                # one short launch on the main stream (no fork / join of the captured graph, no CUs taken from the grouped
+                # weight gradients for 25 us)
+                self.time.backward_hidden(de32, de_lp, P, accumulate, defer=defer, ready=False)
+            else:
+                self.branch.run(lambda: self.time.backward_hidden(de32, de_lp, P, accumulate, defer=defer, ready=False))
             if defer is not None:
                 self._tb_defer = defer[n0:]
         grouped = defer is not None and not accumulate

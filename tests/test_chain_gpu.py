@@ -408,3 +408,33 @@ def test_linear_dgrad_skinny_with_bias_sums(hip, M, N, K, act):
     # shapes outside the kernel's range are refused (the caller falls back), never mis-computed
     assert not hip.linear_dgrad_skinny(torch.zeros(300, N, dtype=BF, device=DEV), w, torch.zeros(300, K, dtype=BF, device=DEV))
     assert not hip.linear_dgrad_skinny(torch.zeros(M, 96, dtype=BF, device=DEV), torch.zeros(96, K, dtype=BF, device=DEV), dx)
+
+
+@pytest.mark.parametrize("B,temb,hid,out", [(256, 128, 512, 1024), (70, 32, 128, 256), (3, 128, 512, 512), (130, 128, 512, 2048)])
+def test_time_mlp_bwd_matches_float64(hip, B, temb, hid, out):
+    """ib_time_mlp_bwd (one launch: few-row dgrad through time_mlp.2 * silu'(zu), the weight gradient of time_mlp.0 and
+    its bias gradient as per-64-window slabs) against float64 on the same bf16 operands; the slabs are summed here in slab
+    order, as the optimizer / ib_step_reduce do.  Ragged batches (rows beyond B contribute nothing)."""
+    assert hip.time_mlp_bwd_supported(temb, hid, out)
+    de = rnd((B, out), 1, 0.3).to(BF)
+    w2 = rnd((out, hid), 2, hid ** -0.5).to(BF)
+    zu = rnd((B, hid), 3, 1.5).to(BF)
+    s = rnd((B, temb), 4, 0.7).to(BF)
+    n = hip.time_mlp_bwd_slab_count(B)
+    assert n == (B + 63) // 64
+    sw = torch.full((n, hid, temb), float("nan"), device=DEV)
+    sb = torch.full((n, hid), float("nan"), device=DEV)
+    d = lambda x: x.to(DEV)
+    hip.time_mlp_bwd(d(de), d(w2), d(zu), d(s), sw, sb)
+    torch.cuda.synchronize()
+    z = zu.to(torch.float64)
+    sg = torch.sigmoid(z)
+    dzu = (de.to(torch.float64) @ w2.to(torch.float64)) * (sg * (1 + z * (1 - sg)))
+    dzu_b = bf(dzu)                                   # the kernel rounds dzu to bf16 before both products
+    close(sw.sum(0), dzu_b.T @ s.to(torch.float64), 2e-2, "dW1")
+    close(sb.sum(0), dzu_b.sum(0), 2e-2, "db1")
+    # deterministic: a second launch reproduces every slab bit for bit
+    sw2, sb2 = torch.zeros_like(sw), torch.zeros_like(sb)
+    hip.time_mlp_bwd(d(de), d(w2), d(zu), d(s), sw2, sb2)
+    torch.cuda.synchronize()
+    assert torch.equal(sw, sw2) and torch.equal(sb, sb2)
