@@ -26,7 +26,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ENTRY_OF = [("gemm_tn_kernel", "", "ib_linear_wgrad_slabs_multi"), ("gemm_nt_kernel<0, 0, false", "", "ib_linear_fwd"),
             ("gemm_nt_kernel<1, 0", "", "ib_linear_fwd"), ("gemm_nt_kernel<0, 1", "", "ib_linear_dgrad"),
             ("gemm_nt_kernel<0, 0, true", "", "ib_linear_dgrad"), ("gemm_nt_kernel", "", "ib_linear_fwd"),
-            ("mlp_chain_kernel", "", "ib_mlp_chain_train"), ("gemm_ring_wgrad_multi_kernel", "", "ib_linear_wgrad_slabs_multi"),
+            ("mlp_chain_kernel", "", "ib_mlp_chain_train"), ("mlp_chain2_kernel", "", "ib_mlp_chain_train"),
+            ("time_mlp_bwd_kernel", "", "ib_time_mlp_bwd"), ("layernorm_bwd512_kernel", "", "ib_layernorm_bwd"),
+            ("layernorm_fwd512_kernel", "", "ib_layernorm_fwd"), ("gemm_ring_wgrad_multi_kernel", "", "ib_linear_wgrad_slabs_multi"),
             ("optim_kernel<true>", "", "ib_optim_step_sources"), ("optim_kernelILb1", "", "ib_optim_step_sources"),
             ("step_reduce_kernel", "", "ib_step_reduce"), ("time_mlp_fwd_kernel", "", "ib_mlp_chain_prep"),
             ("gemm_ring_kernel", "Lb0ELb0ELi2", "ib_linear_wgrad_slabs"), ("gemm_ring_kernel", "Lb1ELb1ELi0", "ib_linear_fwd"),
