@@ -1201,6 +1201,11 @@ extern "C" int ib_linear_fwd(const void* x, int64_t ldx, const void* w, int64_t 
     const int rc = ib_gemm_nt_try(x, ldx, w, ldw, y, ldy, bias, act, nullptr, 0, IB_ACT_NONE, nullptr, 0, M, N, K, ib_s(stream));
     if (rc != IB_E_UNSUPPORTED) return rc;
   }
+  if (dtype == IB_F32 && !add_div && !add_mod) {              // the reference's own batch sizes in fp32: reduction-split tiles
+    const int rc = ib_f32_small_fwd_try((const float*)x, ldx, (const float*)w, ldw, bias, act, (float*)y, ldy, (float*)z, ldz,
+                                        M, N, K, ib_s(stream));
+    if (rc != IB_E_UNSUPPORTED) { IB_PATH(IB_PATH_SMALLM); return rc; }
+  }
   if (dtype == IB_F32) return launch_fwd<float>(p, ib_s(stream));
   if (dtype == IB_BF16) return launch_fwd<bf16_t>(p, ib_s(stream));
   return IB_E_DTYPE;
@@ -1218,6 +1223,11 @@ extern "C" int ib_linear_dgrad(const void* dz, int64_t lddz, const void* w, int6
   p.A = dz; p.lda = lddz; p.B = w; p.ldb = ldw; p.M = (int)M; p.N = (int)K; p.K = (int)N;
   p.C = dx; p.ldc = lddx; p.aux = aux; p.ldaux = ldaux; p.act = act_below; p.seg = 1;
   p.addend = addend; p.ldadd = ldadd;
+  if (dtype == IB_F32) {
+    const int rc = ib_f32_small_dgrad_try((const float*)dz, lddz, (const float*)w, ldw, act_below, (const float*)aux, ldaux,
+                                          (const float*)addend, ldadd, (float*)dx, lddx, M, N, K, ib_s(stream));
+    if (rc != IB_E_UNSUPPORTED) { IB_PATH(IB_PATH_SMALLM); return rc; }
+  }
   if (dtype == IB_F32) return launch_dgrad<float>(p, ib_s(stream));
   if (dtype == IB_BF16) return launch_dgrad<bf16_t>(p, ib_s(stream));
   return IB_E_DTYPE;
@@ -1582,6 +1592,12 @@ extern "C" int ib_linear_wgrad_bias(const void* dz, int64_t lddz, const void* x,
                                     float* dbias, int accumulate, int64_t M, int64_t N, int64_t K, int dtype,
                                     ib_stream_t stream) {
   if (!dz || !x || !dw || !dbias || M <= 0 || N <= 0 || K <= 0 || lddz < N || ldx < K || lddw < K) return IB_E_ARG;
+  if (dtype == IB_F32) {                                    // the reference's batch sizes in fp32 (gemm_f32_small.hip)
+    const int rc = ib_f32_small_wgrad_bias_try((const float*)dz, lddz, (const float*)x, ldx, dw, lddw, dbias, accumulate, M, N, K,
+                                               ib_s(stream));
+    if (rc == IB_OK) IB_PATH(IB_PATH_WGRAD_SMALL);
+    return rc;
+  }
   if (!wsmall::ok(dz, lddz, x, ldx, M, dtype)) return IB_E_UNSUPPORTED;
   IB_PATH(IB_PATH_WGRAD_SMALL);
   hipLaunchKernelGGL(wsmall::wgrad_smallm_kernel, dim3((unsigned)((K + 63) / 64), (unsigned)((N + 63) / 64)), dim3(256), 0,

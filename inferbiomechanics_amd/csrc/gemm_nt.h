@@ -17,3 +17,13 @@ int ib_gemm_tn_splits(int64_t M, int64_t N, int64_t K, int group);
 int ib_gemm_tn_multi(int n, const void* const* dz, const int64_t* lddz, const void* const* x, const int64_t* ldx,
                      void* const* workspace, const size_t* workspace_bytes, float* const* dbias_part, int32_t* nslab_out,
                      const int64_t* M, const int64_t* N, const int64_t* K, hipStream_t s);
+
+// gemm_f32_small.hip: fp32 forward / dgrad of batches of a few rows (16 x 16 tiles, the four waves split the reduction).
+// IB_E_UNSUPPORTED = nothing launched.
+int ib_f32_small_fwd_try(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, int act, float* y,
+                         int64_t ldy, float* z, int64_t ldz, int64_t M, int64_t N, int64_t K, hipStream_t s);
+int ib_f32_small_dgrad_try(const float* dz, int64_t lddz, const float* w, int64_t ldw, int act, const float* aux,
+                           int64_t ldaux, const float* addend, int64_t ldadd, float* dx, int64_t lddx, int64_t M, int64_t N,
+                           int64_t K, hipStream_t s);
+int ib_f32_small_wgrad_bias_try(const float* dz, int64_t lddz, const float* x, int64_t ldx, float* dw, int64_t lddw, float* dbias,
+                                int accumulate, int64_t M, int64_t N, int64_t K, hipStream_t s);

@@ -275,8 +275,8 @@ class DenseStackPlan:
             wn, bn = self.names[i]
             lin_in, bn_in, _, _ = self.saved[i]
             # short reductions (a batch of a few hundred rows): weight and bias gradient from one launch
-            if not (dt == torch.bfloat16 and dz.shape[0] <= 1024
-                    and hip.linear_wgrad_bias(dz, lin_in, P.g(wn), P.g(bn), accumulate)):
+            # (bf16 up to 1024 rows; fp32 up to 256 -- the reference's own batch sizes: csrc/gemm_f32_small.hip)
+            if not (dz.shape[0] <= 1024 and hip.linear_wgrad_bias(dz, lin_in, P.g(wn), P.g(bn), accumulate)):
                 _wgrad(self.buf, dz, lin_in, P.g(wn), accumulate)
                 _colsum(self.buf, f"{tg}.b{i}", dz, P.g(bn), accumulate)
             P.ready(wn)

@@ -504,10 +504,55 @@ def test_linear_wgrad_bias_one_launch(hip, M, N, K):
     assert hip.linear_wgrad_bias(dz, x, dw, db, accumulate=True)
     close(dw, 2 * ew, 2e-5, "dW accumulate")
     close(db, 2 * eb, 2e-5, "db accumulate")
-    # long reductions and fp32 are refused (the caller falls back), never mis-computed
+    # long reductions are refused (the caller falls back), never mis-computed
     big = torch.zeros(2048, N, dtype=bf, device=DEV)
     assert not hip.linear_wgrad_bias(big, torch.zeros(2048, K, dtype=bf, device=DEV), dw, db)
-    assert not hip.linear_wgrad_bias(dz.float(), x.float(), dw, db)
+    # fp32: taken up to 256 rows (csrc/gemm_f32_small.hip, exact-f32 MFMA), refused beyond
+    if M <= 256:
+        assert hip.linear_wgrad_bias(dz.float(), x.float(), dw, db)
+        close(dw, ew, 2e-5, "dW fp32")
+        close(db, eb, 2e-5, "db fp32")
+        assert float((wide[:, K:] - 7.0).abs().max()) == 0.0
+    else:
+        assert not hip.linear_wgrad_bias(dz.float(), x.float(), dw, db)
+
+
+def test_fp32_small_batch_kernels_seeded_shape_sweep(hip):
+    """the reference's batch sizes in fp32 (csrc/gemm_f32_small.hip: 16 x 16 tiles, the four waves split the reduction, exact-f32
+    MFMA): 30 seeded shapes -- ragged rows / columns / reduction tails, every activation, pre-activation output, residual
+    addend, strided destinations -- against float64 at the north_star tolerance (1e-3; observed ~1e-6)"""
+    import random
+    rng = random.Random(4321)
+    acts = ["none", "relu", "tanh", "sigmoid", "silu", "elu"]
+    for case in range(30):
+        M = rng.choice([1, 4, 5, 16, 17, 64, 100, 256])
+        N = rng.choice([16, 30, 48, 300, 512])
+        K = rng.choice([64, 66, 200, 512, 1470])
+        act = acts[case % 6]
+        x = rnd((M, K), 10 + case, 1.0, torch.float32).to(DEV)
+        w = rnd((N, K), 50 + case, K ** -0.5, torch.float32).to(DEV)
+        b = rnd((N,), 90 + case, 0.3, torch.float32).to(DEV)
+        wide = torch.full((M, N + 3), 5.0, device=DEV)
+        y, z = wide[:, :N], torch.zeros(M, N, device=DEV)
+        hip.linear_fwd(x, w, b, y, act=act, z=z if act == "silu" else None)
+        pre = x.double() @ w.double().T + b.double()
+        close(y, R.act(act, pre), 1e-5, f"fp32 small fwd {M}x{N}x{K} {act}")
+        if act == "silu":
+            close(z, pre, 1e-5, "pre-activation")
+        assert float((wide[:, N:] - 5.0).abs().max()) == 0.0
+        # dgrad: dx = (dz w) * act'(aux) + addend ; aux = layer output (pre-activation for silu)
+        dz = rnd((M, N), 130 + case, 1.0, torch.float32).to(DEV)
+        aux = rnd((M, K), 170 + case, 0.8, torch.float32).to(DEV)
+        add = rnd((M, K), 210 + case, 0.5, torch.float32).to(DEV)
+        dx = torch.zeros(M, K, device=DEV)
+        use_add = case % 2 == 0
+        hip.linear_dgrad(dz, w, dx, act_below=act, aux=aux if act != "none" else None, addend=add if use_add else None)
+        a = aux.double()
+        sg = torch.sigmoid(a)
+        fac = {"none": torch.ones_like(a), "relu": (a > 0).double(), "tanh": 1 - a * a, "sigmoid": a * (1 - a),
+               "silu": sg * (1 + a * (1 - sg)), "elu": torch.where(a > 0, torch.ones_like(a), a + 1)}[act]
+        exp = (dz.double() @ w.double()) * fac + (add.double() if use_add else 0)
+        close(dx, exp, 1e-5, f"fp32 small dgrad {M}x{N}x{K} {act}")
 
 
 def test_small_m_kernels_seeded_shape_sweep(hip):
@@ -566,3 +611,51 @@ def test_tiny_matmul_strided_views(hip, M, N, K):
     assert torch.equal(hip.tiny_matmul(A32, Bv, again), first)                    # fixed summation order
     with pytest.raises(hip.HipError):
         hip.tiny_matmul(A32, Bv[:, :1].expand(K, N) if N > 1 else Bv, torch.empty(M + 1, N, device="cuda"))
+
+
+@pytest.mark.parametrize("M", [4096, 12800, 5003])
+@pytest.mark.parametrize("use_res", [True, False])
+def test_layernorm_fast_path_large_batch(hip, M, use_res, monkeypatch):
+    """bf16, N = 512, M >= 4096: the transformer denoiser's LayerNorms take layernorm_{fwd,bwd}512_kernel (every row of a wave
+    requested before the first is used; csrc/rowops.hip).  Against float64, and against the generic kernels on the same
+    inputs (IB_NO_LN_FAST is read once per process, so the generic result is taken at M just below the threshold on a
+    prefix of the same rows)."""
+    N, bf = 512, torch.bfloat16
+    x = rnd((M, N), 1, 1.5, bf)
+    res = rnd((M, N), 2, 1.0, bf) if use_res else None
+    gamma = (1 + rnd((N,), 3, 0.1)).float()
+    beta = rnd((N,), 4, 0.1).float()
+    dy = rnd((M, N), 5, 1.0, bf)
+    xd = x.double().requires_grad_(True)
+    rd = res.double().requires_grad_(True) if use_res else None
+    gd, bd = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    yd = R.layer_norm(xd + (rd if use_res else 0), gd, bd)
+    yd.backward(dy.double())
+    d = lambda t: None if t is None else t.to(DEV)
+    y = torch.empty(M, N, dtype=bf, device=DEV)
+    mean = torch.empty(M, dtype=torch.float32, device=DEV)
+    rstd = torch.empty(M, dtype=torch.float32, device=DEV)
+    hip.layernorm_fwd(d(x), d(gamma), d(beta), y, mean, rstd, res=d(res))
+    close(y, yd, 3e-2, "LN fast fwd")
+    v = xd.detach() + (rd.detach() if use_res else 0)
+    close(mean, v.mean(-1), 1e-4, "mean")
+    dx = torch.empty(M, N, dtype=bf, device=DEV)
+    dg = torch.zeros(N, device=DEV)
+    db = torch.zeros(N, device=DEV)
+    ws = torch.empty(hip.layernorm_bwd_workspace_bytes(M, N), dtype=torch.uint8, device=DEV)
+    hip.layernorm_bwd(d(dy), d(x), d(gamma), mean, rstd, dx, dg, db, ws, res=d(res))
+    close(dx, xd.grad, 3e-2, "LN fast dx")
+    close(dg, gd.grad, 2e-2, "LN fast dgamma")
+    close(db, bd.grad, 2e-2, "LN fast dbeta")
+    # the generic kernels on the first 4000 rows (below the fast path's threshold): the same values row by row up to one bf16 rounding
+    m2 = 4000
+    y2 = torch.empty(m2, N, dtype=bf, device=DEV)
+    mean2 = torch.empty(m2, dtype=torch.float32, device=DEV)
+    rstd2 = torch.empty(m2, dtype=torch.float32, device=DEV)
+    hip.layernorm_fwd(d(x[:m2]), d(gamma), d(beta), y2, mean2, rstd2, res=d(res[:m2]) if use_res else None)
+    assert (y[:m2].float() - y2.float()).abs().max().item() <= 2 ** -7 * y2.float().abs().max().item()     # one bf16 ulp
+    dx2 = torch.empty(m2, N, dtype=bf, device=DEV)
+    ws2 = torch.empty(hip.layernorm_bwd_workspace_bytes(m2, N), dtype=torch.uint8, device=DEV)
+    hip.layernorm_bwd(d(dy[:m2]), d(x[:m2]), d(gamma), mean2, rstd2, dx2, torch.zeros(N, device=DEV), torch.zeros(N, device=DEV),
+                      ws2, res=d(res[:m2]) if use_res else None)
+    assert (dx[:m2].float() - dx2.float()).abs().max().item() <= 2 ** -7 * dx2.float().abs().max().item()

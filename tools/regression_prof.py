@@ -1,5 +1,5 @@
 """Per-launch breakdown of one fused regression training step (feedforward / groundlink): every distinct C-ABI call of
-an eager step is re-timed back-to-back inside a hipGraph.  Usage (GPU box): python tools/regression_prof.py [model] [B] [F]"""
+an eager step is re-timed back-to-back inside a hipGraph.  Usage (GPU box): python tools/regression_prof.py [model] [B] [F] [f32|bf16]"""
 import argparse
 import sys
 
@@ -17,17 +17,18 @@ def main():
     kind = sys.argv[1] if len(sys.argv) > 1 else "feedforward"
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
     F = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+    cdt = torch.float32 if (len(sys.argv) > 4 and sys.argv[4] == "f32") else torch.bfloat16
     dev = torch.device("cuda", 0)
     targs = argparse.Namespace(predict_grf_components=list(range(6)), predict_cop_components=list(range(6)),
                                predict_moment_components=list(range(6)), predict_wrench_components=list(range(12)))
     torch.manual_seed(0)
     if kind == "groundlink":
         from inferbiomechanics_amd.models.Groundlink import Groundlink
-        m = Groundlink(23, 12, 10, "all_frames", device=dev, compute_dtype=torch.bfloat16)
+        m = Groundlink(23, 12, 10, "all_frames", device=dev, compute_dtype=cdt)
         hw = 30
     else:
         from inferbiomechanics_amd.models.FeedForwardRegressionBaseline import FeedForwardBaseline
-        m = FeedForwardBaseline(23, 2, 5 * F, "all_frames", "sigmoid", 5, 10, device=dev, compute_dtype=torch.bfloat16)
+        m = FeedForwardBaseline(23, 2, 5 * F, "all_frames", "sigmoid", 5, 10, device=dev, compute_dtype=cdt)
         hw = 15
     m.train()
     inputs = {k: torch.randn(B, F, w, device=dev) for k, w in zip(INPUT_KEY_ORDER, input_key_widths(23, hw))}
