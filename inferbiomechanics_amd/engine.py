@@ -555,8 +555,46 @@ class HipTrainer:
             rec.end()
         return rec
 
+    def _dict_batch_direct(self, batch):
+        """regression step over a dict batch whose 14 tensors already lie in HBM as contiguous fp32: (pointer key, the
+        launch sequence's inputs = those very tensors); None when any of them would need a staging copy"""
+        if self.task != "regression" or not isinstance(batch, tuple) or len(batch) != 2 or not isinstance(batch[0], dict):
+            return None
+        inputs, labels = batch
+        st, ptrs = {}, []
+        for pre, keys, src in (("in", INPUT_KEY_ORDER, inputs), ("lab", LOSS_KEY_ORDER, labels)):
+            for i, k in enumerate(keys):
+                t = src.get(k)
+                if not isinstance(t, torch.Tensor) or t.device != self.device or t.dtype != torch.float32 \
+                        or not t.is_contiguous() or t.data_ptr() % 16:
+                    return None
+                st[f"{pre}{i}"] = t
+                ptrs.append(t.data_ptr())
+        return tuple(ptrs), st
+
     def _step(self, batch) -> torch.Tensor:
         self._srcs = None
+        # Dict batches that recur at the same addresses (a loader recycling its device buffers; a benchmark loop): from the
+        # second appearance such a batch gets a graph of its own that reads the caller's tensors where they lie -- the 14
+        # staging copies per step (10 input keys + 4 labels, each a tiny D2D launch issued by the host: ~45 us of the 0.12-ms
+        # fp32 reference-shape step) disappear.  Anything else is staged into the static buffers as before.
+        if self.use_graph and self._rec is not None and not os.environ.get("IB_NO_PINNED_GRAPHS"):
+            d = self._dict_batch_direct(batch)
+            if d is not None:
+                key, st_d = d
+                sig_d = tuple((k, tuple(v.shape)) for k, v in st_d.items()) + (("training", bool(self.model.training)),)
+                if sig_d == self._sig:
+                    pin = self._pinned.get(key)
+                    if pin is None and len(self._pinned) < self.MAX_PINNED_GRAPHS:
+                        n = self._seen.get(key, 0) + 1
+                        if len(self._seen) < 4096 or key in self._seen:
+                            self._seen[key] = n
+                        if n >= 2:
+                            pin = self._pinned[key] = (self._capture(st_d), None, list(st_d.values()))
+                    if pin is not None:
+                        pin[0].replay()
+                        self.steps_done += 1
+                        return self.result[0]
         st = self._stage(batch)
         # model.training is baked into a captured graph (Groundlink / dropout layers choose their launches by it)
         sig = tuple((k, tuple(v.shape)) for k, v in st.items()) + (("training", bool(self.model.training)),)

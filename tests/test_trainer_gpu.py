@@ -146,6 +146,56 @@ def test_regression_trainer_matches_oracle():
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_recurring_dict_batches_are_read_in_place_bitwise(dtype, monkeypatch):
+    """a dict batch that comes back at the same device addresses (a loader recycling its buffers) gets, from its second
+    appearance, a captured graph that reads the caller's tensors where they lie -- no staging copies.  Same steps, bit for
+    bit, as a trainer that stages every batch into its static buffers (IB_NO_PINNED_GRAPHS), two alternating batches, and a
+    tensor that does NOT qualify (non-contiguous) falls back to staging."""
+    from inferbiomechanics_amd.engine import HipTrainer
+    from inferbiomechanics_amd.models.FeedForwardRegressionBaseline import FeedForwardBaseline
+    args = argparse.Namespace(predict_grf_components=list(range(6)), predict_cop_components=list(range(6)),
+                              predict_moment_components=list(range(6)), predict_wrench_components=list(range(12)))
+    batches = []
+    for sd in (0, 1):
+        i_, l_ = ff_inputs(8, 10, 23, 5), ff_labels(8, 10)
+        g = torch.Generator().manual_seed(40 + sd)
+        batches.append(({k: (v + 0.1 * torch.randn(v.shape, generator=g)).to(DEV) for k, v in i_.items()},
+                        {k: (v + 0.1 * torch.randn(v.shape, generator=g)).to(DEV) for k, v in l_.items()}))
+    res = {}
+    for mode in ("in_place", "staged"):
+        model = FeedForwardBaseline(23, 2, 50, "all_frames", "sigmoid", 5, 10, hidden_dims=[64, 48], device=DEV,
+                                    compute_dtype=dtype)
+        load_det(model)
+        tr = HipTrainer(model, "regression", "rmsprop", 1e-3, args=args)
+        if mode == "staged":
+            monkeypatch.setenv("IB_NO_PINNED_GRAPHS", "1")
+        else:
+            monkeypatch.delenv("IB_NO_PINNED_GRAPHS", raising=False)
+        losses = []
+        for i in range(10):
+            inp, lab = batches[i % 2]
+            tr.step((inp, lab))
+            losses.append(tr.result[0].clone())
+        torch.cuda.synchronize()
+        res[mode] = (torch.stack(losses).cpu(), tr.flat.detach().cpu().clone(), len(tr._pinned))
+    assert res["in_place"][2] == 2 and res["staged"][2] == 0       # one graph per recurring batch / none
+    assert torch.equal(res["in_place"][0], res["staged"][0])
+    assert torch.equal(res["in_place"][1], res["staged"][1])
+    # a batch with a non-contiguous tensor is staged (and still right)
+    inp, lab = batches[0]
+    k0 = next(iter(inp))
+    wide = torch.zeros(inp[k0].shape[:-1] + (inp[k0].shape[-1] + 3,), device=DEV)
+    wide[..., :inp[k0].shape[-1]] = inp[k0]
+    odd = dict(inp)
+    odd[k0] = wide[..., :inp[k0].shape[-1]]
+    monkeypatch.delenv("IB_NO_PINNED_GRAPHS", raising=False)
+    before = len(tr._pinned)
+    for _ in range(3):
+        tr.step((odd, lab))
+    assert len(tr._pinned) == before
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_window_cache_step_is_bitwise_the_dict_batch_step(dtype):
     """training from the on-device window cache (one gather launch per batch) must be EXACTLY
     training from the reference-layout dict batches of the same windows (gather + cast vs concat + cast: same values)"""
