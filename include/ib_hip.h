@@ -373,6 +373,14 @@ int ib_time_mlp_bwd_slab_count(int64_t B);
 int ib_time_mlp_bwd(const void* de, int64_t ld_de, const void* w2, int64_t ldw2, const void* zu, int64_t ldzu,
                     const void* s, int64_t lds, float* dw1_slabs, float* db1_slabs, int64_t B, int64_t temb,
                     int64_t hidden, int64_t out, ib_stream_t stream);
+/* ib_linear_wgrad_slabs_multi + ib_time_mlp_bwd as ONE launch: the time-MLP backward's workgroups ride in the grouped
+ * weight-gradient launch (the MLP denoiser's group leaves 52 of 256 CUs idle).  IB_E_UNSUPPORTED = nothing launched. */
+int ib_linear_wgrad_slabs_multi_tb(int n, const void* const* dz, const int64_t* lddz, const void* const* x,
+                                   const int64_t* ldx, void* const* workspace, const size_t* workspace_bytes,
+                                   int32_t* nslab_out, const int64_t* M, const int64_t* N, const int64_t* K, int dtype,
+                                   const void* de, int64_t ld_de, const void* w2, int64_t ldw2, const void* zu, int64_t ldzu,
+                                   const void* s, int64_t lds, float* dw1_slabs, float* db1_slabs, int64_t B, int64_t temb,
+                                   int64_t hidden, int64_t out, ib_stream_t stream);
 /* ib_time_mlp_fwd + ib_mlp_chain_pack as ONE launch (both are independent and tiny; saves a kernel boundary) */
 int ib_mlp_chain_prep(const float* table, int64_t table_rows, const int64_t* t, const void* w1, int64_t ldw1,
                       const float* b1, const void* w2, int64_t ldw2, const float* b2, void* s, void* zu, void* u,

@@ -17,6 +17,7 @@
 // row, so bias / embedding / gamma loads and every store are 8- or 16-byte pieces.
 // LayerNorm row statistics: 16-lane-group shuffles + one cross-wave exchange through LDS, fixed order (deterministic).
 #include "ib_common.h"
+#include "time_bwd.h"
 #include <stdlib.h>
 
 namespace {
@@ -1665,142 +1666,11 @@ extern "C" int ib_mlp_chain_prep(const float* table, int64_t table_rows, const i
 // a partial dW1 [16, temb] per 64-window row group.  The row groups' partials are fp32 slabs the optimizer (or
 // ib_step_reduce) sums in row-group order, like every split-M weight gradient -- deterministic, no atomics.
 namespace {
-constexpr int TB_ROWS = 64, TB_THREADS = 256, TB_MAXOUT = 2048;
-struct TimeBwdParams {
-  const bf16_t* de; int64_t ld_de; const bf16_t* w2; int64_t ldw2; const bf16_t* zu; int64_t ldzu;
-  const bf16_t* s; int64_t lds; float* dw1; float* db1; int B, out, hidden;
-};
-
+constexpr int TB_THREADS = 256;
 template <int TE>
 __global__ __launch_bounds__(TB_THREADS) void time_mlp_bwd_kernel(TimeBwdParams p) {
-  constexpr int SS = TB_ROWS + 8;                            // row strides (elements) of the two small transposed images
-  __shared__ __attribute__((aligned(16))) bf16_t wimg[16 * (TB_MAXOUT + 8)];     // W2[:, c0 .. c0+16)^T : [c][n]
-  __shared__ __attribute__((aligned(16))) float xacc[4][TB_ROWS][16];            // the waves' partial accumulators
-  __shared__ __attribute__((aligned(16))) bf16_t dzT[16 * SS];                   // dzu^T : [c][row]
-  __shared__ __attribute__((aligned(16))) bf16_t sT[TE * SS];                    // s^T   : [te][row]
-  __shared__ float cred[TB_ROWS][16];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int c0 = blockIdx.x * 16, r0 = blockIdx.y * TB_ROWS;
-  const int nrows = min(TB_ROWS, p.B - r0);
-  const int WS = p.out + 8;
-  const int r = lane & 15, kq = lane >> 4;
-  const int nkb = p.out / 32, kpw = nkb / 4;                 // k-blocks per wave (out % 128 == 0): kb = wave, wave + 4, ...
-  // Every global request of the workgroup goes out BEFORE anything is waited for (each dependent first-touch round trip
-  // is 2-3 us here; issued one phase at a time -- W2 slice, then the de fragments -- the launch took 11.4 us):
-  // the de fragments of this wave's first eight k-blocks, the W2 slice, the s rows, the pre-activations.
-  constexpr int PF = 8;
-  const bf16_t* drow[4];
-#pragma unroll
-  for (int mt = 0; mt < 4; ++mt) drow[mt] = p.de + (int64_t)min(r0 + 16 * mt + r, p.B - 1) * p.ld_de + 8 * kq;
-  bf16x8_t b[PF][4];
-#pragma unroll
-  for (int i = 0; i < PF; ++i) {
-    const int kb = wave + 4 * min(i, kpw - 1);
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) b[i][mt] = *reinterpret_cast<const bf16x8_t*>(drow[mt] + 32 * kb);
-  }
-  // this thread's pre-activations for step 3 (row tid / 4, columns 4 (tid % 4) ..)
-  const int xrow = tid >> 2, xc = 4 * (tid & 3);
-  const bf16x4_t zu4 = *reinterpret_cast<const bf16x4_t*>(p.zu + (int64_t)min(r0 + xrow, p.B - 1) * p.ldzu + c0 + xc);
-  // s rows of the group -> LDS, transposed (rows beyond the batch: a finite duplicate; their dzu is zero)
-  constexpr int SP = TB_ROWS * (TE / 8) / TB_THREADS > 0 ? TB_ROWS * (TE / 8) / TB_THREADS : 1;   // pieces per thread
-  bf16x8_t sv[SP];
-#pragma unroll
-  for (int j = 0; j < SP; ++j) {
-    const int pc = min(tid + j * TB_THREADS, TB_ROWS * (TE / 8) - 1), row = pc / (TE / 8), t8 = pc % (TE / 8);
-    sv[j] = *reinterpret_cast<const bf16x8_t*>(p.s + (int64_t)min(r0 + row, p.B - 1) * p.lds + 8 * t8);
-  }
-  // 1. W2 slice -> LDS, transposed (16-byte pieces = 8 columns of one reduction row; four pieces per thread in flight)
-  for (int p0 = tid; p0 < p.out * 2; p0 += TB_THREADS * 8) {   // eight pieces per thread in flight (out = 1024: all of them)
-    bf16x8_t v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int pce = min(p0 + TB_THREADS * u, p.out * 2 - 1), k = pce >> 1, half = pce & 1;
-      v[u] = *reinterpret_cast<const bf16x8_t*>(p.w2 + (int64_t)k * p.ldw2 + c0 + 8 * half);
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int pce = p0 + TB_THREADS * u, k = pce >> 1, half = pce & 1;
-      if (pce < p.out * 2) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) wimg[(8 * half + e) * WS + k] = v[u][e];
-      }
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < SP; ++j) {
-    const int pc = tid + j * TB_THREADS, row = pc / (TE / 8), t8 = pc % (TE / 8);
-    if (pc < TB_ROWS * (TE / 8)) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) sT[(8 * t8 + e) * SS + row] = sv[j][e];
-    }
-  }
-  __syncthreads();
-  // 2. partial dzu^T[c][row] over this wave's k-blocks
-  f32x4_t acc[4];
-#pragma unroll
-  for (int mt = 0; mt < 4; ++mt) acc[mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  const bf16_t* wrow = wimg + r * WS + 8 * kq;
-  for (int i0 = 0; i0 < kpw; i0 += PF) {
-    if (i0 > 0) {                                            // out > 1024: the next eight k-blocks
-#pragma unroll
-      for (int i = 0; i < PF; ++i) {
-        const int kb = wave + 4 * min(i0 + i, kpw - 1);
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) b[i][mt] = *reinterpret_cast<const bf16x8_t*>(drow[mt] + 32 * kb);
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < PF; ++i) {
-      if (i0 + i < kpw) {
-        const int kb = wave + 4 * (i0 + i);
-        const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(wrow + 32 * kb);
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[i][mt], acc[mt], 0, 0, 0);
-      }
-    }
-  }
-#pragma unroll
-  for (int mt = 0; mt < 4; ++mt)                              // lane: columns 4 kq .. +3 of row 16 mt + r
-    *reinterpret_cast<f32x4_t*>(&xacc[wave][16 * mt + r][4 * kq]) = acc[mt];
-  __syncthreads();
-  // 3. sum the waves' partials in wave order, * silu'(zu), round; dzu^T image + this row's share of the bias sums
-  {
-    float v[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-      v[e] = ((xacc[0][xrow][xc + e] + xacc[1][xrow][xc + e]) + xacc[2][xrow][xc + e]) + xacc[3][xrow][xc + e];
-    const bool live = xrow < nrows;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float x = (float)zu4[e];
-      const float sg = 1.f / (1.f + __expf(-x));
-      const bf16_t o = (bf16_t)(live ? v[e] * (sg * (1.f + x * (1.f - sg))) : 0.f);
-      dzT[(xc + e) * SS + xrow] = o;
-      cred[xrow][xc + e] = (float)o;                           // the bias gradient sums the STORED values
-    }
-  }
-  __syncthreads();
-  if (tid < 16) {
-    float sm = 0.f;
-#pragma unroll 16
-    for (int row = 0; row < TB_ROWS; ++row) sm += cred[row][tid];
-    p.db1[(int64_t)blockIdx.y * p.hidden + c0 + tid] = sm;
-  }
-  // 4. partial dW1[c0 .. c0+16)[:] = dzu^T s over the group's 64 windows (two k-blocks), n-tiles over the waves
-  for (int nt = wave; nt < TE / 16; nt += 4) {
-    f32x4_t a2 = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kb = 0; kb < TB_ROWS / 32; ++kb) {
-      const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(dzT + r * SS + 32 * kb + 8 * kq);
-      const bf16x8_t b = *reinterpret_cast<const bf16x8_t*>(sT + (16 * nt + r) * SS + 32 * kb + 8 * kq);
-      a2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, a2, 0, 0, 0);
-    }
-    // D[c][te]: this lane holds rows c = 4 kq + e of column te = 16 nt + r
-    float* dst = p.dw1 + ((int64_t)blockIdx.y * p.hidden + c0 + 4 * kq) * TE + 16 * nt + r;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) dst[(int64_t)e * TE] = a2[e];
-  }
+  __shared__ __attribute__((aligned(16))) unsigned char smem[time_bwd_lds<TE, 4>(TB_MAXOUT)];
+  time_bwd_body<TE, 4>(p, (int)blockIdx.x, (int)blockIdx.y, 1, smem);
 }
 }  // namespace
 

@@ -20,6 +20,7 @@
 
 #include "ib_common.h"
 #include "gemm_nt.h"
+#include "time_bwd.h"
 
 namespace {
 
@@ -1681,6 +1682,30 @@ extern "C" int ib_linear_wgrad_slabs_multi_bias(int n, const void* const* dz, co
   hipLaunchKernelGGL(gemm_ring_wgrad_multi_kernel, dim3(blocks), dim3(NTHREADS), 0, ib_s(stream), m);
   IB_CHECK_LAUNCH();
   return IB_OK;
+}
+
+// The grouped weight-gradient launch with the time-MLP's hidden-layer backward (ib_time_mlp_bwd) riding along as extra
+// workgroups of the SAME launch (csrc/gemm_tn.hip).  IB_E_UNSUPPORTED = nothing launched: the caller issues
+// ib_linear_wgrad_slabs_multi and ib_time_mlp_bwd separately.
+extern "C" int ib_linear_wgrad_slabs_multi_tb(int n, const void* const* dz, const int64_t* lddz, const void* const* x,
+                                              const int64_t* ldx, void* const* workspace, const size_t* workspace_bytes,
+                                              int32_t* nslab_out, const int64_t* M, const int64_t* N, const int64_t* K,
+                                              int dtype, const void* de, int64_t ld_de, const void* w2, int64_t ldw2,
+                                              const void* zu, int64_t ldzu, const void* s_rows, int64_t lds, float* dw1_slabs,
+                                              float* db1_slabs, int64_t B, int64_t temb, int64_t hidden, int64_t out,
+                                              ib_stream_t stream) {
+  if (n <= 0 || n > WG_MAX || !dz || !lddz || !x || !ldx || !workspace || !workspace_bytes || !nslab_out || !M || !N || !K)
+    return IB_E_ARG;
+  if (dtype != IB_BF16 || !ib_time_mlp_bwd_supported(temb, hidden, out)) return IB_E_UNSUPPORTED;
+  if (!de || !w2 || !zu || !s_rows || !dw1_slabs || !db1_slabs || B <= 0) return IB_E_ARG;
+  if (ld_de < out || ldw2 < hidden || ldzu < hidden || lds < temb || ld_de % 8 || ldw2 % 8 || lds % 8) return IB_E_ARG;
+  if (!aligned(de, 16) || !aligned(w2, 16) || !aligned(zu, 2) || !aligned(s_rows, 16) || !aligned(dw1_slabs, 16) ||
+      !aligned(db1_slabs, 16))
+    return IB_E_ARG;
+  TimeBwdParams tb{(const bf16_t*)de, ld_de, (const bf16_t*)w2, ldw2, (const bf16_t*)zu, ldzu, (const bf16_t*)s_rows, lds,
+                   dw1_slabs, db1_slabs, (int)B, (int)out, (int)hidden};
+  return ib_gemm_tn_multi(n, dz, lddz, x, ldx, workspace, workspace_bytes, nullptr, nslab_out, M, N, K, ib_s(stream), &tb,
+                          (int)temb);
 }
 
 // ---- y = LayerNorm(res + x W^T + b) for small token counts (the DDIM sampler: M = B*T = 3200): the GEMM is split over

@@ -16,7 +16,9 @@ int ib_gemm_nt_try(const void* A, int64_t lda, const void* B, int64_t ldb, void*
 int ib_gemm_tn_splits(int64_t M, int64_t N, int64_t K, int group);
 int ib_gemm_tn_multi(int n, const void* const* dz, const int64_t* lddz, const void* const* x, const int64_t* ldx,
                      void* const* workspace, const size_t* workspace_bytes, float* const* dbias_part, int32_t* nslab_out,
-                     const int64_t* M, const int64_t* N, const int64_t* K, hipStream_t s);
+                     const int64_t* M, const int64_t* N, const int64_t* K, hipStream_t s, const void* rider = nullptr,
+                     int rider_te = 0);
+// rider: optional TimeBwdParams (time_bwd.h) whose workgroups are appended to the launch (temb = rider_te: 128 or 32)
 
 // gemm_f32_small.hip: fp32 forward / dgrad of batches of a few rows (16 x 16 tiles, the four waves split the reduction).
 // IB_E_UNSUPPORTED = nothing launched.

@@ -23,6 +23,7 @@
 
 #include "ib_common.h"
 #include "gemm_nt.h"
+#include "time_bwd.h"
 
 namespace {
 
@@ -69,7 +70,15 @@ struct TnProblem {
   int tiles_n, tiles_k, splits, chunk;                    // chunk = M / splits, a multiple of 64, >= 256
   int item0;                                              // first work item of this problem
 };
-struct TnParams { TnProblem pr[TN_MAX]; int n, items; long long* prof; };
+// Rider: the time-embedding MLP's hidden-layer backward (time_bwd.h) as EXTRA workgroups of this launch.  The MLP denoiser's
+// grouped launch has 204 work items for 256 CUs: 52 CUs idle for its whole 30 us, enough for the rider's 128 short workgroups
+// (3 rounds of ~8 us) -- as a launch of its own it cost the step 11 us + a boundary.  Blocks [tn_grid, tn_grid + tb_blocks)
+// are rider workgroups (one per 16 hidden columns, every row group); they share nothing with the GEMM's workgroups.
+struct TnParams {
+  TnProblem pr[TN_MAX]; int n, items; long long* prof;
+  int tn_grid;                       // persistent GEMM workgroups (= the stride of the work-item walk)
+  TimeBwdParams tb; int tb_blocks, tb_cgs, tb_te;
+};
 long long* g_tn_prof = nullptr;
 
 // BIAS: some problem of the launch wants its bias gradient.  The extra MFMAs then run unconditionally (every item, every
@@ -78,9 +87,18 @@ long long* g_tn_prof = nullptr;
 template <bool BIAS>
 __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_kernel(TnParams P) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[LDS_BYTES];
+  if ((int)blockIdx.x >= P.tn_grid) {                          // rider workgroups (wave-uniform: whole workgroups)
+    // one rider workgroup per 16 hidden columns walks ALL row groups (the launch has ~50 CUs to spare, a rider round is a
+    // ~10-us latency chain whatever its size: 128 one-group riders took three rounds and stretched the launch 30 -> 37.7 us)
+    const int b = (int)blockIdx.x - P.tn_grid;
+    const int nrg = (P.tb.B + TB_ROWS - 1) / TB_ROWS;
+    if (P.tb_te == 128) time_bwd_body<128, 8>(P.tb, b, 0, nrg, smem);
+    else time_bwd_body<32, 8>(P.tb, b, 0, nrg, smem);
+    return;
+  }
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  const int nwg = (int)gridDim.x;
+  const int nwg = P.tn_grid;
   const int first = ib_xcd_remap((int)blockIdx.x, nwg);
   if (first >= P.items) return;
   const unsigned smem0 = lds_off(smem);
@@ -311,7 +329,7 @@ int ib_gemm_tn_splits(int64_t M, int64_t N, int64_t K, int group) {
 
 int ib_gemm_tn_multi(int n, const void* const* dz, const int64_t* lddz, const void* const* x, const int64_t* ldx,
                      void* const* workspace, const size_t* workspace_bytes, float* const* dbias_part, int32_t* nslab_out,
-                     const int64_t* M, const int64_t* N, const int64_t* K, hipStream_t s) {
+                     const int64_t* M, const int64_t* N, const int64_t* K, hipStream_t s, const void* rider, int rider_te) {
   if (n <= 0 || n > TN_MAX) return IB_E_UNSUPPORTED;
   TnParams P{};
   P.n = n;
@@ -335,7 +353,17 @@ int ib_gemm_tn_multi(int n, const void* const* dz, const int64_t* lddz, const vo
   }
   P.items = items;
   P.prof = g_tn_prof;
-  const int grid = items < 256 ? items : 256;
+  int grid = items < 256 ? items : 256;
+  P.tn_grid = grid;
+  if (rider) {
+    const TimeBwdParams& tb = *reinterpret_cast<const TimeBwdParams*>(rider);
+    if (tb.out % 256 != 0 || (rider_te != 128 && rider_te != 32) ||
+        (rider_te == 128 ? time_bwd_lds<128, 8>(tb.out) : time_bwd_lds<32, 8>(tb.out)) > LDS_BYTES)
+      return IB_E_UNSUPPORTED;
+    P.tb = tb; P.tb_te = rider_te; P.tb_cgs = tb.hidden / 16;
+    P.tb_blocks = P.tb_cgs;
+    grid += P.tb_blocks;
+  }
   bool any_bias = false;
   for (int j = 0; j < n; ++j) any_bias = any_bias || P.pr[j].dbias != nullptr;
   IB_PATH(IB_PATH_TN);

@@ -116,6 +116,8 @@ _SIGS = {
                                      _i64, _i64, _vp, _vp, _vp, _i64, _i64, _c.c_int, _vp, _vp]),
     "ib_time_mlp_fwd": (_c.c_int, [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64,
                                    _i64, _i64, _vp]),
+    "ib_linear_wgrad_slabs_multi_tb": (_c.c_int, [_c.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _c.c_int,
+                                                  _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _vp]),
     "ib_time_mlp_bwd_supported": (_c.c_int, [_i64, _i64, _i64]),
     "ib_time_mlp_bwd_slab_count": (_c.c_int, [_i64]),
     "ib_time_mlp_bwd": (_c.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _vp]),
@@ -660,11 +662,13 @@ def linear_wgrad_slabs(dz, x, workspace) -> int:
     return n.value if not _dry_run else 1
 
 
-def linear_wgrad_slabs_multi(problems, bias_parts=None):
+def linear_wgrad_slabs_multi(problems, bias_parts=None, time_bwd=None):
     """problems: [(dz, x, workspace)] -- split-M slabs of every dW = dz^T x in ONE launch.  Returns the slab counts, or
     None when the shapes do not all qualify for the ring kernel (issue linear_wgrad_slabs one by one then).
     bias_parts: per problem None or an fp32 [32, N] tensor that receives the bias gradient's per-slice partial sums (rows
-    0 .. slab count - 1)."""
+    0 .. slab count - 1).
+    time_bwd = (de, w2, zu, s, dw1_slabs, db1_slabs): the operands of time_mlp_bwd() -- its workgroups ride in this launch
+    (ib_linear_wgrad_slabs_multi_tb).  None is returned when the combined launch does not qualify: NOTHING was launched."""
     n = len(problems)
     if bias_parts is not None:
         for (dz, _, _), bp in zip(problems, bias_parts):
@@ -703,7 +707,24 @@ def linear_wgrad_slabs_multi(problems, bias_parts=None):
         _work_note = (sum(2 * g_[0] * g_[1] * g_[2] for g_ in geo),
                       sum((g_[0] * g_[1] + g_[0] * g_[2]) * es_ + g_[1] * g_[2] * 4 for g_ in geo),
                       [[g_[0], g_[1], g_[2]] for g_ in geo])
-    if bias_parts is not None and any(b is not None for b in bias_parts):
+    if time_bwd is not None:
+        if bias_parts is not None and any(b is not None for b in bias_parts):
+            raise HipError("linear_wgrad_slabs_multi: time_bwd rider and bias_parts cannot be combined")
+        de, w2, zu, s_, sw, sb = time_bwd
+        bt = torch.bfloat16
+        B_, out_, ld_de = _mat(de, "de", bt)
+        o2, hid_, ldw2 = _mat(w2, "w2", bt)
+        Bz, hz, ldzu = _mat(zu, "zu", bt)
+        Bs, temb_, lds_ = _mat(s_, "s", bt)
+        nsl = time_mlp_bwd_slab_count(B_)
+        if o2 != out_ or hz != hid_ or Bz != B_ or Bs != B_ or tuple(sw.shape) != (nsl, hid_, temb_) \
+                or tuple(sb.shape) != (nsl, hid_) or sw.dtype != torch.float32 or sb.dtype != torch.float32 \
+                or not sw.is_contiguous() or not sb.is_contiguous():
+            raise HipError("linear_wgrad_slabs_multi: time_bwd operands do not chain")
+        rc = lib().ib_linear_wgrad_slabs_multi_tb(n, cv(A), cv(LA), cv(X), cv(LX), cv(W), cv(WB), cv(out), cv(Ms), cv(Ns), cv(Ks),
+                                                  dtype_code(dt), _ptr(de), ld_de, _ptr(w2), ldw2, _ptr(zu), ldzu, _ptr(s_), lds_,
+                                                  _ptr(sw), _ptr(sb), B_, temb_, hid_, out_, stream_ptr())
+    elif bias_parts is not None and any(b is not None for b in bias_parts):
         BP = (ctypes.c_void_p * n)(*[(b.data_ptr() if b is not None else None) for b in bias_parts])
         rc = lib().ib_linear_wgrad_slabs_multi_bias(n, cv(A), cv(LA), cv(X), cv(LX), cv(W), cv(WB), cv(BP), cv(out), cv(Ms),
                                                     cv(Ns), cv(Ks), dtype_code(dt), stream_ptr())

@@ -129,7 +129,7 @@ def _colsum(buf: Buffers, tag: str, x2d: torch.Tensor, out_vec: torch.Tensor, ac
         hip.segment_colsum(part, out_vec.view(1, N), seg=part.shape[0], mode=0, accumulate=accumulate)
 
 
-def _wgrad_group(buf: Buffers, problems, defer: list, later: Optional[list] = None):
+def _wgrad_group(buf: Buffers, problems, defer: list, later: Optional[list] = None, time_bwd=None):
     """problems: [(dz, x, dw, ws_tag[, dbias])] -- the slabs of every problem in ONE launch when they all qualify for the ring
     kernel (one by one otherwise); appends (workspace, nslab, dw) to `defer` for the step's single reduction.
     dbias (optional fp32 [N] gradient of the layer's bias) with `later` given: the same launch leaves the bias gradient's
@@ -155,7 +155,13 @@ def _wgrad_group(buf: Buffers, problems, defer: list, later: Optional[list] = No
             for i in grp:
                 if len(problems[i]) > 4 and problems[i][4] is not None:
                     parts[i] = buf.get(problems[i][3] + ".bpart", (32, items[i][0].shape[1]), torch.float32)
-        got = hip.linear_wgrad_slabs_multi([items[i] for i in grp], bias_parts=[parts[i] for i in grp])
+        got = None
+        if time_bwd is not None and len(grp) == len(items) and not any(p_ is not None for p_ in parts):
+            # the time-MLP backward's workgroups ride in this launch (time_bwd = [operands, consumed flag])
+            got = hip.linear_wgrad_slabs_multi([items[i] for i in grp], time_bwd=time_bwd[0])
+            time_bwd[1] = got is not None
+        if got is None:
+            got = hip.linear_wgrad_slabs_multi([items[i] for i in grp], bias_parts=[parts[i] for i in grp])
         if got is not None:
             for i, n in zip(grp, got):
                 ns[i] = n
@@ -802,7 +808,9 @@ class TimeMLPPlan:
         w1, w2 = P.w("time_mlp.0.weight"), P.w("time_mlp.2.weight")
         return hip.time_mlp_bwd_supported(w1.shape[1], w1.shape[0], w2.shape[0])
 
-    def backward_hidden(self, de32, de_lp, P: ParamSource, accumulate=False, defer=None, ready=True):
+    def backward_hidden(self, de32, de_lp, P: ParamSource, accumulate=False, defer=None, ready=True, rider=None):
+        """rider (a list): with the one-launch backward available, do NOT launch it -- append its operands instead (the
+        caller puts its workgroups into the grouped weight-gradient launch, or launches ib_time_mlp_bwd itself)"""
         s, u, zu = self.ctx
         tg = self.tag
         if self.fused_bwd_ok(P, defer, accumulate):
@@ -811,7 +819,10 @@ class TimeMLPPlan:
             nsl = hip.time_mlp_bwd_slab_count(de.shape[0])
             wsw = self.buf.get(tg + ".bww", (nsl, hid, temb), torch.float32)
             wsb = self.buf.get(tg + ".bwb", (nsl, hid), torch.float32)
-            hip.time_mlp_bwd(de, P.w("time_mlp.2.weight"), zu, s, wsw, wsb)
+            if rider is not None:                    # launched by the caller inside its grouped weight-gradient launch
+                rider.append((de, P.w("time_mlp.2.weight"), zu, s, wsw, wsb))
+            else:
+                hip.time_mlp_bwd(de, P.w("time_mlp.2.weight"), zu, s, wsw, wsb)
             defer.append((wsw, nsl, P.g("time_mlp.0.weight")))
             defer.append((wsb, nsl, P.g("time_mlp.0.bias").view(1, hid)))
             if ready:
@@ -1034,15 +1045,19 @@ class DenoiserMLPPlan:
         # (head, blocks, time_mlp.2) goes into ONE grouped launch on the main stream.
         # (issued AFTER the grouped launch instead, the branch's first kernel only started when the grouped launch had
         # finished -- no overlap at all: 0.232 -> 0.250 ms/step)
+        rider_ops = []
         if os.environ.get("IB_SKIP_TIME_BWD"):       # TIMING-ONLY: an upper bound of what the time-MLP backward costs (wrong gradients)
             if defer is not None and getattr(self, "_tb_defer", None):
                 defer.extend(self._tb_defer)
         else:
             n0 = len(defer) if defer is not None else 0
             if self.time.fused_bwd_ok(P, defer, accumulate):
-                # one short launch on the main stream (no fork / join of the captured graph, no CUs taken from the grouped
-                # weight gradients for 25 us)
-                self.time.backward_hidden(de32, de_lp, P, accumulate, defer=defer, ready=False)
+                # one set of independent workgroups, no fork / join of the captured graph: they ride in the grouped
+                # weight-gradient launch below (204 work items for 256 CUs: the launch has 52 CUs to spare), or run as a
+                # launch of their own on the main stream when that launch does not take them
+                rider_ops = []
+                self.time.backward_hidden(de32, de_lp, P, accumulate, defer=defer, ready=False,
+                                          rider=None if os.environ.get("IB_NO_TB_RIDER") else rider_ops)
             else:
                 self.branch.run(lambda: self.time.backward_hidden(de32, de_lp, P, accumulate, defer=defer, ready=False))
             if defer is not None:
@@ -1053,11 +1068,14 @@ class DenoiserMLPPlan:
             probs.append((dz[i], h[i - 1] if i > 0 else xt, P.g(f"blocks.{i}.linear.weight"), f"dm.ws{i}"))
         s_, u_, zu_ = self.time.ctx
         probs.append((de_lp, u_, P.g("time_mlp.2.weight"), self.time.tag + ".ws2"))     # B rows only: rides along
+        tb = [rider_ops[0], False] if rider_ops else None
         if grouped and len(probs) <= 6:
-            _wgrad_group(self.buf, probs, defer)
+            _wgrad_group(self.buf, probs, defer, time_bwd=tb)
         else:
             for dz_, x_, dw_, tag in probs:
                 _wgrad(self.buf, dz_, x_, dw_, accumulate, ws_tag=tag, defer=defer)
+        if tb is not None and not tb[1]:
+            hip.time_mlp_bwd(*tb[0])
         # main stream: every small gradient (LayerNorm gains / biases, linear biases, head bias, time_mlp.2.bias) and
         # the loss in one launch
         tb2 = P.g("time_mlp.2.bias")

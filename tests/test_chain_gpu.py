@@ -438,3 +438,38 @@ def test_time_mlp_bwd_matches_float64(hip, B, temb, hid, out):
     hip.time_mlp_bwd(d(de), d(w2), d(zu), d(s), sw2, sb2)
     torch.cuda.synchronize()
     assert torch.equal(sw, sw2) and torch.equal(sb, sb2)
+
+
+def test_time_mlp_bwd_rides_in_the_grouped_weight_gradient_launch(hip):
+    """ib_linear_wgrad_slabs_multi_tb: the MLP denoiser's four weight-gradient problems (M = 12800 token rows; time_mlp.2 with
+    M = 256) and, as extra workgroups of the SAME launch, the time-MLP hidden layer's backward (8 waves per workgroup there:
+    the reduction split eight ways).  Every output against float64; the GEMM slabs bitwise equal to the launch without rider."""
+    M, T, D, H, B, temb, hid = 12800, 50, 300, 512, 256, 128, 512
+    out = 2 * H
+    mk = lambda shape, seed, sc=1.0: rnd(shape, seed, sc).to(BF).to(DEV)
+    dpred, h1, dz1, h0, dz0 = mk((M, 304), 1)[:, :D], mk((M, H), 2), mk((M, H), 3), mk((M, H), 4), mk((M, H), 5)
+    xt = mk((M, 304), 6)[:, :D]
+    de, u_t = mk((B, out), 7, 0.3), mk((B, hid), 8)
+    w2, zu, s = mk((out, hid), 9, hid ** -0.5), mk((B, hid), 10, 1.5), mk((B, temb), 11, 0.7)
+    probs = [(dpred, h1), (dz1, h0), (dz0, xt), (de, u_t)]
+    ws = lambda: [torch.zeros(int(hip.lib().ib_linear_wgrad_slabs_workspace(a.shape[0], a.shape[1], b.shape[1])),
+                              dtype=torch.uint8, device=DEV) for a, b in probs]
+    n = hip.time_mlp_bwd_slab_count(B)
+    sw = torch.full((n, hid, temb), float("nan"), device=DEV)
+    sb = torch.full((n, hid), float("nan"), device=DEV)
+    w_a, w_b = ws(), ws()
+    ns_a = hip.linear_wgrad_slabs_multi([(a, b, w) for (a, b), w in zip(probs, w_a)], time_bwd=(de, w2, zu, s, sw, sb))
+    assert ns_a is not None, "the combined launch must take the headline shape"
+    ns_b = hip.linear_wgrad_slabs_multi([(a, b, w) for (a, b), w in zip(probs, w_b)])
+    torch.cuda.synchronize()
+    assert ns_a == ns_b
+    for (a, b), wa, wb, k in zip(probs, w_a, w_b, ns_a):
+        N, K = a.shape[1], b.shape[1]
+        sa = wa[:k * N * K * 4].view(torch.float32).view(k, N, K)
+        assert torch.equal(sa, wb[:k * N * K * 4].view(torch.float32).view(k, N, K))
+        close(sa.sum(0), a.double().T @ b.double(), 2e-2, f"dW [{N},{K}]")
+    z = zu.double().cpu()
+    sg = torch.sigmoid(z)
+    dzu_b = bf((de.double().cpu() @ w2.double().cpu()) * (sg * (1 + z * (1 - sg))))
+    close(sw.sum(0), dzu_b.T @ s.double().cpu(), 2e-2, "rider dW1")
+    close(sb.sum(0), dzu_b.sum(0), 2e-2, "rider db1")
