@@ -158,12 +158,15 @@ class TrainCommand(AbstractCommand):
         cache = None
         if args.window_cache and trainer is not None and not diffusion:
             from ..data.WindowCache import DeviceWindowCache, PackedWindows
-            # rank 0 packs and writes (atomically: temporary file + rename); the other ranks wait at the barrier and then
-            # memory-map the finished file -- none of them can open a file that is still being written
+            # rank 0 packs and writes (atomically: temporary file + rename); the other ranks POLL for the finished file and
+            # only then enter the barrier -- packing a full training set can outlast the process group's collective timeout
+            # (~10 min under RCCL), so no collective may span it; none of them can open a file that is still being written
             if not os.path.exists(args.window_cache) and rank == 0:
                 print(f"Packing {len(train_dataset)} training windows into {args.window_cache} ...")
                 PackedWindows.from_windows(train_dataset).save(args.window_cache)
             if distributed:
+                from ..data.WindowCache import wait_for_file
+                wait_for_file(args.window_cache, float(os.environ.get("IB_WINDOW_CACHE_WAIT_S", 6 * 3600)))
                 dist.barrier()
             pack = PackedWindows.load(args.window_cache)
             cache = DeviceWindowCache(pack, device)

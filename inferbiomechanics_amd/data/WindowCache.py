@@ -35,6 +35,18 @@ MAGIC = b"IBWINDOWS1\n"
 HEADER_BYTES = 4096
 
 
+def wait_for_file(path: str, timeout_s: float, poll_s: float = 2.0) -> None:
+    """Sleep-poll until `path` exists.  PackedWindows.save renames the finished file into place, so existence means
+    complete.  Used by the ranks that do not pack (cli/train.py): waiting here instead of inside a collective keeps the
+    process group's watchdog timeout out of a phase whose length depends on the data set."""
+    import time
+    t0 = time.monotonic()
+    while not os.path.exists(path):
+        if time.monotonic() - t0 > timeout_s:
+            raise TimeoutError(f"window cache {path!r} did not appear within {timeout_s:.0f} s (is the packing rank alive?)")
+        time.sleep(poll_s)
+
+
 class PackedWindows:
     """N windows as one fp32 matrix ``rows[N, x_elems + y_elems]`` (+ subject / trial indices)."""
 

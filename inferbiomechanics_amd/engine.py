@@ -522,7 +522,19 @@ class HipTrainer:
         # IB_GRAPH_COLLECTIVES=1: the all-reduces are CAPTURED (c10d enqueues the RCCL kernels on its communication stream,
         # which joins the capture through the event edges it records): one graph per step, no graph cut and no host work per
         # collective.  Validated on the 1-rank RCCL self-test group only (no multi-GPU box in this build's reach), hence a flag.
+        # Limit of the flag: on the bucketed (overlap_comm) path c10d's own communication stream joins the capture, and that
+        # stream carried the eager warm-up steps' collectives whose completion events the c10d watchdog polls from its own
+        # thread -- a poll that lands while the stream captures aborts the process (the hazard _Recorder.begin refuses for
+        # the caller's streams; it cannot see c10d's).  So before capturing: wait on every outstanding Work, drain the
+        # device, and give the watchdog one reap cycle; afterwards nothing it still polls sits on that stream.
         graph_collectives = self.ddp and os.environ.get("IB_GRAPH_COLLECTIVES") == "1"
+        if graph_collectives:
+            self.buckets.finish()
+            if self.device.type == "cuda":
+                torch.cuda.synchronize(self.device)
+            if self.overlap_comm:
+                import time
+                time.sleep(0.5)
 
         def cut(b: int):
             if graph_collectives:

@@ -30,7 +30,12 @@ class _MSEFn(torch.autograd.Function):
         if ctx.dpred is None:
             return None, None
         # dpred already holds 2 (pred - target) / n from the forward launch; the upstream gradient of the scalar loss is
-        # a device scalar: one in-place HIP launch, no ATen arithmetic on the backward
+        # a device scalar: one in-place HIP launch, no ATen arithmetic on the backward.  In place means consumed: a second
+        # backward over the same graph (retain_graph=True) is refused rather than scaled twice.
+        if getattr(ctx, "consumed", False):
+            raise RuntimeError("eps-MSE loss: backward was already run on this graph; its gradient buffer is scaled in "
+                               "place and cannot be reused (call the evaluator again for a second backward)")
+        ctx.consumed = True
         return hip.scale_by_device_scalar(ctx.dpred, _as_f32_scalar(dloss)), None
 
 

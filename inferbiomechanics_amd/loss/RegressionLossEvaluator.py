@@ -72,7 +72,13 @@ class _RegressionLossFn(torch.autograd.Function):
             return (None,) * 7
         # the four gradients are views of ONE [B, 30 F] buffer the forward launch filled: scale it in place by the
         # upstream gradient (a device scalar) with one HIP launch -- no ATen arithmetic on the backward
+        # The buffer is consumed by that: a second backward over the same graph (retain_graph=True) would scale it again,
+        # so it is refused, as torch refuses a second pass over freed saved tensors.
         from .DiffusionLossEvaluator import _as_f32_scalar
+        if getattr(ctx, "consumed", False):
+            raise RuntimeError("regression loss: backward was already run on this graph; its gradient buffer is scaled "
+                               "in place and cannot be reused (call the evaluator again for a second backward)")
+        ctx.consumed = True
         hip.scale_by_device_scalar(ctx.G, _as_f32_scalar(dloss))
         return tuple(ctx.grads) + (None, None, None)
 

@@ -41,8 +41,10 @@ def make_layer_params(d: int, ffn: int, dtype=torch.float32, device=None) -> nn.
 
 
 class TransformerLayer(HipModule):
+    _instances = 0              # construction order; enters each layer's dropout seed (independent masks per layer)
+
     def __init__(self, timestep_vector_dim: int, num_heads: int, dim_feedforward: int, dropout: float = 0.0,
-                 dtype=torch.float32, device=None):
+                 dtype=torch.float32, device=None, seed=None):
         super().__init__(torch.bfloat16 if dtype == torch.bfloat16 else torch.float32)
         if not 0.0 <= dropout < 1.0:
             raise ValueError(f"dropout probability has to be in [0, 1), but got {dropout}")
@@ -57,11 +59,16 @@ class TransformerLayer(HipModule):
         self.train_mode_matters = self.dropout_p > 0.0
         self._fwd_calls = 0
         self._plan = None
+        # seed=None: plans.mask_seed of (construction index, torch's seed, rank) -- stacked layers and data-parallel ranks
+        # draw independent masks, as the reference's nn.Dropout modules do; an int fixes the mask stream (tests)
+        self.seed = seed
+        self._index = TransformerLayer._instances
+        TransformerLayer._instances += 1
 
     def _get_plan(self, device):
         if self._plan is None or self._plan.buf.device != device or self._plan.dtype != self.compute_dtype:
             self._plan = TransformerLayerPlan("", self.d, self.h, self.ffn, self.compute_dtype, device,
-                                              dropout_p=self.dropout_p)
+                                              tag=f"tl{self._index}", dropout_p=self.dropout_p, seed=self.seed)
         return self._plan
 
     def _plan_forward(self, x):

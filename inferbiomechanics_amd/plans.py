@@ -23,6 +23,21 @@ import torch
 from . import hip
 
 
+
+def mask_seed(site: int) -> int:
+    """Seed of a plan's dropout masks: the per-site constant mixed with torch's global seed (so torch.manual_seed(s)
+    selects the mask stream as it does for nn.Dropout in the reference) and the distributed rank (data-parallel
+    ranks must not drop the same elements).  Read when the plan is built; masks stay reproducible within a run because
+    the backward regenerates them from the same (seed, step)."""
+    import torch.distributed as dist
+    rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+    x = (int(site) * 0x9E3779B1 + (torch.initial_seed() & 0xFFFFFFFF) * 0x85EBCA6B + rank * 0xC2B2AE35) & 0xFFFFFFFF
+    x ^= x >> 16
+    x = (x * 0x7FEB352D) & 0xFFFFFFFF
+    x ^= x >> 15
+    return x & 0x7FFFFFF0            # headroom for the "+ site index" the plans add
+
+
 class Buffers:
     """Named HBM buffers, allocated on first use and reused afterwards (graph-capture safe)."""
 
@@ -219,10 +234,10 @@ class DenseStackPlan:
     BatchNorm backward pass instead; the dropout mask (elementwise, commutes) follows in place."""
 
     def __init__(self, names: Sequence[Tuple[str, str]], activation: str, dtype, device, tag="ff",
-                 bn_names: Optional[Sequence[Optional[Tuple[str, str]]]] = None, dropout_p: float = 0.0, seed: int = 0x2F1):
+                 bn_names: Optional[Sequence[Optional[Tuple[str, str]]]] = None, dropout_p: float = 0.0, seed: Optional[int] = None):
         self.names, self.act, self.dtype, self.tag = list(names), activation, dtype, tag
         self.bn = list(bn_names) if bn_names is not None else [None] * len(self.names)
-        self.p, self.seed = float(dropout_p), seed
+        self.p, self.seed = float(dropout_p), mask_seed(0x2F1) if seed is None else int(seed)
         self.bn_buffers: Dict[str, Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]] = {}   # set by the model
         self.buf = Buffers(device)
         self.saved: List = []
@@ -329,8 +344,9 @@ class GroundlinkPlan:
     CONV = (1, 4, 7, 10)
     FC = (2, 5)
 
-    def __init__(self, output_data_format: str, dtype, device, fc_dropout: float = 0.2, k: int = 7, seed: int = 0x1B3):
-        self.fmt, self.dtype, self.p, self.k, self.seed = output_data_format, dtype, float(fc_dropout), k, seed
+    def __init__(self, output_data_format: str, dtype, device, fc_dropout: float = 0.2, k: int = 7, seed: Optional[int] = None):
+        self.fmt, self.dtype, self.p, self.k = output_data_format, dtype, float(fc_dropout), k
+        self.seed = mask_seed(0x1B3) if seed is None else int(seed)
         self.buf = Buffers(device)
         self.ctx = None
         self.fuse_reduce_into_optimizer = False         # set by HipTrainer for single-GPU steps
@@ -499,9 +515,11 @@ class TransformerLayerPlan:
     output (:35).  All masks are counter-based hashes of (seed + site, step, element), regenerated in the backward."""
 
     def __init__(self, prefix: str, d_model: int, num_heads: int, ffn: int, dtype, device, buf: Optional[Buffers] = None,
-                 tag="tl", dropout_p: float = 0.0, seed: int = 0x3A7):
+                 tag="tl", dropout_p: float = 0.0, seed: Optional[int] = None):
         self.p, self.d, self.h, self.ffn, self.dtype, self.tag = prefix, d_model, num_heads, ffn, dtype, tag
-        self.drop_p, self.seed = float(dropout_p), int(seed)
+        self.drop_p = float(dropout_p)
+        # per plan instance: the tag (layer index) enters the seed, so stacked layers draw different masks
+        self.seed = mask_seed(0x3A7 + 16 * sum(map(ord, tag))) if seed is None else int(seed)
         self.buf = buf if buf is not None else Buffers(device)
         self.ctx = None
         # the four weight-gradient GEMMs (+ bias sums) hang off the critical dgrad / LayerNorm / attention chain.  One GPU,

@@ -138,3 +138,27 @@ def test_upstream_gradient_scales_the_kernel_gradients():
         grads.append({k: v.grad.cpu() for k, v in o.items()})
     for k in outs:
         close(grads[1][k], 3.0 * grads[0][k], 1e-6)
+
+
+def test_second_backward_over_the_same_graph_is_refused():
+    """the loss backward scales its saved gradient buffer in place (one launch, no ATen arithmetic): a second backward over
+    the same graph (retain_graph=True) would scale it twice, so it raises instead of returning wrong gradients"""
+    from inferbiomechanics_amd.loss.DiffusionLossEvaluator import DiffusionLossEvaluator
+    from inferbiomechanics_amd.loss.RegressionLossEvaluator import RegressionLossEvaluator
+    g = torch.Generator().manual_seed(3)
+    outs = {k: torch.randn(2, 3, v.shape[-1], generator=g) for k, v in zeros(2, 3).items()}
+    labs = {k: torch.randn(2, 3, v.shape[-1], generator=g) for k, v in zeros(2, 3).items()}
+    ev = RegressionLossEvaluator(None, "dev", device=DEV)
+    o = {k: v.clone().to(DEV).requires_grad_(True) for k, v in outs.items()}
+    loss = ev({}, dict(o), labs, [], [], args_all())
+    (loss * 3.0).backward(retain_graph=True)
+    first = {k: v.grad.clone() for k, v in o.items()}
+    with pytest.raises(RuntimeError, match="already run"):
+        loss.backward()
+    for k, v in o.items():
+        assert torch.equal(v.grad, first[k])
+    pred = torch.randn(4, 5, 6, generator=g).to(DEV).requires_grad_(True)
+    lo = DiffusionLossEvaluator("dev")(pred, torch.randn(4, 5, 6, generator=g))
+    lo.backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="already run"):
+        lo.backward()

@@ -258,3 +258,38 @@ def test_bench_self_launch_relays_the_ranks_return_code():
     assert r.returncode != 0
     assert r.stdout.strip() == ""
     assert "needs a GPU" in r.stderr
+
+
+def test_mask_seed_mixes_torch_seed_rank_and_layer(monkeypatch):
+    """plans.mask_seed: torch.manual_seed selects the dropout stream, data-parallel ranks and stacked transformer layers
+    draw different masks (the reference's nn.Dropout draws independently per module and per process)"""
+    import torch.distributed as dist
+    from inferbiomechanics_amd import plans
+    torch.manual_seed(7)
+    a = plans.mask_seed(0x3A7)
+    assert a == plans.mask_seed(0x3A7) and 0 <= a <= 0x7FFFFFF0
+    assert a != plans.mask_seed(0x3A8)
+    torch.manual_seed(8)
+    assert plans.mask_seed(0x3A7) != a
+    torch.manual_seed(7)
+    monkeypatch.setattr(dist, "is_initialized", lambda: True)
+    monkeypatch.setattr(dist, "get_rank", lambda: 1)
+    assert plans.mask_seed(0x3A7) != a
+    monkeypatch.undo()
+    l0 = plans.TransformerLayerPlan("a.", 64, 4, 128, torch.bfloat16, "cpu", tag="tl0", dropout_p=0.1)
+    l1 = plans.TransformerLayerPlan("b.", 64, 4, 128, torch.bfloat16, "cpu", tag="tl1", dropout_p=0.1)
+    assert l0.seed != l1.seed and abs(l0.seed - l1.seed) > 2
+    assert plans.TransformerLayerPlan("a.", 64, 4, 128, torch.bfloat16, "cpu", seed=5).seed == 5
+
+
+def test_wait_for_file_polls_and_times_out(tmp_path):
+    import threading
+    import time
+    from inferbiomechanics_amd.data.WindowCache import wait_for_file
+    p = tmp_path / "cache.ibw"
+    with pytest.raises(TimeoutError):
+        wait_for_file(str(p), timeout_s=0.05, poll_s=0.01)
+    threading.Timer(0.1, lambda: p.write_bytes(b"x")).start()
+    t0 = time.monotonic()
+    wait_for_file(str(p), timeout_s=5.0, poll_s=0.01)
+    assert time.monotonic() - t0 < 2.0
