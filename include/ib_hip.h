@@ -242,8 +242,11 @@ int ib_optim_step_sources(int opt, float* p, const float* g, float* s1, float* s
                           const void* const* base, const int64_t* stride, const int32_t* count, const float* scale,
                           const float* loss_col, int64_t loss_ld, int64_t loss_rows, float loss_scale, float* loss_out,
                           ib_stream_t stream);
-/* ticket (optional, zero-initialised int32 device word): self-counting mode -- *step_dev then holds the number of
- * COMPLETED steps, the kernel uses *step_dev + 1 and its last-exiting block publishes it (no separate counter launch). */
+/* ticket (optional): self-counting mode -- *step_dev then holds the number of COMPLETED steps, the kernel uses
+ * *step_dev + 1 and its last-exiting block publishes it (no separate counter launch).  The buffer holds
+ * ib_optim_ticket_words() zero-initialised int32 words (a top word + 32 sub-counters, one 128-byte line each: the exit
+ * tickets are drawn in two levels so no single address serialises the grid); the kernel leaves it zeroed. */
+int ib_optim_ticket_words(void);
 
 /* ---- diffusion wrapper [BUILD-DEFINED]: DDPM q_sample, DDIM eta=0 update, table gathers ----- */
 /* ---- tiny matrix products: C[M,N] (+)= sum_k A(m,k) B(k,n), A(m,k) = A[m*sam + k*sak], B(k,n) = B[k*sbk + n*sbn], each

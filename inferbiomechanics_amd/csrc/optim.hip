@@ -17,6 +17,7 @@ struct OptArgs {
 // optimizer sums them itself, in the same fixed order as ib_step_reduce, so the reduction launch, its kernel boundary
 // and the round trip of the reduced gradient through HBM disappear (single-GPU steps only: an all-reduce needs the
 // reduced gradient in memory).
+constexpr int OPT_TICKET_SUBS = 32, OPT_TICKET_LINE = 32;     // sub-counters, int32 words per 128-byte line
 constexpr int OPT_MAXSRC = 64;   // 4 transformer layers x (4 slab sets + 4 bias sums + 4 LayerNorm sums) + the projections
 struct GradSrc {
   int64_t start, len;          // flat element range (start % 4 == 0)
@@ -242,18 +243,31 @@ __global__ __launch_bounds__(256) void optim_kernel(OptArgs a, OptSources S, int
     }
   }
   if (a.ticket) {
+    // Exit tickets, two levels: 1137 blocks (the MLP denoiser's flat buffer) drawing from ONE word were 1137 returning
+    // atomics on one address, serialised in L2 at ~11 ns each -- 12 of the launch's 17 us.  Block b draws from sub-counter
+    // b % 32 (its own 128-byte line: different lines pipeline); the last arriver of a sub-counter resets it and draws from
+    // the top word; the last of those publishes.  The longest same-address chain is grid / 32 + 32 draws.
     __syncthreads();
     if (threadIdx.x == 0) {
-      const int t = atomicAdd(a.ticket, 1);
-      if (t == (int)gridDim.x - 1) {
-        *a.step_dev = step;
-        *a.ticket = 0;
+      const int G = (int)gridDim.x;
+      const int nsub = G < OPT_TICKET_SUBS ? G : OPT_TICKET_SUBS;
+      const int sub = (int)blockIdx.x % OPT_TICKET_SUBS;
+      const int quota = (G - sub + OPT_TICKET_SUBS - 1) / OPT_TICKET_SUBS;
+      int32_t* sc = a.ticket + OPT_TICKET_LINE * (1 + sub);
+      if (atomicAdd(sc, 1) == quota - 1) {
+        *sc = 0;
+        if (atomicAdd(a.ticket, 1) == nsub - 1) {
+          *a.step_dev = step;
+          *a.ticket = 0;
+        }
       }
     }
   }
 }
 
 }  // namespace
+
+extern "C" int ib_optim_ticket_words(void) { return OPT_TICKET_LINE * (1 + OPT_TICKET_SUBS); }
 
 extern "C" int ib_optim_step(int opt, float* p, const float* g, float* s1, float* s2, int64_t n, float lr,
                              float grad_scale, int32_t step, int32_t* step_dev, int32_t* ticket, void* shadow_bf16,

@@ -257,7 +257,7 @@ class HipTrainer:
         self.s1 = torch.zeros_like(flat) if ns >= 1 else None
         self.s2 = torch.zeros_like(flat) if ns >= 2 else None
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)      # completed steps (device-resident)
-        self.ticket = torch.zeros(1, dtype=torch.int32, device=dev)        # exit-ticket word of the optimizer kernel
+        self.ticket = torch.zeros(hip.optim_ticket_words(), dtype=torch.int32, device=dev)   # optimizer exit tickets
         self.steps_done = 0
         model.sync_shadow()
         model._shadow_fresh = True          # from here on the optimizer kernel keeps the shadow current

@@ -120,6 +120,7 @@ _SIGS = {
                                                   _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _vp]),
     "ib_time_mlp_bwd_supported": (_c.c_int, [_i64, _i64, _i64]),
     "ib_time_mlp_bwd_slab_count": (_c.c_int, [_i64]),
+    "ib_optim_ticket_words": (_c.c_int, []),
     "ib_time_mlp_bwd": (_c.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _vp]),
     "ib_sum_partials": (_c.c_int, [_vp, _i64, _f32, _vp, _vp]),
     "ib_q_sample": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _c.c_int, _vp]),
@@ -152,7 +153,7 @@ def declared_symbols() -> List[str]:
     return sorted(set(re.findall(r"\b(ib_[a-z0-9_]+)\s*\(", src)))
 
 
-_HOST_ONLY = ("_workspace", "_supported", "_workgroups", "_packed_elems", "_partial_width", "_last_path", "_slab_count")   # pure host queries: no launch, no stream
+_HOST_ONLY = ("_workspace", "_supported", "_workgroups", "_packed_elems", "_partial_width", "_last_path", "_slab_count", "_ticket_words")   # pure host queries: no launch, no stream
 
 
 class _DryRunLib:
@@ -1173,6 +1174,11 @@ def mse_loss_finalize(workspace, result, n):
 # --------------------------------------------------------------------------------------------
 # optimizer
 # --------------------------------------------------------------------------------------------
+def optim_ticket_words() -> int:
+    """int32 words of the optimizer's exit-ticket buffer (self-counting mode)"""
+    return int(lib().ib_optim_ticket_words())
+
+
 def optim_step(opt: str, p, g, s1, s2, lr, step=1, step_dev=None, grad_scale=1.0, shadow=None, ticket=None,
                sources=None):
     """sources = (items, part, rows, segs): the gradient of some ranges of g is still partial sums -- items =
@@ -1196,6 +1202,8 @@ def optim_step(opt: str, p, g, s1, s2, lr, step=1, step_dev=None, grad_scale=1.0
         _req(step_dev, "step_dev", torch.int32)
     if ticket is not None:
         _req(ticket, "ticket", torch.int32)
+        if ticket.numel() < optim_ticket_words() or not ticket.is_contiguous():
+            raise HipError(f"ticket: {optim_ticket_words()} contiguous zeroed int32 words required (ib_optim_ticket_words)")
     if sources is not None:
         items, part, rows, segs = sources
         ld = 0

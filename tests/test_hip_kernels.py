@@ -391,12 +391,12 @@ def test_optimizer_self_counting_mode(hip, golden_dir, opt):
     p = R.det_fill((n,), 3, 0.5).float().to(DEV)
     s1, s2 = torch.zeros_like(p), torch.zeros_like(p)
     ctr = torch.zeros(1, dtype=torch.int32, device=DEV)
-    tick = torch.zeros(1, dtype=torch.int32, device=DEV)
+    tick = torch.zeros(hip.optim_ticket_words(), dtype=torch.int32, device=DEV)
     for s in range(4):
         grad = R.det_fill((n,), 20 + s, 0.3 * (s + 1)).float().to(DEV)
         hip.optim_step(opt, p, grad, s1, s2, lr=1e-2, step=0, step_dev=ctr, ticket=tick)
         close(p, torch.from_numpy(g[opt][s]), 2e-5, f"{opt} self-counting step {s + 1}")
-        assert int(ctr.cpu()) == s + 1 and int(tick.cpu()) == 0
+        assert int(ctr.cpu()) == s + 1 and int(tick.abs().sum().cpu()) == 0
     # many blocks: the ticket logic must hold with a multi-block grid
     big = torch.zeros(300_000, device=DEV)
     gb = torch.ones_like(big)
@@ -404,7 +404,18 @@ def test_optimizer_self_counting_mode(hip, golden_dir, opt):
     ctr.zero_()
     for s in range(3):
         hip.optim_step("adagrad", big, gb, sb, None, lr=1.0, step=0, step_dev=ctr, ticket=tick)
-    assert int(ctr.cpu()) == 3 and int(tick.cpu()) == 0
+    assert int(ctr.cpu()) == 3 and int(tick.abs().sum().cpu()) == 0
+    # grids below / at / just above the number of sub-counters (blocks of 256 float4): every block count publishes once
+    for nblk in (1, 2, 31, 32, 33, 65):
+        nn = nblk * 1024 - 4
+        bb, g2, s2 = torch.zeros(nn, device=DEV), torch.ones(nn, device=DEV), torch.zeros(nn, device=DEV)
+        ctr.zero_()
+        for s in range(2):
+            hip.optim_step("adagrad", bb, g2, s2, None, lr=1.0, step=0, step_dev=ctr, ticket=tick)
+        assert int(ctr.cpu()) == 2 and int(tick.abs().sum().cpu()) == 0, nblk
+    with pytest.raises(hip.HipError):
+        hip.optim_step("adagrad", big, gb, sb, None, lr=1.0, step=0, step_dev=ctr,
+                       ticket=torch.zeros(1, dtype=torch.int32, device=DEV))
     close(big[:5], -torch.tensor([1.0 + 2 ** -0.5 + 3 ** -0.5] * 5), 1e-5, "adagrad 3 steps")
 
 
