@@ -1467,18 +1467,18 @@ __device__ __forceinline__ void rowmajor_load(const bf16_t* __restrict__ w, int6
 #pragma unroll
     for (int u = 0; u < NT; ++u) wr[kb][u] = *reinterpret_cast<const bf16x8_t*>(wl + (int64_t)16 * u * ldw + 32 * kb);
 }
-// ... and consumed later
-template <int NT, int KB>
+// ... and consumed later (MT m-tiles of 16 rows)
+template <int NT, int KB, int MT>
 __device__ __forceinline__ void reg_gemm(const bf16x8_t (&wr)[KB][NT], const unsigned char* abuf, int rs, int lane,
-                                         f32x4_t (&acc)[4][NT]) {
+                                         f32x4_t (&acc)[MT][NT]) {
   const unsigned char* arow = abuf + (lane & 15) * rs + 16 * (lane >> 4);
 #pragma unroll
   for (int kb = 0; kb < KB; ++kb) {
-    bf16x8_t fa[4];
+    bf16x8_t fa[MT];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) fa[mt] = *reinterpret_cast<const bf16x8_t*>(arow + 16 * mt * rs + 64 * kb);
+    for (int mt = 0; mt < MT; ++mt) fa[mt] = *reinterpret_cast<const bf16x8_t*>(arow + 16 * mt * rs + 64 * kb);
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int u = 0; u < NT; ++u)
         acc[mt][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[kb][u], fa[mt], acc[mt][u], 0, 0, 0);
@@ -1495,50 +1495,61 @@ struct TimeFwdParams {
   long long* prof;      // TIMING-ONLY: [time_blocks][8] stamps (ib_debug_set_chain_prof), else NULL
 };
 
-// NT1 = hidden / 128, KB1 = temb / 32 ; hidden = 128 * NT1 = 32 * KB2 ; output columns: 128 per workgroup (16 per wave)
+// NT1 = hidden / 128, KB1 = temb / 32 ; hidden = 128 * NT1 = 32 * KB2 ; output columns: 128 per workgroup (16 per wave);
+// rows (windows) per workgroup: 16 * MT.  Every column group recomputes the hidden layer of its rows, and that epilogue is
+// the launch's VALU cost (two quarter-rate transcendentals per element: 64 rows x 512 columns on one CU were 4.3 us of
+// the 14 us a workgroup lived).  MT = 1 (16 windows per workgroup, four times the workgroups) is taken while the grid
+// still fits the chip in one round; large batches keep MT = 4.
 // Blocks >= p.time_blocks of the same launch pack the chain kernel's weights (ib_mlp_chain_prep): the two jobs are
 // independent and each far too small to fill the chip; one launch saves a kernel boundary (~4.5 us in a captured step).
-template <int NT1, int KB1>
+template <int NT1, int KB1, int MT>
 __global__ __launch_bounds__(CH_THREADS) void time_mlp_fwd_kernel(TimeFwdParams p, PackParams pp) {
-  constexpr int HID = 128 * NT1, KB2 = 4 * NT1, TE = 32 * KB1;
+  constexpr int HID = 128 * NT1, KB2 = 4 * NT1, TE = 32 * KB1, ROWS = 16 * MT;
   constexpr int RS1 = TE * 2 + 16, RS2 = HID * 2 + 16;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[CH_ROWS * RS1 + CH_ROWS * RS2];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[ROWS * RS1 + ROWS * RS2];
   unsigned char* simg = smem;
-  unsigned char* uimg = smem + CH_ROWS * RS1;
+  unsigned char* uimg = smem + ROWS * RS1;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l16 = lane & 15;
   if ((int)blockIdx.x >= p.time_blocks) {
     pack_blocks(pp, ((int)blockIdx.x - p.time_blocks) * CH_WAVES + wave, ((int)gridDim.x - p.time_blocks) * CH_WAVES, lane);
     return;
   }
-  const int r0 = ((int)blockIdx.x / p.ncg) * CH_ROWS, cg = (int)blockIdx.x % p.ncg;
-  const int nrows = min(CH_ROWS, p.B - r0);
+  const int r0 = ((int)blockIdx.x / p.ncg) * ROWS, cg = (int)blockIdx.x % p.ncg;
+  const int nrows = min(ROWS, p.B - r0);
 #define T_STAMP(k) do { if (p.prof && tid == 0) p.prof[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
   T_STAMP(0);
   bf16x8_t wr1[KB1][NT1], wr2[KB2][1];
   // gather: sinusoid rows (fp32 table) -> bf16 image; the first column group also writes them out (wgrad operand).
-  // Thread (row group tid / (TE/4), column piece tid % (TE/4)) handles NG rows: all timestep loads first, then all
-  // table loads, then the stores (a per-row load -> load -> store loop serialised NG dependent round trips)
+  // Thread (row group tid / (TE/4), column piece tid % (TE/4)) handles NG rows (threads beyond the rows idle).  Issue
+  // order, pinned with scheduling barriers: timesteps (an L2 hit: 0.2 us) -> table rows (2.8 us: the launch's first touch
+  // of that buffer) -> weight slices (32 KiB per wave: 3.6 us through one CU's L2 port).  Measured with stamps between
+  // them: the vector memory pipe serves requests in order, so table rows requested BEHIND the weights start their 2.8 us
+  // only when the last weight request has gone out (gather = 0.2 + 3.6 + 2.8 us); left alone the compiler put half of
+  // them there.  Requested first they overlap the weight stream, which stage 1 waits for anyway.
   {
-    constexpr int PPR = TE / 4, RPI = CH_THREADS / PPR, NG = CH_ROWS / RPI;
+    constexpr int PPR = TE / 4, RPI = CH_THREADS / PPR, NG = (ROWS + RPI - 1) / RPI;
     const int64_t* tsrc = p.slots ? reinterpret_cast<const int64_t*>(p.slots[2]) : p.t;
     const int c = (tid % PPR) * 4, rb = tid / PPR;
     int64_t kk[NG];
 #pragma unroll
     for (int j = 0; j < NG; ++j) {
       const int row = rb + j * RPI;
-      int64_t k = tsrc[r0 + min(row, nrows - 1)];
-      kk[j] = k < 0 ? 0 : (k >= p.table_rows ? p.table_rows - 1 : k);
+      kk[j] = tsrc[r0 + min(row, nrows - 1)];
     }
     float4 v[NG];
 #pragma unroll
-    for (int j = 0; j < NG; ++j) v[j] = *reinterpret_cast<const float4*>(p.table + kk[j] * TE + c);
-    // the weight slices are requested BEHIND the gather's two dependent loads (vmcnt retires in order: issued first,
-    // the 32 KiB per wave of weights delayed the gather by their whole transfer)
+    for (int j = 0; j < NG; ++j) {
+      const int64_t k = kk[j] < 0 ? 0 : (kk[j] >= p.table_rows ? p.table_rows - 1 : kk[j]);
+      v[j] = *reinterpret_cast<const float4*>(p.table + k * TE + c);
+    }
+    __builtin_amdgcn_sched_barrier(0);
     rowmajor_load<NT1, KB1>(p.w1, p.ldw1, wave * 16 * NT1, lane, wr1);
     rowmajor_load<1, KB2>(p.w2, p.ldw2, cg * 128 + wave * 16, lane, wr2);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int j = 0; j < NG; ++j) {
       const int row = rb + j * RPI;
+      if (row >= ROWS) continue;
       bf16x4_t o = pack4(v[j].x, v[j].y, v[j].z, v[j].w);
       if (row >= nrows) o = pack4(0.f, 0.f, 0.f, 0.f);
       else if (cg == 0) *reinterpret_cast<bf16x4_t*>(p.s + (int64_t)(r0 + row) * TE + c) = o;
@@ -1548,9 +1559,12 @@ __global__ __launch_bounds__(CH_THREADS) void time_mlp_fwd_kernel(TimeFwdParams 
   __syncthreads();
   T_STAMP(1);
   {
-    f32x4_t acc[4][NT1];
-    zero_acc<NT1>(acc);
-    reg_gemm<NT1, KB1>(wr1, simg, RS1, lane, acc);
+    f32x4_t acc[MT][NT1];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int u = 0; u < NT1; ++u) acc[mt][u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    reg_gemm<NT1, KB1, MT>(wr1, simg, RS1, lane, acc);
     const int colb = wave * 16 * NT1 + 4 * g;
 #pragma unroll
     for (int u = 0; u < NT1; ++u) {
@@ -1558,7 +1572,7 @@ __global__ __launch_bounds__(CH_THREADS) void time_mlp_fwd_kernel(TimeFwdParams 
       const float4 b4 = *reinterpret_cast<const float4*>(p.b1 + col);
       const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt) {
+      for (int mt = 0; mt < MT; ++mt) {
         const int lr = 16 * mt + l16;
         bf16x4_t zb, ub;
 #pragma unroll
@@ -1579,16 +1593,17 @@ __global__ __launch_bounds__(CH_THREADS) void time_mlp_fwd_kernel(TimeFwdParams 
   __syncthreads();
   T_STAMP(2);
   {
-    f32x4_t acc[4][1];
-    zero_acc<1>(acc);
+    f32x4_t acc[MT][1];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt][0] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     const int n0 = cg * 128 + wave * 16;
-    reg_gemm<1, KB2>(wr2, uimg, RS2, lane, acc);
+    reg_gemm<1, KB2, MT>(wr2, uimg, RS2, lane, acc);
     T_STAMP(3);
     const int col = n0 + 4 * g;
     const float4 b4 = *reinterpret_cast<const float4*>(p.b2 + col);
     const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
+    for (int mt = 0; mt < MT; ++mt) {
       const int lr = 16 * mt + l16;
       if (lr < nrows)
         *reinterpret_cast<bf16x4_t*>(p.e + (int64_t)(r0 + lr) * p.ld_e + col) =
@@ -1623,12 +1638,20 @@ int time_fwd_launch(const float* table, int64_t table_rows, const int64_t* t, co
   p.s = (bf16_t*)s; p.zu = (bf16_t*)zu; p.u = (bf16_t*)u; p.e = (bf16_t*)e; p.ld_e = ld_e;
   p.B = (int)B; p.out = (int)out;
   p.ncg = (int)(out / 128);
-  p.time_blocks = p.ncg * (int)((B + CH_ROWS - 1) / CH_ROWS);
+  // 16 windows per workgroup while that grid fits one round of the chip (beside the packing workgroups), else 64
+  static const bool no_mt1 = getenv("IB_TIME_FWD_MT4") != nullptr;
+  const bool mt1 = !no_mt1 && temb == 128 && (int64_t)p.ncg * ((B + 15) / 16) <= 256;
+  const int rows = mt1 ? 16 : CH_ROWS;
+  p.time_blocks = p.ncg * (int)((B + rows - 1) / rows);
   p.prof = g_chain_prof;
-  const int pack_wgs = pp.total_blocks > 0 ? ib_grid_1d(pp.total_blocks, CH_WAVES, 224) : 0;
+  const int pack_wgs = pp.total_blocks > 0 ? ib_grid_1d(pp.total_blocks, CH_WAVES, mt1 ? 128 : 224) : 0;
   const dim3 grid((unsigned)(p.time_blocks + pack_wgs));
-  if (temb == 128 && hidden == 512) hipLaunchKernelGGL((time_mlp_fwd_kernel<4, 4>), grid, dim3(CH_THREADS), 0, st, p, pp);
-  else hipLaunchKernelGGL((time_mlp_fwd_kernel<1, 1>), grid, dim3(CH_THREADS), 0, st, p, pp);
+  if (temb == 128 && hidden == 512) {
+    if (mt1) hipLaunchKernelGGL((time_mlp_fwd_kernel<4, 4, 1>), grid, dim3(CH_THREADS), 0, st, p, pp);
+    else hipLaunchKernelGGL((time_mlp_fwd_kernel<4, 4, 4>), grid, dim3(CH_THREADS), 0, st, p, pp);
+  } else {
+    hipLaunchKernelGGL((time_mlp_fwd_kernel<1, 1, 4>), grid, dim3(CH_THREADS), 0, st, p, pp);
+  }
   IB_CHECK_LAUNCH();
   return IB_OK;
 }

@@ -48,17 +48,22 @@ def main():
     timeit("time_mlp_fwd", lambda: hip.time_mlp_fwd(table, t, w1, b1, w2, b2, s, zu, u, e))
     timeit("mlp_chain_prep (both)", lambda: hip.time_mlp_fwd(table, t, w1, b1, w2, b2, s, zu, u, e, pack=(W, packed, D, H)))
     import ctypes
-    stamps = torch.zeros(64, 8, dtype=torch.int64, device=dev)
+    stamps = torch.zeros(1024, 8, dtype=torch.int64, device=dev)
     hip.lib().ib_debug_set_chain_prof(ctypes.c_void_p(stamps.data_ptr()))
     for _ in range(20):
         hip.time_mlp_fwd(table, t, w1, b1, w2, b2, s, zu, u, e)
     torch.cuda.synchronize()
     hip.lib().ib_debug_set_chain_prof(None)
-    st = stamps.cpu().double()[:32]
+    st = stamps.cpu().double()
+    st = st[st[:, 0] > 0]                 # the time-MLP workgroups that stamped (16 or 64 windows each)
+    print('time workgroups:', st.shape[0])
     d = (st[:, 1:5] - st[:, 0:4]) * 0.01
     print("time_mlp_fwd phases (us): gather", d[:, 0].mean().item(), "stage1", d[:, 1].mean().item(), "stage2 gemm",
           d[:, 2].mean().item(), "store", d[:, 3].mean().item(), "| per-WG", ((st[:, 4] - st[:, 0]) * 0.01).mean().item(),
           "span", ((st[:, 4].max() - st[:, 0].min()) * 0.01).item())
+    if st[:, 5].max() > 0:               # -DTF_EXP build: stamps inside the gather (t arrived | weights arrived | table rows arrived)
+        print("gather split (us): t", ((st[:, 5] - st[:, 0]) * 0.01).mean().item(), "weights", ((st[:, 6] - st[:, 5]) * 0.01).mean().item(),
+              "table", ((st[:, 7] - st[:, 6]) * 0.01).mean().item(), "stores+barrier", ((st[:, 1] - st[:, 7]) * 0.01).mean().item())
     part = torch.randn(256, 3464, generator=g).to(dev)
     outs = [torch.zeros(512, device=dev) for _ in range(7)]
     segs = [(512 * i, 512, outs[i], None, 1.0) for i in range(6)] + [(3072, 300, outs[6], None, 1.0)]
