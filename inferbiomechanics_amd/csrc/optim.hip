@@ -67,9 +67,21 @@ __device__ __forceinline__ float opt_update(const OptArgs& a, float p, float g, 
 
 // slab-backed ranges are summed by whichever thread owns the element; column-sum ranges are left to the dedicated
 // cooperative blocks below (a single thread summing 256 strided rows was a 100-us tail)
-// (the host passes the sources sorted by start: the scan stops at the first one that begins beyond idx)
+// (the host passes the sources sorted by start).  Two things made this path 40 us of the transformer's 111-us launch
+// beyond its bytes (48 sources, 126 MB of slabs): every thread walked the source list from its head -- up to 48 dependent
+// scalar loads before its first vector load -- and a slab count below 8 (2 for most transformer weights) fell into a
+// rolled one-load-per-trip loop, i.e. `count` HBM round trips in sequence.  Now the wave finds its first candidate by a
+// UNIFORM binary search (6 scalar steps) and every batch of up to 8 slabs is requested at once (predicated on the count), the sum still runs strictly in slab order
+// (= ib_step_reduce / slab_reduce_multi, bitwise).
 __device__ __forceinline__ bool source_grad4(const OptSources& S, const float* g, int64_t idx, float4& t) {
-  for (int j = 0; j < S.n; ++j) {
+  const int64_t idx0 = ((int64_t)__builtin_amdgcn_readfirstlane((int)(idx >> 32)) << 32) |
+                       (uint32_t)__builtin_amdgcn_readfirstlane((int)(idx & 0xffffffff));
+  int lo = 0, hi = S.n;                        // first source whose end lies beyond the wave's first element
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (S.s[mid].start + S.s[mid].len <= idx0) lo = mid + 1; else hi = mid;
+  }
+  for (int j = lo; j < S.n; ++j) {
     const GradSrc& r = S.s[j];
     if (idx < r.start) break;
     if (idx < r.start + r.len) {
@@ -78,15 +90,15 @@ __device__ __forceinline__ bool source_grad4(const OptSources& S, const float* g
       t = make_float4(0.f, 0.f, 0.f, 0.f);
       const float4* q = reinterpret_cast<const float4*>(r.base + o);
       const int64_t st4 = r.stride >> 2;
-      int k = 0;
-      for (; k + 8 <= r.count; k += 8) {      // 8 slabs in flight, added strictly in sequence (= slab_reduce_multi's order)
+      for (int k = 0; k < r.count; k += 8) {  // up to 8 slabs in flight, added strictly in sequence
         float4 v[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = q[(int64_t)(k + e) * st4];
+        for (int e = 0; e < 8; ++e)
+          if (k + e < r.count) v[e] = q[(int64_t)(k + e) * st4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { t.x += v[e].x; t.y += v[e].y; t.z += v[e].z; t.w += v[e].w; }
+        for (int e = 0; e < 8; ++e)
+          if (k + e < r.count) { t.x += v[e].x; t.y += v[e].y; t.z += v[e].z; t.w += v[e].w; }
       }
-      for (; k < r.count; ++k) { const float4 a = q[(int64_t)k * st4]; t.x += a.x; t.y += a.y; t.z += a.z; t.w += a.w; }
       return true;
     }
   }

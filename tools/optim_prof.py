@@ -48,5 +48,39 @@ def main():
             print(f"n={n:9d} {'sources(3x10 slabs)':18s} {us:7.2f} us")
 
 
+def transformer_sources(opt="rmsprop"):
+    """the transformer denoiser's optimizer launch: 13.26 M parameters, per layer 4 slab-backed weights (2 / 8 / 2 / 2
+    slabs) and 8 column-sum ranges over 100 partial rows -- 48 sources"""
+    dev = "cuda"
+    n = 13_263_168
+    p = torch.randn(n, device=dev)
+    g = torch.randn(n, device=dev) * 1e-3
+    s1 = torch.zeros(n, device=dev)
+    sh = torch.zeros(n, device=dev, dtype=torch.bfloat16)
+    sd = torch.zeros(1, dtype=torch.int32, device=dev)
+    tk = torch.zeros(hip.optim_ticket_words(), dtype=torch.int32, device=dev)
+    items, segs, off = [], [], 100_000
+    part = torch.randn(100, 8192, device=dev)
+    for layer in range(4):
+        for (rows, cols, ns) in ((1536, 512, 2), (512, 512, 8), (2048, 512, 2), (512, 2048, 2)):
+            m = rows * cols
+            items.append((torch.randn(ns, m, device=dev) * 1e-4, ns, g[off:off + m]))
+            off += m
+        c0 = 0
+        for w in (1536, 512, 2048, 512, 512, 512, 512, 512):
+            segs.append((c0, w, g[off:off + w], None, 1.0))
+            off += w
+            c0 += w
+    base = timeit(lambda: hip.optim_step(opt, p, g, s1, None, 1e-4, step=0, step_dev=sd, ticket=tk, shadow=sh), 20)
+    us = timeit(lambda: hip.optim_step(opt, p, g, s1, None, 1e-4, step=0, step_dev=sd, ticket=tk, shadow=sh,
+                                       sources=(items, part, 100, segs)), 20)
+    slab_mb = sum(it[0].numel() * 4 for it in items) / 1e6
+    print(f"transformer-shaped: plain {base:.1f} us, with {len(items) + len(segs)} sources ({slab_mb:.0f} MB of slabs) {us:.1f} us")
+
+
 if __name__ == "__main__":
+    if "--transformer" in sys.argv:
+        sys.argv.remove("--transformer")
+        transformer_sources()
+        sys.exit(0)
     main()
