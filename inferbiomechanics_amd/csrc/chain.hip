@@ -1007,7 +1007,20 @@ __global__ __launch_bounds__(CH_THREADS) void mlp_chain2_kernel(ChainParams p) {
     }
     f32x4_t acc[4][NTD];
     zero_acc<NTD>(acc);
-    auto side = [&](int, auto) {};
+    const int colb = wave * 16 * NTD + 4 * g;
+    // the head bias, requested during the GEMM's last k-block (requested in the epilogue it was a cold round trip with
+    // nothing to hide behind -- every phase of this kernel starts where the previous one's last load returned)
+    float4 hb4[NTD];
+    auto side = [&](int kb, auto kbc) {
+      constexpr int KB = decltype(kbc)::value;
+      if (kb == KB - 1) {
+#pragma unroll
+        for (int u = 0; u < NTD; ++u) {
+          const int col = colb + 16 * u;
+          hb4[u] = col < D ? *reinterpret_cast<const float4*>(p.bias[p.L] + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+    };
     chain_gemm<NTD, C::KBH>(p.wf[p.L], wave_s * NTD, imgA, RS, lane_id_now(), acc, side);
     CH_STAMP(2 + 3 * p.L);
 #pragma unroll
@@ -1018,16 +1031,13 @@ __global__ __launch_bounds__(CH_THREADS) void mlp_chain2_kernel(ChainParams p) {
         if (lane + 64 * q < ppr) *reinterpret_cast<uint2*>(imgB + r * RS + (lane + 64 * q) * 8) = re[j][q];
     }
     __syncthreads();
-    const int colb = wave * 16 * NTD + 4 * g;
     float lsum = 0.f;
     float* prow = p.partial + (int64_t)blockIdx.x * p.ld_part;
 #pragma unroll
     for (int u = 0; u < NTD; ++u) {
       const int col = colb + 16 * u;
       const bool cin = col < D;
-      float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (cin) b4 = *reinterpret_cast<const float4*>(p.bias[p.L] + col);
-      const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+      const float bb[4] = {hb4[u].x, hb4[u].y, hb4[u].z, hb4[u].w};
       float cs[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {

@@ -800,20 +800,7 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
     for (int64_t e4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e4 < n4; e4 += (int64_t)gridDim.x * blockDim.x) {
       const float4* p = reinterpret_cast<const float4*>(slabs) + e4;
       const int64_t st4 = slab_stride >> 2;
-      float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-      int k = 0;
-      for (; k + 4 <= nslab; k += 4) {
-        const float4 a = p[(int64_t)k * st4], b = p[(int64_t)(k + 1) * st4], c = p[(int64_t)(k + 2) * st4],
-                     d = p[(int64_t)(k + 3) * st4];
-        s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
-        s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
-        s.x += c.x; s.y += c.y; s.z += c.z; s.w += c.w;
-        s.x += d.x; s.y += d.y; s.z += d.z; s.w += d.w;
-      }
-      for (; k < nslab; ++k) {
-        const float4 a = p[(int64_t)k * st4];
-        s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
-      }
+      float4 s = ib_slab_sum4(p, st4, nslab);
       const int64_t e = e4 << 2;
       const int r = (int)(e / cols), c0 = (int)(e % cols);
       float4* o = reinterpret_cast<float4*>(out + (int64_t)r * ldo + c0);
@@ -1727,16 +1714,32 @@ __global__ __launch_bounds__(256) void slab_ln_kernel(const float* __restrict__ 
   const int l = threadIdx.x % LPR;
   const int row = blockIdx.x * RPB + threadIdx.x / LPR;
   if (row >= M) return;
+  // Slabs in batches of up to SB requested together (predicated on the count), added strictly in slab order.  As a rolled
+  // loop -- one slab per trip, the trip count a runtime value -- this was `nslab` memory round trips in sequence: at the
+  // sampler's M = 200 (16 slabs of the FFN output projection) 10 of the Linear + LayerNorm pair's 17 us.
+  constexpr int SB = NCH <= 2 ? 8 : 4;
   float4 v[NCH];
 #pragma unroll
-  for (int c = 0; c < NCH; ++c) v[c] = *reinterpret_cast<const float4*>(slabs + (int64_t)row * N + (c * LPR + l) * 4);
-  for (int k = 1; k < nslab; ++k) {
-    float4 w[NCH];
+  for (int c = 0; c < NCH; ++c) v[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float* srow = slabs + (int64_t)row * N + l * 4;
+  for (int k0 = 0; k0 < nslab; k0 += SB) {
+    float4 w[SB][NCH];
 #pragma unroll
-    for (int c = 0; c < NCH; ++c)
-      w[c] = *reinterpret_cast<const float4*>(slabs + (int64_t)k * slab_stride + (int64_t)row * N + (c * LPR + l) * 4);
+    for (int e = 0; e < SB; ++e)
+      if (k0 + e < nslab) {
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) { v[c].x += w[c].x; v[c].y += w[c].y; v[c].z += w[c].z; v[c].w += w[c].w; }
+        for (int c = 0; c < NCH; ++c)
+          w[e][c] = *reinterpret_cast<const float4*>(srow + (int64_t)(k0 + e) * slab_stride + c * LPR * 4);
+      }
+#pragma unroll
+    for (int e = 0; e < SB; ++e)
+      if (k0 + e < nslab) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+          if (k0 + e == 0) v[c] = w[e][c];          // the first slab is taken as it is (0 + x would turn -0 into +0)
+          else { v[c].x += w[e][c].x; v[c].y += w[e][c].y; v[c].z += w[e][c].z; v[c].w += w[e][c].w; }
+        }
+      }
   }
   float s1 = 0.f;
 #pragma unroll

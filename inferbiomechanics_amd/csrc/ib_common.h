@@ -109,3 +109,37 @@ static inline int ib_grid_1d(int64_t work_items, int per_block, int cap = 256 * 
   if (g > cap) g = cap;
   return static_cast<int>(g);
 }
+
+// sum of `nslab` float4 slabs (element stride st4 between slabs), added strictly in slab order from +0: batches of up to 8
+// slabs are REQUESTED together (predicated on the count).  A rolled one-slab-per-trip loop -- or a 4-wide loop with a
+// rolled tail -- is one memory round trip per trip in sequence; the slab counts of the split-M weight gradients are 2, 8
+// or 10, so the tails were most of those launches.
+__device__ __forceinline__ float4 ib_slab_sum4(const float4* __restrict__ q, int64_t st4, int nslab) {
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int k0 = 0; k0 < nslab; k0 += 8) {
+    float4 v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (k0 + e < nslab) v[e] = q[(int64_t)(k0 + e) * st4];
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (k0 + e < nslab) { s.x += v[e].x; s.y += v[e].y; s.z += v[e].z; s.w += v[e].w; }
+  }
+  return s;
+}
+
+// partial column sum of one float4 column over rows r0, r0 + step, ... (< rows) of a row-major array (pitch ld), added
+// strictly in that order from +0; batches of up to 8 rows requested together (see ib_slab_sum4)
+__device__ __forceinline__ float4 ib_rows_sum4(const float* __restrict__ base, int64_t ld, int r0, int step, int rows) {
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int r = r0; r < rows; r += 8 * step) {
+    float4 v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (r + e * step < rows) v[e] = *reinterpret_cast<const float4*>(base + (int64_t)(r + e * step) * ld);
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (r + e * step < rows) { s.x += v[e].x; s.y += v[e].y; s.z += v[e].z; s.w += v[e].w; }
+  }
+  return s;
+}

@@ -168,20 +168,8 @@ __global__ __launch_bounds__(256) void optim_kernel(OptArgs a, OptSources S, int
       if (o < r.len) {
         const float* q = r.base + o;
         if (o + 4 <= r.len) {
-          // 8 rows in flight, added strictly in row order (the order of colsum_segments_kernel): one load per trip of a
-          // rolled loop made this block a chain of count/16 memory round trips -- the tail of the whole launch
-          int row = rg;
-          for (; row + 7 * 16 < r.count; row += 8 * 16) {
-            float4 w[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) w[e] = *reinterpret_cast<const float4*>(q + (int64_t)(row + 16 * e) * r.stride);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { v.x += w[e].x; v.y += w[e].y; v.z += w[e].z; v.w += w[e].w; }
-          }
-          for (; row < r.count; row += 16) {
-            const float4 w = *reinterpret_cast<const float4*>(q + (int64_t)row * r.stride);
-            v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
-          }
+          // rows rg, rg + 16, ...: batches of 8 requested together, added strictly in row order (= colsum_segments_kernel)
+          v = ib_rows_sum4(q, r.stride, rg, 16, r.count);
         } else {
           for (int row = rg; row < r.count; row += 16) {
             const float* w = q + (int64_t)row * r.stride;

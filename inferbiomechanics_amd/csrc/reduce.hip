@@ -24,20 +24,7 @@ __device__ __forceinline__ void slab_multi_body(const SlabMulti& p, int bid) {
   const float4* base = reinterpret_cast<const float4*>(p.slabs[e]);
   for (int64_t e4 = (int64_t)(bid - p.blk0[e]) * 256 + threadIdx.x; e4 < n4; e4 += (int64_t)nb * 256) {
     const float4* q = base + e4;
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    int k = 0;
-    for (; k + 4 <= nslab; k += 4) {
-      const float4 a = q[(int64_t)k * st4], b = q[(int64_t)(k + 1) * st4], c = q[(int64_t)(k + 2) * st4],
-                   d = q[(int64_t)(k + 3) * st4];
-      s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
-      s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
-      s.x += c.x; s.y += c.y; s.z += c.z; s.w += c.w;
-      s.x += d.x; s.y += d.y; s.z += d.z; s.w += d.w;
-    }
-    for (; k < nslab; ++k) {
-      const float4 a = q[(int64_t)k * st4];
-      s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
-    }
+    float4 s = ib_slab_sum4(q, st4, nslab);
     const int64_t el = e4 << 2;
     const int r = (int)(el / cols), c0 = (int)(el % cols);
     float4* o = reinterpret_cast<float4*>(p.dw[e] + (int64_t)r * p.lddw[e] + c0);
@@ -72,10 +59,7 @@ __device__ __forceinline__ void colsum_segs_body(const ColsumSegs& p, int bid, f
     const int64_t ld = own ? p.ldv[sgi] : p.ld;
     const int rows = own ? p.rowsv[sgi] : p.rows;
     if (c + 4 <= nc) {
-      for (int r = rg; r < rows; r += 16) {
-        const float4 v = *reinterpret_cast<const float4*>(base + (int64_t)r * ld);
-        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-      }
+      s = ib_rows_sum4(base, ld, rg, 16, rows);
     } else {
       for (int r = rg; r < rows; r += 16) {
         const float* q = base + (int64_t)r * ld;
