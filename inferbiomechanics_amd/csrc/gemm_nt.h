@@ -18,6 +18,12 @@ int ib_gemm_tn_multi(int n, const void* const* dz, const int64_t* lddz, const vo
                      void* const* workspace, const size_t* workspace_bytes, float* const* dbias_part, int32_t* nslab_out,
                      const int64_t* M, const int64_t* N, const int64_t* K, hipStream_t s, const void* rider = nullptr,
                      int rider_te = 0);
+// gemm_tn256.hip: the same contract with 256 x 256 output tiles and ONE split count for the whole group (every N, K a
+// multiple of 256, equal M); ib_gemm_tn_multi tries it first when no rider is attached.  IB_E_UNSUPPORTED = nothing launched.
+int ib_gemm_tn256_splits(int n, const int64_t* M, const int64_t* N, const int64_t* K);
+int ib_gemm_tn256_multi(int n, const void* const* dz, const int64_t* lddz, const void* const* x, const int64_t* ldx,
+                        void* const* workspace, const size_t* workspace_bytes, float* const* dbias_part, int32_t* nslab_out,
+                        const int64_t* M, const int64_t* N, const int64_t* K, hipStream_t s);
 // rider: optional TimeBwdParams (time_bwd.h) whose workgroups are appended to the launch (temb = rider_te: 128 or 32)
 
 // gemm_f32_small.hip: fp32 forward / dgrad of batches of a few rows (16 x 16 tiles, the four waves split the reduction).

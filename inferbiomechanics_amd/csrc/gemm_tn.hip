@@ -331,6 +331,10 @@ int ib_gemm_tn_multi(int n, const void* const* dz, const int64_t* lddz, const vo
                      void* const* workspace, const size_t* workspace_bytes, float* const* dbias_part, int32_t* nslab_out,
                      const int64_t* M, const int64_t* N, const int64_t* K, hipStream_t s, const void* rider, int rider_te) {
   if (n <= 0 || n > TN_MAX) return IB_E_UNSUPPORTED;
+  if (!rider) {      // groups of 256-multiples (the transformer layers): 256 x 256 tiles, equal-length work items
+    const int rc = ib_gemm_tn256_multi(n, dz, lddz, x, ldx, workspace, workspace_bytes, dbias_part, nslab_out, M, N, K, s);
+    if (rc != IB_E_UNSUPPORTED) return rc;
+  }
   TnParams P{};
   P.n = n;
   int items = 0;

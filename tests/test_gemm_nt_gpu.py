@@ -143,6 +143,53 @@ def test_tn_grouped_launch_with_ragged_widths_and_bias_partials():
             assert torch.equal(part[:n].sum(0), rb), (N, K, n)
 
 
+def test_tn256_persistent_walk_over_more_items_than_workgroups():
+    """csrc/gemm_tn256.hip (256 x 256 tiles, one split count per group): a group of 272 + 2 tiles on 256 persistent
+    workgroups -- some workgroups take a second item, across the problem boundary, with the stage stream running on through
+    the first item's epilogue; exact on integer operands, bias partial sums included"""
+    from inferbiomechanics_amd import hip
+    M = 4096
+    shapes = [(4096, 4352), (512, 256)]
+    probs, parts, refs = [], [], []
+    for j, (N, K) in enumerate(shapes):
+        dz = ints((M, N), -3, 3, 70 + j).to(DEV, torch.bfloat16)
+        x = ints((M, K), -2, 2, 80 + j).to(DEV, torch.bfloat16)
+        ws = torch.full((int(hip.lib().ib_linear_wgrad_slabs_workspace(M, N, K)),), 0x7F, dtype=torch.uint8, device=DEV)
+        probs.append((dz, x, ws))
+        parts.append(torch.full((32, N), float("nan"), device=DEV))
+        refs.append((_wgrad_ref(dz, x), dz.float().sum(0)))
+    hip.lib().ib_debug_last_path()                       # read-and-clear
+    ns = hip.linear_wgrad_slabs_multi(probs, bias_parts=parts)
+    path = hip.PATH_NAMES[int(hip.lib().ib_debug_last_path())]
+    assert ns is not None and path == "tn256x256", (ns, path)
+    for (dz, x, ws), n, part, (rw, rb) in zip(probs, ns, parts, refs):
+        N, K = dz.shape[1], x.shape[1]
+        slabs = ws[:n * N * K * 4].view(torch.float32).view(n, N, K)
+        assert torch.equal(slabs.sum(0), rw), (N, K, n, (slabs.sum(0) - rw).abs().max())
+        assert torch.equal(part[:n].sum(0), rb), (N, K, n)
+
+
+def test_tn256_takes_the_transformer_layer_group_with_one_split_count():
+    from inferbiomechanics_amd import hip
+    M = 12800
+    g = torch.Generator().manual_seed(9)
+    probs = []
+    for (N, K) in [(1536, 512), (512, 512), (2048, 512), (512, 2048)]:
+        dz = torch.randn(M, N, generator=g).to(DEV, torch.bfloat16)
+        x = torch.randn(M, K, generator=g).to(DEV, torch.bfloat16)
+        ws = torch.zeros(int(hip.lib().ib_linear_wgrad_slabs_workspace(M, N, K)), dtype=torch.uint8, device=DEV)
+        probs.append((dz, x, ws))
+    hip.lib().ib_debug_last_path()
+    ns = hip.linear_wgrad_slabs_multi(probs)
+    path = hip.PATH_NAMES[int(hip.lib().ib_debug_last_path())]
+    assert path == "tn256x256" and len(set(ns)) == 1 and ns[0] * 48 <= 256, (path, ns)
+    for (dz, x, ws), n in zip(probs, ns):
+        N, K = dz.shape[1], x.shape[1]
+        got = ws[:n * N * K * 4].view(torch.float32).view(n, N, K).sum(0)
+        ref = _wgrad_ref(dz, x)
+        assert (got - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
+
+
 def test_tn_wgrad_is_bitwise_reproducible():
     from inferbiomechanics_amd import hip
     g = torch.Generator().manual_seed(5)
