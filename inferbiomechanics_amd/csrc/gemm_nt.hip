@@ -425,9 +425,9 @@ extern "C" int ib_debug_set_nt_prof(void* buf) { g_nt_prof = reinterpret_cast<lo
 // GEMMs read k-contiguously; refreshed once per step after the optimizer moved the weights).  64 x 64 tiles through LDS.
 namespace {
 constexpr int TR_MAX = 32;
-struct TrMulti { const bf16_t* src[TR_MAX]; bf16_t* dst[TR_MAX]; int rows[TR_MAX], cols[TR_MAX], lds[TR_MAX], ldd[TR_MAX], blk0[TR_MAX + 1]; int n; };
+struct TrMulti { const bf16_t* src[TR_MAX]; bf16_t* dst[TR_MAX]; int rows[TR_MAX], cols[TR_MAX], lds[TR_MAX], ldd[TR_MAX], blk0[TR_MAX + 1]; int n; unsigned vec; };
 __global__ __launch_bounds__(256) void transpose_multi_kernel(TrMulti m) {
-  __shared__ bf16_t tile[64][66];
+  __shared__ __attribute__((aligned(16))) bf16_t tile[64][72];      // 144-byte rows: 16-byte row writes stay aligned
   int e = 0;
   for (int j = 1; j < m.n; ++j)
     if ((int)blockIdx.x >= m.blk0[j]) e = j;
@@ -437,6 +437,27 @@ __global__ __launch_bounds__(256) void transpose_multi_kernel(TrMulti m) {
   const int r0 = (b / tc) * 64, c0 = (b % tc) * 64;
   const bf16_t* src = m.src[e];
   bf16_t* dst = m.dst[e];
+  if ((m.vec >> e) & 1u) {
+    // whole 64 x 64 tiles of 16-byte aligned matrices (every layer weight): 16-byte global accesses on both sides -- two
+    // loads and two stores per thread instead of sixteen 2-byte ones each way (the launch was 21.7 us for 52 MB)
+    const int pr = threadIdx.x >> 3, pc = threadIdx.x & 7;          // row 0..31 (+32), 16-byte piece 0..7
+    uint4 v[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+      v[h] = *reinterpret_cast<const uint4*>(src + (int64_t)(r0 + pr + 32 * h) * m.lds[e] + c0 + 8 * pc);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) *reinterpret_cast<uint4*>(&tile[pr + 32 * h][8 * pc]) = v[h];
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int c = pr + 32 * h;                                    // destination row = source column
+      bf16x8_t o;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] = tile[8 * pc + k][c];
+      *reinterpret_cast<bf16x8_t*>(dst + (int64_t)(c0 + c) * m.ldd[e] + r0 + 8 * pc) = o;
+    }
+    return;
+  }
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   for (int r = ty; r < 64; r += 4)
     tile[r][tx] = (r0 + r < R && c0 + tx < Cc) ? src[(int64_t)(r0 + r) * m.lds[e] + c0 + tx] : (bf16_t)0.f;
@@ -458,6 +479,9 @@ extern "C" int ib_transpose_multi(int n, const void* const* src, const int64_t* 
     m.src[i] = (const bf16_t*)src[i]; m.dst[i] = (bf16_t*)dst[i];
     m.rows[i] = (int)rows[i]; m.cols[i] = (int)cols[i]; m.lds[i] = (int)lds[i]; m.ldd[i] = (int)ldd[i];
     m.blk0[i] = blk;
+    if (rows[i] % 64 == 0 && cols[i] % 64 == 0 && lds[i] % 8 == 0 && ldd[i] % 8 == 0 &&
+        (reinterpret_cast<uintptr_t>(src[i]) & 15) == 0 && (reinterpret_cast<uintptr_t>(dst[i]) & 15) == 0)
+      m.vec |= 1u << i;
     blk += (int)(((rows[i] + 63) / 64) * ((cols[i] + 63) / 64));
   }
   m.blk0[n] = blk;

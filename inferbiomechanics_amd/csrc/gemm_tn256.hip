@@ -270,6 +270,8 @@ int ib_gemm_tn256_splits(int n, const int64_t* M, const int64_t* N, const int64_
     tiles += (N[j] / TM) * (K[j] / TK);
   }
   const int64_t stages = M[0] / BK;
+  static const int forced = []() { const char* e = getenv("IB_TN256_SPLITS"); return e ? atoi(e) : 0; }();   // tuning override
+  if (forced > 0 && forced <= 32 && stages % forced == 0 && stages / forced >= 8 && !((stages / forced) & 1)) return forced;
   int best = 0;
   for (int64_t s = 1; s <= 32; ++s) {
     if (stages % s != 0) continue;
