@@ -1,4 +1,5 @@
-for v in "" "IB_NO_BRANCH=time_bwd" "IB_SKIP_TIME_BWD=1" "IB_CHAIN_V1=1"; do
+# same-box A/B of the MLP denoiser step under environment switches (edit the list)
+for v in "" "IB_TN_TARGET=192" "IB_TN_TARGET=224" "IB_TN_TARGET=320" "IB_TN_TARGET=384" ""; do
   echo "== $v"
   env $v python bench.py --steps 600 --warmup 50 --no-cpu-baseline --no-ddim --no-transformer 2>/dev/null | python -c "
 import json,sys
