@@ -1799,7 +1799,10 @@ int linear_ln_split(int64_t M, int64_t N, int64_t K, int* chunk_out) {
 
 extern "C" size_t ib_linear_ln_fwd_workspace(int64_t M, int64_t N, int64_t K) {
   int chunk;
-  return (size_t)linear_ln_split(M, N, K, &chunk) * (size_t)M * (size_t)N * sizeof(float);
+  int split = linear_ln_split(M, N, K, &chunk);
+  const int nt = ib_gemm_nt_splitk_splits(M, N, K);            // the 256 x 128 kernel's split-K form may use more slabs
+  if (nt > split) split = nt;
+  return (size_t)split * (size_t)M * (size_t)N * sizeof(float);
 }
 
 extern "C" int ib_linear_ln_fwd(const void* x, int64_t ldx, const void* w, int64_t ldw, const float* bias, const void* res,
@@ -1811,11 +1814,21 @@ extern "C" int ib_linear_ln_fwd(const void* x, int64_t ldx, const void* w, int64
   if (res && ldres < N) return IB_E_ARG;
   if (dtype != IB_BF16 || N % 64 != 0 || N > 1024 || K % 32 != 0) return IB_E_UNSUPPORTED;
   int chunk;
-  const int split = linear_ln_split(M, N, K, &chunk);
-  if (workspace_bytes < (size_t)split * M * N * sizeof(float)) return IB_E_WORKSPACE;
+  int split = linear_ln_split(M, N, K, &chunk);
   if (!aligned(workspace, 16) || !aligned(gamma, 16) || !aligned(beta, 16) || (bias && !aligned(bias, 16)) ||
       !aligned(y, 8) || ldy % 4 != 0 || (res && (!aligned(res, 8) || ldres % 4 != 0)) || (a_out && !aligned(a_out, 8)))
     return IB_E_ARG;
+  hipStream_t s = ib_s(stream);
+  // a few thousand rows (the sampler at B = 16: [3200, 512, 2048]): the 256 x 128 LDS-DMA kernel in split-K form -- 52 tiles x
+  // 4 splits = 208 work items of 8 K steps instead of 400 ring-kernel workgroups of 16 short steps
+  bool gemm_done = false;
+  const int nts = ib_gemm_nt_splitk_splits(M, N, K);
+  if (nts >= 2 && dtype == IB_BF16 && workspace_bytes >= (size_t)nts * M * N * sizeof(float)) {
+    const int rc = ib_gemm_nt_splitk(x, ldx, w, ldw, reinterpret_cast<float*>(workspace), nts, M, N, K, s);
+    if (rc == IB_OK) { gemm_done = true; split = nts; }
+    else if (rc != IB_E_UNSUPPORTED) return rc;
+  }
+  if (workspace_bytes < (size_t)split * M * N * sizeof(float)) return IB_E_WORKSPACE;
   GemmParams p{};
   p.A = x; p.lda = ldx; p.B = w; p.ldb = ldw; p.M = (int)M; p.N = (int)N; p.K = (int)K;
   p.seg = 1; p.act = IB_ACT_NONE; p.ablate = g_ablate; p.prof = g_gemm_prof;
@@ -1824,11 +1837,12 @@ extern "C" int ib_linear_ln_fwd(const void* x, int64_t ldx, const void* w, int64
   p.tiles_n = (p.N + BN - 1) / BN; p.tiles_m = (p.M + BM - 1) / BM;
   p.k_chunk = chunk; p.xcd_group = 1;
   p.C = workspace; p.ldc = N; p.slab_stride = (int64_t)M * N; p.accumulate = 0; p.vecC = 1;
-  if (!ring_ok(p, IB_BF16, p.K, chunk)) return IB_E_UNSUPPORTED;
-  hipStream_t s = ib_s(stream);
-  IB_PATH(IB_PATH_LINLN);
-  hipLaunchKernelGGL((gemm_ring_kernel<true, true, EPI_WGRAD>), dim3(p.tiles_m * p.tiles_n * split), dim3(NTHREADS), 0, s, p);
-  IB_CHECK_LAUNCH();
+  if (!gemm_done) {
+    if (!ring_ok(p, IB_BF16, p.K, chunk)) return IB_E_UNSUPPORTED;
+    IB_PATH(IB_PATH_LINLN);
+    hipLaunchKernelGGL((gemm_ring_kernel<true, true, EPI_WGRAD>), dim3(p.tiles_m * p.tiles_n * split), dim3(NTHREADS), 0, s, p);
+    IB_CHECK_LAUNCH();
+  }
 #define IB_SLAB_LN(LPR, NCH)                                                                                            \
   hipLaunchKernelGGL((slab_ln_kernel<LPR, NCH>), dim3((unsigned)((M + 256 / LPR - 1) / (256 / LPR))), dim3(256), 0, s,     \
                      reinterpret_cast<const float*>(workspace), split, (int64_t)M * N, bias,                               \

@@ -10,6 +10,11 @@ int ib_gemm_nt_try(const void* A, int64_t lda, const void* B, int64_t ldb, void*
                    const void* aux, int64_t ldaux, int bwd_act, const void* addend, int64_t ldadd, int64_t M, int64_t N,
                    int64_t K, hipStream_t s);
 
+// split-K form: fp32 partial slabs [splits][M][N] (few output tiles, long reduction); splits = 0: does not qualify
+int ib_gemm_nt_splitk_splits(int64_t M, int64_t N, int64_t K);
+int ib_gemm_nt_splitk(const void* A, int64_t lda, const void* B, int64_t ldb, float* slab, int splits, int64_t M, int64_t N,
+                      int64_t K, hipStream_t s);
+
 // gemm_tn.hip: weight gradients of long reductions, dW_j[N_j,K_j] = dz_j^T x_j as fp32 split slabs, up to 6 problems per
 // launch.  ib_gemm_tn_splits: slab count the kernel will use (0 = the problem does not qualify); ib_gemm_tn_multi returns
 // IB_E_UNSUPPORTED (nothing launched) unless every problem qualifies.

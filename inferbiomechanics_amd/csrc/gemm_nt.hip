@@ -69,6 +69,9 @@ struct NtParams {
   const bf16_t* aux; int64_t ldaux;
   const bf16_t* addend; int64_t ldadd;
   int tiles_m, tiles_n;
+  // split-K form (SLAB kernels): work item = (split, tile); split s reduces k in [s * kchunk, (s + 1) * kchunk) and writes
+  // its fp32 partial tile into slab[s][M][N].  The plain form has splits = 1, kchunk = K.
+  float* slab; int splits, kchunk, tiles_mn;
   long long* prof;             // TIMING-ONLY (tools/nt_prof.py): [gridDim.x][16] wall-clock stamps, else NULL
 };
 long long* g_nt_prof = nullptr;
@@ -112,7 +115,7 @@ __device__ __forceinline__ void wait_vm_rt(int n) {          // n wave-uniform, 
 //
 // FWD_ACT: activation of the forward epilogue (bias added first); BWD_ACT: derivative factor taken from `aux`
 // (IB_ACT_NONE = none); HAS_ADD: a residual addend is added last.
-template <int FWD_ACT, int BWD_ACT, bool HAS_ADD, bool HAS_BIAS>
+template <int FWD_ACT, int BWD_ACT, bool HAS_ADD, bool HAS_BIAS, bool SLAB = false>
 __global__ __launch_bounds__(NT_THREADS, 2) void gemm_nt_kernel(NtParams p) {
   // epilogue operands are requested one K step early (their latency runs beside the last step's MFMAs); EPI_LOADS = how
   // many vector-memory loads that puts behind the prefetched stages (the last step's counted wait leaves them in flight)
@@ -120,8 +123,8 @@ __global__ __launch_bounds__(NT_THREADS, 2) void gemm_nt_kernel(NtParams p) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[LDS_BYTES];
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  const int nk = p.K / BK;                                   // >= 4 (host check)
-  const int tiles = p.tiles_m * p.tiles_n;
+  const int nk = p.kchunk / BK;                              // >= 4 (host check)
+  const int tiles = p.tiles_mn * p.splits;
   const int nwg = (int)gridDim.x;
   // XCD-aware walk: workgroups b and b + 8 share an XCD (round-robin dispatch) -> give each XCD a contiguous run of
   // the logical tile order (column tiles of one row panel are neighbours in it).  Speed only.
@@ -140,16 +143,18 @@ __global__ __launch_bounds__(NT_THREADS, 2) void gemm_nt_kernel(NtParams p) {
   // staging sources per lane as 32-bit ELEMENT offsets from A / B (the host checks they fit): this tile's, the next tile's
   unsigned pa[4], pb[2];
   auto tile_ptrs = [&](int tile, unsigned (&qa)[4], unsigned (&qb)[2]) {
-    const int i0 = (tile / p.tiles_n) * BM, j0 = (tile % p.tiles_n) * BN;
+    const int tmn = tile % p.tiles_mn;
+    const int i0 = (tmn / p.tiles_n) * BM, j0 = (tmn % p.tiles_n) * BN;
+    const unsigned kofs = (unsigned)((tile / p.tiles_mn) * p.kchunk);       // the split's first k
     const int lane = lane_now();
     const int srow = lane >> 3;                             // row inside an 8-row chunk
     const int spc = (lane & 7) ^ srow;                      // the 16-byte piece of that row this lane fetches
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      qa[j] = (unsigned)min(i0 + 8 * (wave + 8 * j) + srow, p.M - 1) * (unsigned)p.lda + 8u * spc;
+      qa[j] = (unsigned)min(i0 + 8 * (wave + 8 * j) + srow, p.M - 1) * (unsigned)p.lda + 8u * spc + kofs;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
-      qb[j] = (unsigned)min(j0 + 8 * (wave + 8 * j) + srow, p.N - 1) * (unsigned)p.ldb + 8u * spc;
+      qb[j] = (unsigned)min(j0 + 8 * (wave + 8 * j) + srow, p.N - 1) * (unsigned)p.ldb + 8u * spc + kofs;
   };
   // LDS-DMA piece j (0..3: A chunks, 4..5: B chunks) of a stage: k offset k0 (elements), slot base `st`
   auto piece = [&](const unsigned (&qa)[4], const unsigned (&qb)[2], int j, int k0, unsigned char* st) {
@@ -179,7 +184,8 @@ __global__ __launch_bounds__(NT_THREADS, 2) void gemm_nt_kernel(NtParams p) {
   NT_STAMP(0);
 
   for (int tile = first_tile; tile < tiles; tile += nwg) {
-    const int i0 = (tile / p.tiles_n) * BM, j0 = (tile % p.tiles_n) * BN;
+    const int tmn = tile % p.tiles_mn;
+    const int i0 = (tmn / p.tiles_n) * BM, j0 = (tmn % p.tiles_n) * BN;
     const bool has_next = tile + nwg < tiles;
     const bool ragged = (i0 + BM > p.M) || (j0 + BN > p.N);
 
@@ -227,7 +233,7 @@ __global__ __launch_bounds__(NT_THREADS, 2) void gemm_nt_kernel(NtParams p) {
       slot = slot1;
     };
     using C0 = std::integral_constant<int, 0>; using C1 = std::integral_constant<int, 1>; using C2 = std::integral_constant<int, 2>;
-    using W6 = std::integral_constant<int, 6>; using W14 = std::integral_constant<int, 14>;
+    using W6 = std::integral_constant<int, 6>;
     using W0 = std::integral_constant<int, 0>; using WN = std::integral_constant<int, -1>;
     // the epilogue's operands: bias (per column group of the lane's accumulators), activation-derivative operand and
     // residual addend (per 16-byte piece the thread will store) -- requested before the LAST K step
@@ -258,7 +264,8 @@ __global__ __launch_bounds__(NT_THREADS, 2) void gemm_nt_kernel(NtParams p) {
     // the registers)
     read_frags((unsigned)(slot * STAGE), 0, fa0, fb0);
     frags_ready(fa0, fb0);
-    if (fresh) step(C1{}, W6{}, C1{}, 0); else step(C1{}, W14{}, C1{}, 0);
+    using WF = std::integral_constant<int, SLAB ? 22 : 14>;    // + the previous tile's stores: 8 (16-byte bf16 pieces) or 16 (fp32 slab)
+    if (fresh) step(C1{}, W6{}, C1{}, 0); else step(C1{}, WF{}, C1{}, 0);
     for (int kt = 1; kt < nk - 3; ++kt) step(C1{}, W6{}, C1{}, kt);
     if (has_next) {
       step(C2{}, W6{}, C1{}, nk - 3); step(C2{}, W6{}, C1{}, nk - 2);
@@ -275,6 +282,27 @@ __global__ __launch_bounds__(NT_THREADS, 2) void gemm_nt_kernel(NtParams p) {
     // left that stage at the barrier of the last step.  All LDS traffic is inline asm (LDS accesses the compiler can see
     // would be ordered behind the in-flight LDS-DMA of the next tile with s_waitcnt vmcnt(0)).
     const int cslot = slot == 0 ? NS - 1 : slot - 1;          // the slot of the tile's last stage
+    if constexpr (SLAB) {
+      // split-K: the fp32 accumulators go straight to this split's slab (a lane holds 4 consecutive columns of one row:
+      // 16-byte stores); no LDS, no barrier -- the stage slots keep streaming
+      const int lane = lane_now();
+      float* sl = p.slab + (size_t)(tile / p.tiles_mn) * (size_t)p.M * (size_t)p.N;
+      const int m0 = i0 + wm * 64 + (lane & 15), n0 = j0 + wn * 64 + 4 * (lane >> 4);
+      if (!ragged) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            *reinterpret_cast<f32x4_t*>(sl + (size_t)(m0 + 16 * t) * p.N + n0 + 16 * u) = acc[t][u];
+      } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (m0 + 16 * t < p.M && n0 + 16 * u < p.N)
+              *reinterpret_cast<f32x4_t*>(sl + (size_t)(m0 + 16 * t) * p.N + n0 + 16 * u) = acc[t][u];
+      }
+    } else {
     const unsigned cimg = smem0 + (unsigned)(cslot * STAGE);
     const int lane = lane_now();
     const int tid = (wave << 6) | lane;
@@ -338,6 +366,7 @@ __global__ __launch_bounds__(NT_THREADS, 2) void gemm_nt_kernel(NtParams p) {
         }
       }
     }
+    }   // !SLAB
     NT_STAMP(2 + 2 * round);
     ++round;
     fresh = ragged;          // after a ragged tile the store count per thread is not uniform: the next wait is conservative
@@ -397,6 +426,7 @@ int ib_gemm_nt_try(const void* A, int64_t lda, const void* B, int64_t ldb, void*
   p.C = (bf16_t*)C; p.ldc = ldc; p.bias = bias; p.aux = (const bf16_t*)aux; p.ldaux = ldaux;
   p.addend = (const bf16_t*)addend; p.ldadd = ldadd;
   p.tiles_m = (int)((M + BM - 1) / BM); p.tiles_n = (int)((N + BN - 1) / BN);
+  p.tiles_mn = p.tiles_m * p.tiles_n; p.splits = 1; p.kchunk = (int)K; p.slab = nullptr;
   p.prof = g_nt_prof;
   if (bwd_act != IB_ACT_NONE) {
     switch (bwd_act) {
@@ -416,6 +446,39 @@ int ib_gemm_nt_try(const void* A, int64_t lda, const void* B, int64_t ldb, void*
     case IB_ACT_ELU: return launch<IB_ACT_ELU, IB_ACT_NONE>(p, s);
     default: return IB_E_UNSUPPORTED;
   }
+}
+
+// Split-K form for GEMMs with few output tiles and a long reduction (the sampler's FFN output projection at a few thousand
+// rows: 52 tiles x 32 K steps): slab[s][M][N] (fp32) = A[:, s-th k range] B[:, s-th k range]^T, `splits` = the slab count
+// ib_gemm_nt_splitk_splits() names.  The caller's reduction (the slab LayerNorm) sums the slabs in order.
+int ib_gemm_nt_splitk_splits(int64_t M, int64_t N, int64_t K) {
+  static const int off = []() { const char* e = getenv("IB_NO_NT_SPLITK"); return e ? atoi(e) : 0; }();
+  static const int min_m = []() { const char* e = getenv("IB_NT_MIN_M"); return e ? atoi(e) : 640; }();
+  if (off || M < min_m || N < 128 || N % 8 != 0 || K % BK != 0) return 0;
+  const int64_t tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+  int best = 0;
+  for (int sp = 2; sp <= 16; ++sp) {                     // the most splits that still give one item per CU, >= 4 K steps each
+    if (K % (sp * BK) != 0 || K / sp < 4 * BK) continue;
+    if (tiles * sp <= 256) best = sp;
+  }
+  return best;
+}
+int ib_gemm_nt_splitk(const void* A, int64_t lda, const void* B, int64_t ldb, float* slab, int splits, int64_t M, int64_t N,
+                      int64_t K, hipStream_t s) {
+  if (splits < 2 || splits != ib_gemm_nt_splitk_splits(M, N, K)) return IB_E_UNSUPPORTED;
+  if (!al16(A) || !al16(B) || !al16(slab) || lda % 8 || ldb % 8) return IB_E_UNSUPPORTED;
+  if (M * lda >= (int64_t(1) << 31) || N * ldb >= (int64_t(1) << 31)) return IB_E_UNSUPPORTED;
+  IB_PATH(IB_PATH_NT);
+  NtParams p{};
+  p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.lda = lda; p.ldb = ldb; p.M = (int)M; p.N = (int)N; p.K = (int)K;
+  p.tiles_m = (int)((M + BM - 1) / BM); p.tiles_n = (int)((N + BN - 1) / BN);
+  p.tiles_mn = p.tiles_m * p.tiles_n; p.splits = splits; p.kchunk = (int)(K / splits); p.slab = slab;
+  p.prof = g_nt_prof;
+  const int tiles = p.tiles_mn * splits;
+  hipLaunchKernelGGL((gemm_nt_kernel<IB_ACT_NONE, IB_ACT_NONE, false, false, true>), dim3(tiles < 256 ? tiles : 256),
+                     dim3(NT_THREADS), 0, s, p);
+  IB_CHECK_LAUNCH();
+  return IB_OK;
 }
 
 // TIMING-ONLY: device buffer of [workgroups][16] int64 stamps filled by the next NT GEMM launches (NULL = off)

@@ -602,8 +602,10 @@ class TransformerLayerPlan:
             w = P.w(p + wname)
             # swept on the sampler (T = 200): K = 2048 fused wins up to the NT kernel's territory (M = 3200: 43.6 -> 30.5 us);
             # K = 512 (two short kernels either way) wins only while the GEMM is far from filling the chip (M <= 2048:
-            # B = 2 / 4 / 8 +4 / +6 / +2 % steps/s; M = 3200: -6 %)
-            if w.shape[1] < 512 or (w.shape[1] < 1024 and M > int(os.environ.get("IB_LINLN_K512_MAX_M", "2048"))):
+            # B = 2 / 4 / 8 +4 / +6 / +2 % steps/s; M = 3200: -6 % on the ring kernel).  Round 3: from 640 rows the GEMM of
+            # the fused form is the 256 x 128 kernel in split-K form (ib_gemm_nt_splitk): K = 2048 31.2 -> 24.0 us at
+            # M = 3200, B = 4 / 8 / 16 +7.5 / +8 / +7 % steps/s; K = 512 fused now pays up to M < 4096 too (+1-2 %)
+            if w.shape[1] < 512 or (w.shape[1] < 1024 and M > int(os.environ.get("IB_LINLN_K512_MAX_M", "4095"))):
                 return False
             if M >= int(os.environ.get("IB_LINLN_MAX_M", "4096")) and not os.environ.get("IB_NO_NT"):
                 return False           # large batches fill the chip without a K split: the 256 x 128 NT kernel + LayerNorm
