@@ -436,7 +436,8 @@ enum {
   IB_PATH_LINLN = 9,        /* gemm.hip: K-split Linear + residual + LayerNorm (sampler) */
   IB_PATH_CHAIN2 = 10,      /* chain.hip: fused MLP-denoiser chain, row-wise epilogues */
   IB_PATH_CHAIN1 = 11,      /* chain.hip: the round-2 chain kernel (IB_CHAIN_V1=1) */
-  IB_PATH_TN256 = 12        /* gemm_tn256.hip: 256 x 256 weight-gradient kernel, grouped, one split count per group */
+  IB_PATH_TN256 = 12,       /* gemm_tn256.hip: 256 x 256 weight-gradient kernel, grouped, one split count per group */
+  IB_PATH_NT_SPLITK = 13    /* gemm_nt.hip in split-K form (fp32 slabs) under the sampler's Linear + LayerNorm */
 };
 int ib_debug_last_path(void);
 int ib_selftest_tr16(const void* in_bf16_64x16, void* out_bf16_64x4, ib_stream_t stream);

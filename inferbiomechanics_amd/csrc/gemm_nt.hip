@@ -468,7 +468,7 @@ int ib_gemm_nt_splitk(const void* A, int64_t lda, const void* B, int64_t ldb, fl
   if (splits < 2 || splits != ib_gemm_nt_splitk_splits(M, N, K)) return IB_E_UNSUPPORTED;
   if (!al16(A) || !al16(B) || !al16(slab) || lda % 8 || ldb % 8) return IB_E_UNSUPPORTED;
   if (M * lda >= (int64_t(1) << 31) || N * ldb >= (int64_t(1) << 31)) return IB_E_UNSUPPORTED;
-  IB_PATH(IB_PATH_NT);
+  IB_PATH(IB_PATH_NT_SPLITK);
   NtParams p{};
   p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.lda = lda; p.ldb = ldb; p.M = (int)M; p.N = (int)N; p.K = (int)K;
   p.tiles_m = (int)((M + BM - 1) / BM); p.tiles_n = (int)((N + BN - 1) / BN);

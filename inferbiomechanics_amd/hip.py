@@ -245,7 +245,7 @@ class _RecordingLib:
 
 
 PATH_NAMES = {0: "-", 1: "nt256x128", 2: "tn256x128", 3: "ring128", 4: "generic", 5: "smallm", 6: "skinny", 7: "wgrad_small",
-              8: "ring_multi", 9: "linear_ln", 10: "chain_v2", 11: "chain_v1", 12: "tn256x256"}
+              8: "ring_multi", 9: "linear_ln", 10: "chain_v2", 11: "chain_v1", 12: "tn256x256", 13: "nt_splitk"}
 _work_note = None     # set by a wrapper right before a grouped launch: (flops, bytes) of that launch, for bench.py
 
 
