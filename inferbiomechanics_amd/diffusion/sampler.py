@@ -22,8 +22,17 @@ class DDIMSampler:
 
     def _step_launches(self, x, t_vec, ctr, tabs, P: ParamSource):
         plan = self.model._get_plan(x.device)
-        eps = plan.forward(x, t_vec, tabs.temb, P)
-        hip.ddim_step(x, eps, tabs.ddim_coef, tabs.ddim_t, step_dev=ctr, t_out=t_vec)
+        eps_buf = self._bufs.get("eps")
+        if eps_buf is not None:
+            # pitched state / noise buffers [B, T, Dp] with zero pad columns (plans.infer_pitch): the plan sees row-padded
+            # 2-D views; the DDIM update runs over the whole pitched buffers (0 stays 0 in the pad columns)
+            B, T, Dp = x.shape
+            D = self._D
+            plan.forward(x.view(B * T, Dp)[:, :D], t_vec, tabs.temb, P, out=eps_buf.view(B * T, Dp)[:, :D], BT=(B, T))
+            hip.ddim_step(x, eps_buf, tabs.ddim_coef, tabs.ddim_t, step_dev=ctr, t_out=t_vec)
+        else:
+            eps = plan.forward(x, t_vec, tabs.temb, P)
+            hip.ddim_step(x, eps, tabs.ddim_coef, tabs.ddim_t, step_dev=ctr, t_out=t_vec)
         hip.counter_add(ctr, 1)
 
     @torch.no_grad()
@@ -57,20 +66,26 @@ class DDIMSampler:
         shadow = m._shadow.data_ptr() if m._shadow is not None else 0
         sig = (tuple(x_T.shape), m.compute_dtype, m._flat.data_ptr(), shadow, tabs.temb.data_ptr(),
                tabs.ddim_coef.data_ptr(), tabs.ddim_t.data_ptr(), self.S)
+        plan = m._get_plan(dev)
+        B, T, D = x_T.shape
+        Dp = plan.infer_pitch(D) if (hasattr(plan, "infer_pitch") and m.compute_dtype == torch.bfloat16) else D
+        sig = sig + (Dp,)
         if sig != self._sig:
             self._sig, self._graph = sig, None
-            self._bufs = {"x": torch.empty(x_T.shape, dtype=m.compute_dtype, device=dev),
+            self._bufs = {"x": torch.zeros((B, T, Dp), dtype=m.compute_dtype, device=dev),
                           "t": torch.empty(x_T.shape[0], dtype=torch.int64, device=dev),
                           "ctr": torch.zeros(1, dtype=torch.int32, device=dev)}
+            if Dp != D:
+                self._bufs["eps"] = torch.zeros((B, T, Dp), dtype=m.compute_dtype, device=dev)
+        self._D = D
         x, t_vec, ctr = self._bufs["x"], self._bufs["t"], self._bufs["ctr"]
-        x.copy_(x_T.to(device=dev, dtype=m.compute_dtype))
+        x[:, :, :D].copy_(x_T.to(device=dev, dtype=m.compute_dtype))
         ctr.zero_()
         hip.fill_i64(t_vec, int(tabs.ddim_t[0]))
         P = m.param_source()
-        plan = m._get_plan(dev)
         if hasattr(plan, "set_inference"):
             plan.set_inference(True)             # weights are frozen for the whole loop
-            plan.prepare_inference(P, x.shape[1], x.shape[2], table=tabs.temb)
+            plan.prepare_inference(P, T, D, table=tabs.temb)
         try:
             return self._loop(x, t_vec, ctr, tabs, P, steps)
         finally:
@@ -94,4 +109,4 @@ class DDIMSampler:
                 self._graph.launch()
             else:
                 self._step_launches(x, t_vec, ctr, tabs, P)
-        return x.clone()
+        return x[:, :, :self._D].clone()

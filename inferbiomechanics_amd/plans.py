@@ -1176,6 +1176,21 @@ class DenoiserTransformerPlan:
         hip.tiny_matmul(pos, w_in[:, D:].t(), posproj)
         self._posproj_T = T
         self._e_all = None
+        # zero-padded copies of the two D-wide projections (D = 300: rows of 600 bytes are not 16-byte aligned, so both ran on
+        # the generic register-staged kernel: 18.6 + 13.5 us of a 380-us step at B = 16).  With the sampler's state and
+        # noise buffers pitched to infer_pitch(D) columns (pad columns zero) the input projection reduces over 320 columns on
+        # the LDS-DMA ring kernel and the output projection writes 320 columns on the 256 x 128 NT kernel.
+        self._pad = None
+        Kp = self.infer_pitch(D)
+        if Kp != D and self.dtype == torch.bfloat16:
+            w_in_pad = self.buf.get("dt.w_in_pad", (self.d, Kp), self.dtype)
+            w_out_pad = self.buf.get("dt.w_out_pad", (Kp, self.d), self.dtype)
+            b_out_pad = self.buf.get("dt.b_out_pad", (Kp,), torch.float32)
+            w_in_pad.zero_(); w_out_pad.zero_(); b_out_pad.zero_()
+            hip.cast2d(w_in[:, :D], w_in_pad[:, :D])
+            hip.cast2d(P.w("out_proj.weight"), w_out_pad[:D])
+            b_out_pad[:D].copy_(P.v("out_proj.bias"))
+            self._pad = (Kp, w_in_pad, w_out_pad, b_out_pad)
         if table is not None and not os.environ.get("IB_NO_TIME_TABLE"):
             steps = table.shape[0]
             every_t = torch.arange(steps, dtype=torch.int64, device=table.device)
@@ -1185,8 +1200,15 @@ class DenoiserTransformerPlan:
             self._e_all = e_all
 
     _e_all = None
+    _pad = None
 
     inference = False
+
+    @staticmethod
+    def infer_pitch(D: int) -> int:
+        """row pitch (elements) the sampler gives its state / noise buffers: D rounded up to 64 (the K step of the LDS-DMA
+        kernels) unless IB_NO_PAD; the pad columns must be zero"""
+        return D if (os.environ.get("IB_NO_PAD") or D % 64 == 0) else (D + 63) // 64 * 64
 
     def branches(self) -> List[Branch]:
         return [lp.branch for lp in self.layers] + [self.br_time, self.br_thid, self.br_pos, self.br_wt]
@@ -1221,14 +1243,26 @@ class DenoiserTransformerPlan:
             hip.tiny_matmul(pos, w_in[:, D:].t(), posproj)
         self.br_time.join()
         h0 = g("dt.h0", (B, T, self.d), dt)
-        hip.linear_fwd(x2, w_in[:, :D], P.v("in_proj.bias"), h0.view(M, self.d), add_div=e,
-                       add_mod=posproj, seg=T)
+        # sampler with pitched buffers (prepare_inference): both projections over the padded width
+        padded = (self.inference and self._pad is not None and out is not None and x2.dim() == 2 and out.dim() == 2
+                  and x2.stride(0) == self._pad[0] and out.stride(0) == self._pad[0] and x2.stride(1) == 1
+                  and M >= int(os.environ.get("IB_PAD_MIN_M", "2560")))   # below: B = 4 / 8 -1.6 %, B = 16 / 32 +3 %
+        if padded:
+            Kp, w_in_pad, w_out_pad, b_out_pad = self._pad
+            hip.linear_fwd(x2.as_strided((M, Kp), (Kp, 1)), w_in_pad, P.v("in_proj.bias"), h0.view(M, self.d), add_div=e,
+                           add_mod=posproj, seg=T)
+        else:
+            hip.linear_fwd(x2, w_in[:, :D], P.v("in_proj.bias"), h0.view(M, self.d), add_div=e,
+                           add_mod=posproj, seg=T)
         h = h0
         for lp in self.layers:
             h = lp.forward(h, P)
         out = out if out is not None else g("dt.out", (B, T, D), dt)
-        hip.linear_fwd(h.view(M, self.d), P.w("out_proj.weight"), P.v("out_proj.bias"),
-                       out if out.dim() == 2 else out.view(M, D))
+        if padded:
+            hip.linear_fwd(h.view(M, self.d), w_out_pad, b_out_pad, out.as_strided((M, Kp), (Kp, 1)))
+        else:
+            hip.linear_fwd(h.view(M, self.d), P.w("out_proj.weight"), P.v("out_proj.bias"),
+                           out if out.dim() == 2 else out.view(M, D))
         self.br_wt.join()
         self.ctx = (x2, pos, h, B, T)
         return out
