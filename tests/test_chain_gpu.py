@@ -156,7 +156,7 @@ def test_chain_matches_float64_restatement(hip, B, T, D, H, L):
     close(dbh_k, pred.grad.sum(0), tol, "dbias head")
 
 
-@pytest.mark.parametrize("B,temb,hid,out", [(256, 128, 512, 1024), (70, 32, 128, 256), (3, 128, 512, 512)])
+@pytest.mark.parametrize("B,temb,hid,out", [(256, 128, 512, 1024), (70, 32, 128, 256), (3, 128, 512, 512), (1000, 128, 512, 1024), (37, 128, 512, 1024)])
 def test_time_mlp_fwd_matches_float64(hip, B, temb, hid, out):
     assert hip.time_mlp_fwd_supported(temb, hid, out)
     table = R.timestep_embedding(torch.arange(1000), temb).to(torch.float32)
