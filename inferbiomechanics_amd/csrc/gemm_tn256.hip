@@ -259,7 +259,7 @@ inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 }  // namespace
 
 // Common split count of a group of qualifying problems (0: the group does not qualify): the largest divisor s of M / 32
-// with s x (total tiles) <= 256 work items (one per CU), items at least 8 stages long and an even stage count, s <= 32
+// with s x (total tiles) <= 224 work items (at most one per CU), items at least 8 stages long and an even stage count, s <= 32
 // (the bias partial sums have 32 rows).
 int ib_gemm_tn256_splits(int n, const int64_t* M, const int64_t* N, const int64_t* K) {
   static const bool off = getenv("IB_NO_TN256") != nullptr;
@@ -277,7 +277,10 @@ int ib_gemm_tn256_splits(int n, const int64_t* M, const int64_t* N, const int64_
     if (stages % s != 0) continue;
     const int64_t nk = stages / s;
     if (nk < 8 || (nk & 1)) continue;
-    if (s * tiles <= 256 || best == 0) best = (int)s;      // s = 1 when even that exceeds the chip (several rounds)
+    // 224, not 256: the launch runs on a side stream beside the backward's main-stream GEMMs, and every split is one more
+    // fp32 slab for the optimizer to read (transformer layer, 48 tiles, same box: 4 splits 2.110-2.116 ms per step, 5 splits
+    // 2.126-2.159)
+    if (s * tiles <= 224 || best == 0) best = (int)s;      // s = 1 when even that exceeds the chip (several rounds)
   }
   return best;
 }
