@@ -670,3 +670,57 @@ def test_layernorm_fast_path_large_batch(hip, M, use_res, monkeypatch):
     hip.layernorm_bwd(d(dy[:m2]), d(x[:m2]), d(gamma), mean2, rstd2, dx2, torch.zeros(N, device=DEV), torch.zeros(N, device=DEV),
                       ws2, res=d(res[:m2]) if use_res else None)
     assert (dx[:m2].float() - dx2.float()).abs().max().item() <= 2 ** -7 * dx2.float().abs().max().item()
+
+
+def test_optimizer_gradient_sources_many_irregular_ranges(hip):
+    """ib_optim_step_sources with 40 sources of irregular lengths (4-element ranges, neighbours inside one wave's 256 elements,
+    gaps that read g, slab counts 1 .. 11 across the 8-slab batches, column sums over 5 .. 200 partial rows): bitwise equal to
+    the plain optimizer fed a gradient reduced in the same fixed orders (slabs in sequence; rows r = g, g + 16, ... per row
+    group, groups combined in order).  Guards the wave-uniform source search and the predicated slab batches."""
+    g = torch.Generator().manual_seed(11)
+    n = 40_000
+    p0 = torch.randn(n, generator=g).to(DEV)
+    grad = (torch.randn(n, generator=g) * 1e-2).to(DEV)
+    ref_grad = grad.clone()
+    items, segs, off = [], [], 12
+    lens = [4, 8, 4, 256, 252, 1024, 36, 4, 4, 640, 3000, 16, 128, 2048, 4, 100 * 4, 512, 8, 8, 1200]
+    part = torch.randn(200, 4096, generator=g).to(DEV)
+    col = 0
+    for i, ln in enumerate(lens):
+        ns = 1 + (i * 3) % 11
+        ws = (torch.randn(ns, ln, generator=g) * 1e-2).to(DEV)
+        items.append((ws, ns, grad[off:off + ln]))
+        acc = torch.zeros(ln, device=DEV)
+        for k in range(ns):
+            acc = acc + ws[k]
+        ref_grad[off:off + ln] = acc
+        off += ln + (0 if i % 3 else 8)                    # every third source is followed by a gap that reads g
+        # a column-sum range right behind it (its own row count through a 7-tuple segment)
+        nc = [4, 30, 64, 130, 7][i % 5]
+        rows = [5, 16, 17, 200, 33][i % 5]
+        start = (off + 3) // 4 * 4
+        segs.append((col, nc, grad[start:start + nc], None, 0.5, part, rows))
+        parts16 = []
+        for rg in range(16):
+            a = torch.zeros(nc, device=DEV)
+            for r in range(rg, rows, 16):
+                a = a + part[r, col:col + nc]
+            parts16.append(a)
+        tot = parts16[0]
+        for rg in range(1, 16):
+            tot = tot + parts16[rg]
+        ref_grad[start:start + nc] = tot * 0.5
+        pad_end = start + (nc + 3) // 4 * 4               # alignment padding behind a ragged range: never updated by the
+        grad[start + nc:pad_end] = 0.0                     # fused kernel; a zero gradient leaves it untouched in the reference too
+        ref_grad[start + nc:pad_end] = 0.0
+        col += (nc + 3) // 4 * 4
+        off = start + (nc + 3) // 4 * 4
+    assert off < n and len(items) + len(segs) == 40
+    for opt in ("rmsprop", "adam"):
+        pa, pb = p0.clone(), p0.clone()
+        s1a, s1b = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+        s2a, s2b = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+        for step in (1, 2):
+            hip.optim_step(opt, pa, grad, s1a, s2a, 1e-3, step=step, sources=(items, None, 0, segs))
+            hip.optim_step(opt, pb, ref_grad, s1b, s2b, 1e-3, step=step)
+        assert torch.equal(pa, pb) and torch.equal(s1a, s1b) and torch.equal(s2a, s2b), opt
