@@ -4,6 +4,8 @@ T = 200, forward + every gradient against the float64 CPU oracle; the fused trai
 oracle run; the benchmarked 100-step DDIM loop at T = 200 against the oracle's ddim_sample; and the bf16 loss curve at
 the headline shape (B = 256, T = 50, D = 300) against the fp32 one.  Small batches keep the CPU oracle to seconds.
 Tolerances: fp32 <= 1e-3 relative (north_star); bf16 stated per test (8 significant bits of storage)."""
+import os
+
 import pytest
 import torch
 
@@ -40,7 +42,7 @@ def make_transformer(T, dtype, layers=LAYERS, seed=0):
 
 
 @pytest.mark.parametrize("T", [50, 200])
-@pytest.mark.parametrize("dtype,rt", [(torch.float32, 1e-3), (torch.bfloat16, 6e-2)])
+@pytest.mark.parametrize("dtype,rt", [(torch.float32, 1e-3), (torch.bfloat16, 3e-2)])
 def test_transformer_denoiser_config_size_matches_oracle(dtype, rt, T):
     """configs[2] (T = 50) and configs[4] (T = 200) model, B = 2: eps_hat, loss and all 58 parameter gradients"""
     from inferbiomechanics_amd.loss.DiffusionLossEvaluator import DiffusionLossEvaluator
@@ -71,7 +73,12 @@ def test_transformer_denoiser_config_size_matches_oracle(dtype, rt, T):
             worst[k] = 0.5 * float((a - e).norm() / e.norm())       # so the same threshold reads "<= 4 rt = 24 %"
         else:
             worst[k] = rel_err(q.grad, p[k].grad)
-    bad = {k: v for k, v in worst.items() if v > (rt if dtype == torch.float32 else 2 * rt)}
+    bound = rt if dtype == torch.float32 else 2 * rt
+    if os.environ.get("IB_TEST_REPORT"):            # measurement aid (pytest -s): the tensors closest to the bound
+        top = sorted(worst.items(), key=lambda kv: -kv[1])[:4]
+        print(f"[tol] T={T} {dtype}: eps_hat {rel_err(pred, pe) / rt:.3f} of rt; gradients (fraction of the bound):",
+              [(k, round(v / bound, 3)) for k, v in top])
+    bad = {k: v for k, v in worst.items() if v > bound}
     assert not bad, bad
     if dtype == torch.bfloat16:
         # SHOWN, not asserted: hand the float64 oracle the ReLU gate the kernel used (the stored post-ReLU activations

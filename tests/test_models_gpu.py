@@ -35,6 +35,8 @@ def close(actual, expected, rtol, what="", atol=0.0):
     assert torch.isfinite(a).all(), f"{what}: non-finite"
     err = (a - e).abs().max().item() if a.numel() else 0.0
     ref = max(e.abs().max().item(), 1e-30) if e.numel() else 1.0
+    if os.environ.get("IB_TEST_REPORT"):            # measurement aid: how much of the tolerance a comparison uses (pytest -s)
+        print(f"[tol] {what}: used {err / max(atol + rtol * ref, 1e-300):.3f} of the bound (rtol {rtol:.1e})")
     assert err <= atol + rtol * ref, f"{what}: max err {err:.3e} > {atol:.1e} + {rtol:.1e} * {ref:.3e}"
 
 
@@ -153,7 +155,7 @@ def _oracle_params(model):
     return {k: v.detach().cpu().double().requires_grad_(True) for k, v in model.state_dict().items()}
 
 
-@pytest.mark.parametrize("dtype,rt", [(torch.float32, 1e-3), (torch.bfloat16, 6e-2)])
+@pytest.mark.parametrize("dtype,rt", [(torch.float32, 1e-3), (torch.bfloat16, 3e-2)])
 def test_diffusion_mlp_matches_oracle(dtype, rt):
     from inferbiomechanics_amd.models.DiffusionDenoisers import DiffusionMLP
     from inferbiomechanics_amd.loss.DiffusionLossEvaluator import DiffusionLossEvaluator
@@ -179,7 +181,7 @@ def test_diffusion_mlp_matches_oracle(dtype, rt):
         close(q.grad, p[k].grad, rt * (1 if dtype == torch.float32 else 2), "grad/" + k, atol=rt * 0.05 * gn)
 
 
-@pytest.mark.parametrize("dtype,rt", [(torch.float32, 1e-3), (torch.bfloat16, 8e-2)])
+@pytest.mark.parametrize("dtype,rt", [(torch.float32, 1e-3), (torch.bfloat16, 6e-2)])
 def test_diffusion_transformer_matches_oracle(dtype, rt):
     from inferbiomechanics_amd.models.DiffusionDenoisers import DiffusionTransformer
     from inferbiomechanics_amd.loss.DiffusionLossEvaluator import DiffusionLossEvaluator
@@ -204,7 +206,7 @@ def test_diffusion_transformer_matches_oracle(dtype, rt):
         close(q.grad, p[k].grad, rt * (1 if dtype == torch.float32 else 2), "grad/" + k, atol=rt * 0.05 * gn)
 
 
-@pytest.mark.parametrize("dtype,rt", [(torch.float32, 2e-3), (torch.bfloat16, 8e-2)])
+@pytest.mark.parametrize("dtype,rt", [(torch.float32, 2e-3), (torch.bfloat16, 4e-2)])
 def test_ddim_sampler_loop_matches_oracle(dtype, rt):
     """the whole sampling loop (device step counter, one captured step replayed) against the oracle's ddim_sample over
     the oracle denoiser; bf16 additionally runs the fused Linear + residual + LayerNorm inference path and must agree
