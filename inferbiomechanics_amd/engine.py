@@ -369,10 +369,14 @@ class HipTrainer:
             # operand pieces are then aligned 16-byte loads (the unpadded rows were 8-byte aligned: +11 us per wgrad)
             if hasattr(plan, "fuse_reduce_into_optimizer"):
                 plan.fuse_reduce_into_optimizer = not self.ddp and not os.environ.get("IB_NO_OPT_FUSE")
-            Dp = D if os.environ.get("IB_NO_PAD") else (D + 7) // 8 * 8
-            xt = plan.buf.get("tr.xt", (M, Dp), dt)[:, :D]
-            pred = plan.buf.get("tr.pred", (M, Dp), dt)[:, :D]
-            dpred = plan.buf.get("tr.dpred", (M, Dp), dt)[:, :D]
+            if hasattr(plan, "train_pitch"):
+                Dp = plan.train_pitch(D, M)        # 320 for the transformer denoiser at training batch sizes (plans._train_pad)
+            else:
+                Dp = D if os.environ.get("IB_NO_PAD") else (D + 7) // 8 * 8
+            # zeroed once at creation: the pad columns are operands of the padded projections and never written otherwise
+            xt = plan.buf.get("tr.xt", (M, Dp), dt, zero=True)[:, :D]
+            pred = plan.buf.get("tr.pred", (M, Dp), dt, zero=True)[:, :D]
+            dpred = plan.buf.get("tr.dpred", (M, Dp), dt, zero=True)[:, :D]
             hip.q_sample(x0, eps, t, tabs.sqrt_ab, tabs.sqrt_1mab, xt)
             plan.forward(xt, t, tabs.temb, P, out=pred, BT=(B, T))
             ws = plan.buf.bytes("tr.mse", hip.mse_loss_workspace_bytes(M * D))

@@ -45,11 +45,12 @@ class Buffers:
         self.device = device
         self._b: Dict[tuple, torch.Tensor] = {}
 
-    def get(self, name: str, shape, dtype) -> torch.Tensor:
+    def get(self, name: str, shape, dtype, zero: bool = False) -> torch.Tensor:
+        """zero: cleared ONCE, when the buffer is created (pad columns that no launch ever writes)"""
         key = (name, tuple(int(s) for s in shape), dtype)
         t = self._b.get(key)
         if t is None:
-            t = torch.empty(key[1], dtype=dtype, device=self.device)
+            t = (torch.zeros if zero else torch.empty)(key[1], dtype=dtype, device=self.device)
             self._b[key] = t
         return t
 
@@ -1204,6 +1205,29 @@ class DenoiserTransformerPlan:
 
     inference = False
 
+    def train_pitch(self, D: int, M: int) -> int:
+        """row pitch (elements) of the trainer's D-wide activation buffers (x_t, prediction, dL/dprediction): D rounded up to
+        64 when the padded projections below apply (bf16, the large-M kernels), else to 8 (16-byte aligned rows)"""
+        if (self.dtype == torch.bfloat16 and M >= 4096 and D % 64 != 0
+                and not (os.environ.get("IB_NO_PAD") or os.environ.get("IB_NO_TRAIN_PAD") or os.environ.get("IB_NO_NT"))):
+            return (D + 63) // 64 * 64
+        return D if os.environ.get("IB_NO_PAD") else (D + 7) // 8 * 8
+
+    def _train_pad(self, M: int, D: int, x2: torch.Tensor, out: Optional[torch.Tensor]):
+        """training step with pitched activation buffers (train_pitch): zero-padded copies of the D-wide projection weights,
+        refreshed every step beside the weight transposes, so that the input projection reduces over 320 columns on the
+        LDS-DMA ring kernel and the output projection / its input gradient run on the 256 x 128 NT kernel (the 300-wide
+        operands put all three on the generic register-staged kernel: 23.6 + 17.1 + 16.8 us per step)"""
+        Kp = self.train_pitch(D, M)
+        if Kp % 64 != 0 or Kp == D or out is None or x2.dim() != 2 or out.dim() != 2 or x2.stride(0) != Kp \
+                or out.stride(0) != Kp or x2.stride(1) != 1:
+            return None
+        g, dt = self.buf.get, self.dtype
+        return {"Kp": Kp, "w_in": g("dt.tp.w_in", (self.d, Kp), dt, zero=True), "w_out": g("dt.tp.w_out", (Kp, self.d), dt, zero=True),
+                "w_outT": g("dt.tp.w_outT", (self.d, Kp), dt, zero=True), "b_out": g("dt.tp.b_out", (Kp,), torch.float32, zero=True)}
+
+    _tp = None
+
     @staticmethod
     def infer_pitch(D: int) -> int:
         """row pitch (elements) the sampler gives its state / noise buffers: D rounded up to 64 (the K step of the LDS-DMA
@@ -1234,11 +1258,25 @@ class DenoiserTransformerPlan:
             e = self.time.forward(t, table, P)                               # [B, d]
         else:
             # training: the time-MLP and the weight transposes (read by the backward only) beside the projection below
+            tp = self._tp = self._train_pad(M, D, x2, out)
             box = []
-            self.br_time.run(lambda: box.append(self.time.forward(t, table, P)))
+
+            def t_branch():
+                box.append(self.time.forward(t, table, P))
+                if tp:
+                    hip.cast2d(w_in[:, :D], tp["w_in"][:, :D])
+            self.br_time.run(t_branch)
             e = box[0]
-            if pairs:
-                self.br_wt.run(lambda: hip.transpose_multi(pairs))
+            if pairs or tp:
+                def wt_branch():
+                    pr = list(pairs)
+                    if tp:
+                        w_out = P.w("out_proj.weight")
+                        pr.append((w_out, tp["w_outT"][:, :D]))
+                        hip.cast2d(w_out, tp["w_out"][:D])
+                        hip.cast2d(P.v("out_proj.bias").view(1, D), tp["b_out"].view(1, -1)[:, :D])
+                    hip.transpose_multi(pr)
+                self.br_wt.run(wt_branch)
         if not (self.inference and self._posproj_T == T):    # frozen weights (sampling): projected once per sample()
             hip.tiny_matmul(pos, w_in[:, D:].t(), posproj)
         self.br_time.join()
@@ -1247,10 +1285,14 @@ class DenoiserTransformerPlan:
         padded = (self.inference and self._pad is not None and out is not None and x2.dim() == 2 and out.dim() == 2
                   and x2.stride(0) == self._pad[0] and out.stride(0) == self._pad[0] and x2.stride(1) == 1
                   and M >= int(os.environ.get("IB_PAD_MIN_M", "2560")))   # below: B = 4 / 8 -1.6 %, B = 16 / 32 +3 %
+        tp = None if self.inference else self._tp
         if padded:
             Kp, w_in_pad, w_out_pad, b_out_pad = self._pad
             hip.linear_fwd(x2.as_strided((M, Kp), (Kp, 1)), w_in_pad, P.v("in_proj.bias"), h0.view(M, self.d), add_div=e,
                            add_mod=posproj, seg=T)
+        elif tp:
+            hip.linear_fwd(x2.as_strided((M, tp["Kp"]), (tp["Kp"], 1)), tp["w_in"], P.v("in_proj.bias"), h0.view(M, self.d),
+                           add_div=e, add_mod=posproj, seg=T)
         else:
             hip.linear_fwd(x2, w_in[:, :D], P.v("in_proj.bias"), h0.view(M, self.d), add_div=e,
                            add_mod=posproj, seg=T)
@@ -1260,6 +1302,9 @@ class DenoiserTransformerPlan:
         out = out if out is not None else g("dt.out", (B, T, D), dt)
         if padded:
             hip.linear_fwd(h.view(M, self.d), w_out_pad, b_out_pad, out.as_strided((M, Kp), (Kp, 1)))
+        elif tp:
+            self.br_wt.join()                     # the padded copies of out_proj (made beside the transposes)
+            hip.linear_fwd(h.view(M, self.d), tp["w_out"], tp["b_out"], out.as_strided((M, tp["Kp"]), (tp["Kp"], 1)))
         else:
             hip.linear_fwd(h.view(M, self.d), P.w("out_proj.weight"), P.v("out_proj.bias"),
                            out if out.dim() == 2 else out.view(M, D))
@@ -1291,7 +1336,10 @@ class DenoiserTransformerPlan:
         _colsum(self.buf, "dt.bo", dout, P.g("out_proj.bias"), accumulate)
         P.ready("out_proj.bias")
         dh = g("dt.dh", (B, T, self.d), dt)
-        hip.linear_dgrad(dout, P.w("out_proj.weight"), dh.view(M, self.d))
+        tp = self._tp
+        if not (tp and dout.stride(0) == tp["Kp"] and dout.stride(1) == 1 and
+                hip.linear_dgrad_wt(dout.as_strided((M, tp["Kp"]), (tp["Kp"], 1)), tp["w_outT"], dh.view(M, self.d))):
+            hip.linear_dgrad(dout, P.w("out_proj.weight"), dh.view(M, self.d))
         P.flush()
         for lp in reversed(self.layers):
             dh = lp.backward(dh, P, accumulate)

@@ -1,5 +1,5 @@
-# the transformer step under IB_TN256_SPLITS / IB_NO_TN256, same box (edit the list)
-for v in "IB_TN256_SPLITS=4" "IB_TN256_SPLITS=5" "IB_TN256_SPLITS=4" "IB_TN256_SPLITS=5" "IB_TN256_SPLITS=4" "IB_TN256_SPLITS=5"; do
+# the transformer step under environment switches, same box (edit the list)
+for v in "" "IB_NO_TRAIN_PAD=1" "" "IB_NO_TRAIN_PAD=1"; do
   echo "== $v"
   env $v python bench.py --workload transformer_denoiser_T50 --steps 400 --warmup 40 --no-cpu-baseline --no-ddim --no-transformer 2>/dev/null | python -c "
 import json,sys
