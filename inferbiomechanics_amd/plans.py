@@ -544,9 +544,23 @@ class TransformerLayerPlan:
         self.later: Optional[list] = None
         self.flush_on_exit = False   # data parallel with overlapped all-reduces: join the side stream and let the trainer
                                      # launch the completed buckets at the end of every layer's backward
+        # data parallel, set by a parent plan for every layer but the one whose backward runs last: the layer's grouped
+        # weight-gradient launch + its reduction are NOT issued by backward(); they are handed back (take_lagged) and the
+        # parent forks them beside the NEXT layer's backward, joins them at that layer's end and only then reports the
+        # gradients ready and flushes.  A captured graph segment must end with every side stream joined, so without the lag
+        # each layer's 100-us launch sat on the critical path once per bucket.
+        self.lag_group = False
+        self.parent_flushes = False  # set with lag_group on ALL layers of such a parent: gradients are reported to the parent
+                                     # (take_lagged), which keeps the ready order and does the flushes
+        self._lagged = None
 
     def branches(self) -> List["Branch"]:
         return [self.branch]
+
+    def take_lagged(self):
+        """(closure issuing the layer's grouped weight-gradient launch + reduction, names to report ready) or None"""
+        lg, self._lagged = self._lagged, None
+        return lg
 
     WT_NAMES = ("feedforward.2.weight", "feedforward.0.weight", "multihead_attention.out_proj.weight",
                 "multihead_attention.in_proj_weight")
@@ -658,6 +672,10 @@ class TransformerLayerPlan:
         if local:
             defer, later = [], []
         group = [] if (defer is not None and dt == torch.bfloat16 and not os.environ.get("IB_NO_LAYER_GROUP")) else None
+        lag = self.lag_group and self.parent_flushes and local and group is not None
+        lag_names: List[str] = []
+        if self.parent_flushes:       # gradients are reported ready by the parent, in its order, after its joins
+            P = ParamSource(P.w, P.v, P.g, ready=lag_names.append, flush=lambda: None)
         fork = self._always_fork or (group is not None and not local and not self.flush_on_exit and M >= 4096)
         side = self.branch.run if fork else (lambda fn: fn())
 
@@ -754,12 +772,17 @@ class TransformerLayerPlan:
                     later.append((part, part.shape[0], P.g(p + bname)))
                 if local:     # reads the slabs of the launch above: same stream
                     hip.step_reduce_parts(defer, [(part, rows, dst) for part, rows, dst in later])
+            if lag:
+                self._lagged = (run_group, lag_names)
+                return dx
             side(run_group)
         elif local:
             hip.step_reduce_parts(defer, [(part, rows, dst) for part, rows, dst in later])
         if self.join_on_exit or self.flush_on_exit:
             self.branch.join()
-        if self.flush_on_exit:
+        if self.parent_flushes:
+            self._lagged = (None, lag_names)          # everything issued; the parent reports and flushes
+        elif self.flush_on_exit:
             P.flush()
         return dx
 
@@ -1155,8 +1178,11 @@ class DenoiserTransformerPlan:
     def flush_each_layer(self, on: bool):
         """overlapped data-parallel steps: keep the layers' side streams, hand completed gradient buckets to the trainer at
         every layer boundary (ParamSource.flush) instead of running the whole backward on one stream"""
-        for lp in self.layers:
+        lag = bool(on) and not os.environ.get("IB_NO_LAG_GROUP")
+        for i, lp in enumerate(self.layers):
             lp.flush_on_exit = bool(on)
+            lp.parent_flushes = lag
+            lp.lag_group = lag and i > 0            # layer 0's backward runs last: nothing to hide its launch behind
 
     def set_inference(self, on: bool):
         """forward-only mode with frozen weights (the DDIM sampler): fused Linear + residual + LayerNorm in every layer,
@@ -1341,8 +1367,28 @@ class DenoiserTransformerPlan:
                 hip.linear_dgrad_wt(dout.as_strided((M, tp["Kp"]), (tp["Kp"], 1)), tp["w_outT"], dh.view(M, self.d))):
             hip.linear_dgrad(dout, P.w("out_proj.weight"), dh.view(M, self.d))
         P.flush()
+        prev = None                                   # (layer plan, closure, names) whose launches lag one layer
         for lp in reversed(self.layers):
+            if prev is not None:
+                prev[0].branch.run(prev[1])           # beside this layer's backward
             dh = lp.backward(dh, P, accumulate)
+            lg = lp.take_lagged()                     # None unless the layers report through this plan (data parallel)
+            if prev is not None:
+                prev[0].branch.join()
+                for nm in prev[2]:
+                    P.ready(nm)
+                prev = None
+                if lg is None or lg[0] is not None:
+                    P.flush()                         # the bucket(s) completed by the lagged layer
+            if lg is not None:
+                if lg[0] is None:                     # issued by the layer itself (small batches; the last layer)
+                    for nm in lg[1]:
+                        P.ready(nm)
+                    P.flush()
+                else:
+                    prev = (lp, lg[0], lg[1])
+        if prev is not None:
+            raise hip.HipError("the last layer's weight-gradient launch must not lag")
         dz0 = dh.view(M, self.d)
         w_in, gw_in = P.w("in_proj.weight"), P.g("in_proj.weight")
         # tail: three chains of small launches hang off dz0 -- the time-MLP's two halves and the frame-embedding gradients

@@ -1,5 +1,5 @@
 # the transformer step in data-parallel form (1-rank RCCL) under environment switches, same box (edit the list)
-for v in "" "IB_NO_TN256=1" "IB_TN256_SPLITS=2" "" "IB_NO_TN256=1" "IB_NO_TRAIN_PAD=1"; do
+for v in "" "IB_NO_LAG_GROUP=1" "" "IB_NO_LAG_GROUP=1"; do
   echo "== $v"
   env $v IB_DDP_SELFTEST=1 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 MASTER_ADDR=127.0.0.1 MASTER_PORT=29577 python bench.py --workload transformer_denoiser_T50 --steps 300 --warmup 30 --no-cpu-baseline --no-ddim --no-transformer 2>/dev/null | python -c "
 import json,sys
