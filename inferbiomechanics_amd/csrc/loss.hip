@@ -34,6 +34,9 @@ __device__ __forceinline__ float rl_wave_sum(float v) {
   return ((r0 + r1) + r2) + r3;
 }
 
+__device__ __forceinline__ void rl_finalize(const float* tot, const float* __restrict__ comp_w, float* __restrict__ result,
+                                            int B, int F);
+
 template <typename T>
 __global__ __launch_bounds__(256) void regression_loss_partial_kernel(
     const T* __restrict__ o_cop, const T* __restrict__ o_force, const T* __restrict__ o_torque,
@@ -43,7 +46,7 @@ __global__ __launch_bounds__(256) void regression_loss_partial_kernel(
     const float* __restrict__ l_torque, const float* __restrict__ l_wrench, const float* __restrict__ comp_w,
     float threshold, T* __restrict__ g_cop, T* __restrict__ g_force, T* __restrict__ g_torque, T* __restrict__ g_wrench,
     int64_t gs_cop, int64_t gs_force, int64_t gs_torque, int64_t gs_wrench, int fg_cop, int fg_force, int fg_torque,
-    int fg_wrench, float* __restrict__ partial, int B, int F) {
+    int fg_wrench, float* __restrict__ partial, int B, int F, float* __restrict__ result_inline) {
   __shared__ float red[4][NPART];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float acc[NPART];
@@ -51,18 +54,36 @@ __global__ __launch_bounds__(256) void regression_loss_partial_kernel(
   for (int i = 0; i < NPART; ++i) acc[i] = 0.f;
   const int rows = B * F;
   const float gscale = 2.f / (float)rows;
+  float cw[30];                                     // component weights: requested once, ahead of the rows
+#pragma unroll
+  for (int c = 0; c < 30; ++c) cw[c] = comp_w[c];
   for (int row = blockIdx.x * blockDim.x + threadIdx.x; row < rows; row += gridDim.x * blockDim.x) {
     const int b = row / F, f = row % F;
     const bool last = (f == F - 1);
-    float d6[6], lf[6], of[6];
-    // ---- force (also feeds the CoP mask and the COM-acc metric)
+    // every operand of the row is requested before the first is used (48 output / label values): written section by section
+    // -- load, square, store the gradient, next key -- the kernel was four dependent memory round trips (10 us for 40 rows)
+    float of[6], lf[6], oc[6], lc[6], ot[6], lt[6], ow[12], lw[12];
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
       of[c] = ib_to_f32(o_force[(int64_t)b * bs_force + f * fo_force + c]);
       lf[c] = l_force[(int64_t)row * 6 + c];
+      oc[c] = ib_to_f32(o_cop[(int64_t)b * bs_cop + f * fo_cop + c]);
+      lc[c] = l_cop[(int64_t)row * 6 + c];
+      ot[c] = ib_to_f32(o_torque[(int64_t)b * bs_torque + f * fo_torque + c]);
+      lt[c] = l_torque[(int64_t)row * 6 + c];
+    }
+#pragma unroll
+    for (int c = 0; c < 12; ++c) {
+      ow[c] = ib_to_f32(o_wrench[(int64_t)b * bs_wrench + f * fo_wrench + c]);
+      lw[c] = l_wrench[(int64_t)row * 12 + c];
+    }
+    float d6[6];
+    // ---- force (also feeds the CoP mask and the COM-acc metric)
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
       d6[c] = of[c] - lf[c];
       acc[c] += d6[c] * d6[c];
-      if (g_force) g_force[(int64_t)b * gs_force + f * fg_force + c] = ib_from_f32<T>(comp_w[c] * gscale * d6[c]);
+      if (g_force) g_force[(int64_t)b * gs_force + f * fg_force + c] = ib_from_f32<T>(cw[c] * gscale * d6[c]);
     }
     float mask[2];
 #pragma unroll
@@ -81,19 +102,18 @@ __global__ __launch_bounds__(256) void regression_loss_partial_kernel(
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
       const float m = mask[c / 3];
-      const float o = ib_to_f32(o_cop[(int64_t)b * bs_cop + f * fo_cop + c]);
-      d6[c] = o * m - l_cop[(int64_t)row * 6 + c] * m;
+      d6[c] = oc[c] * m - lc[c] * m;
       acc[6 + c] += d6[c] * d6[c];
-      if (g_cop) g_cop[(int64_t)b * gs_cop + f * fg_cop + c] = ib_from_f32<T>(comp_w[6 + c] * gscale * d6[c] * m);
+      if (g_cop) g_cop[(int64_t)b * gs_cop + f * fg_cop + c] = ib_from_f32<T>(cw[6 + c] * gscale * d6[c] * m);
     }
     if (last)
       acc[32] += sqrtf(d6[0] * d6[0] + d6[1] * d6[1] + d6[2] * d6[2]) + sqrtf(d6[3] * d6[3] + d6[4] * d6[4] + d6[5] * d6[5]);
     // ---- moment
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
-      d6[c] = ib_to_f32(o_torque[(int64_t)b * bs_torque + f * fo_torque + c]) - l_torque[(int64_t)row * 6 + c];
+      d6[c] = ot[c] - lt[c];
       acc[12 + c] += d6[c] * d6[c];
-      if (g_torque) g_torque[(int64_t)b * gs_torque + f * fg_torque + c] = ib_from_f32<T>(comp_w[12 + c] * gscale * d6[c]);
+      if (g_torque) g_torque[(int64_t)b * gs_torque + f * fg_torque + c] = ib_from_f32<T>(cw[12 + c] * gscale * d6[c]);
     }
     if (last)
       acc[31] += sqrtf(d6[0] * d6[0] + d6[1] * d6[1] + d6[2] * d6[2]) + sqrtf(d6[3] * d6[3] + d6[4] * d6[4] + d6[5] * d6[5]);
@@ -101,9 +121,9 @@ __global__ __launch_bounds__(256) void regression_loss_partial_kernel(
     float d12[12];
 #pragma unroll
     for (int c = 0; c < 12; ++c) {
-      d12[c] = ib_to_f32(o_wrench[(int64_t)b * bs_wrench + f * fo_wrench + c]) - l_wrench[(int64_t)row * 12 + c];
+      d12[c] = ow[c] - lw[c];
       acc[18 + c] += d12[c] * d12[c];
-      if (g_wrench) g_wrench[(int64_t)b * gs_wrench + f * fg_wrench + c] = ib_from_f32<T>(comp_w[18 + c] * gscale * d12[c]);
+      if (g_wrench) g_wrench[(int64_t)b * gs_wrench + f * fg_wrench + c] = ib_from_f32<T>(cw[18 + c] * gscale * d12[c]);
     }
     if (last) {
       float n0 = 0.f, n1 = 0.f;
@@ -122,7 +142,15 @@ __global__ __launch_bounds__(256) void regression_loss_partial_kernel(
   __syncthreads();
   if (threadIdx.x < NPART) {
     const int i = threadIdx.x;
-    partial[(int64_t)blockIdx.x * NPART + i] = ((red[0][i] + red[1][i]) + red[2][i]) + red[3][i];
+    const float v = ((red[0][i] + red[1][i]) + red[2][i]) + red[3][i];
+    partial[(int64_t)blockIdx.x * NPART + i] = v;
+    if (result_inline) red[0][i] = 0.f + v;            // what the final kernel's one-part sum would hold
+  }
+  // a single block (the reference's batch sizes: B x F <= 256 pairs) finishes the loss itself: the second launch was 5 us
+  // of launch latency for 37 additions
+  if (result_inline) {
+    __syncthreads();
+    if (threadIdx.x == 0) rl_finalize(red[0], comp_w, result_inline, B, F);
   }
 }
 
@@ -131,11 +159,25 @@ __global__ void regression_loss_final_kernel(const float* __restrict__ partial, 
   __shared__ float tot[NPART];
   if (threadIdx.x < NPART) {
     float s = 0.f;
-    for (int b = 0; b < nparts; ++b) s += partial[(int64_t)b * NPART + threadIdx.x];
+    for (int b0 = 0; b0 < nparts; b0 += 8) {           // up to 8 partial rows requested together, added in block order
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (b0 + e < nparts) v[e] = partial[(int64_t)(b0 + e) * NPART + threadIdx.x];
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (b0 + e < nparts) s += v[e];
+    }
     tot[threadIdx.x] = s;
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
+  if (threadIdx.x == 0) rl_finalize(tot, comp_w, result, B, F);
+}
+
+// the loss value, the 30 per-component means and the metric means from the NPART column totals (one thread)
+__device__ __forceinline__ void rl_finalize(const float* tot, const float* __restrict__ comp_w, float* __restrict__ result,
+                                            int B, int F) {
+  {
     const float inv = 1.f / (float)(B * F);
     float loss = 0.f;
     for (int c = 0; c < 30; ++c) {
@@ -247,25 +289,28 @@ extern "C" int ib_regression_loss_strided(const void* o_cop, const void* o_force
   if (!workspace || workspace_bytes < (size_t)parts * NPART * sizeof(float)) return IB_E_WORKSPACE;
   float* partial = reinterpret_cast<float*>(workspace);
   hipStream_t s = ib_s(stream);
+  float* inline_result = parts == 1 ? result : nullptr;       // one block: it writes the result itself, no second launch
   if (dtype == IB_F32) {
     hipLaunchKernelGGL((regression_loss_partial_kernel<float>), dim3(parts), dim3(256), 0, s, (const float*)o_cop,
                        (const float*)o_force, (const float*)o_torque, (const float*)o_wrench, o_bs[0], o_bs[1], o_bs[2],
                        o_bs[3], (int)of[0], (int)of[1], (int)of[2], (int)of[3], l_cop, l_force, l_torque, l_wrench, comp_w,
                        threshold, (float*)g_cop, (float*)g_force, (float*)g_torque, (float*)g_wrench, gb[0], gb[1], gb[2],
-                       gb[3], (int)gf[0], (int)gf[1], (int)gf[2], (int)gf[3], partial, (int)B, (int)F);
+                       gb[3], (int)gf[0], (int)gf[1], (int)gf[2], (int)gf[3], partial, (int)B, (int)F, inline_result);
   } else if (dtype == IB_BF16) {
     hipLaunchKernelGGL((regression_loss_partial_kernel<bf16_t>), dim3(parts), dim3(256), 0, s, (const bf16_t*)o_cop,
                        (const bf16_t*)o_force, (const bf16_t*)o_torque, (const bf16_t*)o_wrench, o_bs[0], o_bs[1],
                        o_bs[2], o_bs[3], (int)of[0], (int)of[1], (int)of[2], (int)of[3], l_cop, l_force, l_torque,
                        l_wrench, comp_w, threshold, (bf16_t*)g_cop, (bf16_t*)g_force, (bf16_t*)g_torque,
                        (bf16_t*)g_wrench, gb[0], gb[1], gb[2], gb[3], (int)gf[0], (int)gf[1], (int)gf[2], (int)gf[3],
-                       partial, (int)B, (int)F);
+                       partial, (int)B, (int)F, inline_result);
   } else {
     return IB_E_DTYPE;
   }
   IB_CHECK_LAUNCH();
-  hipLaunchKernelGGL(regression_loss_final_kernel, dim3(1), dim3(64), 0, s, partial, parts, comp_w, result, (int)B, (int)F);
-  IB_CHECK_LAUNCH();
+  if (!inline_result) {
+    hipLaunchKernelGGL(regression_loss_final_kernel, dim3(1), dim3(64), 0, s, partial, parts, comp_w, result, (int)B, (int)F);
+    IB_CHECK_LAUNCH();
+  }
   return IB_OK;
 }
 
