@@ -274,11 +274,12 @@ int ib_ddim_step(void* x, const void* eps, const float* coef, const int64_t* tim
                  int64_t num_steps, int32_t step, const int32_t* step_dev, int64_t* t_out, int64_t B,
                  int64_t n, int dtype, ib_stream_t stream);
 /* on-device window cache: table = packed fp32 rows [rows, row_elems], one per window:
- * [model input (x_elems, frame-major, zero-padded to a multiple of 4) | labels key-major: cop, force, torque, wrench];
- * gathers idx[B] rows into the
+ * [model input (x_elems, frame-major) | labels key-major: cop, force, torque, wrench], every block zero-padded to a
+ * multiple of 4 values (row_elems = pad4(x_elems) + sum pad4(lab_elems[k])); gathers idx[B] rows into the
  * model input (fp32 or bf16) and the four contiguous fp32 label tensors in ONE launch.  Replaces
  * AddBiomechanicsDataset.__getitem__ (:161-285) + collate + the model's torch.concat (FeedForwardRegressionBaseline.py
- * :97-108) for windows that are already packed.  lab_out / lab_elems: host arrays of 4; every count % 4 == 0. */
+ * :97-108) for windows that are already packed.  lab_out / lab_elems: host arrays of 4 (values per window of each label
+ * tensor, e.g. 6 | 6 | 6 | 12 for 'last_frame'; blocks that are whole 16-byte pieces are copied as such). */
 int ib_gather_windows(const float* table, int64_t row_elems, int64_t rows, const int64_t* idx, int64_t B,
                       void* x_out, int64_t x_elems, int dtype_x, float* const* lab_out, const int64_t* lab_elems,
                       ib_stream_t stream);

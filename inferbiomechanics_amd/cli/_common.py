@@ -8,7 +8,8 @@ from typing import Optional
 
 import torch
 
-from ..data.AddBiomechanicsDataset import SyntheticMotionWindows, SyntheticWindowDataset
+from ..data.AddBiomechanicsDataset import (AddBiomechanicsDataset, MotionWindowView, SyntheticMotionWindows,
+                                               SyntheticWindowDataset)
 
 
 def add_component_flags(p: argparse.ArgumentParser, train_defaults: bool):
@@ -42,8 +43,9 @@ def is_diffusion(model_type: str) -> bool:
 
 
 def open_dataset(args, split: str, history_len: int, stride: int, output_data_format: str, geometry: Optional[str]):
-    """Real .b3d windows need the reference's nimblephysics loader ('next'); synthetic
-    windows reproduce its per-item layout."""
+    """`.b3d` windows through data/AddBiomechanicsDataset.py (needs the nimblephysics wheel at run time), or seeded
+    synthetic windows with the same per-item layout.  The diffusion models see a window as one [F, D] matrix
+    (`MotionWindowView`: the model-input channels and the four label blocks of every frame side by side)."""
     n = getattr(args, 'synthetic_windows', 0)
     model_type = getattr(args, 'model_type', 'feedforward')
     if n > 0:
@@ -55,12 +57,20 @@ def open_dataset(args, split: str, history_len: int, stride: int, output_data_fo
                                       history_width=30 if model_type == 'groundlink' else 0)   # root_history_len = 10
     path = os.path.abspath(os.path.join(args.dataset_home, split))
     try:
-        import nimblephysics  # noqa: F401
+        from ..data.AddBiomechanicsDataset import _nimble
+        _nimble()
     except ImportError:
         raise SystemExit(f"Reading {path} needs the `nimblephysics` .b3d loader, which is not installed. "
                          f"Pass --synthetic-windows N to run the hot path on seeded synthetic windows.")
-    raise SystemExit("The .b3d window loader is not part of this build yet (SURVEY.md §8f rank 2); "
-                     "use --synthetic-windows N.")
+    # the reference call (train.py:141-148, analyze.py:82-88, visualize.py:94-101)
+    dataset = AddBiomechanicsDataset(path, history_len, geometry, device=torch.device('cpu'), stride=stride,
+                                     output_data_format=output_data_format,
+                                     testing_with_short_dataset=bool(getattr(args, 'short', False)),
+                                     skip_loading_skeletons=not getattr(args, 'compute_report', False)
+                                     and getattr(args, 'command', 'train') == 'train')
+    if is_diffusion(model_type):
+        return MotionWindowView(dataset)
+    return dataset
 
 
 def pick_device(args) -> torch.device:

@@ -60,7 +60,7 @@ class AnalyzeCommand(AbstractCommand):
                 model.eval()
             evaluator = RegressionLossEvaluator(dataset=dataset, split=split, device=device)
             loader = DataLoader(dataset, batch_size=1, shuffle=False, num_workers=args.data_loading_workers)
-            compute_report = hasattr(dataset, 'skeletons')       # inverse dynamics needs nimble skeletons
+            compute_report = bool(getattr(dataset, 'skeletons', None))   # inverse dynamics needs nimble skeletons
             n = len(loader)
             with torch.no_grad(), open(os.path.join(checkpoint_dir, csv_name), 'a') as f:
                 writer = None

@@ -133,7 +133,7 @@ class TrainCommand(AbstractCommand):
                                activation=args.activation, batchnorm=args.batchnorm, dropout=args.dropout,
                                dropout_prob=args.dropout_prob, root_history_len=10,
                                output_data_format=args.output_data_format, device=device, compute_dtype=dtype_of(args),
-                               feat_dim=args.feat_dim, window=window).to(device)
+                               feat_dim=getattr(train_dataset, 'feat', args.feat_dim), window=window).to(device)
         if not any(p.requires_grad for p in model.parameters()):
             print("No parameters to optimize. Skipping training loop.")
             return False
@@ -163,7 +163,7 @@ class TrainCommand(AbstractCommand):
             # (~10 min under RCCL), so no collective may span it; none of them can open a file that is still being written
             if not os.path.exists(args.window_cache) and rank == 0:
                 print(f"Packing {len(train_dataset)} training windows into {args.window_cache} ...")
-                PackedWindows.from_windows(train_dataset).save(args.window_cache)
+                PackedWindows.from_dataset(train_dataset, workers=args.data_loading_workers).save(args.window_cache)
             if distributed:
                 from ..data.WindowCache import wait_for_file
                 wait_for_file(args.window_cache, float(os.environ.get("IB_WINDOW_CACHE_WAIT_S", 6 * 3600)))

@@ -181,14 +181,15 @@ extern "C" int ib_fill_i64(int64_t* dst, int64_t value, int64_t n, ib_stream_t s
 
 // ---- on-device window cache (replaces AddBiomechanicsDataset.__getitem__ `:161-285` + the
 // DataLoader collate + the model's torch.concat `FeedForwardRegressionBaseline.py:97-108` for cached windows):
-// one packed fp32 row per window = [model input, frame-major F x 147 | labels, key-major: cop F x 6, force F x 6,
-// torque F x 6, wrench F x 12].  One launch gathers a batch of rows into the model's input tensor (compute dtype) and the
+// one packed fp32 row per window = [model input, frame-major F x 147 | labels, key-major: cop F' x 6, force F' x 6,
+// torque F' x 6, wrench F' x 12], every block zero-padded to 4 values so each starts on a 16-byte boundary of the row
+// ('last_frame' labels: 6 | 6 | 6 | 12 values in 8 | 8 | 8 | 12 slots).  One launch gathers a batch of rows into the model's input tensor (compute dtype) and the
 // four contiguous label tensors the loss kernel takes.
 namespace {
 struct GatherWin {
   const float* table; int64_t row_elems, rows; const int64_t* idx; int64_t B;
   void* x_out; int64_t x_elems, x_pad; int x_bf16;
-  float* lab[4]; int64_t lab_elems[4];
+  float* lab[4]; int64_t lab_elems[4], lab_pad[4];
 };
 __global__ __launch_bounds__(256) void gather_windows_kernel(GatherWin p) {
   const int64_t per = p.row_elems / 4;                     // float4 pieces per window row (row_elems % 4 == 0)
@@ -221,8 +222,19 @@ __global__ __launch_bounds__(256) void gather_windows_kernel(GatherWin p) {
       int64_t d = 4 * (q - xq);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        if (d < p.lab_elems[k]) { *reinterpret_cast<float4*>(p.lab[k] + b * p.lab_elems[k] + d) = v; break; }
-        d -= p.lab_elems[k];
+        if (d < p.lab_pad[k]) {
+          float* dst = p.lab[k] + b * p.lab_elems[k] + d;
+          if (p.lab_elems[k] == p.lab_pad[k]) {
+            *reinterpret_cast<float4*>(dst) = v;
+          } else {                       // a label block that is not a whole number of 16-byte pieces: element stores
+            const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+              if (d + c < p.lab_elems[k]) dst[c] = e[c];
+          }
+          break;
+        }
+        d -= p.lab_pad[k];
       }
     }
   }
@@ -238,9 +250,9 @@ extern "C" int ib_gather_windows(const float* table, int64_t row_elems, int64_t 
   int64_t total = x_pad;
   GatherWin p{};
   for (int k = 0; k < 4; ++k) {
-    if (!lab_out[k] || lab_elems[k] <= 0 || lab_elems[k] % 4 != 0 || (reinterpret_cast<uintptr_t>(lab_out[k]) % 16)) return IB_E_ARG;
-    p.lab[k] = lab_out[k]; p.lab_elems[k] = lab_elems[k];
-    total += lab_elems[k];
+    if (!lab_out[k] || lab_elems[k] <= 0 || (reinterpret_cast<uintptr_t>(lab_out[k]) % 16)) return IB_E_ARG;
+    p.lab[k] = lab_out[k]; p.lab_elems[k] = lab_elems[k]; p.lab_pad[k] = (lab_elems[k] + 3) / 4 * 4;
+    total += p.lab_pad[k];
   }
   if (total != row_elems || (reinterpret_cast<uintptr_t>(table) % 16) ||
       (reinterpret_cast<uintptr_t>(x_out) % (dtype_x == IB_BF16 ? 8 : 16)))

@@ -29,7 +29,7 @@ from typing import Dict, Iterable, Iterator, List, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
-from .AddBiomechanicsDataset import INPUT_KEY_ORDER, LOSS_KEY_ORDER, LOSS_KEY_WIDTHS
+from .AddBiomechanicsDataset import INPUT_KEY_ORDER, LOSS_KEY_ORDER, LOSS_KEY_WIDTHS, packed_row_layout
 
 MAGIC = b"IBWINDOWS1\n"
 HEADER_BYTES = 4096
@@ -47,6 +47,21 @@ def wait_for_file(path: str, timeout_s: float, poll_s: float = 2.0) -> None:
         time.sleep(poll_s)
 
 
+class _RowView(torch.utils.data.Dataset):
+    """index -> (packed row, subject, trial): lets DataLoader workers run `window_row`"""
+
+    def __init__(self, dataset, n: int, row_elems: int, widths):
+        self.dataset, self.n, self.row_elems, self.widths = dataset, n, row_elems, list(widths)
+
+    def __len__(self) -> int:
+        return self.n
+
+    def __getitem__(self, i: int):
+        row = np.empty(self.row_elems, dtype=np.float32)
+        s, t = self.dataset.window_row(i, row, self.widths)
+        return torch.from_numpy(row), s, t
+
+
 class PackedWindows:
     """N windows as one fp32 matrix ``rows[N, x_elems + y_elems]`` (+ subject / trial indices)."""
 
@@ -54,13 +69,11 @@ class PackedWindows:
                  subjects: Optional[np.ndarray] = None, trials: Optional[np.ndarray] = None):
         self.rows, self.frames, self.out_frames = rows, int(frames), int(out_frames)
         self.input_widths = [int(w) for w in input_widths]
-        self.x_elems = self.frames * sum(self.input_widths)
-        self.x_pad = (self.x_elems + 3) // 4 * 4          # 1470 values at the reference defaults -> 1472 (16-byte pieces)
-        self.label_elems = [self.out_frames * c for c in LOSS_KEY_WIDTHS]
-        if rows.ndim != 2 or rows.dtype != np.float32 or rows.shape[1] != self.x_pad + sum(self.label_elems):
-            raise ValueError("PackedWindows: rows must be float32 [N, x_pad + label elems]")
-        if any(e % 4 for e in self.label_elems):
-            raise ValueError("PackedWindows: every label segment must hold a multiple of 4 values (16-byte pieces)")
+        # 1470 input values at the reference defaults -> 1472; 'last_frame' labels 6 | 6 | 6 | 12 -> 8 | 8 | 8 | 12
+        self.x_elems, self.x_pad, self.label_elems, self.label_pad, row_elems = \
+            packed_row_layout(self.frames, self.out_frames, self.input_widths)
+        if rows.ndim != 2 or rows.dtype != np.float32 or rows.shape[1] != row_elems:
+            raise ValueError("PackedWindows: rows must be float32 [N, x_pad + padded label elems]")
         n = rows.shape[0]
         self.subjects = np.zeros(n, np.int32) if subjects is None else np.asarray(subjects, np.int32)
         self.trials = np.zeros(n, np.int32) if trials is None else np.asarray(trials, np.int32)
@@ -73,11 +86,10 @@ class PackedWindows:
     def row_of(inputs: Dict[str, torch.Tensor], labels: Dict[str, torch.Tensor]) -> np.ndarray:
         """one window -> its packed row: inputs concatenated per frame in the model's key order
         (FeedForwardRegressionBaseline.py:97-107), labels key-major in the loss order"""
+        pad4 = lambda v: torch.cat([v, torch.zeros((-v.numel()) % 4, dtype=torch.float32)])
         x = torch.cat([inputs[k].to(torch.float32).reshape(inputs[k].shape[0], -1) for k in INPUT_KEY_ORDER], dim=-1)
-        y = [labels[k].to(torch.float32).reshape(-1) for k in LOSS_KEY_ORDER]
-        x = x.reshape(-1)
-        pad = torch.zeros((-x.numel()) % 4, dtype=torch.float32)
-        return torch.cat([x, pad] + y).numpy()
+        y = [pad4(labels[k].to(torch.float32).reshape(-1)) for k in LOSS_KEY_ORDER]
+        return torch.cat([pad4(x.reshape(-1))] + y).numpy()
 
     @classmethod
     def from_windows(cls, windows: Iterable[Tuple], limit: Optional[int] = None) -> "PackedWindows":
@@ -104,6 +116,30 @@ class PackedWindows:
         return cls(np.stack(rows).astype(np.float32, copy=False), geo[0], geo[1], geo[2], subj, trial)
 
     @classmethod
+    def from_dataset(cls, dataset, limit: Optional[int] = None, workers: int = 0, chunk: int = 256) -> "PackedWindows":
+        """Pack a window data set.  A loader that can write packed rows itself (`AddBiomechanicsDataset.window_row`)
+        fills the row matrix in place -- no per-window tensor dicts, no collate; `workers` > 0 spreads the reads over
+        DataLoader worker processes (each re-opens its `.b3d` handles).  Anything else goes through `from_windows`."""
+        if not hasattr(dataset, "window_row"):
+            return cls.from_windows(dataset, limit)
+        n = len(dataset) if limit is None else min(int(limit), len(dataset))
+        frames, out_frames, widths = dataset.row_geometry()
+        rows = np.empty((n, packed_row_layout(frames, out_frames, widths)[4]), dtype=np.float32)
+        subj, trial = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        if workers <= 0:
+            for i in range(n):
+                subj[i], trial[i] = dataset.window_row(i, rows[i], widths)
+        else:
+            view = _RowView(dataset, n, rows.shape[1], widths)
+            loader = torch.utils.data.DataLoader(view, batch_size=chunk, shuffle=False, num_workers=workers)
+            a = 0
+            for r, s, t in loader:
+                b = a + r.shape[0]
+                rows[a:b], subj[a:b], trial[a:b] = r.numpy(), s.numpy(), t.numpy()
+                a = b
+        return cls(rows, frames, out_frames, widths, subj, trial)
+
+    @classmethod
     def from_pickled_blocks(cls, paths: Sequence[str]) -> "PackedWindows":
         """the reference's `pickle-data` blocks: each file is torch.save(list of window tuples)"""
         packs = [cls.from_windows(torch.load(p, map_location="cpu", weights_only=False)) for p in paths]
@@ -123,9 +159,9 @@ class PackedWindows:
             inputs[k] = x[:, off:off + w].clone()
             off += w
         labels, off = {}, self.x_pad
-        for k, c, e in zip(LOSS_KEY_ORDER, LOSS_KEY_WIDTHS, self.label_elems):
+        for k, c, e, ep in zip(LOSS_KEY_ORDER, LOSS_KEY_WIDTHS, self.label_elems, self.label_pad):
             labels[k] = r[off:off + e].reshape(self.out_frames, c).clone()
-            off += e
+            off += ep
         return inputs, labels, int(self.subjects[i]), int(self.trials[i])
 
     # ---- file format ------------------------------------------------------------------------------------------

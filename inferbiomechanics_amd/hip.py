@@ -1323,7 +1323,7 @@ def gather_windows(table, idx, x_out, labels):
         if t.shape[0] != B or not t.is_contiguous():
             raise HipError("gather_windows: labels must be contiguous fp32 [B, ...]")
         le.append(t.numel() // B)
-    if len(labels) != 4 or (x_out.shape[1] + 3) // 4 * 4 + sum(le) != row_elems:
+    if len(labels) != 4 or (x_out.shape[1] + 3) // 4 * 4 + sum((e + 3) // 4 * 4 for e in le) != row_elems:
         raise HipError("gather_windows: x_out + labels do not add up to the packed row")
     lp = (ctypes.c_void_p * 4)(*[t.data_ptr() for t in labels])
     ln = (ctypes.c_int64 * 4)(*le)

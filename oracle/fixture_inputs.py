@@ -91,3 +91,13 @@ def ff_opt_state(shapes, seed0=21.0):
         else:
             new[k] = det_fill(shp, seed0 + i, 0.05)
     return new
+
+
+# window-loader fixture (tests/golden/loader_windows.npz): (name, window_size, stride, output_data_format, dtype)
+LOADER_CASES = [("w50s5_all", 50, 5, "all_frames", "float32"), ("w50s5_last", 50, 5, "last_frame", "float32"),
+                ("w10s1_all", 10, 1, "all_frames", "float32"), ("w20s3_all_f64", 20, 3, "all_frames", "float64")]
+
+
+def loader_sample(n):
+    """indices of the windows stored whole: a spread over the index (all three subjects, first and last window)"""
+    return sorted({int(round(j * (n - 1) / 5)) for j in range(6)})

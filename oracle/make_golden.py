@@ -332,19 +332,81 @@ def gen_optim():
     print("optim ok")
 
 
+def gen_loader():
+    """the REAL reference window loader (src/data/AddBiomechanicsDataset.py:63-139 index, :161-285 __getitem__,
+    :287-303 worker re-open) over oracle/fake_nimble.py's closed-form subjects: window index, contact-body order,
+    `--short` slice and a spread of whole windows (10 input + 7 label tensors) per case"""
+    import tempfile
+    from oracle import fake_nimble
+    from oracle.fixture_inputs import LOADER_CASES, loader_sample
+    import data.AddBiomechanicsDataset as refds          # already imported (with the MagicMock) by the model modules
+    refds.nimble = fake_nimble                           # the module-level name every nimble call goes through
+    d = {"meta_torch": np.array(torch.__version__)}
+    with tempfile.TemporaryDirectory() as tmp:
+        root = os.path.join(tmp, "train")
+        paths = fake_nimble.make_tree(root)
+        for name, window, stride, fmt, dt in LOADER_CASES:
+            ds = refds.AddBiomechanicsDataset(root, window, None, dtype=getattr(torch, dt), stride=stride,
+                                              output_data_format=fmt, skip_loading_skeletons=(name != LOADER_CASES[0][0]))
+            assert ds.subject_paths == paths
+            d[f"{name}/windows"] = np.array(ds.windows, dtype=np.int64).reshape(-1, 3)
+            d[f"{name}/contact_bodies"] = np.array(ds.contact_bodies)
+            d[f"{name}/num_dofs"] = np.array(ds.num_dofs)
+            for i in loader_sample(len(ds)):
+                inputs, labels, subj, trial = ds[i]
+                d[f"{name}/{i}/meta"] = np.array([subj, trial])
+                for k, v in inputs.items():
+                    d[f"{name}/{i}/in/{k}"] = np_(v)
+                for k, v in labels.items():
+                    d[f"{name}/{i}/lab/{k}"] = np_(v)
+            print("loader", name, len(ds), "windows")
+        # a single-file data path, and the --short slice over a 13-subject tree
+        one = refds.AddBiomechanicsDataset(paths[1], 50, None, stride=5, output_data_format="all_frames",
+                                           skip_loading_skeletons=True)
+        d["single/windows"] = np.array(one.windows, dtype=np.int64).reshape(-1, 3)
+        d["single/contact_bodies"] = np.array(one.contact_bodies)
+        inputs, labels, _, _ = one[7]
+        d["single/7/force"] = np_(labels[K_FORCE])
+        d["single/7/wrench"] = np_(labels[K_WRENCH])
+        root2 = os.path.join(tmp, "short")
+        names = ["alpha"] + [f"tiny{j:02d}" for j in range(12)]
+        paths2 = fake_nimble.make_tree(root2, names)
+        short = refds.AddBiomechanicsDataset(root2, 50, None, stride=5, output_data_format="last_frame",
+                                             testing_with_short_dataset=True, skip_loading_skeletons=True)
+        assert short.subject_paths == paths2[11:12]
+        d["short/windows"] = np.array(short.windows, dtype=np.int64).reshape(-1, 3)
+        d["short/subject"] = np.array(os.path.basename(short.subject_paths[0]))
+    np.savez_compressed(os.path.join(OUT, "loader_windows.npz"), **d)
+    print("loader ok")
+
+
 def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", nargs="*", default=None, help="stages to regenerate (default: all)")
+    only = ap.parse_args().only
+    want = lambda stage: only is None or stage in only
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     torch.set_num_threads(4)
     FF, TL, RLE = import_reference()
-    gen_feedforward(FF, RLE)
-    gen_feedforward_options(FF, RLE)
-    gen_transformer_layer(TL)
-    gen_transformer_layer_dropout(TL)
-    gen_groundlink(RLE)
-    gen_loss(RLE)
-    gen_checkpoint_analyze(FF, RLE)
-    gen_optim()
+    if want("feedforward"):
+        gen_feedforward(FF, RLE)
+    if want("feedforward_options"):
+        gen_feedforward_options(FF, RLE)
+    if want("transformer_layer"):
+        gen_transformer_layer(TL)
+    if want("transformer_layer_dropout"):
+        gen_transformer_layer_dropout(TL)
+    if want("groundlink"):
+        gen_groundlink(RLE)
+    if want("loss"):
+        gen_loss(RLE)
+    if want("checkpoint_analyze"):
+        gen_checkpoint_analyze(FF, RLE)
+    if want("optim"):
+        gen_optim()
+    if want("loader"):
+        gen_loader()
 
 
 if __name__ == "__main__":
