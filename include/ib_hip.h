@@ -273,6 +273,22 @@ int ib_q_sample(const void* x0, const void* eps, const int64_t* t, const float* 
 int ib_ddim_step(void* x, const void* eps, const float* coef, const int64_t* timesteps,
                  int64_t num_steps, int32_t step, const int32_t* step_dev, int64_t* t_out, int64_t B,
                  int64_t n, int dtype, ib_stream_t stream);
+/* The diffusion batch made on the device (csrc/noise.hip; replaces host torch.randint / torch.randn + H2D copies in the
+ * training loop, cli/train.py -- the reference has no diffusion path).  For window b < B:
+ *   x0_out[b, :per] = table[idx[b], :per]           (table NULL: x0 untouched; row_pitch % 8 == 0, row_pitch >= per)
+ *   t_out[b]        = floor(word0(b) * num_train_steps / 2^32)                          (t_out NULL: not drawn)
+ *   eps_out[b, :]   = N(0,1) by Box-Muller over Philox4x32-10 words                       (eps_out NULL: not drawn)
+ * Philox counter = (block, step + *step_dev, stream_id, domain), key = seed; element e of the [B, per] batch uses block
+ * e / 4, domain 0; timesteps use block b, domain 1.  Words and timesteps are bit-exact against oracle/ref_cpu.py
+ * (philox4x32, draw_timesteps); the normals use hardware log2 / sin / cos (compared at 2e-5 absolute).  step_dev (device
+ * int32, may be NULL) lets a replayed hipGraph draw fresh numbers every step.  dtype = storage type of table / x0 / eps. */
+int ib_diffusion_draw(const void* table, int64_t table_rows, int64_t row_pitch, const int64_t* idx, void* x0_out,
+                      void* eps_out, int64_t* t_out, int64_t B, int64_t per, int32_t num_train_steps, uint64_t seed,
+                      int32_t step, const int32_t* step_dev, uint32_t stream_id, int dtype, ib_stream_t stream);
+/* out[4 * i .. 4 * i + 3] = Philox4x32-10 words of counter (i, step, stream_id, domain), key = seed, i < blocks: the raw
+ * stream behind ib_diffusion_draw (parity tests; bit-exact against oracle/ref_cpu.py::draw_words). */
+int ib_philox_words(uint32_t* out, int64_t blocks, uint64_t seed, uint32_t step, uint32_t stream_id, uint32_t domain,
+                    ib_stream_t stream);
 /* on-device window cache: table = packed fp32 rows [rows, row_elems], one per window:
  * [model input (x_elems, frame-major) | labels key-major: cop, force, torque, wrench], every block zero-padded to a
  * multiple of 4 values (row_elems = pad4(x_elems) + sum pad4(lab_elems[k])); gathers idx[B] rows into the

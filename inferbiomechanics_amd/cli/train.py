@@ -15,6 +15,7 @@ type, `git_hash` storing the function object; wandb is optional.
 import argparse
 import logging
 import os
+import time
 from datetime import timedelta
 from typing import Dict, List
 
@@ -34,6 +35,8 @@ DEV = 'dev'   # the dev split directory (analyze.py:80); the reference train.py 
 
 
 class TrainCommand(AbstractCommand):
+    last_run_stats = None        # {"epoch", "steps", "seconds", "windows_per_s"} of the last finished training epoch
+
     def __init__(self):
         super().__init__()
 
@@ -73,8 +76,17 @@ class TrainCommand(AbstractCommand):
         p.add_argument('--bucket-mb', type=float, default=13.0, help='Gradient all-reduce bucket size (MiB).')
         p.add_argument('--window-cache', type=str, default=None,
                        help='Packed-window file (data/WindowCache.py): loaded if it exists, else built from the training '
-                            'set and saved; the regression models then train from an on-device window cache (one '
-                            'gather launch per batch instead of the DataLoader pipeline).')
+                            'set and saved; training then runs from an on-device window cache (one gather launch per '
+                            'batch instead of the DataLoader pipeline).  Regression models: packed-window file '
+                            '(data/WindowCache.py); diffusion models: a .npy of [N, T, D] motion windows, and the '
+                            "step's timesteps / noise are drawn on the device by the same launch; the word `hbm` with "
+                            '--synthetic-windows draws the synthetic windows straight into HBM (no file).')
+        p.add_argument('--max-dev-steps', type=int, default=0,
+                       help='Evaluate at most this many dev batches before each epoch (0 = follow --max-steps).')
+        p.add_argument('--loss-every', type=int, default=1,
+                       help='[diffusion, --window-cache] keep the device-resident loss of every Nth step for the report.')
+        p.add_argument('--seed', type=int, default=None,
+                       help='torch.manual_seed for this run (initial weights, dropout masks, diffusion noise).')
 
     # ------------------------------------------------------------------------------------------
     def run(self, args: argparse.Namespace):
@@ -86,6 +98,8 @@ class TrainCommand(AbstractCommand):
         log_to_wandb: bool = not args.no_wandb
         diffusion = is_diffusion(model_type)
 
+        if getattr(args, 'seed', None) is not None:
+            torch.manual_seed(args.seed)
         geometry = self.ensure_geometry(args.geometry_folder)
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC for RCCL (before the first HIP call)
         device = pick_device(args)
@@ -156,31 +170,52 @@ class TrainCommand(AbstractCommand):
                                  args=args, use_graph=not args.no_graph, bucket_mb=args.bucket_mb)
 
         cache = None
-        if args.window_cache and trainer is not None and not diffusion:
-            from ..data.WindowCache import DeviceWindowCache, PackedWindows
+        if args.window_cache and trainer is not None:
+            from ..data.WindowCache import DeviceMotionCache, DeviceWindowCache, PackedWindows, wait_for_file
             # rank 0 packs and writes (atomically: temporary file + rename); the other ranks POLL for the finished file and
             # only then enter the barrier -- packing a full training set can outlast the process group's collective timeout
             # (~10 min under RCCL), so no collective may span it; none of them can open a file that is still being written
-            if not os.path.exists(args.window_cache) and rank == 0:
+            in_hbm = diffusion and args.window_cache == 'hbm' and getattr(args, 'synthetic_windows', 0) > 0
+            if in_hbm:
+                pass                  # synthetic windows are drawn straight into HBM below: no file, no host pass
+            elif not os.path.exists(args.window_cache) and rank == 0:
                 print(f"Packing {len(train_dataset)} training windows into {args.window_cache} ...")
-                PackedWindows.from_dataset(train_dataset, workers=args.data_loading_workers).save(args.window_cache)
-            if distributed:
-                from ..data.WindowCache import wait_for_file
+                if diffusion:
+                    save_motion_windows(train_dataset, args.window_cache)
+                else:
+                    PackedWindows.from_dataset(train_dataset, workers=args.data_loading_workers).save(args.window_cache)
+            if distributed and not in_hbm:
                 wait_for_file(args.window_cache, float(os.environ.get("IB_WINDOW_CACHE_WAIT_S", 6 * 3600)))
                 dist.barrier()
-            pack = PackedWindows.load(args.window_cache)
-            cache = DeviceWindowCache(pack, device)
-            print(f"[rank={rank}] window cache: {len(cache)} windows, {cache.table.numel() * 4 / 2**20:.1f} MiB in HBM")
+            if in_hbm:
+                cache = DeviceMotionCache.synthetic(len(train_dataset), window, train_dataset.feat, device,
+                                                    model.compute_dtype, seed=0)
+            elif diffusion:
+                import numpy as np
+                cache = DeviceMotionCache(torch.from_numpy(np.load(args.window_cache, mmap_mode='r')), device,
+                                          model.compute_dtype)
+            else:
+                cache = DeviceWindowCache(PackedWindows.load(args.window_cache), device)
+            print(f"[rank={rank}] window cache: {len(cache)} windows, "
+                  f"{cache.table.numel() * cache.table.element_size() / 2**20:.1f} MiB in HBM")
 
         epoch_checkpoint, _ = self.load_latest_checkpoint(model, optimizer=trainer if trainer is not None else optimizer,
                                                           checkpoint_dir=checkpoint_dir)
-        gen = torch.Generator().manual_seed(1234 + rank)
+        from .. import hip
+        noise_seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
+        draws = [0]
 
-        def diffusion_batch(x0):
-            B = x0.shape[0]
-            t = torch.randint(0, model.num_train_steps, (B,), generator=gen, dtype=torch.int64)
-            eps = torch.randn(x0.shape, generator=gen)
-            return x0, t, eps
+        def device_batch(x0, stream_id):
+            """x0 [B, T, D] (host or device) -> (x0, t, eps) on the device in the model's dtype; t / eps from the
+            counter-based generator (csrc/noise.hip): the dev-set evaluation and the --eager loop draw like the fused
+            trainer does, nothing random is made on the host"""
+            xd = x0.to(device, model.compute_dtype).contiguous()
+            ed = torch.empty_like(xd)
+            td = torch.empty(xd.shape[0], dtype=torch.int64, device=device)
+            hip.diffusion_draw(noise_seed, step=draws[0], stream_id=stream_id, eps=ed, t=td,
+                               num_train_steps=model.num_train_steps)
+            draws[0] += 1
+            return xd, td, ed
 
         adopted = False
         for epoch in range(epoch_checkpoint + 1, args.epochs):
@@ -191,18 +226,16 @@ class TrainCommand(AbstractCommand):
                 model.eval()
                 for i, batch in enumerate(dev_dataloader):
                     if diffusion:
-                        x0, t, eps = diffusion_batch(batch)
+                        draws[0] = i                     # the dev set sees the same noise before every epoch
+                        xd, td, ed = device_batch(batch, 0x80000000 | rank)
                         tabs = model.tables(device)
-                        from .. import hip
-                        xd = x0.to(device, model.compute_dtype)
-                        ed = eps.to(device, model.compute_dtype)
                         xt = torch.empty_like(xd)
-                        hip.q_sample(xd, ed, t.to(device), tabs.sqrt_ab, tabs.sqrt_1mab, xt)
-                        dev_eval(model(xt, t), ed)
+                        hip.q_sample(xd, ed, td, tabs.sqrt_ab, tabs.sqrt_1mab, xt)
+                        dev_eval(model(xt, td), ed)
                     else:
                         inputs, labels, subj, trial = batch
                         dev_eval(inputs, model(inputs), labels, subj, trial, args, compute_report=args.compute_report)
-                    if args.max_steps and i + 1 >= args.max_steps:
+                    if (args.max_dev_steps or args.max_steps) and i + 1 >= (args.max_dev_steps or args.max_steps):
                         break
                 print(f'[rank={rank}] Dev Set Evaluation: ')
                 dev_eval.print_report(args, log_to_wandb=log_to_wandb) if not diffusion else dev_eval.print_report()
@@ -218,24 +251,27 @@ class TrainCommand(AbstractCommand):
             else:
                 train_batches = train_dataloader
             n_batches = len(train_batches)
+            t_epoch, steps_epoch = time.perf_counter(), 0
             for i, batch in enumerate(train_batches):
-                if cache is not None:
+                steps_epoch += 1
+                if cache is not None and diffusion:
+                    loss = trainer.step_drawn(cache, batch)           # gather + draw + fused step: all on the device
+                    if (i + 1) % args.loss_every == 0:
+                        train_eval.losses.append(loss.detach().clone())
+                elif cache is not None:
                     trainer.step_windows(cache, batch)
                     train_eval.record_result(trainer.result)
                 elif diffusion:
-                    x0, t, eps = diffusion_batch(batch)
                     if trainer is not None:
-                        loss = trainer.step((x0.to(device, non_blocking=True), t.to(device, non_blocking=True),
-                                             eps.to(device, non_blocking=True)))
+                        loss = trainer.step_x0(batch.to(device, non_blocking=True))
                         train_eval.losses.append(loss.detach().clone())
                     else:
-                        from .. import hip
                         optimizer.zero_grad()
                         tabs = model.tables(device)
-                        xd, ed = x0.to(device, model.compute_dtype), eps.to(device, model.compute_dtype)
+                        xd, td, ed = device_batch(batch, rank)
                         xt = torch.empty_like(xd)
-                        hip.q_sample(xd, ed, t.to(device), tabs.sqrt_ab, tabs.sqrt_1mab, xt)
-                        loss = train_eval(ddp_model(xt, t), ed)
+                        hip.q_sample(xd, ed, td, tabs.sqrt_ab, tabs.sqrt_1mab, xt)
+                        loss = train_eval(ddp_model(xt, td), ed)
                         loss.backward()
                         optimizer.step()
                 else:
@@ -259,6 +295,13 @@ class TrainCommand(AbstractCommand):
                         save_checkpoint(checkpoint_dir, epoch, i, model, trainer if trainer is not None else optimizer)
                 if last:
                     break
+            if device.type == 'cuda':
+                torch.cuda.synchronize(device)
+            dt_epoch = time.perf_counter() - t_epoch
+            TrainCommand.last_run_stats = {"epoch": epoch, "steps": steps_epoch, "seconds": dt_epoch,
+                                           "windows_per_s": steps_epoch * args.batch_size * world_size / max(dt_epoch, 1e-9)}
+            print(f"[rank={rank}] epoch {epoch}: {steps_epoch} steps in {dt_epoch:.3f} s = "
+                  f"{self.last_run_stats['windows_per_s']:.0f} windows/s (all ranks, reports and checkpoints included)")
             logging.info('-' * 80)
             logging.info(f'[rank={rank}] Epoch {epoch}/{args.epochs} Training Set Evaluation: ')
             train_eval.print_report(args, log_to_wandb=log_to_wandb) if not diffusion else train_eval.print_report()
@@ -269,6 +312,21 @@ class TrainCommand(AbstractCommand):
         if distributed:
             dist.destroy_process_group()
         return True
+
+
+def save_motion_windows(dataset, path: str, chunk: int = 4096):
+    """the [N, T, D] motion windows of a data set as one float32 .npy (written under a temporary name, then renamed)"""
+    import numpy as np
+    n = len(dataset)
+    first = dataset[0]
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    tmp = f"{path}.tmp.{os.getpid()}.npy"
+    out = np.lib.format.open_memmap(tmp, mode='w+', dtype=np.float32, shape=(n,) + tuple(first.shape))
+    for i in range(n):
+        out[i] = dataset[i].to(torch.float32).numpy()
+    out.flush()
+    del out
+    os.replace(tmp, path)
 
 
 def make_torch_optimizer(opt_type: str, params, lr: float):

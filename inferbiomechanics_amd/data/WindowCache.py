@@ -206,6 +206,82 @@ class PackedWindows:
         return cls(rows, hdr["frames"], hdr["out_frames"], hdr["input_widths"], tail[:n], tail[n:])
 
 
+def sharded_batches(n: int, device, batch_size: int, rank: int = 0, world: int = 1, drop_last: bool = True,
+                    shuffle_seed: Optional[int] = None) -> Iterator[torch.Tensor]:
+    """int64 index tensors ON THE DEVICE.  Sharding = DistributedSampler(shuffle=False, drop_last=True) as the reference
+    constructs it (train.py:143,149): rank r owns windows r, r + world, ...; `shuffle_seed` permutes the rank's share per
+    epoch (the reference never shuffles)."""
+    per = n // world if drop_last else (n + world - 1) // world
+    own = torch.arange(rank, rank + per * world, world, dtype=torch.int64) % n
+    if shuffle_seed is not None:
+        own = own[torch.randperm(per, generator=torch.Generator().manual_seed(shuffle_seed))]
+    own = own.to(device)
+    stop = per - per % batch_size if drop_last else per
+    for a in range(0, stop, batch_size):
+        yield own[a:a + batch_size]
+
+
+class DeviceMotionCache:
+    """[BUILD-DEFINED] motion windows ``[N, T, D]`` for the diffusion denoisers, resident in HBM in the model's compute
+    dtype (bf16: 30 KB per 50 x 300 window, 9.6 M windows per 288 GB); rows pitched to 8 values so every window starts
+    on a 16-byte boundary.  `HipTrainer.step_drawn(cache, idx)` gathers a batch out of it and draws that step's timesteps
+    and noise in the same launch (`ib_diffusion_draw`): the training loop touches no host tensor."""
+
+    @classmethod
+    def synthetic(cls, num_windows: int, window: int, feat: int, device, dtype: torch.dtype = torch.bfloat16,
+                  seed: int = 0) -> "DeviceMotionCache":
+        """x0 ~ N(0,1) synthetic windows drawn straight into HBM by the counter-based generator
+        (csrc/noise.hip) -- a million 50 x 300 windows (30 GB of bf16) in milliseconds, nothing staged through the host"""
+        from .. import hip
+        self = cls.__new__(cls)
+        self.device = torch.device(device)
+        self.window, self.feat = int(window), int(feat)
+        per = self.window * self.feat
+        self.pitch = (per + 7) // 8 * 8
+        self.table = torch.zeros((int(num_windows), self.pitch), dtype=dtype, device=self.device)
+        rows = max(1, (1 << 31) // self.pitch)               # a draw call addresses < 2^32 four-value blocks
+        for a in range(0, int(num_windows), rows):
+            part = self.table[a:a + rows]
+            hip.diffusion_draw(seed, step=a // rows, stream_id=0x20000000, eps=part)
+        if self.pitch != per:
+            self.table[:, per:].zero_()
+        return self
+
+    def __init__(self, windows, device, dtype: torch.dtype = torch.bfloat16, chunk_windows: int = 2048):
+        self.device = torch.device(device)
+        n = len(windows)
+        if n == 0:
+            raise ValueError("DeviceMotionCache: no windows")
+        first = windows[0]
+        if first.dim() != 2:
+            raise ValueError("DeviceMotionCache: every window must be a [T, D] matrix")
+        self.window, self.feat = int(first.shape[0]), int(first.shape[1])
+        per = self.window * self.feat
+        self.pitch = (per + 7) // 8 * 8
+        self.table = torch.zeros((n, self.pitch), dtype=dtype, device=self.device)
+        pin = self.device.type == "cuda"
+        stage = torch.zeros((min(chunk_windows, n), per), dtype=torch.float32, pin_memory=pin)
+        for a in range(0, n, stage.shape[0]):
+            b = min(n, a + stage.shape[0])
+            if isinstance(windows, torch.Tensor):
+                stage[:b - a].copy_(windows[a:b].reshape(b - a, per))
+            else:
+                for i in range(a, b):
+                    w = windows[i]
+                    if tuple(w.shape) != (self.window, self.feat):
+                        raise ValueError(f"DeviceMotionCache: window {i} is {tuple(w.shape)}, expected "
+                                         f"{(self.window, self.feat)}")
+                    stage[i - a].copy_(w.reshape(per))
+            self.table[a:b, :per].copy_(stage[:b - a])      # fp32 -> compute dtype on the device (one rounding)
+
+    def __len__(self) -> int:
+        return self.table.shape[0]
+
+    def batches(self, batch_size: int, rank: int = 0, world: int = 1, drop_last: bool = True,
+                shuffle_seed: Optional[int] = None) -> Iterator[torch.Tensor]:
+        return sharded_batches(len(self), self.device, batch_size, rank, world, drop_last, shuffle_seed)
+
+
 class DeviceWindowCache:
     """The packed rows resident in HBM (fp32: 12.7 KB per window at the reference defaults, i.e. 22 M windows per
     288 GB) + per-rank batch index generation.  Upload goes through one pinned staging buffer, `chunk_windows` rows at
@@ -232,15 +308,7 @@ class DeviceWindowCache:
         """int64 index tensors ON THE DEVICE.  Sharding = DistributedSampler(shuffle=False, drop_last=True) as the
         reference constructs it (train.py:143,149): rank r owns windows r, r + world, ...; `shuffle_seed` permutes the
         rank's share per epoch (the reference never shuffles)."""
-        n = len(self)
-        per = n // world if drop_last else (n + world - 1) // world
-        own = torch.arange(rank, rank + per * world, world, dtype=torch.int64) % n
-        if shuffle_seed is not None:
-            own = own[torch.randperm(per, generator=torch.Generator().manual_seed(shuffle_seed))]
-        own = own.to(self.device)
-        stop = per - per % batch_size if drop_last else per
-        for a in range(0, stop, batch_size):
-            yield own[a:a + batch_size]
+        return sharded_batches(len(self), self.device, batch_size, rank, world, drop_last, shuffle_seed)
 
     def label_shapes(self, B: int) -> List[Tuple[int, int, int]]:
         return [(B, self.out_frames, c) for c in LOSS_KEY_WIDTHS]

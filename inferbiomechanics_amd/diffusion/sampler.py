@@ -52,6 +52,18 @@ class DDIMSampler:
         cur.wait_stream(self._stream)
         return out
 
+    @torch.no_grad()
+    def sample_noise(self, batch: int, window: int, feat: int, seed: Optional[int] = None, draw: int = 0,
+                     steps: Optional[int] = None) -> torch.Tensor:
+        """x_T ~ N(0,1) drawn ON the device (csrc/noise.hip: Philox keyed by (seed, draw); `seed` defaults to torch's) and
+        denoised to x_0 -- no host random numbers, no H2D copy of the start state."""
+        m = self.model
+        dev = next(m.parameters()).device
+        x_T = torch.empty((batch, window, feat), dtype=m.compute_dtype, device=dev)
+        seed = int(torch.initial_seed()) if seed is None else int(seed)
+        hip.diffusion_draw(seed, step=int(draw), stream_id=0x40000000, eps=x_T)
+        return self.sample(x_T, steps)
+
     def _sample(self, x_T: torch.Tensor, steps: Optional[int] = None) -> torch.Tensor:
         m = self.model
         m.ensure_packed()

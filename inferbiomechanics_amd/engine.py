@@ -276,6 +276,10 @@ class HipTrainer:
         self.stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         from .plans import Branch
         self._br_loss = Branch(dev, enabled=not self.overlap_comm, name="loss")
+        # device-side batch draw (step_drawn): Philox key = torch's seed (torch.manual_seed(s) selects the noise as it would
+        # for torch.randn), stream = data-parallel rank (ranks must not draw the same noise), step = the device counter
+        self.noise_seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
+        self.noise_stream = dist.get_rank(group) if (dist.is_available() and dist.is_initialized()) else 0
         self._static: Dict[str, torch.Tensor] = {}
         self._rec: Optional[_Recorder] = None
         self._sig = None
@@ -356,6 +360,14 @@ class HipTrainer:
             tabs = m.tables(self.device)
             B, T, D = x0.shape
             M = B * T
+            if "draw" in st:
+                # the batch is made on the device by ONE launch: x0 gathered out of the HBM window table (or already staged),
+                # t and eps drawn from the counter-based generator keyed by the device-resident step counter -- a replayed
+                # graph draws fresh numbers every step
+                mc = self._mcache if "widx" in st else None
+                hip.diffusion_draw(self.noise_seed, step_dev=self.step_dev, stream_id=self.noise_stream, eps=eps, t=t,
+                                   num_train_steps=m.num_train_steps, table=None if mc is None else mc.table,
+                                   idx=st.get("widx"), x0=x0 if mc is not None else None)
             if hasattr(plan, "chain_ok") and plan.chain_ok(D):
                 plan.fuse_reduce_into_optimizer = not self.ddp and not os.environ.get("IB_NO_OPT_FUSE")
                 # MLP denoiser, bf16: q_sample + forward + loss + the dgrad chain are ONE launch (csrc/chain.hip)
@@ -441,7 +453,31 @@ class HipTrainer:
         """copy the batch into the static input buffers the (captured) launch sequence reads"""
         dt = self.model.compute_dtype
         st: Dict[str, torch.Tensor] = {}
-        if self.task == "diffusion":
+        if self.task == "diffusion" and isinstance(batch[0], str):
+            # ("motion", cache, idx): x0 from the HBM window table; ("draw", x0): x0 from the caller -- t / eps drawn on the
+            # device in both.  The launch sequence reads the trainer's own static buffers (fixed addresses: the pointer
+            # slots of the chain path never change, so the step replays from a pinned graph without a pointer launch).
+            if batch[0] == "motion":
+                _, cache, idx = batch
+                if cache.table.dtype != dt:
+                    raise hip.HipError(f"motion cache holds {cache.table.dtype}, the model computes in {dt}")
+                if self._mcache is not cache:
+                    self._mcache, self._rec, self._sig = cache, None, None          # another table: re-capture
+                B, T, D = idx.numel(), cache.window, cache.feat
+                b = self._sbuf("widx", idx, torch.int64)
+                b.copy_(idx, non_blocking=True)
+                st["widx"] = b
+                st["x0"] = self._sbuf("x0", torch.empty((B, T, D), device="meta"), dt)
+            else:
+                x0 = batch[1]
+                st["x0"] = self._sbuf("x0", x0, dt)
+                st["x0"].copy_(x0, non_blocking=True)
+            st["eps"] = self._sbuf("eps", st["x0"], dt)
+            st["t"] = self._sbuf("t", torch.empty((st["x0"].shape[0],), device="meta"), torch.int64)
+            st["draw"] = st["t"]
+            self._srcs = [st["x0"], st["eps"], st["t"]]
+            self._last_drawn = (st["x0"], st["t"], st["eps"])
+        elif self.task == "diffusion":
             x0, t, eps = batch
             srcs = []
             for name, src, d in (("x0", x0, dt), ("eps", eps, dt), ("t", t, torch.int64)):
@@ -513,6 +549,30 @@ class HipTrainer:
         if self.task != "regression":
             raise hip.HipError("step_windows: the window cache feeds the regression models")
         return self.step(("windows", cache, idx))
+
+    _mcache = None
+    _last_drawn = None
+
+    def step_drawn(self, cache, idx: torch.Tensor) -> torch.Tensor:
+        """one fused diffusion step over windows `idx` (int64, on the device) of a `data.WindowCache.DeviceMotionCache`:
+        x0 is gathered and that step's timesteps / noise are drawn ON the device by one launch (`ib_diffusion_draw`) ahead
+        of the step -- no host random numbers, no H2D copy.  The draw is a pure function of (torch seed, completed steps,
+        rank, element), so a run is reproducible and ranks draw different noise."""
+        if self.task != "diffusion":
+            raise hip.HipError("step_drawn: the motion cache feeds the diffusion models")
+        return self.step(("motion", cache, idx))
+
+    def step_x0(self, x0: torch.Tensor) -> torch.Tensor:
+        """as step_drawn for windows the caller supplies (a DataLoader batch [B, T, D], host or device memory)"""
+        if self.task != "diffusion":
+            raise hip.HipError("step_x0: diffusion models only")
+        return self.step(("draw", x0))
+
+    def drawn_batch(self) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """(x0, t, eps) of the LAST step_drawn / step_x0 call, as the device left them (tests; dev-set evaluation)"""
+        if self._last_drawn is None:
+            raise hip.HipError("drawn_batch: no step_drawn / step_x0 call yet")
+        return self._last_drawn
 
     _srcs = None            # this step's {x0, eps, t} tensors behind the pointer slots (chain path), else None
     _cap_stream = None

@@ -95,6 +95,9 @@ _SIGS = {
     "ib_im2col_replicate": (_c.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _c.c_int, _c.c_int, _vp]),
     "ib_col2im_replicate": (_c.c_int, [_vp, _i64, _vp, _c.c_int, _vp, _i64, _i64, _i64, _c.c_int, _c.c_int, _vp]),
     "ib_dropout": (_c.c_int, [_vp, _vp, _i64, _f32, _c.c_uint32, _i32, _vp, _c.c_int, _vp]),
+    "ib_diffusion_draw": (_c.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _c.c_uint64, _i32, _vp,
+                                     _c.c_uint32, _c.c_int, _vp]),
+    "ib_philox_words": (_c.c_int, [_vp, _i64, _c.c_uint64, _c.c_uint32, _c.c_uint32, _c.c_uint32, _vp]),
     "ib_gather_windows": (_c.c_int, [_vp, _i64, _i64, _vp, _i64, _vp, _i64, _c.c_int, _vp, _vp, _vp]),
     "ib_gather_rows": (_c.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _c.c_int, _vp]),
     "ib_mlp_chain_supported": (_c.c_int, [_i64, _i64, _c.c_int]),
@@ -1330,6 +1333,52 @@ def gather_windows(table, idx, x_out, labels):
     _check(lib().ib_gather_windows(_ptr(table), row_elems, rows, _ptr(idx), B, _ptr(x_out), x_out.shape[1],
                                    dtype_code(x_out.dtype), ctypes.cast(lp, ctypes.c_void_p),
                                    ctypes.cast(ln, ctypes.c_void_p), stream_ptr()), "ib_gather_windows")
+
+
+def diffusion_draw(seed: int, step: int = 0, step_dev=None, stream_id: int = 0, eps=None, t=None, num_train_steps: int = 0,
+                   table=None, idx=None, x0=None):
+    """One launch that makes a diffusion batch on the device (csrc/noise.hip): `x0[b] = table[idx[b]]` (optional),
+    `t[b] ~ U{0..num_train_steps-1}` (optional), `eps ~ N(0,1)` (optional) from the counter-based Philox stream keyed by
+    (seed, step + *step_dev, stream_id).  eps / x0: contiguous [B, ...] in fp32 or bf16; table: [rows, pitch] with
+    pitch % 8 == 0; t: int64 [B]."""
+    ref = eps if eps is not None else x0
+    if ref is None:
+        if t is None:
+            raise HipError("diffusion_draw: nothing to draw")
+        B, per, code = t.numel(), 1, F32
+    else:
+        _req(ref, "eps/x0")
+        if not ref.is_contiguous() or ref.dim() < 2:
+            raise HipError("diffusion_draw: eps / x0 must be contiguous [B, ...]")
+        B, per, code = ref.shape[0], ref.numel() // ref.shape[0], dtype_code(ref.dtype)
+    if eps is not None and x0 is not None and (eps.shape != x0.shape or eps.dtype != x0.dtype or not x0.is_contiguous()):
+        raise HipError("diffusion_draw: x0 and eps must agree in shape / dtype")
+    rows = pitch = 0
+    if table is not None:
+        rows, pitch, _ = _mat(table, "table", x0.dtype if x0 is not None else None)
+        if x0 is None or idx is None or not table.is_contiguous() or pitch % 8 or pitch < per:
+            raise HipError("diffusion_draw: table needs x0 + idx, contiguous rows with pitch % 8 == 0 and pitch >= T * D")
+        _req(idx, "idx", torch.int64, 1)
+        if idx.numel() != B:
+            raise HipError("diffusion_draw: one index per window")
+    if t is not None:
+        _req(t, "t", torch.int64, 1)
+        if t.numel() != B or num_train_steps <= 0 or not t.is_contiguous():
+            raise HipError("diffusion_draw: t must be contiguous int64 [B] and num_train_steps > 0")
+    if step_dev is not None:
+        _req(step_dev, "step_dev", torch.int32)
+    _check(lib().ib_diffusion_draw(_ptr(table), rows, pitch, _ptr(idx), _ptr(x0), _ptr(eps), _ptr(t), B, per,
+                                   int(num_train_steps), int(seed) & 0xFFFFFFFFFFFFFFFF, int(step), _ptr(step_dev),
+                                   int(stream_id) & 0xFFFFFFFF, code, stream_ptr()), "ib_diffusion_draw")
+
+
+def philox_words(out, seed: int, step: int, stream_id: int, domain: int):
+    """out: int32 / uint32-viewed tensor of 4 * blocks words (16-byte aligned): the raw Philox4x32-10 stream"""
+    _req(out, "out", torch.int32, 1)
+    if out.numel() % 4 or not out.is_contiguous():
+        raise HipError("philox_words: out must hold whole 4-word blocks")
+    _check(lib().ib_philox_words(_ptr(out), out.numel() // 4, int(seed) & 0xFFFFFFFFFFFFFFFF, int(step) & 0xFFFFFFFF,
+                                 int(stream_id) & 0xFFFFFFFF, int(domain), stream_ptr()), "ib_philox_words")
 
 
 def q_sample(x0, eps, t, sqrt_ab, sqrt_1mab, x_t):

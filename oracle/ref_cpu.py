@@ -598,3 +598,65 @@ def ddim_sample(eps_fn, x_T: torch.Tensor, num_train_steps: int = 1000,
         ab_p = ab[ts[i + 1]] if i + 1 < len(ts) else torch.tensor(1.0, dtype=torch.float64)
         x = ddim_step(x, eps, ab[t].to(x.dtype), ab_p.to(x.dtype))
     return x
+
+
+# =====================================================================================================
+# [BUILD-DEFINED] counter-based noise for the diffusion training step (no reference counterpart: the reference has no
+# diffusion path).  Philox4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel Random Numbers: As Easy as
+# 1, 2, 3", SC'11; constants and known answers from the Random123 distribution's kat_vectors) -- pinned by those known
+# answers in tests/test_oracle_golden.py.  The kernel (csrc/diffusion.hip::diffusion_draw_kernel) must produce exactly
+# these 32-bit words and timestep indices; its normals are Box-Muller over the same words in float32 hardware
+# transcendentals and are compared with `philox_normals` within a stated tolerance.
+# =====================================================================================================
+PHILOX_M0, PHILOX_M1 = 0xD2511F53, 0xCD9E8D57
+PHILOX_W0, PHILOX_W1 = 0x9E3779B9, 0xBB67AE85
+DRAW_DOMAIN_EPS, DRAW_DOMAIN_T = 0, 1       # counter word 3: which quantity a block of words feeds
+
+
+def philox4x32(counter, key, rounds: int = 10):
+    """counter: uint32 array [..., 4]; key: (k0, k1).  Returns uint32 [..., 4]."""
+    import numpy as np
+    c = np.asarray(counter, dtype=np.uint64) & 0xFFFFFFFF
+    c0, c1, c2, c3 = (c[..., i].copy() for i in range(4))
+    k0, k1 = int(key[0]) & 0xFFFFFFFF, int(key[1]) & 0xFFFFFFFF
+    for _ in range(rounds):
+        p0 = PHILOX_M0 * c0                       # 64-bit products
+        p1 = PHILOX_M1 * c2
+        hi0, lo0 = p0 >> 32, p0 & 0xFFFFFFFF
+        hi1, lo1 = p1 >> 32, p1 & 0xFFFFFFFF
+        c0, c1, c2, c3 = hi1 ^ c1 ^ k0, lo1, hi0 ^ c3 ^ k1, lo0
+        k0 = (k0 + PHILOX_W0) & 0xFFFFFFFF
+        k1 = (k1 + PHILOX_W1) & 0xFFFFFFFF
+    return np.stack([c0, c1, c2, c3], axis=-1).astype(np.uint32)
+
+
+def draw_words(n_blocks: int, seed: int, step: int, stream: int, domain: int):
+    """words of blocks 0..n_blocks-1: counter = (block, step, stream, domain), key = (seed low, seed high)"""
+    import numpy as np
+    ctr = np.zeros((n_blocks, 4), dtype=np.uint64)
+    ctr[:, 0] = np.arange(n_blocks, dtype=np.uint64)
+    ctr[:, 1], ctr[:, 2], ctr[:, 3] = step & 0xFFFFFFFF, stream & 0xFFFFFFFF, domain
+    return philox4x32(ctr, (seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF))
+
+
+def draw_timesteps(B: int, num_train_steps: int, seed: int, step: int, stream: int):
+    """t[b] = floor(word0(block b) * num_train_steps / 2^32): uniform on {0 .. num_train_steps-1}; int64 [B].  Bit-exact
+    contract with the kernel."""
+    import numpy as np
+    w = draw_words(B, seed, step, stream, DRAW_DOMAIN_T)[:, 0].astype(np.uint64)
+    return torch.from_numpy(((w * np.uint64(num_train_steps)) >> np.uint64(32)).astype(np.int64))
+
+
+def philox_normals(n: int, seed: int, step: int, stream: int):
+    """float64 N(0,1) values 0..n-1: element e lives in block e // 4; words (w0, w1) give elements 4b, 4b+1 and (w2, w3)
+    give 4b+2, 4b+3 by Box-Muller on the words' top 24 bits (exact in float32): u1 = ((w >> 8) + 1) / 2^24 in (0, 1],
+    u2 = (w' >> 8) / 2^24 in [0, 1), r = sqrt(-2 ln u1), z = r cos(2 pi u2), r sin(2 pi u2)  (|z| <= 5.77)."""
+    import numpy as np
+    nb = (n + 3) // 4
+    w = (draw_words(nb, seed, step, stream, DRAW_DOMAIN_EPS) >> np.uint32(8)).astype(np.float64)
+    out = np.empty((nb, 4), dtype=np.float64)
+    for a in (0, 2):
+        r = np.sqrt(-2.0 * np.log((w[:, a] + 1.0) * 2.0 ** -24))
+        th = 2.0 * np.pi * (w[:, a + 1] * 2.0 ** -24)
+        out[:, a], out[:, a + 1] = r * np.cos(th), r * np.sin(th)
+    return torch.from_numpy(out.reshape(-1)[:n])

@@ -287,3 +287,23 @@ def test_dropout_is_identity_in_eval_mode_of_the_reference(golden_dir):
             np.testing.assert_array_equal(g[k], g["bn_eval/" + k.split("/", 1)[1]])
             n += 1
     assert n == 5
+
+
+def test_philox_known_answers_and_draw_definitions():
+    """[BUILD-DEFINED noise generator] Philox4x32-10 against the Random123 known-answer vectors (kat_vectors:
+    `philox4x32 10` rows), then the draw definitions the kernel is held to (tests/test_noise_gpu.py)"""
+    import numpy as np
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+            (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        assert [int(v) for v in R.philox4x32(np.array(ctr, dtype=np.uint64), key)] == list(want)
+    w = R.draw_words(5, 0x0000_0007_0000_0003, 9, 2, R.DRAW_DOMAIN_T)
+    assert np.array_equal(w[3], R.philox4x32(np.array([3, 9, 2, 1], dtype=np.uint64), (3, 7)))
+    t = R.draw_timesteps(4096, 1000, 1, 0, 0)
+    assert t.dtype == torch.int64 and int(t.min()) >= 0 and int(t.max()) <= 999
+    assert torch.equal(t[:5], torch.from_numpy((R.draw_words(5, 1, 0, 0, 1)[:, 0].astype(np.uint64) * 1000 >> 32).astype(np.int64)))
+    z = R.philox_normals(1 << 18, 1, 0, 0).numpy()
+    assert abs(z.mean()) < 0.01 and abs(z.std() - 1) < 0.01 and np.abs(z).max() <= 5.77
+    assert np.array_equal(R.philox_normals(10, 1, 0, 0).numpy(), z[:10])         # a prefix is a prefix

@@ -293,3 +293,22 @@ def test_wait_for_file_polls_and_times_out(tmp_path):
     t0 = time.monotonic()
     wait_for_file(str(p), timeout_s=5.0, poll_s=0.01)
     assert time.monotonic() - t0 < 2.0
+
+
+def test_cli_diffusion_trains_from_the_motion_cache(dry, tmp_path):
+    """`main.py train --model-type diffusion-mlp --window-cache f.npy`: windows written once, loaded into the (here: CPU
+    stand-in of the) HBM table, every step = index copy + ONE draw launch + the fused step; no host random numbers"""
+    import numpy as np
+    from inferbiomechanics_amd.cli.train import TrainCommand
+    from inferbiomechanics_amd.main import main
+    cache = str(tmp_path / "motion.npy")
+    base = ['--no-wandb', '--synthetic-windows', '24', '--batch-size', '8', '--checkpoint-dir', str(tmp_path / "ck"),
+            '--data-loading-workers', '0', '--model-type', 'diffusion-mlp', '--feat-dim', '24', '--hidden-dims', '32', '32',
+            '--stride', '1', '--history-len', '6', '--compute-dtype', 'bf16', '--seed', '7']
+    assert main(['train', '--epochs', '1', '--window-cache', cache, '--loss-every', '2'] + base)
+    assert np.load(cache).shape == (24, 6, 24)
+    assert TrainCommand.last_run_stats["steps"] == 3 and TrainCommand.last_run_stats["windows_per_s"] > 0
+    calls = dry.lib().calls
+    assert calls.count("ib_diffusion_draw") >= 3 + 3            # dev evaluation + training steps
+    assert main(['train', '--epochs', '2', '--max-steps', '1'] + base)                       # DataLoader x0, device-drawn t / eps
+    assert main(['train', '--epochs', '3', '--max-steps', '1', '--eager'] + base)
