@@ -65,30 +65,40 @@ def make_batches(nb, B, T, D, dtype, dev, seed):
     return out
 
 
-def cpu_baseline(kind, T, D, B, budget_s=15.0):
-    """The oracle (torch-eager CPU port of the reference arithmetic + build-defined diffusion wrapper),
-    fp32, all host cores, same workload shape; bounded sample."""
+def cpu_baseline(kind, T, D, B, dev, budget_s=12.0, ncmp=20):
+    """The oracle (torch-eager CPU port of the reference arithmetic + build-defined diffusion wrapper), fp32, one GPU's
+    share of the host cores, same workload shape; bounded sample.  "At matched diffusion loss" (north_star): the CPU run and
+    the fused GPU trainer (fp32 parity mode and the benchmarked bf16 mode) start from the SAME initial weights and take the
+    SAME batches; the loss each computes at step `ncmp` is reported side by side."""
+    from inferbiomechanics_amd.engine import HipTrainer
     from oracle import ref_cpu as R
     # one GPU's share of the host (the GPU box gives 16 worker CPUs per GPU); all 256 logical CPUs of the box
     # on these small GEMMs is 80x SLOWER (thread oversubscription: 9.8 windows/s measured)
     torch.set_num_threads(min(os.cpu_count() or 1, 16))
-    torch.manual_seed(0)
+    g = torch.Generator().manual_seed(1234)
+    host = [(torch.randn(B, T, D, generator=g), torch.randint(0, 1000, (B,), generator=g), torch.randn(B, T, D, generator=g))
+            for _ in range(4)]
+    w0, gpu_loss = None, {}
+    for name, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+        model = build_model(kind, T, D, dt, dev)                     # torch.manual_seed(0) inside: same init both times
+        if w0 is None:
+            w0 = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
+        tr = HipTrainer(model, "diffusion", "rmsprop", 1e-4, use_graph=True)
+        for i in range(ncmp + 1):
+            x0, t, eps = host[i % len(host)]
+            tr.step((x0.to(dev, dt), t.to(dev), eps.to(dev, dt)))
+        gpu_loss[name] = tr.loss_value()                             # computed at step `ncmp`, before that step's update
+        del tr, model
+    params = {k: v.clone().requires_grad_(True) for k, v in w0.items()}
     if kind == "mlp":
-        shapes = R.denoiser_mlp_param_shapes(D, [512, 512])
         fwd = lambda p, x, t: R.denoiser_mlp_forward(p, x, t, [512, 512])
     else:
-        shapes = R.denoiser_transformer_param_shapes(D, T)
         fwd = lambda p, x, t: R.denoiser_transformer_forward(p, x, t, 4, 8)
-    params = {k: (torch.randn(s) / (s[-1] ** 0.5 if len(s) > 1 else 10.0)).requires_grad_(True) for k, s in shapes.items()}
-    for k in params:
-        if k.endswith("norm.weight") or k.endswith("norm1.weight") or k.endswith("norm2.weight"):
-            params[k].data.fill_(1.0)
     state = {k: R.optim_init_state("rmsprop", v.detach()) for k, v in params.items()}
     tabs = {k: v.to(torch.float32) for k, v in R.schedule_tables().items()}
-    x0, eps = torch.randn(B, T, D), torch.randn(B, T, D)
-    t = torch.randint(0, 1000, (B,))
 
     def step(i):
+        x0, t, eps = host[i % len(host)]
         for v in params.values():
             v.grad = None
         xt = R.q_sample(x0, t, eps, tabs)
@@ -97,19 +107,36 @@ def cpu_baseline(kind, T, D, B, budget_s=15.0):
         with torch.no_grad():
             for k, v in params.items():
                 v.copy_(R.optim_step("rmsprop", v, v.grad, state[k], 1e-4, i + 1))
-        return loss
+        return float(loss.detach())
 
-    for i in range(2):
-        step(i)
+    cpu_loss = None
+    for i in range(ncmp + 1):
+        cpu_loss = step(i)
     n, t0 = 0, time.perf_counter()
     while True:
-        step(n + 2)
+        step(ncmp + 1 + n)
         n += 1
         el = time.perf_counter() - t0
         if el > budget_s or n >= 200:
             break
+    rel = lambda a: round(abs(a - cpu_loss) / max(abs(cpu_loss), 1e-30), 6)
     return {"value": round(B * n / el, 1), "unit": "windows/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} training steps of batch {B} ({kind} denoiser, T={T}, D={D}, fp32, RMSprop) in {el:.1f} s"}
+            "sample": f"{n} training steps of batch {B} ({kind} denoiser, T={T}, D={D}, fp32, RMSprop) in {el:.1f} s "
+                      f"(after {ncmp + 1} untimed matched-loss steps)",
+            "matched_loss": {"step": ncmp, "cpu_oracle_f32": round(cpu_loss, 6), "gpu_f32": round(gpu_loss["f32"], 6),
+                             "gpu_bf16": round(gpu_loss["bf16"], 6), "rel_diff_f32": rel(gpu_loss["f32"]),
+                             "rel_diff_bf16": rel(gpu_loss["bf16"]),
+                             "note": "same initial weights (seed 0), same 4 host batches cycled, RMSprop 1e-4; each side's "
+                                     "loss as computed at this step"}}
+
+
+def cli_path_leg(windows=1 << 18, epochs=3):
+    """the SAME workload through the product surface: `main.py train --model-type diffusion-mlp --compute-dtype bf16
+    --window-cache hbm` (tools/cli_rate.py): windows resident in HBM, x0 gather + t / eps drawn on the device per step"""
+    from tools.cli_rate import cli_rate
+    r = cli_rate(windows=windows, epochs=epochs)
+    return {"windows_per_s": r["windows_per_s"], "epoch_windows_per_s": r["epoch_windows_per_s"],
+            "steps_per_epoch": r["steps_per_epoch"], "command": r["command"], "note": r["note"]}
 
 
 def regression_ref_shape_leg(dev, B, gpu_steps=400, cpu_budget_s=4.0):
@@ -543,6 +570,7 @@ def main():
     ap.add_argument("--batches", type=int, default=64, help="pre-generated synthetic batches resident in HBM (SURVEY §8d: >= 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ddim", action="store_true")
+    ap.add_argument("--no-cli-path", action="store_true", help="skip the `main.py train` rate of the same workload")
     ap.add_argument("--no-transformer", action="store_true", help="skip the configs[2] / configs[3] transformer leg")
     ap.add_argument("--bucket-mb", type=float, default=13.0,
                     help="gradient bucket size when all-reduces overlap the backward: each bucket boundary cuts the captured "
@@ -636,7 +664,11 @@ def main():
             line["ddim"] = ddim_leg(dev, dtype)                                  # B = 16: the quoted figure
             line["ddim_batches"] = [ddim_leg(dev, dtype, B=b) for b in (1, 256)]   # B in {1,16,256}
         if not a.no_cpu_baseline and world == 1:            # rank 0 at N=1 only (the other ranks wait at the barrier)
-            line["cpu_baseline"] = cpu_baseline(kind, T, D, B)
+            line["cpu_baseline"] = cpu_baseline(kind, T, D, B, dev)
+            if kind == "mlp" and not a.no_cli_path:
+                cp = cli_path_leg()
+                cp["fraction_of_bench_value"] = round(cp["windows_per_s"] / main_leg["value"], 3)
+                line["cli_path"] = cp
             # BASELINE.json configs[0]: the reference's own CPU-runnable case (plumbing; launch-latency bound on the GPU)
             line["regression_ref_shape"] = {
                 "workload": "FeedForwardBaseline([512,512], sigmoid) 1470->300, fp32, RMSprop 1e-4, reference loss "

@@ -35,14 +35,18 @@ def cli_rate(windows=1 << 20, epochs=3, batch_size=256, model_type="diffusion-ml
                 "--report-every", str(steps), "--loss-every", str(loss_every), "--seed", "0"]
         rates = []
         sink = io.StringIO()
-        for _ in range(1):
-            with (contextlib.redirect_stdout(sink) if quiet else contextlib.nullcontext()):
-                # epochs run back to back in ONE invocation; the stats object holds the last epoch, so collect per epoch
-                # through the print-outs as well
-                ok = main(argv)
-            if not ok:
-                raise SystemExit("cli_rate: main.py train did not run")
-        for ln in sink.getvalue().splitlines():
+        import torch
+        prev = torch.cuda.current_stream() if torch.cuda.is_available() else None
+        with (contextlib.redirect_stdout(sink) if quiet else contextlib.nullcontext()):
+            # epochs run back to back in ONE invocation; the stats object holds the last epoch, so the per-epoch figures
+            # are collected from the print-outs
+            ok = main(argv)
+        if prev is not None:                 # the training loop adopted the trainer's stream: hand the caller's back
+            torch.cuda.synchronize()
+            torch.cuda.set_stream(prev)
+        if not ok:
+            raise SystemExit("cli_rate: main.py train did not run")
+        for ln in (sink.getvalue().splitlines() if quiet else []):
             if "windows/s" in ln and "epoch" in ln:
                 rates.append(float(ln.split("=")[-1].split("windows/s")[0]))
         last = TrainCommand.last_run_stats
