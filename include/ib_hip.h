@@ -211,6 +211,20 @@ int ib_regression_loss_strided(const void* o_cop, const void* o_force, const voi
                                const int64_t* g_bs, const int64_t* g_fs, void* workspace, size_t workspace_bytes,
                                int64_t B, int64_t F, int dtype, ib_stream_t stream);
 
+/* The evaluator's four static helpers as entry points of their own (src/loss/RegressionLossEvaluator.py:73-158; the
+ * training step uses the fused ib_regression_loss above).  o / l: contiguous [B, F, C] (rows = B*F), fp32 or bf16.
+ *   ib_sqdiff_mean:      out[c] = mean over rows of (o - l)^2                 get_squared_diff_mean_vector :73-83
+ *   ib_sqdiff_mean_bwd:  d_o[r, c] = dout[c] * 2 (o - l) / rows               (its autograd)
+ *   ib_mask_by_threes:   mask[.., 3k..3k+2] = (||t[.., 3k..3k+2]|| > threshold) as fp32, n = element count   :85-108
+ *   ib_mean_norm_error:  mean over (window, chunk of vec_size) of ||(o - l)[window, LAST frame, chunk]|| :119-141;
+ *                        fold_halves: the two halves of the last dimension are added first (get_com_acc_error :143-158) */
+int ib_sqdiff_mean(const void* o, const void* l, float* out, int64_t rows, int64_t C, int dtype, ib_stream_t stream);
+int ib_sqdiff_mean_bwd(const void* o, const void* l, const float* dout, void* d_o, int64_t rows, int64_t C, int dtype,
+                       ib_stream_t stream);
+int ib_mask_by_threes(const void* t, float* mask, int64_t n, float threshold, int dtype, ib_stream_t stream);
+int ib_mean_norm_error(const void* o, const void* l, float* out, int64_t B, int64_t F, int64_t C, int vec_size,
+                       int fold_halves, int dtype, ib_stream_t stream);
+
 /* diffusion eps-prediction loss [BUILD-DEFINED; no reference counterpart, SURVEY.md §0.1]:
  * loss = mean((pred - target)^2) -> result[0]; dpred = 2 (pred - target) / n. */
 size_t ib_mse_loss_workspace(int64_t n);
@@ -262,6 +276,10 @@ int ib_tiny_matmul(const void* A, int a_dtype, int64_t sam, int64_t sak, const v
  * cast once).  idx int64. */
 int ib_gather_rows(const float* table, const int64_t* idx, void* out, int64_t B, int64_t dim,
                    int64_t table_rows, int dtype_out, ib_stream_t stream);
+/* gradient of ib_gather_rows w.r.t. the table (nn.Embedding backward, TransformerBaseline.py:41-48): dtable[r, :] = sum
+ * of dout[i, :] over the positions with idx[i] == r, in position order; all fp32. */
+int ib_gather_rows_bwd(const float* dout, const int64_t* idx, float* dtable, int64_t n, int64_t dim, int64_t table_rows,
+                       ib_stream_t stream);
 /* x_t[b,f,:] = sqrt_ab[t[b]] * x0[b,f,:] + sqrt_1mab[t[b]] * eps[b,f,:]; x0 / eps contiguous [B,T,D];
  * x_t is [B*T, D] with leading dimension ld_xt >= D (a 16-byte-aligned row pitch for D = 300). */
 int ib_q_sample(const void* x0, const void* eps, const int64_t* t, const float* sqrt_ab,

@@ -180,10 +180,17 @@ class TrainCommand(AbstractCommand):
                 pass                  # synthetic windows are drawn straight into HBM below: no file, no host pass
             elif not os.path.exists(args.window_cache) and rank == 0:
                 print(f"Packing {len(train_dataset)} training windows into {args.window_cache} ...")
-                if diffusion:
-                    save_motion_windows(train_dataset, args.window_cache)
-                else:
-                    PackedWindows.from_dataset(train_dataset, workers=args.data_loading_workers).save(args.window_cache)
+                try:
+                    if os.path.exists(args.window_cache + ".failed"):
+                        os.remove(args.window_cache + ".failed")
+                    if diffusion:
+                        save_motion_windows(train_dataset, args.window_cache)
+                    else:
+                        PackedWindows.from_dataset(train_dataset, workers=args.data_loading_workers).save(args.window_cache)
+                except BaseException as exc:      # the waiting ranks poll for this instead of sitting out their timeout
+                    with open(args.window_cache + ".failed", "w") as f:
+                        f.write(repr(exc))
+                    raise
             if distributed and not in_hbm:
                 wait_for_file(args.window_cache, float(os.environ.get("IB_WINDOW_CACHE_WAIT_S", 6 * 3600)))
                 dist.barrier()

@@ -420,7 +420,7 @@ template <int NT, bool DROP>
 int launch_fwd2(const void* qkv, void* out, float* lse, int64_t B, int64_t T, int64_t H, float scale, int slot,
                 const IbAttnDrop& a, hipStream_t s) {
   const size_t lds = (size_t)2 * NT * 16 * LDR * 2;
-  static const bool one_pass = getenv("IB_ATTN_ONE_PASS") != nullptr;
+  static const bool one_pass = ib_ab_set("IB_ATTN_ONE_PASS");
   // long windows: two-pass kernel, eight waves per workgroup -- when that still fills the chip (a single window is better
   // off with four query-block groups per head on the one-pass kernel: 5.5 against 7.9 us at B = 1, T = 200)
   if (NT > 4 && !one_pass && B * H * ((T + 127) / 128) >= 256) {

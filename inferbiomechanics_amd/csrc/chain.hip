@@ -23,7 +23,9 @@
 namespace {
 
 constexpr int CH_ROWS = 64, CH_WAVES = 8, CH_THREADS = 512, CH_MAXL = 4;
-long long* g_chain_prof = nullptr;
+#ifdef IB_AB
+long long* g_chain_prof = nullptr;     // TIMING-ONLY, measurement builds
+#endif
 #define CH_STAMP(k) do { if (p.prof && tid == 0) p.prof[blockIdx.x * 64 + (k)] = wall_clock64(); } while (0)
 
 struct ChainParams {
@@ -1316,7 +1318,11 @@ void chain_layout(int64_t D, int64_t H, int L, const ChainShape& s, PackLayout* 
 }  // namespace
 
 // TIMING-ONLY: device buffer of [workgroups][16] int64 stamps filled by the next chain launches (NULL = off)
+#ifdef IB_AB
 extern "C" int ib_debug_set_chain_prof(void* buf) { g_chain_prof = reinterpret_cast<long long*>(buf); return IB_OK; }
+#else
+extern "C" int ib_debug_set_chain_prof(void*) { return IB_E_UNSUPPORTED; }     // measurement builds only
+#endif
 
 extern "C" int ib_mlp_chain_supported(int64_t D, int64_t H, int L) {
   ChainShape s;
@@ -1430,11 +1436,11 @@ extern "C" int ib_mlp_chain_train(const void* x0, const void* eps, const int64_t
   p.xt = (bf16_t*)xt; p.ld_xt = ld_xt; p.dpred = (bf16_t*)dpred; p.ld_dpred = ld_dpred;
   p.partial = partial; p.ld_part = ld_part;
   p.gscale = 2.f / ((float)M * (float)D); p.ln_eps = ln_eps;
-  p.prof = g_chain_prof;
+  p.prof = IB_AB_PROF(g_chain_prof);
   hipStream_t st = ib_s(stream);
   // v2 (row-wise epilogues) is the kernel; IB_CHAIN_V1=1 selects the round-2 kernel for A/B measurements.  v2 keeps u in
   // registers for L <= 2 (u[i] may then be NULL: nothing is stored); deeper stacks pass u through HBM as v1 does.
-  static const bool use_v1 = getenv("IB_CHAIN_V1") != nullptr;
+  static const bool use_v1 = ib_ab_set("IB_CHAIN_V1");
   const bool keep = L <= 2;
   for (int i = 0; i < L; ++i)
     if (!u[i] && (use_v1 || !keep)) return IB_E_ARG;
@@ -1649,11 +1655,11 @@ int time_fwd_launch(const float* table, int64_t table_rows, const int64_t* t, co
   p.B = (int)B; p.out = (int)out;
   p.ncg = (int)(out / 128);
   // 16 windows per workgroup while that grid fits one round of the chip (beside the packing workgroups), else 64
-  static const bool no_mt1 = getenv("IB_TIME_FWD_MT4") != nullptr;
+  static const bool no_mt1 = ib_ab_set("IB_TIME_FWD_MT4");
   const bool mt1 = !no_mt1 && temb == 128 && (int64_t)p.ncg * ((B + 15) / 16) <= 256;
   const int rows = mt1 ? 16 : CH_ROWS;
   p.time_blocks = p.ncg * (int)((B + rows - 1) / rows);
-  p.prof = g_chain_prof;
+  p.prof = IB_AB_PROF(g_chain_prof);
   const int pack_wgs = pp.total_blocks > 0 ? ib_grid_1d(pp.total_blocks, CH_WAVES, mt1 ? 128 : 224) : 0;
   const dim3 grid((unsigned)(p.time_blocks + pack_wgs));
   if (temb == 128 && hidden == 512) {

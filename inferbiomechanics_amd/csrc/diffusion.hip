@@ -179,6 +179,36 @@ extern "C" int ib_fill_i64(int64_t* dst, int64_t value, int64_t n, ib_stream_t s
   return IB_OK;
 }
 
+// ---- gradient of a row gather (nn.Embedding backward, TransformerBaseline.py:41-48): dtable[r, :] = sum over the
+// positions i with idx[i] == r of dout[i, :], added in position order (deterministic; tables of a few dozen rows)
+namespace {
+__global__ __launch_bounds__(256) void gather_rows_bwd_kernel(const float* __restrict__ dout, const int64_t* __restrict__ idx,
+                                                              float* __restrict__ dtable, int64_t n, int64_t dim,
+                                                              int64_t table_rows) {
+  const int64_t total = table_rows * dim;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = e / dim, d = e % dim;
+    float s = 0.f;
+    for (int64_t i = 0; i < n; ++i) {
+      int64_t k = idx[i];
+      k = k < 0 ? 0 : (k >= table_rows ? table_rows - 1 : k);
+      if (k == r) s += dout[i * dim + d];
+    }
+    dtable[e] = s;
+  }
+}
+}  // namespace
+
+extern "C" int ib_gather_rows_bwd(const float* dout, const int64_t* idx, float* dtable, int64_t n, int64_t dim,
+                                  int64_t table_rows, ib_stream_t stream) {
+  if (!dout || !idx || !dtable || n <= 0 || dim <= 0 || table_rows <= 0) return IB_E_ARG;
+  if (n * table_rows * dim > ((int64_t)1 << 32)) return IB_E_UNSUPPORTED;      // meant for per-frame tables
+  hipLaunchKernelGGL(gather_rows_bwd_kernel, dim3(ib_grid_1d(table_rows * dim, 256)), dim3(256), 0, ib_s(stream), dout, idx,
+                     dtable, n, dim, table_rows);
+  IB_CHECK_LAUNCH();
+  return IB_OK;
+}
+
 // ---- on-device window cache (replaces AddBiomechanicsDataset.__getitem__ `:161-285` + the
 // DataLoader collate + the model's torch.concat `FeedForwardRegressionBaseline.py:97-108` for cached windows):
 // one packed fp32 row per window = [model input, frame-major F x 147 | labels, key-major: cop F' x 6, force F' x 6,

@@ -39,8 +39,13 @@ enum { EPI_FWD = 0, EPI_DGRAD = 1, EPI_WGRAD = 2 };
 
 // TIMING-ONLY ablation switch (tools/kbench.py --ablate): bit0 skip steady-state global loads, bit1 skip LDS
 // stores, bit2 skip MFMAs, bit3 skip the epilogue stores.  Results are wrong when non-zero; never set by product code.
+#ifdef IB_AB
 int g_ablate = 0;
 long long* g_gemm_prof = nullptr;   // TIMING-ONLY (tools/gemm_prof.py): [workgroups][8] wall-clock stamps of the ring kernel
+#define IB_ABLATE g_ablate
+#else
+#define IB_ABLATE 0
+#endif
 
 struct GemmParams {
   const void* A; const void* B; int64_t lda, ldb;
@@ -836,7 +841,7 @@ template <typename T> bool vec_store_ok(const void* p, int64_t ld) {
 int wgrad_split(int64_t M, int64_t N, int64_t K, int bk, int* chunk_out, int group = 1) {
   // reduction length is M; output tiles over [N, K]
   const int64_t tiles = ((N + BM - 1) / BM) * ((K + BN - 1) / BN);
-  static const int env_target = []() { const char* e = getenv("IB_WGRAD_TARGET"); return e ? atoi(e) : 0; }();
+  static const int env_target = ib_ab_int("IB_WGRAD_TARGET", 0);
   const int target = env_target ? env_target : (group <= 1 ? 256 : (group >= 4 ? 128 : 512 / group));
   // ~1 workgroup per CU: with the ring-pipelined main loop fewer, longer slices win (half the slab traffic; measured
   // step 0.310 -> 0.305 ms against 2 per CU).  IB_WGRAD_TARGET: tuning override.
@@ -854,7 +859,7 @@ int wgrad_split(int64_t M, int64_t N, int64_t K, int bk, int* chunk_out, int gro
 
 // ring kernel: bf16, every staged piece 16-byte aligned, exact reduction tiling, >= 2 K steps of 32
 bool ring_ok(const GemmParams& p, int dtype, int red_len, int red_chunk) {
-  static const int off = []() { const char* e = getenv("IB_NO_RING"); return e ? atoi(e) : 0; }();
+  static const int off = ib_ab_int("IB_NO_RING", 0);
   return !off && dtype == IB_BF16 && p.gldsA && p.gldsB && red_len % 32 == 0 && red_chunk % 32 == 0 && red_len >= 64 &&
          p.lda >= 8 && p.ldb >= 8;
 }
@@ -1059,12 +1064,12 @@ __global__ __launch_bounds__(256) void dgrad_smallm_kernel(const bf16_t* __restr
 // up to this many 128 x 128 tiles the small tiles win (Groundlink F=10 step: cap 32 0.528 ms, 64 0.489, 128 0.491,
 // 256 0.502; the DDIM step at M = 3200, 100 tiles: 492 us of kernels at 32 / 64, 515 at 128)
 inline int tile_cap() {
-  static const int cap = []() { const char* e = getenv("IB_SMALLM_TILES"); return e ? atoi(e) : 64; }();
+  static const int cap = ib_ab_int("IB_SMALLM_TILES", 64);
   return cap;
 }
 // GemmParams of a dgrad: A = dz [M, red], B = w [red, cols], C = dx [M, cols]; p.N = output columns, p.K = reduction length
 inline bool dgrad_ok(const GemmParams& p) {
-  static const int off = []() { const char* e = getenv("IB_NO_SMALLM"); return e ? atoi(e) : 0; }();
+  static const int off = ib_ab_int("IB_NO_SMALLM", 0);
   const int64_t tiles = (int64_t)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   return !off && tiles <= tile_cap() && !p.addend && p.K >= 64 && p.K <= RMAX && p.N % 16 == 0 && p.lda % 2 == 0 && aligned(p.A, 4) &&
          p.ldb % 8 == 0 && aligned(p.B, 16) && p.ldc % 4 == 0 && aligned(p.C, 8) &&
@@ -1090,7 +1095,7 @@ int launch_dgrad(const GemmParams& p, hipStream_t s) {
 
 // few 128 x 128 tiles (tile_cap()), plain epilogue (bias, the two row-broadcast addends, activation), rows 4-byte aligned
 inline bool ok(const GemmParams& p) {
-  static const int off = []() { const char* e = getenv("IB_NO_SMALLM"); return e ? atoi(e) : 0; }();
+  static const int off = ib_ab_int("IB_NO_SMALLM", 0);
   const int64_t tiles = (int64_t)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   return !off && tiles <= tile_cap() && !p.Z && p.lda % 2 == 0 && p.ldb % 2 == 0 && aligned(p.A, 4) && aligned(p.B, 4) &&
          p.K >= 64;
@@ -1118,7 +1123,7 @@ int launch(const GemmParams& p, hipStream_t s) {
 
 template <typename T>
 int launch_fwd(GemmParams& p, hipStream_t s) {
-  p.ablate = g_ablate; p.prof = g_gemm_prof;
+  p.ablate = IB_ABLATE; p.prof = IB_AB_PROF(g_gemm_prof);
   p.vecA = vec_load_ok<T>(p.A, p.lda);
   p.vecB = vec_load_ok<T>(p.B, p.ldb);
   p.gldsA = glds_ok<T>(p.A, p.lda); p.gldsB = glds_ok<T>(p.B, p.ldb);
@@ -1144,7 +1149,7 @@ int launch_fwd(GemmParams& p, hipStream_t s) {
 
 template <typename T>
 int launch_dgrad(GemmParams& p, hipStream_t s) {
-  p.ablate = g_ablate; p.prof = g_gemm_prof;
+  p.ablate = IB_ABLATE; p.prof = IB_AB_PROF(g_gemm_prof);
   p.vecA = vec_load_ok<T>(p.A, p.lda);
   p.vecB = vec_load_ok<T>(p.B, p.ldb);
   p.gldsA = glds_ok<T>(p.A, p.lda); p.gldsB = glds_ok<T>(p.B, p.ldb);
@@ -1169,8 +1174,13 @@ int launch_dgrad(GemmParams& p, hipStream_t s) {
 
 }  // namespace
 
+#ifdef IB_AB
 extern "C" int ib_debug_set_ablate(int mask) { g_ablate = mask; return IB_OK; }
 extern "C" int ib_debug_set_gemm_prof(void* buf) { g_gemm_prof = reinterpret_cast<long long*>(buf); return IB_OK; }
+#else       // measurement builds only (lib/ab/libib_hip_ab.so)
+extern "C" int ib_debug_set_ablate(int) { return IB_E_UNSUPPORTED; }
+extern "C" int ib_debug_set_gemm_prof(void*) { return IB_E_UNSUPPORTED; }
+#endif
 
 extern "C" int ib_linear_fwd(const void* x, int64_t ldx, const void* w, int64_t ldw, const float* bias,
                              const void* add_div, int64_t ld_add_div, const void* add_mod,
@@ -1397,7 +1407,7 @@ int wgrad_params(const void* dz, int64_t lddz, const void* x, int64_t ldx, float
   p = GemmParams{};
   p.A = dz; p.lda = lddz; p.B = x; p.ldb = ldx; p.M = (int)N; p.N = (int)K; p.K = (int)M;
   p.seg = 1; p.act = IB_ACT_NONE; p.accumulate = accumulate;
-  p.ablate = g_ablate; p.prof = g_gemm_prof;
+  p.ablate = IB_ABLATE; p.prof = IB_AB_PROF(g_gemm_prof);
   p.tiles_n = (p.N + BN - 1) / BN; p.tiles_m = (p.M + BM - 1) / BM;
   p.k_chunk = chunk;
   // all tiles of one M-chunk on one XCD only while that chunk's dz + x slices fit comfortably in the XCD's 4 MiB
@@ -1555,7 +1565,7 @@ __global__ __launch_bounds__(256) void wgrad_smallm_kernel(const bf16_t* __restr
 }
 
 inline bool ok(const void* dz, int64_t lddz, const void* x, int64_t ldx, int64_t M, int dtype) {
-  static const int off = []() { const char* e = getenv("IB_NO_SMALLM"); return e ? atoi(e) : 0; }();
+  static const int off = ib_ab_int("IB_NO_SMALLM", 0);
   // M <= 1024: with 2560 rows (Groundlink, F = 10) the ten serial LDS chunks per workgroup lose to the split-M kernels
   // (step 0.496 -> 0.789 ms when the limit was raised to 4096)
   return !off && dtype == IB_BF16 && M <= 1024 && lddz % 2 == 0 && ldx % 2 == 0 && aligned(dz, 4) && aligned(x, 4);
@@ -1831,7 +1841,7 @@ extern "C" int ib_linear_ln_fwd(const void* x, int64_t ldx, const void* w, int64
   if (workspace_bytes < (size_t)split * M * N * sizeof(float)) return IB_E_WORKSPACE;
   GemmParams p{};
   p.A = x; p.lda = ldx; p.B = w; p.ldb = ldw; p.M = (int)M; p.N = (int)N; p.K = (int)K;
-  p.seg = 1; p.act = IB_ACT_NONE; p.ablate = g_ablate; p.prof = g_gemm_prof;
+  p.seg = 1; p.act = IB_ACT_NONE; p.ablate = IB_ABLATE; p.prof = IB_AB_PROF(g_gemm_prof);
   p.vecA = vec_load_ok<bf16_t>(p.A, p.lda); p.vecB = vec_load_ok<bf16_t>(p.B, p.ldb);
   p.gldsA = glds_ok<bf16_t>(p.A, p.lda); p.gldsB = glds_ok<bf16_t>(p.B, p.ldb);
   p.tiles_n = (p.N + BN - 1) / BN; p.tiles_m = (p.M + BM - 1) / BM;

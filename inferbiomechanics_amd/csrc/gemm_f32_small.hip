@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void f32_small_wgrad_kernel(const float* __res
 inline bool al8(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7) == 0; }
 // up to this many 128 x 128 tiles of the generic kernel the 16 x 16 reduction-split tiles win
 inline bool few_tiles(int64_t M, int64_t Ncols) {
-  static const int off = []() { const char* e = getenv("IB_NO_F32_SMALL"); return e ? atoi(e) : 0; }();
+  static const int off = ib_ab_int("IB_NO_F32_SMALL", 0);
   return !off && ((M + 127) / 128) * ((Ncols + 127) / 128) <= 16 && M <= 1024;
 }
 
@@ -264,7 +264,7 @@ int ib_f32_small_dgrad_try(const float* dz, int64_t lddz, const float* w, int64_
 
 int ib_f32_small_wgrad_bias_try(const float* dz, int64_t lddz, const float* x, int64_t ldx, float* dw, int64_t lddw, float* dbias,
                                 int accumulate, int64_t M, int64_t N, int64_t K, hipStream_t s) {
-  static const int off = []() { const char* e = getenv("IB_NO_F32_SMALL"); return e ? atoi(e) : 0; }();
+  static const int off = ib_ab_int("IB_NO_F32_SMALL", 0);
   if (off || M > 256) return IB_E_UNSUPPORTED;
   const dim3 grid((unsigned)((K + 63) / 64), (unsigned)((N + 15) / 16)), block(256);
   hipLaunchKernelGGL(f32_small_wgrad_kernel, grid, block, 0, s, dz, lddz, x, ldx, dw, lddw, dbias, accumulate, (int)M, (int)N, (int)K);

@@ -74,7 +74,9 @@ struct NtParams {
   float* slab; int splits, kchunk, tiles_mn;
   long long* prof;             // TIMING-ONLY (tools/nt_prof.py): [gridDim.x][16] wall-clock stamps, else NULL
 };
+#ifdef IB_AB
 long long* g_nt_prof = nullptr;
+#endif
 #define NT_STAMP(k) do { if (p.prof && threadIdx.x == 0 && (k) < 16) p.prof[blockIdx.x * 16 + (k)] = wall_clock64(); } while (0)
 
 template <int ACT> __device__ __forceinline__ float nt_act(float v) {
@@ -411,8 +413,8 @@ int launch(const NtParams& p, hipStream_t s) {
 int ib_gemm_nt_try(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const float* bias, int fwd_act,
                    const void* aux, int64_t ldaux, int bwd_act, const void* addend, int64_t ldadd, int64_t M, int64_t N,
                    int64_t K, hipStream_t s) {
-  static const int off = []() { const char* e = getenv("IB_NO_NT"); return e ? atoi(e) : 0; }();
-  static const int min_m = []() { const char* e = getenv("IB_NT_MIN_M"); return e ? atoi(e) : 640; }();
+  static const int off = ib_ab_int("IB_NO_NT", 0);
+  static const int min_m = ib_ab_int("IB_NT_MIN_M", 640);
   if (off || M < min_m || N < 128 || N % 8 != 0 || K < 4 * BK || K % BK != 0) return IB_E_UNSUPPORTED;
   if (!al16(A) || !al16(B) || !al16(C) || lda % 8 || ldb % 8 || ldc % 8) return IB_E_UNSUPPORTED;
   if (M * lda >= (int64_t(1) << 31) || N * ldb >= (int64_t(1) << 31)) return IB_E_UNSUPPORTED;     // 32-bit element offsets
@@ -427,7 +429,7 @@ int ib_gemm_nt_try(const void* A, int64_t lda, const void* B, int64_t ldb, void*
   p.addend = (const bf16_t*)addend; p.ldadd = ldadd;
   p.tiles_m = (int)((M + BM - 1) / BM); p.tiles_n = (int)((N + BN - 1) / BN);
   p.tiles_mn = p.tiles_m * p.tiles_n; p.splits = 1; p.kchunk = (int)K; p.slab = nullptr;
-  p.prof = g_nt_prof;
+  p.prof = IB_AB_PROF(g_nt_prof);
   if (bwd_act != IB_ACT_NONE) {
     switch (bwd_act) {
       case IB_ACT_RELU: return launch<IB_ACT_NONE, IB_ACT_RELU>(p, s);
@@ -452,8 +454,8 @@ int ib_gemm_nt_try(const void* A, int64_t lda, const void* B, int64_t ldb, void*
 // rows: 52 tiles x 32 K steps): slab[s][M][N] (fp32) = A[:, s-th k range] B[:, s-th k range]^T, `splits` = the slab count
 // ib_gemm_nt_splitk_splits() names.  The caller's reduction (the slab LayerNorm) sums the slabs in order.
 int ib_gemm_nt_splitk_splits(int64_t M, int64_t N, int64_t K) {
-  static const int off = []() { const char* e = getenv("IB_NO_NT_SPLITK"); return e ? atoi(e) : 0; }();
-  static const int min_m = []() { const char* e = getenv("IB_NT_MIN_M"); return e ? atoi(e) : 640; }();
+  static const int off = ib_ab_int("IB_NO_NT_SPLITK", 0);
+  static const int min_m = ib_ab_int("IB_NT_MIN_M", 640);
   if (off || M < min_m || N < 128 || N % 8 != 0 || K % BK != 0) return 0;
   const int64_t tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
   int best = 0;
@@ -473,7 +475,7 @@ int ib_gemm_nt_splitk(const void* A, int64_t lda, const void* B, int64_t ldb, fl
   p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.lda = lda; p.ldb = ldb; p.M = (int)M; p.N = (int)N; p.K = (int)K;
   p.tiles_m = (int)((M + BM - 1) / BM); p.tiles_n = (int)((N + BN - 1) / BN);
   p.tiles_mn = p.tiles_m * p.tiles_n; p.splits = splits; p.kchunk = (int)(K / splits); p.slab = slab;
-  p.prof = g_nt_prof;
+  p.prof = IB_AB_PROF(g_nt_prof);
   const int tiles = p.tiles_mn * splits;
   hipLaunchKernelGGL((gemm_nt_kernel<IB_ACT_NONE, IB_ACT_NONE, false, false, true>), dim3(tiles < 256 ? tiles : 256),
                      dim3(NT_THREADS), 0, s, p);
@@ -482,7 +484,11 @@ int ib_gemm_nt_splitk(const void* A, int64_t lda, const void* B, int64_t ldb, fl
 }
 
 // TIMING-ONLY: device buffer of [workgroups][16] int64 stamps filled by the next NT GEMM launches (NULL = off)
+#ifdef IB_AB
 extern "C" int ib_debug_set_nt_prof(void* buf) { g_nt_prof = reinterpret_cast<long long*>(buf); return IB_OK; }
+#else
+extern "C" int ib_debug_set_nt_prof(void*) { return IB_E_UNSUPPORTED; }       // measurement builds only
+#endif
 
 // ---- dst_i[c][r] = src_i[r][c] for several bf16 matrices in ONE launch (the transposed weight copies the backward
 // GEMMs read k-contiguously; refreshed once per step after the optimizer moved the weights).  64 x 64 tiles through LDS.

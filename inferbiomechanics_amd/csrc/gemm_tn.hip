@@ -79,7 +79,9 @@ struct TnParams {
   int tn_grid;                       // persistent GEMM workgroups (= the stride of the work-item walk)
   TimeBwdParams tb; int tb_blocks, tb_cgs, tb_te;
 };
+#ifdef IB_AB
 long long* g_tn_prof = nullptr;
+#endif
 
 // BIAS: some problem of the launch wants its bias gradient.  The extra MFMAs then run unconditionally (every item, every
 // wave): the K loop is bound by the LDS-DMA ingest (0.82 us per step against 0.49 us of MFMA), so +25 % matrix work is free,
@@ -306,12 +308,12 @@ inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 // number of reduction splits the TN kernel uses for a problem that shares its launch with `group - 1` others (0: the
 // problem does not qualify).  Splits divide M / 64 exactly (every work item has the same number of K steps, >= 4).
 int ib_gemm_tn_splits(int64_t M, int64_t N, int64_t K, int group) {
-  static const int off = []() { const char* e = getenv("IB_NO_TN"); return e ? atoi(e) : 0; }();
+  static const int off = ib_ab_int("IB_NO_TN", 0);
   // work items per launch the split selection aims at (256 = one per CU).  More items fill the tail rounds better but every
   // split is one more fp32 slab of the gradient for the step's final reduction to read (measured, B = 256, T = 50: MLP denoiser
   // step 0.227 / 0.214 / 0.227 / 0.227 ms and transformer step 2.81 / 2.50 / 2.69 / 2.55 ms at 192 / 256 / 384 / 512).
   // IB_TN_TARGET: tuning override.
-  static const int total = []() { const char* e = getenv("IB_TN_TARGET"); return e ? atoi(e) : 256; }();
+  static const int total = ib_ab_int("IB_TN_TARGET", 256);
   // a lone problem must be long (short reductions have their own one-pass kernel); inside a group a short one rides along
   if (off || M % 64 != 0 || M < 256 || (group <= 1 && M < 4096) || N < 64 || K < 64 || K % 4 != 0) return 0;
   const int64_t steps = M / 64;
@@ -356,7 +358,7 @@ int ib_gemm_tn_multi(int n, const void* const* dz, const int64_t* lddz, const vo
     nslab_out[j] = sp;
   }
   P.items = items;
-  P.prof = g_tn_prof;
+  P.prof = IB_AB_PROF(g_tn_prof);
   int grid = items < 256 ? items : 256;
   P.tn_grid = grid;
   if (rider) {

@@ -262,7 +262,7 @@ inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 // with s x (total tiles) <= 224 work items (at most one per CU), items at least 8 stages long and an even stage count, s <= 32
 // (the bias partial sums have 32 rows).
 int ib_gemm_tn256_splits(int n, const int64_t* M, const int64_t* N, const int64_t* K) {
-  static const bool off = getenv("IB_NO_TN256") != nullptr;
+  static const bool off = ib_ab_set("IB_NO_TN256");
   if (off || n <= 0 || n > MAXP) return 0;
   int64_t tiles = 0;
   for (int j = 0; j < n; ++j) {
@@ -270,7 +270,7 @@ int ib_gemm_tn256_splits(int n, const int64_t* M, const int64_t* N, const int64_
     tiles += (N[j] / TM) * (K[j] / TK);
   }
   const int64_t stages = M[0] / BK;
-  static const int forced = []() { const char* e = getenv("IB_TN256_SPLITS"); return e ? atoi(e) : 0; }();   // tuning override
+  static const int forced = ib_ab_int("IB_TN256_SPLITS", 0);   // tuning override
   if (forced > 0 && forced <= 32 && stages % forced == 0 && stages / forced >= 8 && !((stages / forced) & 1)) return forced;
   int best = 0;
   for (int64_t s = 1; s <= 32; ++s) {

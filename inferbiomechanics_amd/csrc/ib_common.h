@@ -19,8 +19,24 @@ typedef __attribute__((ext_vector_type(4))) short s16x4_t;
     if (e__ != hipSuccess) return IB_E_LAUNCH;               \
   } while (0)
 
-extern int g_ib_last_path;                       // util.hip; see ib_debug_last_path()
+// dispatch-debug word (util.hip; ib_debug_last_path()): which kernel family the calling THREAD's last entry point took.
+// thread_local: the library keeps no mutable state that two host threads share (re-entrant C-ABI).
+extern thread_local int g_ib_last_path;
 #define IB_PATH(code) (g_ib_last_path = (code))
+
+// A/B switches and in-kernel profiling hooks exist only in MEASUREMENT builds (-DIB_AB: lib/ab/libib_hip_ab.so, loaded by
+// tools/ and two tests through IB_HIP_LIB).  The shipping library reads no environment variable: every switch is its
+// default, a compile-time constant.
+#ifdef IB_AB
+#include <stdlib.h>
+static inline int ib_ab_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+static inline bool ib_ab_set(const char* name) { return getenv(name) != nullptr; }
+#define IB_AB_PROF(ptr) (ptr)
+#else
+static inline int ib_ab_int(const char*, int dflt) { return dflt; }
+static inline bool ib_ab_set(const char*) { return false; }
+#define IB_AB_PROF(ptr) (nullptr)
+#endif
 
 static inline hipStream_t ib_s(ib_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 

@@ -369,3 +369,118 @@ extern "C" int ib_mse_loss(const void* pred, const void* target, void* dpred, fl
   if (rc != IB_OK) return rc;
   return ib_mse_loss_finalize(workspace, workspace_bytes, result, n, stream);
 }
+
+// ---- the four static helpers of the reference evaluator as entry points of their own (API surface:
+// src/loss/RegressionLossEvaluator.py:73-158; the fused kernel above is what the training step uses).  Tiny problems
+// ([B, F, 6 | 12]): one workgroup per output column / one thread per 3-vector, fixed summation order.
+namespace {
+template <typename T>
+__global__ __launch_bounds__(256) void sqdiff_mean_kernel(const T* __restrict__ o, const T* __restrict__ l,
+                                                          float* __restrict__ out, int rows, int C) {
+  __shared__ float red[256];
+  const int c = blockIdx.x;
+  float s = 0.f;
+  for (int r = threadIdx.x; r < rows; r += 256) {
+    const float d = ib_to_f32(o[(int64_t)r * C + c]) - ib_to_f32(l[(int64_t)r * C + c]);
+    s += d * d;
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[c] = red[0] / (float)rows;
+}
+// d out[c] / d o[r, c] = 2 (o - l) / rows
+template <typename T>
+__global__ __launch_bounds__(256) void sqdiff_mean_bwd_kernel(const T* __restrict__ o, const T* __restrict__ l,
+                                                              const float* __restrict__ dout, T* __restrict__ d_o,
+                                                              int64_t n, int C, float scale) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    d_o[i] = ib_from_f32<T>(dout[i % C] * scale * (ib_to_f32(o[i]) - ib_to_f32(l[i])));
+}
+template <typename T>
+__global__ __launch_bounds__(256) void mask_by_threes_kernel(const T* __restrict__ t, float* __restrict__ mask, int64_t nvec,
+                                                             float threshold) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+    const float a = ib_to_f32(t[3 * i]), b = ib_to_f32(t[3 * i + 1]), c = ib_to_f32(t[3 * i + 2]);
+    const float m = sqrtf(a * a + b * b + c * c) > threshold ? 1.f : 0.f;
+    mask[3 * i] = m; mask[3 * i + 1] = m; mask[3 * i + 2] = m;
+  }
+}
+// mean over (window, chunk) of || (o - l)[window, LAST frame, chunk of vec] ||; fold: the two halves of the last dimension
+// are added first (left + right force, get_com_acc_error :143-158)
+template <typename T>
+__global__ __launch_bounds__(256) void mean_norm_error_kernel(const T* __restrict__ o, const T* __restrict__ l,
+                                                              float* __restrict__ out, int B, int F, int C, int vec, int fold) {
+  __shared__ float red[256];
+  const int Ce = fold ? C / 2 : C, chunks = Ce / vec;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < B * chunks; i += 256) {
+    const int b = i / chunks, k = i % chunks;
+    const int64_t base = ((int64_t)b * F + (F - 1)) * C + k * vec;
+    float q = 0.f;
+    for (int e = 0; e < vec; ++e) {
+      float d = ib_to_f32(o[base + e]) - ib_to_f32(l[base + e]);
+      if (fold) d = (ib_to_f32(o[base + e]) + ib_to_f32(o[base + e + Ce])) - (ib_to_f32(l[base + e]) + ib_to_f32(l[base + e + Ce]));
+      q += d * d;
+    }
+    s += sqrtf(q);
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = red[0] / (float)(B * chunks);
+}
+}  // namespace
+
+extern "C" int ib_sqdiff_mean(const void* o, const void* l, float* out, int64_t rows, int64_t C, int dtype,
+                              ib_stream_t stream) {
+  if (!o || !l || !out || rows <= 0 || C <= 0 || rows >= (1 << 30) || C > 65535) return IB_E_ARG;
+  if (dtype == IB_F32)
+    hipLaunchKernelGGL(sqdiff_mean_kernel<float>, dim3((int)C), dim3(256), 0, ib_s(stream), (const float*)o, (const float*)l, out, (int)rows, (int)C);
+  else if (dtype == IB_BF16)
+    hipLaunchKernelGGL(sqdiff_mean_kernel<bf16_t>, dim3((int)C), dim3(256), 0, ib_s(stream), (const bf16_t*)o, (const bf16_t*)l, out, (int)rows, (int)C);
+  else return IB_E_DTYPE;
+  IB_CHECK_LAUNCH();
+  return IB_OK;
+}
+extern "C" int ib_sqdiff_mean_bwd(const void* o, const void* l, const float* dout, void* d_o, int64_t rows, int64_t C,
+                                  int dtype, ib_stream_t stream) {
+  if (!o || !l || !dout || !d_o || rows <= 0 || C <= 0) return IB_E_ARG;
+  const int64_t n = rows * C;
+  const float scale = 2.f / (float)rows;
+  if (dtype == IB_F32)
+    hipLaunchKernelGGL(sqdiff_mean_bwd_kernel<float>, dim3(ib_grid_1d(n, 256)), dim3(256), 0, ib_s(stream), (const float*)o, (const float*)l, dout, (float*)d_o, n, (int)C, scale);
+  else if (dtype == IB_BF16)
+    hipLaunchKernelGGL(sqdiff_mean_bwd_kernel<bf16_t>, dim3(ib_grid_1d(n, 256)), dim3(256), 0, ib_s(stream), (const bf16_t*)o, (const bf16_t*)l, dout, (bf16_t*)d_o, n, (int)C, scale);
+  else return IB_E_DTYPE;
+  IB_CHECK_LAUNCH();
+  return IB_OK;
+}
+extern "C" int ib_mask_by_threes(const void* t, float* mask, int64_t n, float threshold, int dtype, ib_stream_t stream) {
+  if (!t || !mask || n <= 0 || n % 3) return IB_E_ARG;
+  if (dtype == IB_F32)
+    hipLaunchKernelGGL(mask_by_threes_kernel<float>, dim3(ib_grid_1d(n / 3, 256)), dim3(256), 0, ib_s(stream), (const float*)t, mask, n / 3, threshold);
+  else if (dtype == IB_BF16)
+    hipLaunchKernelGGL(mask_by_threes_kernel<bf16_t>, dim3(ib_grid_1d(n / 3, 256)), dim3(256), 0, ib_s(stream), (const bf16_t*)t, mask, n / 3, threshold);
+  else return IB_E_DTYPE;
+  IB_CHECK_LAUNCH();
+  return IB_OK;
+}
+extern "C" int ib_mean_norm_error(const void* o, const void* l, float* out, int64_t B, int64_t F, int64_t C, int vec_size,
+                                  int fold_halves, int dtype, ib_stream_t stream) {
+  if (!o || !l || !out || B <= 0 || F <= 0 || C <= 0 || vec_size <= 0 || B * C >= (1 << 30)) return IB_E_ARG;
+  if (fold_halves ? (C % 2 || (C / 2) % vec_size) : (C % vec_size)) return IB_E_ARG;
+  if (dtype == IB_F32)
+    hipLaunchKernelGGL(mean_norm_error_kernel<float>, dim3(1), dim3(256), 0, ib_s(stream), (const float*)o, (const float*)l, out, (int)B, (int)F, (int)C, vec_size, fold_halves);
+  else if (dtype == IB_BF16)
+    hipLaunchKernelGGL(mean_norm_error_kernel<bf16_t>, dim3(1), dim3(256), 0, ib_s(stream), (const bf16_t*)o, (const bf16_t*)l, out, (int)B, (int)F, (int)C, vec_size, fold_halves);
+  else return IB_E_DTYPE;
+  IB_CHECK_LAUNCH();
+  return IB_OK;
+}

@@ -628,7 +628,7 @@ extern "C" int ib_layernorm_fwd(const void* x, const void* res, int act, const f
   }
   if (dtype == IB_BF16) {
     const int vec = (N % 8 == 0) && al(x, 16) && al(res, 16) && al(y, 16) && al(add_div, 16) && (ld_add % 8 == 0);
-    static const bool no_fast = getenv("IB_NO_LN_FAST") != nullptr;
+    static const bool no_fast = ib_ab_set("IB_NO_LN_FAST");
     if (!no_fast && N == LNF_N && vec && vecp && act == IB_ACT_NONE && !add_div && M >= 4096) {
       hipLaunchKernelGGL(layernorm_fwd512_kernel, dim3((unsigned)((M + 4 * LNF_ROWS - 1) / (4 * LNF_ROWS))), dim3(256), 0, s,
                          (const bf16_t*)x, (const bf16_t*)res, gamma, beta, (bf16_t*)y, mean, rstd, (int)M, eps);
@@ -668,7 +668,7 @@ extern "C" int ib_layernorm_bwd(const void* dy, const void* x, const void* res, 
   } else if (dtype == IB_BF16) {
     const int vec = (N % 8 == 0) && al(x, 16) && al(res, 16) && al(dy, 16) && al(dx, 16) && al(dres, 16) &&
                     al(add_div, 16) && (ld_add % 8 == 0);
-    static const bool no_fast = getenv("IB_NO_LN_FAST") != nullptr;
+    static const bool no_fast = ib_ab_set("IB_NO_LN_FAST");
     if (!no_fast && N == LNF_N && vec && vecp && act == IB_ACT_NONE && !add_div && !dres && M >= 4096) {
       hipLaunchKernelGGL(layernorm_bwd512_kernel, dim3(parts), dim3(LNF_WAVES * 64), 0, s, (const bf16_t*)dy, (const bf16_t*)x,
                          (const bf16_t*)res, gamma, mean, rstd, (bf16_t*)dx, partial, (int)M);

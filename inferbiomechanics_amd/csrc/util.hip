@@ -3,7 +3,7 @@
 
 extern "C" int ib_version(void) { return 100; }
 
-int g_ib_last_path = IB_PATH_NONE;
+thread_local int g_ib_last_path = IB_PATH_NONE;
 extern "C" int ib_debug_last_path(void) { const int v = g_ib_last_path; g_ib_last_path = IB_PATH_NONE; return v; }   // read and clear
 
 extern "C" const char* ib_error_string(int code) {

@@ -42,6 +42,8 @@ def wait_for_file(path: str, timeout_s: float, poll_s: float = 2.0) -> None:
     import time
     t0 = time.monotonic()
     while not os.path.exists(path):
+        if os.path.exists(path + ".failed"):           # the packing rank died (cli/train.py writes it on any exception)
+            raise RuntimeError(f"window cache {path!r}: the packing rank failed: " + open(path + ".failed").read()[:500])
         if time.monotonic() - t0 > timeout_s:
             raise TimeoutError(f"window cache {path!r} did not appear within {timeout_s:.0f} s (is the packing rank alive?)")
         time.sleep(poll_s)

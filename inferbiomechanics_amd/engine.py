@@ -22,6 +22,7 @@ at construction (DDP ctor), optimizer arithmetic = torch.optim defaults with onl
 from __future__ import annotations
 
 import os
+import weakref
 from collections import OrderedDict
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
@@ -577,6 +578,8 @@ class HipTrainer:
     _srcs = None            # this step's {x0, eps, t} tensors behind the pointer slots (chain path), else None
     _cap_stream = None
     MAX_PINNED_GRAPHS = 128
+    MAX_DICT_CAPTURES = 16      # in-run captures of dict-batch graphs (each ~1 ms of host work in the middle of a run)
+    _dict_captures = 0
 
     captures = 0            # graphs captured so far (bench.py asserts that none falls inside its timed region)
 
@@ -654,19 +657,32 @@ class HipTrainer:
         # second appearance such a batch gets a graph of its own that reads the caller's tensors where they lie -- the 14
         # staging copies per step (10 input keys + 4 labels, each a tiny D2D launch issued by the host: ~45 us of the 0.12-ms
         # fp32 reference-shape step) disappear.  Anything else is staged into the static buffers as before.
-        if self.use_graph and self._rec is not None and not os.environ.get("IB_NO_PINNED_GRAPHS"):
+        if self.use_graph and self._rec is not None and not os.environ.get("IB_NO_PINNED_GRAPHS") \
+                and not (self.ddp and os.environ.get("IB_GRAPH_COLLECTIVES") == "1"):
             d = self._dict_batch_direct(batch)
             if d is not None:
                 key, st_d = d
                 sig_d = tuple((k, tuple(v.shape)) for k, v in st_d.items()) + (("training", bool(self.model.training)),)
                 if sig_d == self._sig:
+                    # Only the SAME tensor objects coming back qualify (held by weak references): an ordinary loader makes
+                    # fresh `.to(device)` tensors every step and the caching allocator recycles their addresses -- an address
+                    # tuple seen twice is then no sign of a recycled buffer, and a graph pinned on it would keep 14 dead
+                    # tensors (and itself) alive for nothing.  A pinned entry whose tensors have died is dropped.
+                    tensors = list(st_d.values())
+                    same = lambda refs: len(refs) == len(tensors) and all(r() is t for r, t in zip(refs, tensors))
                     pin = self._pinned.get(key)
-                    if pin is None and len(self._pinned) < self.MAX_PINNED_GRAPHS:
-                        n = self._seen.get(key, 0) + 1
-                        if len(self._seen) < 4096 or key in self._seen:
-                            self._seen[key] = n
-                        if n >= 2:
-                            pin = self._pinned[key] = (self._capture(st_d), None, list(st_d.values()))
+                    if pin is not None and not same(pin[2]):
+                        del self._pinned[key]
+                        pin = None
+                    if pin is None and len(self._pinned) < self.MAX_PINNED_GRAPHS \
+                            and self._dict_captures < self.MAX_DICT_CAPTURES:
+                        seen = self._seen.get(key)
+                        if seen is not None and same(seen):
+                            self._dict_captures += 1
+                            pin = self._pinned[key] = (self._capture(st_d), None, seen)
+                            del self._seen[key]
+                        elif len(self._seen) < 256 or key in self._seen:
+                            self._seen[key] = [weakref.ref(t) for t in tensors]
                     if pin is not None:
                         pin[0].replay()
                         self.steps_done += 1

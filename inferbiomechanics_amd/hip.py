@@ -17,6 +17,9 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # IB_HIP_LIB: another build of the same library (A/B runs of kernel variants inside one gpurun call); never a fallback
 LIB_PATH = os.environ.get("IB_HIP_LIB") or os.path.join(_HERE, "lib", "libib_hip.so")
+# the measurement build of the same sources (-DIB_AB: environment A/B switches + in-kernel stamp hooks); selected ONLY through
+# IB_HIP_LIB by tools/ and by the tests that compare kernel families -- the product never loads it
+AB_LIB_PATH = os.path.join(_HERE, "lib", "ab", "libib_hip_ab.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "ib_hip.h")
 
 F32, BF16 = 0, 1
@@ -95,6 +98,11 @@ _SIGS = {
     "ib_im2col_replicate": (_c.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _c.c_int, _c.c_int, _vp]),
     "ib_col2im_replicate": (_c.c_int, [_vp, _i64, _vp, _c.c_int, _vp, _i64, _i64, _i64, _c.c_int, _c.c_int, _vp]),
     "ib_dropout": (_c.c_int, [_vp, _vp, _i64, _f32, _c.c_uint32, _i32, _vp, _c.c_int, _vp]),
+    "ib_sqdiff_mean": (_c.c_int, [_vp, _vp, _vp, _i64, _i64, _c.c_int, _vp]),
+    "ib_sqdiff_mean_bwd": (_c.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _c.c_int, _vp]),
+    "ib_mask_by_threes": (_c.c_int, [_vp, _vp, _i64, _f32, _c.c_int, _vp]),
+    "ib_mean_norm_error": (_c.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _c.c_int, _c.c_int, _c.c_int, _vp]),
+    "ib_gather_rows_bwd": (_c.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp]),
     "ib_diffusion_draw": (_c.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _c.c_uint64, _i32, _vp,
                                      _c.c_uint32, _c.c_int, _vp]),
     "ib_philox_words": (_c.c_int, [_vp, _i64, _c.c_uint64, _c.c_uint32, _c.c_uint32, _c.c_uint32, _vp]),
@@ -389,6 +397,11 @@ def lib():
             fn.argtypes = args
         _lib = _DryRunLib(l) if _dry_run else l
     return _lib
+
+
+def measurement_build() -> bool:
+    """True while the -DIB_AB build of the library is the one loaded (tools/ and A/B tests select it through IB_HIP_LIB)"""
+    return os.path.basename(LIB_PATH) != "libib_hip.so"
 
 
 def _check(rc: int, what: str):
@@ -1268,6 +1281,61 @@ def gather_rows(table, idx, out):
     _check(lib().ib_gather_rows(_ptr(table), _ptr(idx), _ptr(out), B, dim, table.shape[0], dtype_code(out.dtype),
                                 stream_ptr()), "ib_gather_rows")
     return out
+
+
+def gather_rows_bwd(dout, idx, dtable):
+    """dtable[r] = sum of dout[i] over idx[i] == r (fp32, position order)"""
+    _req(dout, "dout", torch.float32, 2)
+    _req(idx, "idx", torch.int64, 1)
+    _req(dtable, "dtable", torch.float32, 2)
+    n, dim = dout.shape
+    if idx.numel() != n or dtable.shape[1] != dim or not dout.is_contiguous() or not dtable.is_contiguous():
+        raise HipError("gather_rows_bwd shape mismatch")
+    _check(lib().ib_gather_rows_bwd(_ptr(dout), _ptr(idx), _ptr(dtable), n, dim, dtable.shape[0], stream_ptr()),
+           "ib_gather_rows_bwd")
+    return dtable
+
+
+def _pair3(o, l, what):
+    _req(o, what + " output")
+    _req(l, what + " label")
+    if o.dtype != l.dtype or o.shape != l.shape or o.dim() != 3 or not o.is_contiguous() or not l.is_contiguous():
+        raise HipError(f"{what}: contiguous [B, F, C] tensors of one shape and dtype required")
+    return o.shape
+
+
+def sqdiff_mean(o, l):
+    B, F, C = _pair3(o, l, "sqdiff_mean")
+    out = torch.empty(C, dtype=torch.float32, device=o.device)
+    _check(lib().ib_sqdiff_mean(_ptr(o), _ptr(l), _ptr(out), B * F, C, dtype_code(o.dtype), stream_ptr()), "ib_sqdiff_mean")
+    return out
+
+
+def sqdiff_mean_bwd(o, l, dout):
+    B, F, C = _pair3(o, l, "sqdiff_mean_bwd")
+    _req(dout, "dout", torch.float32, 1)
+    d_o = torch.empty_like(o)
+    _check(lib().ib_sqdiff_mean_bwd(_ptr(o), _ptr(l), _ptr(dout), _ptr(d_o), B * F, C, dtype_code(o.dtype), stream_ptr()),
+           "ib_sqdiff_mean_bwd")
+    return d_o
+
+
+def mask_by_threes(t, threshold: float):
+    _req(t, "tensor")
+    if not t.is_contiguous() or t.numel() % 3:
+        raise HipError("mask_by_threes: contiguous tensor with a multiple of 3 values required")
+    mask = torch.empty(t.shape, dtype=torch.float32, device=t.device)
+    _check(lib().ib_mask_by_threes(_ptr(t), _ptr(mask), t.numel(), float(threshold), dtype_code(t.dtype), stream_ptr()),
+           "ib_mask_by_threes")
+    return mask
+
+
+def mean_norm_error(o, l, vec_size: int = 3, fold_halves: bool = False):
+    B, F, C = _pair3(o, l, "mean_norm_error")
+    out = torch.empty(1, dtype=torch.float32, device=o.device)
+    _check(lib().ib_mean_norm_error(_ptr(o), _ptr(l), _ptr(out), B, F, C, int(vec_size), int(bool(fold_halves)),
+                                    dtype_code(o.dtype), stream_ptr()), "ib_mean_norm_error")
+    return out[0]
 
 
 def im2col_replicate(x, col, N: int, F: int, k: int):

@@ -83,6 +83,20 @@ class _RegressionLossFn(torch.autograd.Function):
         return tuple(ctx.grads) + (None, None, None)
 
 
+class _SqDiffMean(torch.autograd.Function):
+    """mean((o - l)^2, dim=(0, 1)) of device tensors through the library, differentiable w.r.t. the output"""
+
+    @staticmethod
+    def forward(ctx, o, l):
+        ctx.save_for_backward(o, l)
+        return hip.sqdiff_mean(o, l)
+
+    @staticmethod
+    def backward(ctx, dout):
+        o, l = ctx.saved_tensors
+        return hip.sqdiff_mean_bwd(o, l, dout.detach().to(torch.float32).contiguous()), None
+
+
 class RegressionLossEvaluator:
     def __init__(self, dataset, split: str, device='cpu'):
         self.dataset = dataset
@@ -104,7 +118,16 @@ class RegressionLossEvaluator:
         self._comp_w_cache = {}
         self._warned_wandb = False
 
-    # ---- static helpers (API compatibility; src/loss/RegressionLossEvaluator.py:73-158) ----------
+    # ---- static helpers (src/loss/RegressionLossEvaluator.py:73-158) ------------------------------------------------
+    # Same checks and messages as the reference.  Tensors in HBM go through the library (ib_sqdiff_mean / ib_mask_by_threes /
+    # ib_mean_norm_error; `get_squared_diff_mean_vector` stays differentiable through ib_sqdiff_mean_bwd).  HOST tensors --
+    # what the reference's own unit tests pass -- take the explicit host path below: a few torch expressions on the CPU,
+    # an API shim outside the GPU hot path (the training step never calls these; it uses the fused ib_regression_loss).
+    @staticmethod
+    def _on_device(*tensors) -> bool:
+        return all(isinstance(t, torch.Tensor) and t.is_cuda for t in tensors) and \
+            all(t.dtype in (torch.float32, torch.bfloat16) for t in tensors) and len({t.dtype for t in tensors}) == 1
+
     @staticmethod
     def get_squared_diff_mean_vector(output_tensor: torch.Tensor, label_tensor: torch.Tensor) -> torch.Tensor:
         if output_tensor.shape != label_tensor.shape:
@@ -113,7 +136,9 @@ class RegressionLossEvaluator:
             raise ValueError('Output and label tensors must be 3-dimensional')
         if output_tensor.numel() == 0:
             raise ValueError('Output and label tensors must not be empty')
-        return torch.mean((output_tensor - label_tensor) ** 2, dim=(0, 1))
+        if RegressionLossEvaluator._on_device(output_tensor, label_tensor):
+            return _SqDiffMean.apply(output_tensor.contiguous(), label_tensor.contiguous())
+        return torch.mean((output_tensor - label_tensor) ** 2, dim=(0, 1))          # host tensors
 
     @staticmethod
     def get_mask_by_threes(tensor: torch.Tensor, threshold: float = 0.0) -> torch.Tensor:
@@ -124,7 +149,9 @@ class RegressionLossEvaluator:
                 raise ValueError('Mask tensor must not be empty')
             if tensor.shape[-1] % 3 != 0:
                 raise ValueError('Mask tensor must have a final dimension divisible by 3')
-            norms = torch.norm(tensor.reshape(tensor.shape[0], tensor.shape[1], -1, 3), dim=-1)
+            if RegressionLossEvaluator._on_device(tensor):
+                return hip.mask_by_threes(tensor.contiguous(), threshold)
+            norms = torch.norm(tensor.reshape(tensor.shape[0], tensor.shape[1], -1, 3), dim=-1)       # host tensors
             mask = (norms > threshold).to(torch.float32)
             return mask.unsqueeze(3).expand(-1, -1, -1, 3).reshape(tensor.shape)
 
@@ -138,7 +165,10 @@ class RegressionLossEvaluator:
             raise ValueError('Output and label tensors must not be empty')
         if output_tensor.shape[-1] % vec_size != 0:
             raise ValueError('Tensors must have a final dimension divisible by vec_size=' + str(vec_size))
-        diffs = output_tensor - label_tensor
+        if RegressionLossEvaluator._on_device(output_tensor, label_tensor):
+            with torch.no_grad():
+                return hip.mean_norm_error(output_tensor.contiguous(), label_tensor.contiguous(), vec_size)
+        diffs = output_tensor - label_tensor                                                          # host tensors
         last = diffs.reshape(diffs.shape[0], diffs.shape[1], -1, vec_size)[:, -1:, :, :]   # last frame only (:136)
         return torch.mean(torch.norm(last, dim=3))
 
@@ -152,7 +182,11 @@ class RegressionLossEvaluator:
             raise ValueError('Output and label tensors must not be empty')
         if output_force_tensor.shape[-1] != 6:
             raise ValueError('Output and label tensors must have a 6 dimensional final dimension')
-        o = output_force_tensor[:, :, :3] + output_force_tensor[:, :, 3:]
+        if RegressionLossEvaluator._on_device(output_force_tensor, label_force_tensor):
+            with torch.no_grad():
+                return hip.mean_norm_error(output_force_tensor.contiguous(), label_force_tensor.contiguous(), 3,
+                                           fold_halves=True)
+        o = output_force_tensor[:, :, :3] + output_force_tensor[:, :, 3:]                             # host tensors
         l = label_force_tensor[:, :, :3] + label_force_tensor[:, :, 3:]
         return RegressionLossEvaluator.get_mean_norm_error(o, l, vec_size=3)
 

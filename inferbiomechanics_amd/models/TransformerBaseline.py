@@ -14,6 +14,8 @@ import math
 import torch
 import torch.nn as nn
 
+from .. import hip
+
 from ..module import HipModule
 from ..plans import TransformerLayerPlan
 
@@ -87,12 +89,40 @@ class TransformerLayer(HipModule):
         return self.run_plan(x)
 
 
+class _EmbeddingRows(torch.autograd.Function):
+    """weight[idx] through ib_gather_rows; the weight gradient through ib_gather_rows_bwd (position order: deterministic)"""
+
+    @staticmethod
+    def forward(ctx, weight, idx):
+        out = torch.empty((idx.numel(), weight.shape[1]), dtype=torch.float32, device=weight.device)
+        hip.gather_rows(weight.detach().contiguous(), idx, out)
+        ctx.save_for_backward(idx)
+        ctx.rows = weight.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (idx,) = ctx.saved_tensors
+        dw = torch.empty((ctx.rows, dout.shape[1]), dtype=torch.float32, device=dout.device)
+        hip.gather_rows_bwd(dout.detach().to(torch.float32).contiguous(), idx, dw)
+        return dw, None
+
+
 class TemporalEmbedding(nn.Module):
-    """Learned per-frame vector (src/models/TransformerBaseline.py:41-48); looked up with arange(T)."""
+    """Learned per-frame vector (src/models/TransformerBaseline.py:41-48); looked up with arange(T).  The parameter keeps
+    nn.Embedding's name (`embedding.weight`, the checkpoint grammar); a float32 table in HBM is read through the library's
+    row gather (fwd) and its position-order transpose (bwd).  A host table, or the reference's float64 default, takes
+    nn.Embedding's own lookup (host-only shim: the denoiser plans never call this forward -- they gather the rows inside
+    their own launch sequence)."""
 
     def __init__(self, window_size: int, embedding_dim: int, dtype=torch.float32, device=None):
         super().__init__()
         self.embedding = nn.Embedding(window_size, embedding_dim, dtype=dtype, device=device)
 
     def forward(self, x):
+        w = self.embedding.weight
+        if (w.is_cuda or hip._dry_run) and w.dtype == torch.float32 and isinstance(x, torch.Tensor) \
+                and x.dtype in (torch.int64, torch.int32):
+            idx = x.to(device=w.device, dtype=torch.int64).contiguous()
+            return _EmbeddingRows.apply(w, idx.reshape(-1)).reshape(tuple(idx.shape) + (w.shape[1],))
         return self.embedding(x)

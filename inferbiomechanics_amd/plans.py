@@ -16,6 +16,7 @@ Reference arithmetic implemented here (file:line relative to the reference root)
 from __future__ import annotations
 
 import os
+import zlib
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -519,8 +520,9 @@ class TransformerLayerPlan:
                  tag="tl", dropout_p: float = 0.0, seed: Optional[int] = None):
         self.p, self.d, self.h, self.ffn, self.dtype, self.tag = prefix, d_model, num_heads, ffn, dtype, tag
         self.drop_p = float(dropout_p)
-        # per plan instance: the tag (layer index) enters the seed, so stacked layers draw different masks
-        self.seed = mask_seed(0x3A7 + 16 * sum(map(ord, tag))) if seed is None else int(seed)
+        # per plan instance: the tag (it carries the layer index) enters the seed through a CRC of the whole string, so
+        # stacked layers draw different masks ('tl12' and 'tl21' too: a character sum does not see digit order)
+        self.seed = mask_seed(0x3A7 + 16 * (zlib.crc32(tag.encode()) & 0xFFFFFF)) if seed is None else int(seed)
         self.buf = buf if buf is not None else Buffers(device)
         self.ctx = None
         # the four weight-gradient GEMMs (+ bias sums) hang off the critical dgrad / LayerNorm / attention chain.  One GPU,
@@ -1090,7 +1092,9 @@ class DenoiserMLPPlan:
         # (issued AFTER the grouped launch instead, the branch's first kernel only started when the grouped launch had
         # finished -- no overlap at all: 0.232 -> 0.250 ms/step)
         rider_ops = []
-        if os.environ.get("IB_SKIP_TIME_BWD"):       # TIMING-ONLY: an upper bound of what the time-MLP backward costs (wrong gradients)
+        if os.environ.get("IB_SKIP_TIME_BWD") and hip.measurement_build():
+            # TIMING-ONLY (wrong gradients): an upper bound of what the time-MLP backward costs.  Honoured only while the
+            # measurement build of the library is loaded (tools/, IB_HIP_LIB) -- the product ignores the variable
             if defer is not None and getattr(self, "_tb_defer", None):
                 defer.extend(self._tb_defer)
         else:

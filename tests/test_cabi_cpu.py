@@ -92,3 +92,25 @@ def test_no_cpu_fallback():
     ev = RegressionLossEvaluator(None, 'train', device='cpu')
     with pytest.raises(hip.HipError):
         ev({}, {}, {}, [], [], argparse.Namespace())
+
+
+def test_shipping_library_reads_no_environment_and_has_no_profiling_hooks():
+    """no global mutable state in the C-ABI.  The A/B switches (IB_NO_NT, IB_TN_TARGET, ...) and the in-kernel
+    stamp hooks are compiled only into the measurement build (lib/ab/libib_hip_ab.so, -DIB_AB); the shipping library imports
+    no getenv at all, answers IB_E_UNSUPPORTED to every ib_debug_set_* call, and both builds export the same symbols"""
+    import os
+    import subprocess
+    from inferbiomechanics_amd import hip
+    assert os.path.basename(hip.LIB_PATH) == "libib_hip.so" and not hip.measurement_build()
+    und = subprocess.run(["nm", "-D", "--undefined-only", hip.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in und
+    lib = hip.lib()
+    for setter in ("ib_debug_set_chain_prof", "ib_debug_set_gemm_prof", "ib_debug_set_nt_prof"):
+        assert getattr(lib, setter)(None) == -5, setter
+    assert lib.ib_debug_set_ablate(1) == -5
+    assert os.path.exists(hip.AB_LIB_PATH), "the measurement build was not built (make -C inferbiomechanics_amd/csrc)"
+    ab = ctypes.CDLL(hip.AB_LIB_PATH)
+    for n in hip.declared_symbols():
+        assert hasattr(ab, n), f"libib_hip_ab.so does not export {n}"
+    assert "getenv" in subprocess.run(["nm", "-D", "--undefined-only", hip.AB_LIB_PATH], capture_output=True, text=True,
+                                      check=True).stdout

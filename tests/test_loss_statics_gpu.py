@@ -1,0 +1,90 @@
+"""The evaluator's static helpers on DEVICE tensors (ib_sqdiff_mean / ib_mask_by_threes / ib_mean_norm_error;
+src/loss/RegressionLossEvaluator.py:73-158): the reference's own 24 unit-test vectors (tests/test_loss_statics_cpu.py's
+tables, taken from test/loss/test_RegressionLossEvaluator.py:7-192) pushed through the library, seeded tensors against the
+oracle, the autograd of the squared-difference mean, and `TemporalEmbedding.forward` through ib_gather_rows.  -m gpu."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ref_cpu as R  # noqa: E402
+from tests.test_loss_statics_cpu import ERROR_CASES, VALUE_CASES  # noqa: E402
+
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+
+
+def fns():
+    from inferbiomechanics_amd.loss.RegressionLossEvaluator import RegressionLossEvaluator as E
+    return dict(sq=E.get_squared_diff_mean_vector, mask=E.get_mask_by_threes, mne=E.get_mean_norm_error, com=E.get_com_acc_error)
+
+
+@pytest.mark.parametrize("case", range(len(VALUE_CASES)))
+def test_reference_value_vectors_on_the_device(case):
+    from inferbiomechanics_amd import hip
+    fn, args, kw, want, exact = VALUE_CASES[case]
+    with hip.record_launches() as rec:
+        got = fns()[fn](*[a.to(DEV) for a in args], **kw)
+    assert got.is_cuda and any(n.startswith(("ib_sqdiff", "ib_mask", "ib_mean_norm")) for n, _ in rec.calls), rec.calls
+    if exact:
+        assert torch.equal(got.cpu(), want), (got, want)
+    else:
+        assert torch.allclose(got.cpu().reshape(want.shape), want, rtol=1e-6, atol=1e-7), (got, want)
+
+
+@pytest.mark.parametrize("case", range(len(ERROR_CASES)))
+def test_reference_error_vectors_on_the_device(case):
+    fn, args = ERROR_CASES[case]
+    with pytest.raises(ValueError):
+        fns()[fn](*[a.to(DEV) for a in args])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_seeded_tensors_match_the_oracle_and_autograd(dtype):
+    g = torch.Generator().manual_seed(3)
+    o = (torch.randn(37, 11, 12, generator=g) * 8).to(dtype)
+    l = (torch.randn(37, 11, 12, generator=g) * 8).to(dtype)
+    f = fns()
+    od = o.to(DEV).requires_grad_(True)
+    got = f["sq"](od, l.to(DEV))
+    want = R.squared_diff_mean_vector(o.double(), l.double())
+    assert torch.allclose(got.cpu().double(), want, rtol=2e-6)
+    w = torch.linspace(0.5, 2.0, 12)
+    (got * w.to(DEV)).sum().backward()
+    oo = o.double().requires_grad_(True)
+    (R.squared_diff_mean_vector(oo, l.double()) * w.double()).sum().backward()
+    tol = 1e-6 if dtype == torch.float32 else 2.0 ** -8
+    assert torch.allclose(od.grad.cpu().double(), oo.grad, rtol=tol, atol=tol * float(oo.grad.abs().max()))
+    assert torch.equal(f["mask"](o.to(DEV), threshold=10.0).cpu(), R.mask_by_threes(o.float(), 10.0))
+    for vs in (3, 6, 4):
+        assert torch.allclose(f["mne"](o.to(DEV), l.to(DEV), vec_size=vs).cpu().double(),
+                              R.mean_norm_error(o.double(), l.double(), vs), rtol=2e-6)
+    o6, l6 = o[:, :, :6].contiguous(), l[:, :, :6].contiguous()
+    assert torch.allclose(f["com"](o6.to(DEV), l6.to(DEV)).cpu().double(), R.com_acc_error(o6.double(), l6.double()), rtol=2e-6)
+
+
+def test_temporal_embedding_reads_and_differentiates_through_the_library():
+    from inferbiomechanics_amd import hip
+    from inferbiomechanics_amd.models.TransformerBaseline import TemporalEmbedding
+    torch.manual_seed(2)
+    emb = TemporalEmbedding(50, 30, device=DEV)
+    ref = torch.nn.Embedding(50, 30)
+    ref.weight.data.copy_(emb.embedding.weight.detach().cpu())
+    idx = torch.tensor([[0, 49, 7, 7], [3, 0, 0, 21]])
+    with hip.record_launches() as rec:
+        out = emb(idx.to(DEV))
+    assert [n for n, _ in rec.calls] == ["ib_gather_rows"]
+    want = ref(idx)
+    assert out.shape == (2, 4, 30) and torch.equal(out.cpu(), want)
+    coef = torch.randn(2, 4, 30)
+    (out * coef.to(DEV)).sum().backward()
+    (want * coef).sum().backward()
+    assert torch.allclose(emb.embedding.weight.grad.cpu(), ref.weight.grad, rtol=1e-6, atol=1e-7)
+    assert list(emb.state_dict()) == ["embedding.weight"]                 # checkpoint grammar of the reference class
+    # the reference's call: arange(T) (TransformerBaseline.py:119-126)
+    assert torch.equal(emb(torch.arange(50)).cpu(), ref.weight.detach())

@@ -459,6 +459,9 @@ def test_large_batch_kernel_paths_agree():
         for k in ("IB_NO_NT", "IB_NO_TN", "IB_NO_WGRAD_BIAS", "IB_DDP_SELFTEST", "IB_GRAPH_COLLECTIVES"):
             env.pop(k, None)
         env.update(extra)
+        if name == "ring":         # IB_NO_TN is a C-level switch: it exists only in the measurement build of the library
+            from inferbiomechanics_amd import hip as _hip
+            env["IB_HIP_LIB"] = _hip.AB_LIB_PATH
         r = subprocess.run([sys.executable, os.path.join(root, "tools", "path_ab.py")], capture_output=True, text=True, env=env,
                            timeout=600)
         assert r.returncode == 0, r.stderr[-3000:]

@@ -7,8 +7,9 @@ NAME=$1; SRC=$2; shift 2
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 C=$ROOT/inferbiomechanics_amd/csrc
 make -s -C $C -j8 >/dev/null
-mkdir -p $C/build/ab $ROOT/inferbiomechanics_amd/lib/ab
-hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall -Wno-unused-function "$@" -c $C/$SRC -o $C/build/ab/${SRC%.hip}_$NAME.o
-OBJS=$(ls $C/build/*.o | grep -v "/${SRC%.hip}.o")
-hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/inferbiomechanics_amd/lib/ab/libib_hip_$NAME.so $OBJS $C/build/ab/${SRC%.hip}_$NAME.o
+mkdir -p $C/build_ab/var $ROOT/inferbiomechanics_amd/lib/ab
+# variants are measurement builds: -DIB_AB objects (A/B switches, stamp hooks) + the one re-compiled source
+hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall -Wno-unused-function -DIB_AB "$@" -c $C/$SRC -o $C/build_ab/var/${SRC%.hip}_$NAME.o
+OBJS=$(ls $C/build_ab/*.o | grep -v "/${SRC%.hip}.o")
+hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/inferbiomechanics_amd/lib/ab/libib_hip_$NAME.so $OBJS $C/build_ab/var/${SRC%.hip}_$NAME.o
 echo $ROOT/inferbiomechanics_amd/lib/ab/libib_hip_$NAME.so

@@ -7,6 +7,7 @@ import sys
 import torch
 
 sys.path.insert(0, ".")
+import tools._ab  # noqa: E402,F401  (the -DIB_AB measurement build: A/B switches + stamp hooks)
 from inferbiomechanics_amd import hip  # noqa: E402
 
 

@@ -11,6 +11,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import tools._ab  # noqa: E402,F401  (the -DIB_AB measurement build: A/B switches + stamp hooks)
 from inferbiomechanics_amd import hip  # noqa: E402
 from tools.kbench import timeit  # noqa: E402
 
