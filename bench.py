@@ -558,6 +558,51 @@ def self_launch(n):
     return p.returncode
 
 
+def graph_collectives_child(n, steps=60, warmup=10, timeout_s=240):
+    """Data-parallel runs only: the SAME main workload once more with the gradient all-reduces CAPTURED inside the step's
+    hipGraph (IB_GRAPH_COLLECTIVES=1: one graph per step, no graph cut and no host action per collective) -- in FRESH child
+    processes (a new torch.distributed.run launch of n ranks; nothing that has touched a GPU is ever re-exec'd), bounded by a
+    timeout, and fenced: whatever happens there (non-zero exit, timeout, no JSON) becomes an `error` string in the extra key
+    and never costs the record of the default (cut-graph) run."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE",
+              "ROLE_WORLD_SIZE", "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS"):
+        env.pop(k, None)
+    env.update(IB_GRAPH_COLLECTIVES="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), "--gpus", str(n), "--steps", str(steps), "--warmup",
+           str(warmup), "--no-transformer", "--no-ddim", "--no-cpu-baseline", "--no-variant-child", "--no-roofline"]
+    t0 = time.perf_counter()
+    try:
+        p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, start_new_session=True)
+        try:
+            out, _ = p.communicate(timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            import signal
+            os.killpg(p.pid, signal.SIGKILL)          # the launcher's own process group: exactly the children started here
+            p.communicate()
+            return {"error": f"timed out after {timeout_s} s", "seconds": round(time.perf_counter() - t0, 1)}
+        for ln in out.decode(errors="replace").splitlines():
+            ln = ln.strip()
+            if ln.startswith("{") and '"metric"' in ln:
+                try:
+                    d = json.loads(ln)
+                    return {"ms_per_step": d["ms_per_step"], "value": d["value"], "unit": d["unit"], "steps": steps,
+                            "warmup": warmup, "final_loss": d.get("final_loss"), "rccl_world": d.get("rccl_world"),
+                            "seconds": round(time.perf_counter() - t0, 1)}
+                except (ValueError, KeyError):
+                    pass
+        return {"error": f"child exited with code {p.returncode} and printed no result line",
+                "seconds": round(time.perf_counter() - t0, 1)}
+    except Exception as exc:                          # nothing in here may cost the record
+        return {"error": repr(exc)[:300]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -571,6 +616,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ddim", action="store_true")
     ap.add_argument("--no-cli-path", action="store_true", help="skip the `main.py train` rate of the same workload")
+    ap.add_argument("--no-variant-child", action="store_true",
+                    help="[N > 1] skip the captured-collectives variant (IB_GRAPH_COLLECTIVES=1) run in child processes")
+    ap.add_argument("--no-roofline", action="store_true", help="skip the per-launch roofline leg (child runs)")
     ap.add_argument("--no-transformer", action="store_true", help="skip the configs[2] / configs[3] transformer leg")
     ap.add_argument("--bucket-mb", type=float, default=13.0,
                     help="gradient bucket size when all-reduces overlap the backward: each bucket boundary cuts the captured "
@@ -621,6 +669,8 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
         backend = dist.get_backend()
+    # a host-side group for waits that must not occupy the GPUs (the variant child below runs its own RCCL kernels)
+    host_group = dist.new_group(backend="gloo") if (world > 1 and not rehearsal) else None
 
     from inferbiomechanics_amd import hip
     hip.lib()
@@ -633,7 +683,7 @@ def main():
 
     kind, T, D, B = WORKLOADS[a.workload]
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
-    main_leg = train_leg(a.workload, a, dev, world, rank, a.steps, a.warmup, sync)
+    main_leg = train_leg(a.workload, a, dev, world, rank, a.steps, a.warmup, sync, with_roofline=not a.no_roofline)
     # BASELINE configs[2] (one GPU) / configs[3] (data parallel, per-GPU batch 256): the 4-layer d = 512 transformer
     # denoiser at T = 50, its own step count (3 ms steps), every rank takes part (the step holds the all-reduces)
     tr_leg = None
@@ -642,6 +692,15 @@ def main():
         # control flow just as well)
         tr_leg = train_leg("transformer_denoiser_T50", a, dev, world, rank, 8 if rehearsal else 100, 2 if rehearsal else 10,
                            sync)
+    variant = None
+    # (IB_BENCH_FORCE_VARIANT=1 with IB_DDP_SELFTEST=1: the same mechanism on a one-GPU box, a 1-rank child)
+    want_variant = world > 1 or (selftest and os.environ.get("IB_BENCH_FORCE_VARIANT") == "1")
+    if want_variant and not rehearsal and not a.no_variant_child and os.environ.get("IB_GRAPH_COLLECTIVES") != "1":
+        sync()
+        if rank == 0:
+            variant = graph_collectives_child(world)
+        if host_group is not None:
+            dist.barrier(group=host_group)             # the other ranks wait on the HOST (gloo), their GPUs idle
     if rank == 0:
         cfg = dict(main_leg["config"])
         cfg["workload"] = main_leg["workload"] + (" (BASELINE.json configs[1])" if kind == "mlp" else "")
@@ -657,6 +716,10 @@ def main():
                   "step_sum_of_kernel_us", "step_breakdown"):
             if k in main_leg:
                 line[k] = main_leg[k]
+        if variant is not None:
+            variant["what"] = ("same workload, IB_GRAPH_COLLECTIVES=1 (all-reduces captured inside the step's hipGraph) in fresh "
+                               "child processes; the headline value above is the default cut-graph form")
+            line["graph_collectives_variant"] = variant
         if tr_leg is not None:
             tr_leg["workload"] += " (BASELINE.json configs[2]" + ("; configs[3] data-parallel form)" if world > 1 else ")")
             line["transformer_T50"] = tr_leg

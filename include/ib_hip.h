@@ -262,6 +262,31 @@ int ib_optim_step_sources(int opt, float* p, const float* g, float* s1, float* s
  * tickets are drawn in two levels so no single address serialises the grid); the kernel leaves it zeroed. */
 int ib_optim_ticket_words(void);
 
+/* ---- fused feed-forward sublayer of the post-norm encoder layer (csrc/ffn_chain.hip; replaces, per layer and direction,
+ * two nn.Linear GEMMs + residual + nn.LayerNorm: TransformerBaseline.py:15-19,33-36 and their autograd), bf16, d == 512,
+ * ffn a multiple of 512 (<= 4096).  One launch over panels of <= 64 token rows (ib_ffn_chain_workgroups), the hidden width
+ * walked in chunks of 512 columns, weights streamed from a fragment-major packed image:
+ *   ib_ffn_chain_pack   packed[l] (ib_ffn_chain_packed_elems bf16 elements each) <- w1[l] = feedforward.0.weight [ffn, d],
+ *                       w2[l] = feedforward.2.weight [d, ffn]  (forward and transposed images of both), all layers in ONE launch;
+ *   ib_ffn_chain_fwd    y = LN(x1 + relu(x1 W1^T + b1) W2^T + b2); also stores f1 = relu(..) [M, ffn] (weight-gradient operand),
+ *                       s2 = the LayerNorm input [M, d], mean / rstd [M], and the ReLU bits (`mask`, ib_ffn_chain_mask_bytes);
+ *   ib_ffn_chain_bwd    ds2 = LN-backward(dy) [M, d] (= d f2 and the residual addend), dz1 = (ds2 W2) * relu'(.) [M, ffn],
+ *                       dx1 = dz1 W1 + ds2 [M, d]; partial fp32 [2 x workgroups, d]: dgamma of every panel, then dbeta of every
+ *                       panel (summed in workgroup order by the optimizer / ib_step_reduce).  The weight and bias gradients
+ *                       stay GEMMs. */
+int ib_ffn_chain_supported(int64_t d, int64_t ffn);
+size_t ib_ffn_chain_packed_elems(int64_t d, int64_t ffn);
+int ib_ffn_chain_workgroups(int64_t M, int64_t d, int64_t ffn, int* rows_per_wg);
+size_t ib_ffn_chain_mask_bytes(int64_t M, int64_t d, int64_t ffn);
+int ib_ffn_chain_pack(const void* const* w1, const int64_t* ld1, const void* const* w2, const int64_t* ld2,
+                      void* const* packed, int layers, int64_t d, int64_t ffn, ib_stream_t stream);
+int ib_ffn_chain_fwd(const void* x1, const void* packed, const float* b1, const float* b2, const float* gamma,
+                     const float* beta, void* f1, void* s2, void* y, float* mean, float* rstd, void* mask, int64_t M,
+                     int64_t d, int64_t ffn, float ln_eps, ib_stream_t stream);
+int ib_ffn_chain_bwd(const void* dy, const void* s2, const float* mean, const float* rstd, const float* gamma,
+                     const void* packed, const void* mask, void* ds2, void* dz1, void* dx1, float* partial, int64_t M,
+                     int64_t d, int64_t ffn, ib_stream_t stream);
+
 /* ---- diffusion wrapper [BUILD-DEFINED]: DDPM q_sample, DDIM eta=0 update, table gathers ----- */
 /* ---- tiny matrix products: C[M,N] (+)= sum_k A(m,k) B(k,n), A(m,k) = A[m*sam + k*sak], B(k,n) = B[k*sbk + n*sbn], each
  * operand with its own storage dtype (IB_F32 / IB_BF16), fp32 accumulation in a fixed order.  The frame-embedding
@@ -472,7 +497,8 @@ enum {
   IB_PATH_CHAIN2 = 10,      /* chain.hip: fused MLP-denoiser chain, row-wise epilogues */
   IB_PATH_CHAIN1 = 11,      /* chain.hip: the round-2 chain kernel (IB_CHAIN_V1=1) */
   IB_PATH_TN256 = 12,       /* gemm_tn256.hip: 256 x 256 weight-gradient kernel, grouped, one split count per group */
-  IB_PATH_NT_SPLITK = 13    /* gemm_nt.hip in split-K form (fp32 slabs) under the sampler's Linear + LayerNorm */
+  IB_PATH_NT_SPLITK = 13,   /* gemm_nt.hip in split-K form (fp32 slabs) under the sampler's Linear + LayerNorm */
+  IB_PATH_FFN_CHAIN = 14    /* ffn_chain.hip: fused feed-forward sublayer (Linear + ReLU + Linear + residual + LayerNorm) */
 };
 int ib_debug_last_path(void);
 int ib_selftest_tr16(const void* in_bf16_64x16, void* out_bf16_64x4, ib_stream_t stream);

@@ -98,6 +98,13 @@ _SIGS = {
     "ib_im2col_replicate": (_c.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _c.c_int, _c.c_int, _vp]),
     "ib_col2im_replicate": (_c.c_int, [_vp, _i64, _vp, _c.c_int, _vp, _i64, _i64, _i64, _c.c_int, _c.c_int, _vp]),
     "ib_dropout": (_c.c_int, [_vp, _vp, _i64, _f32, _c.c_uint32, _i32, _vp, _c.c_int, _vp]),
+    "ib_ffn_chain_supported": (_c.c_int, [_i64, _i64]),
+    "ib_ffn_chain_packed_elems": (_sz, [_i64, _i64]),
+    "ib_ffn_chain_workgroups": (_c.c_int, [_i64, _i64, _i64, _vp]),
+    "ib_ffn_chain_mask_bytes": (_sz, [_i64, _i64, _i64]),
+    "ib_ffn_chain_pack": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _c.c_int, _i64, _i64, _vp]),
+    "ib_ffn_chain_fwd": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _f32, _vp]),
+    "ib_ffn_chain_bwd": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
     "ib_sqdiff_mean": (_c.c_int, [_vp, _vp, _vp, _i64, _i64, _c.c_int, _vp]),
     "ib_sqdiff_mean_bwd": (_c.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _c.c_int, _vp]),
     "ib_mask_by_threes": (_c.c_int, [_vp, _vp, _i64, _f32, _c.c_int, _vp]),
@@ -164,7 +171,7 @@ def declared_symbols() -> List[str]:
     return sorted(set(re.findall(r"\b(ib_[a-z0-9_]+)\s*\(", src)))
 
 
-_HOST_ONLY = ("_workspace", "_supported", "_workgroups", "_packed_elems", "_partial_width", "_last_path", "_slab_count", "_ticket_words")   # pure host queries: no launch, no stream
+_HOST_ONLY = ("_workspace", "_supported", "_workgroups", "_packed_elems", "_partial_width", "_last_path", "_slab_count", "_ticket_words", "_mask_bytes")   # pure host queries: no launch, no stream
 
 
 class _DryRunLib:
@@ -256,7 +263,7 @@ class _RecordingLib:
 
 
 PATH_NAMES = {0: "-", 1: "nt256x128", 2: "tn256x128", 3: "ring128", 4: "generic", 5: "smallm", 6: "skinny", 7: "wgrad_small",
-              8: "ring_multi", 9: "linear_ln", 10: "chain_v2", 11: "chain_v1", 12: "tn256x256", 13: "nt_splitk"}
+              8: "ring_multi", 9: "linear_ln", 10: "chain_v2", 11: "chain_v1", 12: "tn256x256", 13: "nt_splitk", 14: "ffn_chain"}
 _work_note = None     # set by a wrapper right before a grouped launch: (flops, bytes) of that launch, for bench.py
 
 
@@ -1281,6 +1288,87 @@ def gather_rows(table, idx, out):
     _check(lib().ib_gather_rows(_ptr(table), _ptr(idx), _ptr(out), B, dim, table.shape[0], dtype_code(out.dtype),
                                 stream_ptr()), "ib_gather_rows")
     return out
+
+
+# --------------------------------------------------------------------------------------------
+# fused feed-forward sublayer (csrc/ffn_chain.hip)
+# --------------------------------------------------------------------------------------------
+def ffn_chain_supported(d: int, ffn: int) -> bool:
+    return bool(lib().ib_ffn_chain_supported(int(d), int(ffn)))
+
+
+def ffn_chain_packed_elems(d: int, ffn: int) -> int:
+    return int(lib().ib_ffn_chain_packed_elems(int(d), int(ffn)))
+
+
+def ffn_chain_workgroups(M: int, d: int, ffn: int) -> int:
+    return int(lib().ib_ffn_chain_workgroups(int(M), int(d), int(ffn), None))
+
+
+def ffn_chain_mask_bytes(M: int, d: int, ffn: int) -> int:
+    return int(lib().ib_ffn_chain_mask_bytes(int(M), int(d), int(ffn)))
+
+
+def ffn_chain_pack(layers):
+    """layers: [(w1 [ffn, d] bf16, w2 [d, ffn] bf16, packed bf16 [ffn_chain_packed_elems])] -- ONE launch for all of them"""
+    n = len(layers)
+    ffn, d = layers[0][0].shape
+    for w1, w2, pk in layers:
+        _mat(w1, "w1", torch.bfloat16)
+        _mat(w2, "w2", torch.bfloat16)
+        _req(pk, "packed", torch.bfloat16, 1)
+        if tuple(w1.shape) != (ffn, d) or tuple(w2.shape) != (d, ffn) or pk.numel() < ffn_chain_packed_elems(d, ffn) \
+                or not pk.is_contiguous():
+            raise HipError("ffn_chain_pack: weight / packed-image shapes do not agree")
+    arr = lambda ts: ctypes.cast((ctypes.c_void_p * n)(*[t.data_ptr() for t in ts]), ctypes.c_void_p)
+    lds = lambda ts: ctypes.cast((ctypes.c_int64 * n)(*[t.stride(0) for t in ts]), ctypes.c_void_p)
+    w1s, w2s, pks = [l[0] for l in layers], [l[1] for l in layers], [l[2] for l in layers]
+    _check(lib().ib_ffn_chain_pack(arr(w1s), lds(w1s), arr(w2s), lds(w2s), arr(pks), n, d, ffn, stream_ptr()),
+           "ib_ffn_chain_pack")
+
+
+def _ffn_rows(t, name, M, N, dtype=torch.bfloat16):
+    _req(t, name, dtype, 2)
+    if tuple(t.shape) != (M, N) or not t.is_contiguous():
+        raise HipError(f"{name}: contiguous {dtype} [{M}, {N}] required, got {tuple(t.shape)} strides {t.stride()}")
+
+
+def ffn_chain_fwd(x1, packed, b1, b2, gamma, beta, f1, s2, y, mean, rstd, mask, eps: float = 1e-5):
+    M, d = x1.shape
+    ffn = f1.shape[1]
+    for t, n, w in ((x1, "x1", d), (f1, "f1", ffn), (s2, "s2", d), (y, "y", d)):
+        _ffn_rows(t, n, M, w)
+    for t, n, w in ((b1, "b1", ffn), (b2, "b2", d), (gamma, "gamma", d), (beta, "beta", d), (mean, "mean", M), (rstd, "rstd", M)):
+        _req(t, n, torch.float32, 1)
+        if t.numel() != w or not t.is_contiguous():
+            raise HipError(f"ffn_chain_fwd: {n} must be contiguous fp32 [{w}]")
+    _req(packed, "packed", torch.bfloat16, 1)
+    _req(mask, "mask", torch.uint8, 1)
+    if packed.numel() < ffn_chain_packed_elems(d, ffn) or mask.numel() < ffn_chain_mask_bytes(M, d, ffn):
+        raise HipError("ffn_chain_fwd: packed image / mask buffer too small")
+    _check(lib().ib_ffn_chain_fwd(_ptr(x1), _ptr(packed), _ptr(b1), _ptr(b2), _ptr(gamma), _ptr(beta), _ptr(f1), _ptr(s2),
+                                  _ptr(y), _ptr(mean), _ptr(rstd), _ptr(mask), M, d, ffn, float(eps), stream_ptr()),
+           "ib_ffn_chain_fwd")
+    return y
+
+
+def ffn_chain_bwd(dy, s2, mean, rstd, gamma, packed, mask, ds2, dz1, dx1, partial):
+    M, d = dy.shape
+    ffn = dz1.shape[1]
+    for t, n, w in ((dy, "dy", d), (s2, "s2", d), (ds2, "ds2", d), (dz1, "dz1", ffn), (dx1, "dx1", d)):
+        _ffn_rows(t, n, M, w)
+    _req(partial, "partial", torch.float32, 2)
+    if tuple(partial.shape) != (2 * ffn_chain_workgroups(M, d, ffn), d) or not partial.is_contiguous():
+        raise HipError("ffn_chain_bwd: partial must be contiguous fp32 [2 x workgroups, d]")
+    for t, n in ((mean, "mean"), (rstd, "rstd"), (gamma, "gamma")):
+        _req(t, n, torch.float32, 1)
+    _req(mask, "mask", torch.uint8, 1)
+    if packed.numel() < ffn_chain_packed_elems(d, ffn) or mask.numel() < ffn_chain_mask_bytes(M, d, ffn):
+        raise HipError("ffn_chain_bwd: packed image / mask buffer too small")
+    _check(lib().ib_ffn_chain_bwd(_ptr(dy), _ptr(s2), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(packed), _ptr(mask), _ptr(ds2),
+                                  _ptr(dz1), _ptr(dx1), _ptr(partial), M, d, ffn, stream_ptr()),
+           "ib_ffn_chain_bwd")
+    return dx1
 
 
 def gather_rows_bwd(dout, idx, dtable):

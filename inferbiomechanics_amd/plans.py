@@ -574,13 +574,32 @@ class TransformerLayerPlan:
         if self.dtype != torch.bfloat16 or self.inference or M < 4096 or os.environ.get("IB_NO_NT"):
             return []
         pairs = []
+        skip = ("feedforward.2.weight", "feedforward.0.weight") if self.ffn_fused(M) else ()
         for n in self.WT_NAMES:
+            if n in skip:          # the fused feed-forward sublayer streams its own packed images (ffn_pack_item)
+                continue
             w = P.w(self.p + n)
             wt = self.buf.get(self.tag + ".wt." + n, (w.shape[1], w.shape[0]), self.dtype)
             self._wt[n] = wt
             pairs.append((w, wt))
         self._wt_fresh = True
         return pairs
+
+    def ffn_fused(self, M: int) -> bool:
+        """the feed-forward sublayer (Linear + ReLU + Linear + residual + LayerNorm, TransformerBaseline.py:15-19,33-36) and
+        its backward as ONE launch each (csrc/ffn_chain.hip): bf16 training at chip-filling token counts, d = 512, a hidden
+        width of whole 512-column chunks, no dropout2 between the second Linear and the residual"""
+        return (self.dtype == torch.bfloat16 and not self.inference and M >= 4096 and self.drop_p == 0.0
+                and not os.environ.get("IB_NO_FFN_CHAIN") and not os.environ.get("IB_NO_NT")
+                and hip.ffn_chain_supported(self.d, self.ffn))
+
+    def ffn_pack_item(self, P: ParamSource, M: int):
+        """(feedforward.0.weight, feedforward.2.weight, this layer's packed image) for ib_ffn_chain_pack -- refreshed once
+        per training step, all layers of a parent plan in ONE launch -- or None"""
+        if not self.ffn_fused(M):
+            return None
+        pk = self.buf.get(self.tag + ".ffnpk", (hip.ffn_chain_packed_elems(self.d, self.ffn),), self.dtype)
+        return (P.w(self.p + "feedforward.0.weight"), P.w(self.p + "feedforward.2.weight"), pk)
 
     def _dgrad(self, P: ParamSource, dz, wname: str, dx, act_below="none", aux=None, addend=None):
         wt = self._wt.get(wname) if self._wt_fresh else None
@@ -598,10 +617,13 @@ class TransformerLayerPlan:
             if self.inference:
                 raise hip.HipError("TransformerLayerPlan: inference mode with training=True")
             drop = (self.drop_p, self.seed, step, step_dev)
+        ffn_fused = self.ffn_fused(M) and drop is None
         if self.own_wt:
             pairs = self.wt_pairs(P, M)
             if pairs:
                 hip.transpose_multi(pairs)
+            if ffn_fused:
+                hip.ffn_chain_pack([self.ffn_pack_item(P, M)])
         x = x3.view(M, d)
         qkv = g(tg + ".qkv", (B, T, 3 * d), dt)
         hip.linear_fwd(x, P.w(p + "multihead_attention.in_proj_weight"), P.v(p + "multihead_attention.in_proj_bias"),
@@ -640,6 +662,17 @@ class TransformerLayerPlan:
                 hip.dropout(a, a, self.drop_p, self.seed + 1, step, step_dev)
             m1, r1 = g(tg + ".m1", (M,), torch.float32), g(tg + ".r1", (M,), torch.float32)
             hip.layernorm_fwd(a, P.v(p + "norm1.weight"), P.v(p + "norm1.bias"), x1, m1, r1, res=x)
+        self._ffn_fused = ffn_fused
+        if ffn_fused:
+            # f2 of the context = the LayerNorm INPUT x1 + f2 the kernel stores (its backward normalises that; no `res`)
+            f2 = g(tg + ".s2", (M, d), dt)
+            m2, r2 = g(tg + ".m2", (M,), torch.float32), g(tg + ".r2", (M,), torch.float32)
+            mask = self.buf.get(tg + ".ffnmask", (hip.ffn_chain_mask_bytes(M, d, self.ffn),), torch.uint8)
+            hip.ffn_chain_fwd(x1, self.buf.get(tg + ".ffnpk", (hip.ffn_chain_packed_elems(d, self.ffn),), dt),
+                              P.v(p + "feedforward.0.bias"), P.v(p + "feedforward.2.bias"), P.v(p + "norm2.weight"),
+                              P.v(p + "norm2.bias"), f1, f2, x2.view(M, d), m2, r2, mask)
+            self.ctx = (x, qkv, attn, lse, a, x1, m1, r1, f1, f2, m2, r2, B, T, drop)
+            return x2
         hip.linear_fwd(x1, P.w(p + "feedforward.0.weight"), P.v(p + "feedforward.0.bias"), f1, act="relu")
         if not (fuse and lin_ln(f1, "feedforward.2.weight", "feedforward.2.bias", "norm2", x1, x2.view(M, d), ".lnws2")):
             f2 = g(tg + ".f2", (M, d), dt)
@@ -722,7 +755,25 @@ class TransformerLayerPlan:
             P.ready(p + name)
         # LN2: d(f2 + x1)
         ds2 = g(tg + ".ds2", (M, d), dt)
-        ln_bwd("norm2", dx2.view(M, d), f2, m2, r2, ds2, x1)
+        dz1 = g(tg + ".dz1", (M, self.ffn), dt)
+        dx1 = g(tg + ".dx1", (M, d), dt)
+        fused_ffn = getattr(self, "_ffn_fused", False)
+        if fused_ffn:
+            # LayerNorm2 backward + both dgrad GEMMs of the sublayer in ONE launch (csrc/ffn_chain.hip); `f2` is the saved
+            # LayerNorm input.  dgamma / dbeta leave as per-panel partial sums, finished with the layer's other partials.
+            if later is None:
+                raise hip.HipError("fused feed-forward backward needs the deferred partial-sum path (bf16, M >= 4096)")
+            nwg = hip.ffn_chain_workgroups(M, d, self.ffn)
+            part = self.buf.get(tg + ".ffnpart", (2 * nwg, d), torch.float32)
+            hip.ffn_chain_bwd(dx2.view(M, d), f2, m2, r2, P.v(p + "norm2.weight"),
+                              self.buf.get(tg + ".ffnpk", (hip.ffn_chain_packed_elems(d, self.ffn),), dt),
+                              self.buf.get(tg + ".ffnmask", (hip.ffn_chain_mask_bytes(M, d, self.ffn),), torch.uint8),
+                              ds2, dz1, dx1, part)
+            later.append((part[:nwg], nwg, P.g(p + "norm2.weight")))
+            later.append((part[nwg:], nwg, P.g(p + "norm2.bias")))
+            P.ready(p + "norm2.weight"); P.ready(p + "norm2.bias")
+        else:
+            ln_bwd("norm2", dx2.view(M, d), f2, m2, r2, ds2, x1)
         # ds2 = d(x1 + Drop(f2)): the residual path takes it as is, the feedforward path through dropout2's mask
         df2 = ds2
         if drop:
@@ -732,14 +783,14 @@ class TransformerLayerPlan:
         def g_ffn2():
             wgrad(df2, f1, "feedforward.2.weight", tg + ".ws2", bias=(tg + ".b2", "feedforward.2.bias"))
         side(g_ffn2)
-        dz1 = g(tg + ".dz1", (M, self.ffn), dt)
-        self._dgrad(P, df2, "feedforward.2.weight", dz1, act_below="relu", aux=f1)
+        if not fused_ffn:
+            self._dgrad(P, df2, "feedforward.2.weight", dz1, act_below="relu", aux=f1)
 
         def g_ffn1():
             wgrad(dz1, x1, "feedforward.0.weight", tg + ".ws1", bias=(tg + ".b1", "feedforward.0.bias"))
         side(g_ffn1)
-        dx1 = g(tg + ".dx1", (M, d), dt)
-        self._dgrad(P, dz1, "feedforward.0.weight", dx1, addend=ds2)       # + residual path
+        if not fused_ffn:
+            self._dgrad(P, dz1, "feedforward.0.weight", dx1, addend=ds2)       # + residual path
         # LN1: d(a + x)
         ds1 = g(tg + ".ds1", (M, d), dt)
         ln_bwd("norm1", dx1, a, m1, r1, ds1, x)
@@ -1281,6 +1332,7 @@ class DenoiserTransformerPlan:
         pos = P.w("temporal_embedding.embedding.weight")[:T]                 # [T, Pd]
         posproj = g("dt.posproj", (T, self.d), dt)
         pairs = [pr for lp in self.layers for pr in lp.wt_pairs(P, M)]
+        ffn_items = [it for it in (lp.ffn_pack_item(P, M) for lp in self.layers) if it is not None]
         if self.inference and self._e_all is not None:
             e = g("dt.e_rows", (B, self.d), dt)
             hip.gather_rows(self._e_all, t, e)                               # rows of the per-timestep table
@@ -1297,8 +1349,10 @@ class DenoiserTransformerPlan:
                     hip.cast2d(w_in[:, :D], tp["w_in"][:, :D])
             self.br_time.run(t_branch)
             e = box[0]
-            if pairs or tp:
+            if pairs or tp or ffn_items:
                 def wt_branch():
+                    if ffn_items:        # first: layer 0's feed-forward sublayer is the first reader
+                        hip.ffn_chain_pack(ffn_items)
                     pr = list(pairs)
                     if tp:
                         w_out = P.w("out_proj.weight")
@@ -1327,6 +1381,8 @@ class DenoiserTransformerPlan:
             hip.linear_fwd(x2, w_in[:, :D], P.v("in_proj.bias"), h0.view(M, self.d), add_div=e,
                            add_mod=posproj, seg=T)
         h = h0
+        if ffn_items and not self.inference:
+            self.br_wt.join()                         # layer 0's fused feed-forward sublayer reads the packed images
         for lp in self.layers:
             h = lp.forward(h, P)
         out = out if out is not None else g("dt.out", (B, T, D), dt)

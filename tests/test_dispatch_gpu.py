@@ -17,7 +17,7 @@ def test_every_baseline_shape_takes_its_kernel_family(golden_dir):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     for k in ("IB_NO_NT", "IB_NO_TN", "IB_NO_RING", "IB_NO_SMALLM", "IB_NO_CHAIN", "IB_CHAIN_V1", "IB_NT_MIN_M",
-              "IB_SMALLM_TILES", "IB_LINLN_MAX_M", "IB_LINLN_K512_MAX_M", "IB_TN_TARGET", "IB_NO_LINEAR_LN"):
+              "IB_SMALLM_TILES", "IB_LINLN_MAX_M", "IB_LINLN_K512_MAX_M", "IB_TN_TARGET", "IB_NO_LINEAR_LN", "IB_NO_FFN_CHAIN"):
         assert k not in os.environ, f"{k} is set: the dispatch table describes the default build"
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -34,6 +34,6 @@ def test_every_baseline_shape_takes_its_kernel_family(golden_dir):
     # grouped weight gradients
     fam = lambda wl: {f for _, _, f in got[wl]}
     assert "chain_v2" in fam("mlp_denoiser_T50_B256_bf16_train_step")
-    assert {"nt256x128", "tn256x128"} <= fam("transformer_denoiser_T50_B256_bf16_train_step")
+    assert {"nt256x128", "tn256x128", "ffn_chain"} <= fam("transformer_denoiser_T50_B256_bf16_train_step")
     assert "smallm" in fam("transformer_denoiser_T200_B1_bf16_ddim_step")
     assert {"smallm", "wgrad_small"} <= fam("feedforward_ref_shape_B4_fp32_train_step")     # fp32: csrc/gemm_f32_small.hip
