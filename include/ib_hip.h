@@ -262,30 +262,38 @@ int ib_optim_step_sources(int opt, float* p, const float* g, float* s1, float* s
  * tickets are drawn in two levels so no single address serialises the grid); the kernel leaves it zeroed. */
 int ib_optim_ticket_words(void);
 
-/* ---- fused feed-forward sublayer of the post-norm encoder layer (csrc/ffn_chain.hip; replaces, per layer and direction,
- * two nn.Linear GEMMs + residual + nn.LayerNorm: TransformerBaseline.py:15-19,33-36 and their autograd), bf16, d == 512,
- * ffn a multiple of 512 (<= 4096).  One launch over panels of <= 64 token rows (ib_ffn_chain_workgroups), the hidden width
- * walked in chunks of 512 columns, weights streamed from a fragment-major packed image:
+/* ---- fused token-local half of the post-norm encoder layer (csrc/ffn_chain.hip), bf16, d == 512, ffn a multiple of 512
+ * (<= 4096).  Replaces, per layer and direction, the feed-forward sublayer's two nn.Linear GEMMs + residual + nn.LayerNorm
+ * (TransformerBaseline.py:15-19,33-36) and -- with the attention epilogue -- the attention out-projection + residual +
+ * LayerNorm1 in front of it (:12-13,29-31), and their autograd.  One launch over panels of <= 64 token rows
+ * (ib_ffn_chain_workgroups), the hidden width walked in chunks of 512 columns, weights streamed from a packed image:
  *   ib_ffn_chain_pack   packed[l] (ib_ffn_chain_packed_elems bf16 elements each) <- w1[l] = feedforward.0.weight [ffn, d],
- *                       w2[l] = feedforward.2.weight [d, ffn]  (forward and transposed images of both), all layers in ONE launch;
- *   ib_ffn_chain_fwd    y = LN(x1 + relu(x1 W1^T + b1) W2^T + b2); also stores f1 = relu(..) [M, ffn] (weight-gradient operand),
- *                       s2 = the LayerNorm input [M, d], mean / rstd [M], and the ReLU bits (`mask`, ib_ffn_chain_mask_bytes);
- *   ib_ffn_chain_bwd    ds2 = LN-backward(dy) [M, d] (= d f2 and the residual addend), dz1 = (ds2 W2) * relu'(.) [M, ffn],
- *                       dx1 = dz1 W1 + ds2 [M, d]; partial fp32 [2 x workgroups, d]: dgamma of every panel, then dbeta of every
- *                       panel (summed in workgroup order by the optimizer / ib_step_reduce).  The weight and bias gradients
- *                       stay GEMMs. */
+ *                       w2[l] = feedforward.2.weight [d, ffn], wo[l] = out_proj.weight [d, d] (wo / wo[l] may be NULL): the
+ *                       forward and transposed fragment-major images of each, all layers in ONE launch;
+ *   ib_ffn_chain_fwd    y = LN2(x1 + relu(x1 W1^T + b1) W2^T + b2); also stores f1 = relu(..) [M, ffn] (weight-gradient
+ *                       operand), s2 = the LayerNorm2 input [M, d], mean / rstd [M], the ReLU bits (`mask`,
+ *                       ib_ffn_chain_mask_bytes).  attn != NULL (attention epilogue): the first argument is the LAYER input x
+ *                       and x1 = LN1(x + attn Wo^T + bo) is computed here: x1_out [M, d], s1 = its LayerNorm input, mean1 / rstd1;
+ *   ib_ffn_chain_bwd    ds2 = LN2-backward(dy) [M, d] (= d f2 and the residual addend), dz1 = (ds2 W2) * relu'(.) [M, ffn],
+ *                       dx1 = dz1 W1 + ds2 [M, d]; partial fp32 [2 (4) x workgroups, d]: dgamma2, dbeta2 (, dgamma1, dbeta1) of
+ *                       every panel (summed in workgroup order by the optimizer / ib_step_reduce).  s1 != NULL: dx1 is not
+ *                       stored; ds1 = LN1-backward(dx1) [M, d] (the out-projection's weight-gradient operand and the layer
+ *                       input's residual addend) and dattn = ds1 Wo [M, d] are.  The weight / bias gradients stay GEMMs. */
 int ib_ffn_chain_supported(int64_t d, int64_t ffn);
 size_t ib_ffn_chain_packed_elems(int64_t d, int64_t ffn);
 int ib_ffn_chain_workgroups(int64_t M, int64_t d, int64_t ffn, int* rows_per_wg);
 size_t ib_ffn_chain_mask_bytes(int64_t M, int64_t d, int64_t ffn);
 int ib_ffn_chain_pack(const void* const* w1, const int64_t* ld1, const void* const* w2, const int64_t* ld2,
-                      void* const* packed, int layers, int64_t d, int64_t ffn, ib_stream_t stream);
+                      const void* const* wo, const int64_t* ldo, void* const* packed, int layers, int64_t d, int64_t ffn,
+                      ib_stream_t stream);
 int ib_ffn_chain_fwd(const void* x1, const void* packed, const float* b1, const float* b2, const float* gamma,
-                     const float* beta, void* f1, void* s2, void* y, float* mean, float* rstd, void* mask, int64_t M,
-                     int64_t d, int64_t ffn, float ln_eps, ib_stream_t stream);
+                     const float* beta, void* f1, void* s2, void* y, float* mean, float* rstd, void* mask,
+                     const void* attn, const float* bo, const float* gamma1, const float* beta1, void* s1, void* x1_out,
+                     float* mean1, float* rstd1, int64_t M, int64_t d, int64_t ffn, float ln_eps, ib_stream_t stream);
 int ib_ffn_chain_bwd(const void* dy, const void* s2, const float* mean, const float* rstd, const float* gamma,
-                     const void* packed, const void* mask, void* ds2, void* dz1, void* dx1, float* partial, int64_t M,
-                     int64_t d, int64_t ffn, ib_stream_t stream);
+                     const void* packed, const void* mask, void* ds2, void* dz1, void* dx1, float* partial,
+                     const void* s1, const float* mean1, const float* rstd1, const float* gamma1, void* ds1, void* dattn,
+                     int64_t M, int64_t d, int64_t ffn, ib_stream_t stream);
 
 /* ---- diffusion wrapper [BUILD-DEFINED]: DDPM q_sample, DDIM eta=0 update, table gathers ----- */
 /* ---- tiny matrix products: C[M,N] (+)= sum_k A(m,k) B(k,n), A(m,k) = A[m*sam + k*sak], B(k,n) = B[k*sbk + n*sbn], each
@@ -463,6 +471,7 @@ int ib_step_reduce_parts(int n, const void* const* slabs, const int32_t* nslab, 
 int ib_debug_stamp(void* slot, ib_stream_t stream);   /* timing-only: *slot = 100 MHz wall clock when the stream gets here */
 int ib_debug_set_gemm_prof(void* stamps);    /* timing-only: [workgroups][8] stamps of the ring GEMM kernel, NULL = off */
 int ib_debug_set_chain_prof(void* stamps);   /* timing-only: [workgroups][16] int64 wall-clock stamps, NULL = off */
+int ib_debug_set_ffn_prof(void* stamps);     /* timing-only: [workgroups][64] stamps of ib_ffn_chain_fwd (measurement builds) */
 int ib_sum_partials(const float* partial, int64_t parts, float scale, float* out, ib_stream_t stream);
 
 /* ---- hipGraph capture of a launch sequence (the captured denoise / train step) */

@@ -98,13 +98,14 @@ _SIGS = {
     "ib_im2col_replicate": (_c.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _c.c_int, _c.c_int, _vp]),
     "ib_col2im_replicate": (_c.c_int, [_vp, _i64, _vp, _c.c_int, _vp, _i64, _i64, _i64, _c.c_int, _c.c_int, _vp]),
     "ib_dropout": (_c.c_int, [_vp, _vp, _i64, _f32, _c.c_uint32, _i32, _vp, _c.c_int, _vp]),
+    "ib_debug_set_ffn_prof": (_c.c_int, [_vp]),
     "ib_ffn_chain_supported": (_c.c_int, [_i64, _i64]),
     "ib_ffn_chain_packed_elems": (_sz, [_i64, _i64]),
     "ib_ffn_chain_workgroups": (_c.c_int, [_i64, _i64, _i64, _vp]),
     "ib_ffn_chain_mask_bytes": (_sz, [_i64, _i64, _i64]),
-    "ib_ffn_chain_pack": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _c.c_int, _i64, _i64, _vp]),
-    "ib_ffn_chain_fwd": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _f32, _vp]),
-    "ib_ffn_chain_bwd": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
+    "ib_ffn_chain_pack": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _c.c_int, _i64, _i64, _vp]),
+    "ib_ffn_chain_fwd": (_c.c_int, [_vp] * 20 + [_i64, _i64, _i64, _f32, _vp]),
+    "ib_ffn_chain_bwd": (_c.c_int, [_vp] * 17 + [_i64, _i64, _i64, _vp]),
     "ib_sqdiff_mean": (_c.c_int, [_vp, _vp, _vp, _i64, _i64, _c.c_int, _vp]),
     "ib_sqdiff_mean_bwd": (_c.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _c.c_int, _vp]),
     "ib_mask_by_threes": (_c.c_int, [_vp, _vp, _i64, _f32, _c.c_int, _vp]),
@@ -1310,21 +1311,28 @@ def ffn_chain_mask_bytes(M: int, d: int, ffn: int) -> int:
 
 
 def ffn_chain_pack(layers):
-    """layers: [(w1 [ffn, d] bf16, w2 [d, ffn] bf16, packed bf16 [ffn_chain_packed_elems])] -- ONE launch for all of them"""
+    """layers: [(w1 [ffn, d] bf16, w2 [d, ffn] bf16, packed bf16 [ffn_chain_packed_elems])] or with a 4th element, the
+    attention out-projection weight [d, d] (the attention epilogue's images) -- ONE launch for all of them"""
     n = len(layers)
     ffn, d = layers[0][0].shape
-    for w1, w2, pk in layers:
+    for it in layers:
+        w1, w2, pk = it[0], it[1], it[2]
         _mat(w1, "w1", torch.bfloat16)
         _mat(w2, "w2", torch.bfloat16)
         _req(pk, "packed", torch.bfloat16, 1)
         if tuple(w1.shape) != (ffn, d) or tuple(w2.shape) != (d, ffn) or pk.numel() < ffn_chain_packed_elems(d, ffn) \
                 or not pk.is_contiguous():
             raise HipError("ffn_chain_pack: weight / packed-image shapes do not agree")
-    arr = lambda ts: ctypes.cast((ctypes.c_void_p * n)(*[t.data_ptr() for t in ts]), ctypes.c_void_p)
-    lds = lambda ts: ctypes.cast((ctypes.c_int64 * n)(*[t.stride(0) for t in ts]), ctypes.c_void_p)
+        if len(it) > 3 and it[3] is not None:
+            _mat(it[3], "wo", torch.bfloat16)
+            if tuple(it[3].shape) != (d, d):
+                raise HipError("ffn_chain_pack: the out-projection weight must be [d, d]")
+    arr = lambda ts: ctypes.cast((ctypes.c_void_p * n)(*[(t.data_ptr() if t is not None else None) for t in ts]), ctypes.c_void_p)
+    lds = lambda ts: ctypes.cast((ctypes.c_int64 * n)(*[(t.stride(0) if t is not None else 0) for t in ts]), ctypes.c_void_p)
     w1s, w2s, pks = [l[0] for l in layers], [l[1] for l in layers], [l[2] for l in layers]
-    _check(lib().ib_ffn_chain_pack(arr(w1s), lds(w1s), arr(w2s), lds(w2s), arr(pks), n, d, ffn, stream_ptr()),
-           "ib_ffn_chain_pack")
+    wos = [(l[3] if len(l) > 3 else None) for l in layers]
+    _check(lib().ib_ffn_chain_pack(arr(w1s), lds(w1s), arr(w2s), lds(w2s), arr(wos), lds(wos), arr(pks), n, d, ffn,
+                                   stream_ptr()), "ib_ffn_chain_pack")
 
 
 def _ffn_rows(t, name, M, N, dtype=torch.bfloat16):
@@ -1333,41 +1341,67 @@ def _ffn_rows(t, name, M, N, dtype=torch.bfloat16):
         raise HipError(f"{name}: contiguous {dtype} [{M}, {N}] required, got {tuple(t.shape)} strides {t.stride()}")
 
 
-def ffn_chain_fwd(x1, packed, b1, b2, gamma, beta, f1, s2, y, mean, rstd, mask, eps: float = 1e-5):
+def _ffn_vec(t, name, n):
+    _req(t, name, torch.float32, 1)
+    if t.numel() != n or not t.is_contiguous():
+        raise HipError(f"{name} must be contiguous fp32 [{n}]")
+
+
+def ffn_chain_fwd(x1, packed, b1, b2, gamma, beta, f1, s2, y, mean, rstd, mask, eps: float = 1e-5, attn_out=None):
+    """attn_out = (attn [M, d], bo, gamma1, beta1, s1, x1_out, mean1, rstd1): the attention epilogue -- `x1` is then the layer
+    input x and x1_out = LN1(x + attn Wo^T + bo) is computed (and stored) here"""
     M, d = x1.shape
     ffn = f1.shape[1]
     for t, n, w in ((x1, "x1", d), (f1, "f1", ffn), (s2, "s2", d), (y, "y", d)):
         _ffn_rows(t, n, M, w)
     for t, n, w in ((b1, "b1", ffn), (b2, "b2", d), (gamma, "gamma", d), (beta, "beta", d), (mean, "mean", M), (rstd, "rstd", M)):
-        _req(t, n, torch.float32, 1)
-        if t.numel() != w or not t.is_contiguous():
-            raise HipError(f"ffn_chain_fwd: {n} must be contiguous fp32 [{w}]")
+        _ffn_vec(t, n, w)
     _req(packed, "packed", torch.bfloat16, 1)
     _req(mask, "mask", torch.uint8, 1)
     if packed.numel() < ffn_chain_packed_elems(d, ffn) or mask.numel() < ffn_chain_mask_bytes(M, d, ffn):
         raise HipError("ffn_chain_fwd: packed image / mask buffer too small")
+    extra = [None] * 8
+    if attn_out is not None:
+        attn, bo, g1, b1n, s1, x1o, m1, r1 = attn_out
+        for t, n in ((attn, "attn"), (s1, "s1"), (x1o, "x1_out")):
+            _ffn_rows(t, n, M, d)
+        for t, n, w in ((bo, "bo", d), (g1, "gamma1", d), (b1n, "beta1", d), (m1, "mean1", M), (r1, "rstd1", M)):
+            _ffn_vec(t, n, w)
+        extra = [_ptr(t) for t in attn_out]
     _check(lib().ib_ffn_chain_fwd(_ptr(x1), _ptr(packed), _ptr(b1), _ptr(b2), _ptr(gamma), _ptr(beta), _ptr(f1), _ptr(s2),
-                                  _ptr(y), _ptr(mean), _ptr(rstd), _ptr(mask), M, d, ffn, float(eps), stream_ptr()),
+                                  _ptr(y), _ptr(mean), _ptr(rstd), _ptr(mask), *extra, M, d, ffn, float(eps), stream_ptr()),
            "ib_ffn_chain_fwd")
     return y
 
 
-def ffn_chain_bwd(dy, s2, mean, rstd, gamma, packed, mask, ds2, dz1, dx1, partial):
+def ffn_chain_bwd(dy, s2, mean, rstd, gamma, packed, mask, ds2, dz1, dx1, partial, attn_out=None):
+    """attn_out = (s1, mean1, rstd1, gamma1, ds1, dattn): LayerNorm1 backward + the out-projection's dgrad in the same launch
+    (dx1 may then be None: it is not stored); partial: fp32 [2 x workgroups, d], or [4 x workgroups, d] with attn_out"""
     M, d = dy.shape
     ffn = dz1.shape[1]
-    for t, n, w in ((dy, "dy", d), (s2, "s2", d), (ds2, "ds2", d), (dz1, "dz1", ffn), (dx1, "dx1", d)):
+    for t, n, w in ((dy, "dy", d), (s2, "s2", d), (ds2, "ds2", d), (dz1, "dz1", ffn)) + (((dx1, "dx1", d),) if dx1 is not None else ()):
         _ffn_rows(t, n, M, w)
     _req(partial, "partial", torch.float32, 2)
-    if tuple(partial.shape) != (2 * ffn_chain_workgroups(M, d, ffn), d) or not partial.is_contiguous():
-        raise HipError("ffn_chain_bwd: partial must be contiguous fp32 [2 x workgroups, d]")
-    for t, n in ((mean, "mean"), (rstd, "rstd"), (gamma, "gamma")):
-        _req(t, n, torch.float32, 1)
+    nq = 4 if attn_out is not None else 2
+    if tuple(partial.shape) != (nq * ffn_chain_workgroups(M, d, ffn), d) or not partial.is_contiguous():
+        raise HipError(f"ffn_chain_bwd: partial must be contiguous fp32 [{nq} x workgroups, d]")
+    for t, n, w in ((mean, "mean", M), (rstd, "rstd", M), (gamma, "gamma", d)):
+        _ffn_vec(t, n, w)
     _req(mask, "mask", torch.uint8, 1)
     if packed.numel() < ffn_chain_packed_elems(d, ffn) or mask.numel() < ffn_chain_mask_bytes(M, d, ffn):
         raise HipError("ffn_chain_bwd: packed image / mask buffer too small")
+    extra = [None] * 6
+    if attn_out is not None:
+        s1, m1, r1, g1, ds1, dattn = attn_out
+        for t, n in ((s1, "s1"), (ds1, "ds1"), (dattn, "dattn")):
+            _ffn_rows(t, n, M, d)
+        for t, n, w in ((m1, "mean1", M), (r1, "rstd1", M), (g1, "gamma1", d)):
+            _ffn_vec(t, n, w)
+        extra = [_ptr(t) for t in attn_out]
+    elif dx1 is None:
+        raise HipError("ffn_chain_bwd: dx1 is required without the attention epilogue")
     _check(lib().ib_ffn_chain_bwd(_ptr(dy), _ptr(s2), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(packed), _ptr(mask), _ptr(ds2),
-                                  _ptr(dz1), _ptr(dx1), _ptr(partial), M, d, ffn, stream_ptr()),
-           "ib_ffn_chain_bwd")
+                                  _ptr(dz1), _ptr(dx1), _ptr(partial), *extra, M, d, ffn, stream_ptr()), "ib_ffn_chain_bwd")
     return dx1
 
 

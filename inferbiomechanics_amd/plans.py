@@ -574,7 +574,7 @@ class TransformerLayerPlan:
         if self.dtype != torch.bfloat16 or self.inference or M < 4096 or os.environ.get("IB_NO_NT"):
             return []
         pairs = []
-        skip = ("feedforward.2.weight", "feedforward.0.weight") if self.ffn_fused(M) else ()
+        skip = ("feedforward.2.weight", "feedforward.0.weight", "multihead_attention.out_proj.weight") if self.ffn_fused(M) else ()
         for n in self.WT_NAMES:
             if n in skip:          # the fused feed-forward sublayer streams its own packed images (ffn_pack_item)
                 continue
@@ -586,9 +586,10 @@ class TransformerLayerPlan:
         return pairs
 
     def ffn_fused(self, M: int) -> bool:
-        """the feed-forward sublayer (Linear + ReLU + Linear + residual + LayerNorm, TransformerBaseline.py:15-19,33-36) and
-        its backward as ONE launch each (csrc/ffn_chain.hip): bf16 training at chip-filling token counts, d = 512, a hidden
-        width of whole 512-column chunks, no dropout2 between the second Linear and the residual"""
+        """everything of the layer behind the attention core -- out-projection + residual + LayerNorm1, then the feed-forward
+        sublayer Linear + ReLU + Linear + residual + LayerNorm2 (TransformerBaseline.py:12-19,29-36) -- and its backward as
+        ONE launch each (csrc/ffn_chain.hip): bf16 training at chip-filling token counts, d = 512, a hidden width of whole
+        512-column chunks, no dropout between the Linears and the residuals"""
         return (self.dtype == torch.bfloat16 and not self.inference and M >= 4096 and self.drop_p == 0.0
                 and not os.environ.get("IB_NO_FFN_CHAIN") and not os.environ.get("IB_NO_NT")
                 and hip.ffn_chain_supported(self.d, self.ffn))
@@ -599,7 +600,8 @@ class TransformerLayerPlan:
         if not self.ffn_fused(M):
             return None
         pk = self.buf.get(self.tag + ".ffnpk", (hip.ffn_chain_packed_elems(self.d, self.ffn),), self.dtype)
-        return (P.w(self.p + "feedforward.0.weight"), P.w(self.p + "feedforward.2.weight"), pk)
+        return (P.w(self.p + "feedforward.0.weight"), P.w(self.p + "feedforward.2.weight"), pk,
+                P.w(self.p + "multihead_attention.out_proj.weight"))
 
     def _dgrad(self, P: ParamSource, dz, wname: str, dx, act_below="none", aux=None, addend=None):
         wt = self._wt.get(wname) if self._wt_fresh else None
@@ -653,6 +655,21 @@ class TransformerLayerPlan:
             return hip.linear_ln_fwd(inp, w, P.v(p + bname), res, P.v(p + nname + ".weight"), P.v(p + nname + ".bias"), y, ws)
 
         a = m1 = r1 = f2 = m2 = r2 = None
+        self._ffn_fused = ffn_fused
+        if ffn_fused:
+            # a / f2 of the context = the LayerNorm INPUTS x + o and x1 + f2 the kernel stores (its backward normalises
+            # those; no `res`)
+            a, f2 = g(tg + ".s1", (M, d), dt), g(tg + ".s2", (M, d), dt)
+            m1, r1 = g(tg + ".m1", (M,), torch.float32), g(tg + ".r1", (M,), torch.float32)
+            m2, r2 = g(tg + ".m2", (M,), torch.float32), g(tg + ".r2", (M,), torch.float32)
+            mask = self.buf.get(tg + ".ffnmask", (hip.ffn_chain_mask_bytes(M, d, self.ffn),), torch.uint8)
+            hip.ffn_chain_fwd(x, self.buf.get(tg + ".ffnpk", (hip.ffn_chain_packed_elems(d, self.ffn),), dt),
+                              P.v(p + "feedforward.0.bias"), P.v(p + "feedforward.2.bias"), P.v(p + "norm2.weight"),
+                              P.v(p + "norm2.bias"), f1, f2, x2.view(M, d), m2, r2, mask,
+                              attn_out=(attn.view(M, d), P.v(p + "multihead_attention.out_proj.bias"),
+                                        P.v(p + "norm1.weight"), P.v(p + "norm1.bias"), a, x1, m1, r1))
+            self.ctx = (x, qkv, attn, lse, a, x1, m1, r1, f1, f2, m2, r2, B, T, drop)
+            return x2
         if not (fuse and lin_ln(attn.view(M, d), "multihead_attention.out_proj.weight",
                                 "multihead_attention.out_proj.bias", "norm1", x, x1, ".lnws1")):
             a = g(tg + ".a", (M, d), dt)
@@ -662,17 +679,6 @@ class TransformerLayerPlan:
                 hip.dropout(a, a, self.drop_p, self.seed + 1, step, step_dev)
             m1, r1 = g(tg + ".m1", (M,), torch.float32), g(tg + ".r1", (M,), torch.float32)
             hip.layernorm_fwd(a, P.v(p + "norm1.weight"), P.v(p + "norm1.bias"), x1, m1, r1, res=x)
-        self._ffn_fused = ffn_fused
-        if ffn_fused:
-            # f2 of the context = the LayerNorm INPUT x1 + f2 the kernel stores (its backward normalises that; no `res`)
-            f2 = g(tg + ".s2", (M, d), dt)
-            m2, r2 = g(tg + ".m2", (M,), torch.float32), g(tg + ".r2", (M,), torch.float32)
-            mask = self.buf.get(tg + ".ffnmask", (hip.ffn_chain_mask_bytes(M, d, self.ffn),), torch.uint8)
-            hip.ffn_chain_fwd(x1, self.buf.get(tg + ".ffnpk", (hip.ffn_chain_packed_elems(d, self.ffn),), dt),
-                              P.v(p + "feedforward.0.bias"), P.v(p + "feedforward.2.bias"), P.v(p + "norm2.weight"),
-                              P.v(p + "norm2.bias"), f1, f2, x2.view(M, d), m2, r2, mask)
-            self.ctx = (x, qkv, attn, lse, a, x1, m1, r1, f1, f2, m2, r2, B, T, drop)
-            return x2
         hip.linear_fwd(x1, P.w(p + "feedforward.0.weight"), P.v(p + "feedforward.0.bias"), f1, act="relu")
         if not (fuse and lin_ln(f1, "feedforward.2.weight", "feedforward.2.bias", "norm2", x1, x2.view(M, d), ".lnws2")):
             f2 = g(tg + ".f2", (M, d), dt)
@@ -758,19 +764,23 @@ class TransformerLayerPlan:
         dz1 = g(tg + ".dz1", (M, self.ffn), dt)
         dx1 = g(tg + ".dx1", (M, d), dt)
         fused_ffn = getattr(self, "_ffn_fused", False)
+        ds1 = g(tg + ".ds1", (M, d), dt)
+        dattn = g(tg + ".dattn", (B, T, d), dt)
         if fused_ffn:
-            # LayerNorm2 backward + both dgrad GEMMs of the sublayer in ONE launch (csrc/ffn_chain.hip); `f2` is the saved
-            # LayerNorm input.  dgamma / dbeta leave as per-panel partial sums, finished with the layer's other partials.
+            # LayerNorm2 backward + both dgrad GEMMs of the feed-forward sublayer + LayerNorm1 backward + the out-projection's
+            # dgrad in ONE launch (csrc/ffn_chain.hip); `f2` / `a` are the saved LayerNorm inputs.  dgamma / dbeta leave as
+            # per-panel partial sums, finished with the layer's other partials.
             if later is None:
                 raise hip.HipError("fused feed-forward backward needs the deferred partial-sum path (bf16, M >= 4096)")
             nwg = hip.ffn_chain_workgroups(M, d, self.ffn)
-            part = self.buf.get(tg + ".ffnpart", (2 * nwg, d), torch.float32)
+            part = self.buf.get(tg + ".ffnpart", (4 * nwg, d), torch.float32)
             hip.ffn_chain_bwd(dx2.view(M, d), f2, m2, r2, P.v(p + "norm2.weight"),
                               self.buf.get(tg + ".ffnpk", (hip.ffn_chain_packed_elems(d, self.ffn),), dt),
                               self.buf.get(tg + ".ffnmask", (hip.ffn_chain_mask_bytes(M, d, self.ffn),), torch.uint8),
-                              ds2, dz1, dx1, part)
+                              ds2, dz1, None, part,
+                              attn_out=(a, m1, r1, P.v(p + "norm1.weight"), ds1, dattn.view(M, d)))
             later.append((part[:nwg], nwg, P.g(p + "norm2.weight")))
-            later.append((part[nwg:], nwg, P.g(p + "norm2.bias")))
+            later.append((part[nwg:2 * nwg], nwg, P.g(p + "norm2.bias")))
             P.ready(p + "norm2.weight"); P.ready(p + "norm2.bias")
         else:
             ln_bwd("norm2", dx2.view(M, d), f2, m2, r2, ds2, x1)
@@ -789,11 +799,14 @@ class TransformerLayerPlan:
         def g_ffn1():
             wgrad(dz1, x1, "feedforward.0.weight", tg + ".ws1", bias=(tg + ".b1", "feedforward.0.bias"))
         side(g_ffn1)
-        if not fused_ffn:
+        if fused_ffn:
+            later.append((part[2 * nwg:3 * nwg], nwg, P.g(p + "norm1.weight")))
+            later.append((part[3 * nwg:], nwg, P.g(p + "norm1.bias")))
+            P.ready(p + "norm1.weight"); P.ready(p + "norm1.bias")
+        else:
             self._dgrad(P, dz1, "feedforward.0.weight", dx1, addend=ds2)       # + residual path
-        # LN1: d(a + x)
-        ds1 = g(tg + ".ds1", (M, d), dt)
-        ln_bwd("norm1", dx1, a, m1, r1, ds1, x)
+            # LN1: d(a + x)
+            ln_bwd("norm1", dx1, a, m1, r1, ds1, x)
         da = ds1                       # d(x + Drop(a)): dropout1's mask on the attention path only
         if drop:
             da = g(tg + ".da", (M, d), dt)
@@ -803,8 +816,8 @@ class TransformerLayerPlan:
             wgrad(da, attn.view(M, d), "multihead_attention.out_proj.weight", tg + ".wso",
                   bias=(tg + ".bo", "multihead_attention.out_proj.bias"))
         side(g_out)
-        dattn = g(tg + ".dattn", (B, T, d), dt)
-        self._dgrad(P, da, "multihead_attention.out_proj.weight", dattn.view(M, d))
+        if not fused_ffn:
+            self._dgrad(P, da, "multihead_attention.out_proj.weight", dattn.view(M, d))
         dqkv = g(tg + ".dqkv", (B, T, 3 * d), dt)
         hip.attention_bwd(qkv, attn, dattn, lse, dqkv, self.h, drop=drop)
         dq2 = dqkv.view(M, 3 * d)

@@ -126,6 +126,65 @@ def test_ffn_chain_matches_the_restatement(M, ffn):
     assert rel(y, yy.detach()) < 6e-3 and rel(dx1, x.grad) < 1.5e-2, (rel(y, yy.detach()), rel(dx1, x.grad))
 
 
+@pytest.mark.parametrize("M,ffn", [(100, 1024), (12800, 2048)])
+def test_attention_epilogue_form_matches_the_restatement(M, ffn):
+    """attn != NULL: x1 = LN1(x + attn Wo^T + bo) is computed inside the launch (TransformerBaseline.py:29-31) and the backward
+    continues through LayerNorm1 and the out-projection's dgrad; every stage held to the kernel's own previous stage"""
+    from inferbiomechanics_amd import hip
+    d = 512
+    pr = problem(M, ffn, seed=7 * M + ffn)
+    g = torch.Generator().manual_seed(M)
+    q = lambda *sh, sc=1.0: (torch.randn(*sh, generator=g) * sc).to(BF)
+    x, attn, wo = q(M, d), q(M, d), q(d, d, sc=d ** -0.5)
+    bo, gamma1, beta1 = torch.randn(d, generator=g) * 0.1, 1 + 0.2 * torch.randn(d, generator=g), 0.1 * torch.randn(d, generator=g)
+    dev = {k: v.to(DEV) for k, v in pr.items()}
+    packed = torch.zeros(hip.ffn_chain_packed_elems(d, ffn), dtype=BF, device=DEV)
+    hip.ffn_chain_pack([(dev["w1"], dev["w2"], packed, wo.to(DEV))])
+    nan = lambda *sh: torch.full(sh, float("nan"), dtype=BF, device=DEV)
+    f1, s2, y, s1, x1o = nan(M, ffn), nan(M, d), nan(M, d), nan(M, d), nan(M, d)
+    mean, rstd, mean1, rstd1 = (torch.zeros(M, device=DEV) for _ in range(4))
+    mask = torch.zeros(hip.ffn_chain_mask_bytes(M, d, ffn), dtype=torch.uint8, device=DEV)
+    hip.ffn_chain_fwd(x.to(DEV), packed, dev["b1"], dev["b2"], dev["gamma"], dev["beta"], f1, s2, y, mean, rstd, mask,
+                      attn_out=(attn.to(DEV), bo.to(DEV), gamma1.to(DEV), beta1.to(DEV), s1, x1o, mean1, rstd1))
+    torch.cuda.synchronize()
+    close(s1, rb(x.double() + attn.double() @ wo.double().t() + bo.double()), 2, "s1")
+    pr1 = dict(gamma=gamma1, beta=beta1)
+    ex1, em1, er1 = layer_norm_of(s1.cpu().double(), pr1)
+    close(x1o, ex1, 2, "x1")
+    assert torch.allclose(mean1.cpu().double(), em1, rtol=1e-5, atol=1e-5) and torch.allclose(rstd1.cpu().double(), er1, rtol=1e-4)
+    # the feed-forward part continues from the kernel's own x1
+    pr2 = dict(pr, x1=x1o.cpu())
+    ex = restate_fwd(pr2)
+    near0 = ex["z"].abs() < 1e-4
+    got_f1 = f1.cpu().double()
+    assert not bool(((got_f1 - ex["f1"]).abs() > 2.0 ** -7 * ex["f1"].abs() + 1e-4)[~near0].any())
+    close(s2, rb(pr2["x1"].double() + got_f1 @ pr["w2"].double().t() + pr["b2"].double()), 2, "s2")
+    ey, _, _ = layer_norm_of(s2.cpu().double(), pr)
+    close(y, ey, 2, "y")
+    # backward
+    nwg = hip.ffn_chain_workgroups(M, d, ffn)
+    ds2, dz1, ds1, dattn = nan(M, d), nan(M, ffn), nan(M, d), nan(M, d)
+    part = torch.full((4 * nwg, d), float("nan"), device=DEV)
+    hip.ffn_chain_bwd(dev["dy"], s2, mean, rstd, dev["gamma"], packed, mask, ds2, dz1, None, part,
+                      attn_out=(s1, mean1, rstd1, gamma1.to(DEV), ds1, dattn))
+    torch.cuda.synchronize()
+    eb = restate_bwd(pr, s2.cpu().double(), mean.cpu().double(), rstd.cpu().double(), (got_f1 > 0).double())
+    close(ds2, eb["ds2"], 2, "ds2")
+    dx1 = rb(dz1.cpu().double() @ pr["w1"].double() + ds2.cpu().double())          # the kernel rounds dx1 into its LDS image
+    s1k, m1k, r1k = s1.cpu().double(), mean1.cpu().double(), rstd1.cpu().double()
+    xh1 = (s1k - m1k[:, None]) * r1k[:, None]
+    dxh1 = dx1 * gamma1.double()
+    want_ds1 = rb(r1k[:, None] * (dxh1 - dxh1.mean(-1, keepdim=True) - xh1 * (dxh1 * xh1).mean(-1, keepdim=True)))
+    # (dx1 is re-rounded here from the kernel's bf16 dz1 / ds2 in float64; the kernel rounds its fp32 sum -- two of 6.5 M
+    # elements land on the other side of a rounding boundary of dx1 and move ds1 by one more ulp)
+    close(ds1, want_ds1, 5, "ds1")
+    close(dattn, ds1.cpu().double() @ wo.double(), 2, "dattn")
+    sums = [part[k * nwg:(k + 1) * nwg].sum(0).cpu().double() for k in range(4)]
+    for got, want in zip(sums, (eb["dgamma"], eb["dbeta"], (dx1 * xh1).sum(0), dx1.sum(0))):
+        assert torch.allclose(got, want, rtol=2e-3, atol=2e-3 * float(want.abs().max()))
+    assert bool(torch.isfinite(part).all())
+
+
 def test_pack_layout_of_all_four_images():
     """block (nt, kb) of W_eff at (kb * 32 + nt) KiB, lane (n = lane % 16, q = lane / 16) holding k = 8 q .. 8 q + 7"""
     from inferbiomechanics_amd import hip
@@ -135,7 +194,7 @@ def test_pack_layout_of_all_four_images():
     w2 = torch.randn(d, ffn, generator=g).to(BF)
     packed = torch.zeros(hip.ffn_chain_packed_elems(d, ffn), dtype=BF, device=DEV)
     hip.ffn_chain_pack([(w1.to(DEV), w2.to(DEV), packed)])
-    pk = packed.cpu().view(4, 2, 16, 32, 64, 8)                     # image, chunk, kb, nt, lane, j
+    pk = packed.cpu()[:4 * 2 * 512 * 512].view(4, 2, 16, 32, 64, 8)  # image, chunk, kb, nt, lane, j (then Wo, Wo^T)
     eff = {0: lambda c: w1[512 * c:512 * c + 512, :], 1: lambda c: w2[:, 512 * c:512 * c + 512],
            2: lambda c: w2[:, 512 * c:512 * c + 512].t(), 3: lambda c: w1[512 * c:512 * c + 512, :].t()}
     for img in range(4):
