@@ -799,6 +799,9 @@ class TransformerLayerPlan:
         def g_ffn1():
             wgrad(dz1, x1, "feedforward.0.weight", tg + ".ws1", bias=(tg + ".b1", "feedforward.0.bias"))
         side(g_ffn1)
+        # (measured and dropped, round 4: sending the feed-forward half of the group off right here, beside the attention
+        # backward and the QKV dgrad -- two launches per layer with their own split counts, 5 + 10 slabs per weight instead
+        # of 4, one more fork / join per layer: 1.97 -> 2.19 ms per step)
         if fused_ffn:
             later.append((part[2 * nwg:3 * nwg], nwg, P.g(p + "norm1.weight")))
             later.append((part[3 * nwg:], nwg, P.g(p + "norm1.bias")))
