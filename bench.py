@@ -230,6 +230,8 @@ KERNEL_OF = {   # C-ABI entry -> device kernel it launches (names as rocprofv3 -
     "ib_linear_wgrad": "gemm_kernel<T, false, false, EPI_WGRAD> (+ slab_reduce_kernel)",
     "ib_layernorm_fwd": "layernorm_fwd_kernel", "ib_layernorm_bwd": "layernorm_bwd_kernel (+ segment_colsum_kernel)",
     "ib_attention_fwd": "attn_fwd_mfma", "ib_attention_bwd": "attn_bwd_mfma", "ib_segment_colsum": "segment_colsum_kernel",
+    "ib_ffn_chain_fwd": "ffn_chain_fwd_kernel<true>", "ib_ffn_chain_bwd": "ffn_chain_bwd_kernel<true>",
+    "ib_ffn_chain_pack": "ffn_pack_kernel", "ib_diffusion_draw": "diffusion_draw_kernel",
     "ib_mse_loss": "mse_partial_kernel (+ mse_final_kernel)", "ib_q_sample": "q_sample_kernel",
     "ib_gather_rows": "gather_rows_kernel", "ib_cast": "cast2d_kernel", "ib_cast2d": "cast2d_kernel"}
 
@@ -303,6 +305,13 @@ def roofline_leg(rec, dtype_name, gemm_family=False, workload=None):
             B_, T_, H_, dh = d[-5], d[-4], d[-3], d[-2]
             io = B_ * T_ * H_ * dh * es
             return (4 if e.endswith("fwd") else 10) * T_ * T_ * dh * B_ * H_, (4 if e.endswith("fwd") else 8) * io
+        if e in ("ib_ffn_chain_fwd", "ib_ffn_chain_bwd"):
+            # the token-local half of a layer: out-projection (d x d) + both feed-forward GEMMs (2 x d x ffn) per token row,
+            # forward or dgrad.  Bytes: what must cross HBM -- attn / x (dy / s2 / s1) in, x1 / s1 / s2 / y (ds2 / ds1 / dattn)
+            # and the [M, ffn] weight-gradient operand out, the packed weights once
+            M, d_, ff = d[-3], d[-2], d[-1]
+            io = (6 if e.endswith("fwd") else 6) * M * d_ * es + M * ff * es
+            return 2 * M * (d_ * d_ + 2 * d_ * ff), io + (d_ * d_ + 2 * d_ * ff) * es
         if e in ("ib_layernorm_fwd", "ib_layernorm_bwd"):
             M, N = d[-3], d[-2]
             return 0, (2 if e.endswith("fwd") else 3) * M * N * es

@@ -23,7 +23,9 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ENTRY_OF = [("gemm_tn_kernel", "", "ib_linear_wgrad_slabs_multi"), ("gemm_nt_kernel<0, 0, false", "", "ib_linear_fwd"),
+ENTRY_OF = [("ffn_chain_fwd_kernel", "", "ib_ffn_chain_fwd"), ("ffn_chain_bwd_kernel", "", "ib_ffn_chain_bwd"),
+            ("ffn_pack_kernel", "", "ib_ffn_chain_pack"), ("diffusion_draw_kernel", "", "ib_diffusion_draw"),
+            ("gemm_tn256_kernel", "", "ib_linear_wgrad_slabs_multi"), ("gemm_tn_kernel", "", "ib_linear_wgrad_slabs_multi"), ("gemm_nt_kernel<0, 0, false", "", "ib_linear_fwd"),
             ("gemm_nt_kernel<1, 0", "", "ib_linear_fwd"), ("gemm_nt_kernel<0, 1", "", "ib_linear_dgrad"),
             ("gemm_nt_kernel<0, 0, true", "", "ib_linear_dgrad"), ("gemm_nt_kernel", "", "ib_linear_fwd"),
             ("mlp_chain_kernel", "", "ib_mlp_chain_train"), ("mlp_chain2_kernel", "", "ib_mlp_chain_train"),
