@@ -40,6 +40,9 @@ def bf(x):
     return x.to(BF).to(torch.float64)
 
 
+from tests.chain_restatement import chain_restatement  # noqa: E402
+
+
 CASES = [(256, 50, 300, 512, 2),     # BASELINE configs[1]: 12800 tokens -> 256 workgroups of 50
          (7, 50, 300, 512, 2),       # 350 tokens: ragged last workgroup
          (300, 50, 300, 512, 3),     # 15000 tokens: 64-token panels, three blocks
@@ -67,34 +70,9 @@ def test_chain_matches_float64_restatement(hip, B, T, D, H, L):
     gamma = [(1.0 + rnd((H,), 50 + i, 0.2)).to(torch.float32) for i in range(L)]
     beta = [rnd((H,), 60 + i, 0.1).to(torch.float32) for i in range(L)]
 
-    # ---- float64 restatement (autograd) with the kernel's storage points
-    a = sab.to(torch.float64)[t][:, None, None]
-    s = s1m.to(torch.float64)[t][:, None, None]
-    xt_ref = bf(a * x0.to(torch.float64) + s * eps.to(torch.float64)).reshape(M, D)
-    hcur = xt_ref.clone().requires_grad_(True)
-    us, hs = [], []
-    g64 = [g.to(torch.float64).requires_grad_(True) for g in gamma]
-    b64 = [b.to(torch.float64).requires_grad_(True) for b in beta]
-    for i in range(L):
-        z = hcur @ W[i].to(torch.float64).T + bias[i].to(torch.float64) \
-            + e.to(torch.float64)[:, i * H:(i + 1) * H].repeat_interleave(T, dim=0)
-        # value rounded to bf16, gradient passes straight through
-        u = z + (bf(z) - z).detach()
-        u.retain_grad()
-        v = u * torch.sigmoid(u)
-        mu = v.mean(-1, keepdim=True)
-        var = ((v - mu) ** 2).mean(-1, keepdim=True)
-        hh = (v - mu) / torch.sqrt(var + 1e-5) * g64[i] + b64[i]
-        hh = hh + (bf(hh) - hh).detach()
-        us.append(u)
-        hs.append(hh)
-        hcur = hh
-    pred = hcur @ W[L].to(torch.float64).T + bias[L].to(torch.float64)
-    pred = pred + (bf(pred) - pred).detach()
-    pred.retain_grad()
-    loss = ((pred - eps.to(torch.float64).reshape(M, D)) ** 2).mean()
-    loss.backward()
-
+    # ---- float64 restatement (autograd) with the kernel's storage points; the SAME function with the rounding switched off is
+    # held to oracle/ref_cpu.denoiser_mlp_forward + autograd on CPU (tests/test_oracle_golden.py::test_chain_restatement_...)
+    xt_ref, us, hs, pred, loss, g64, b64 = chain_restatement(x0, eps, t, sab, s1m, e, W, bias, gamma, beta, bf)
     # ---- kernel
     d = lambda x: x.to(DEV)
     packed = torch.zeros(hip.mlp_chain_packed_elems(D, H, L), dtype=BF, device=DEV)

@@ -29,7 +29,8 @@ def _free_port():
 def _transformer(dtype, T, D, seed=7):
     from inferbiomechanics_amd.models.DiffusionDenoisers import DiffusionTransformer
     torch.manual_seed(seed)
-    return DiffusionTransformer(D, T, d_model=256, num_heads=4, dim_feedforward=512, num_layers=3, temporal_embedding_dim=6,
+    # d_model = 512 with a 1024-wide feed-forward: the fused token-local launches (csrc/ffn_chain.hip) are part of the path
+    return DiffusionTransformer(D, T, d_model=512, num_heads=8, dim_feedforward=1024, num_layers=3, temporal_embedding_dim=6,
                                 temb_dim=32, temb_hidden=64, device="cuda", compute_dtype=dtype)
 
 
@@ -57,6 +58,7 @@ def _lag_worker(port, q):
             model = _transformer(dt, T, D)
             tr = HipTrainer(model, "diffusion", "sgd", 1e-2, bucket_mb=0.5, overlap_comm=True if ddp else None)
             info = {"ddp": tr.ddp, "overlap": tr.overlap_comm, "buckets": len(tr.buckets.ranges),
+                    "fused_ffn": all(lp.ffn_fused(B * T) for lp in tr.plan.layers),
                     "lagging": [bool(lp.lag_group and lp.parent_flushes) for lp in tr.plan.layers]}
             losses = []
             for i in range(steps):
@@ -98,6 +100,7 @@ def test_lagged_weight_gradient_path_is_bitwise_the_unlagged_and_the_single_gpu_
     (fa, la, ia), (fb, lb, ib), (fc, lc, ic) = out["lag"], out["nolag"], out["single"]
     assert ia["ddp"] and ia["overlap"] and ia["buckets"] > 1 and ia["captured"] and ia["graph_cuts"] >= ia["buckets"]
     assert ia["lagging"] == [False, True, True], ia                    # every layer but the one whose backward runs last
+    assert ia["fused_ffn"] and ib["fused_ffn"] and ic["fused_ffn"]
     assert ib["lagging"] == [False, False, False] and not ic["ddp"]
     assert ia["ready_is_layout_order"] and ib["ready_is_layout_order"] and ic["ready_is_layout_order"]
     assert la == lb and np.array_equal(fa, fb), "lagging a layer's weight-gradient launch changed the numbers"

@@ -307,3 +307,39 @@ def test_philox_known_answers_and_draw_definitions():
     z = R.philox_normals(1 << 18, 1, 0, 0).numpy()
     assert abs(z.mean()) < 0.01 and abs(z.std() - 1) < 0.01 and np.abs(z).max() <= 5.77
     assert np.array_equal(R.philox_normals(10, 1, 0, 0).numpy(), z[:10])         # a prefix is a prefix
+
+
+def test_chain_restatement_equals_the_oracle_denoiser():
+    """tests/test_chain_gpu.py holds the fused bf16 chain kernel to `chain_restatement` (with bf16 rounding at the kernel's
+    storage points).  Here the SAME function, rounding switched off, must be the oracle's MLP denoiser: x_t = q_sample, the
+    prediction = denoiser_mlp_forward, the loss = eps_mse, and the gradients w.r.t. the prediction and the LayerNorm
+    parameters those of autograd through the oracle -- so the kernel test's expectation IS the pinned oracle arithmetic."""
+    from tests.chain_restatement import chain_restatement
+    B, T, D, hidden, temb = 5, 7, 12, [16, 16], 8
+    shapes = R.denoiser_mlp_param_shapes(D, hidden, temb_dim=temb, temb_hidden=10)
+    p = {k: v.requires_grad_(True) for k, v in R.det_params(shapes, seed0=2.0).items()}
+    g = torch.Generator().manual_seed(0)
+    x0, eps = torch.randn(B, T, D, generator=g, dtype=torch.float64), torch.randn(B, T, D, generator=g, dtype=torch.float64)
+    t = torch.tensor([0, 17, 500, 998, 999])
+    tabs = R.schedule_tables()
+    xt = R.q_sample(x0, t, eps, tabs)
+    pred = R.denoiser_mlp_forward(p, xt, t, hidden, temb_dim=temb)
+    pred.retain_grad()
+    loss = R.eps_mse(pred, eps)
+    loss.backward()
+    e = R.time_mlp({k: v.detach() for k, v in p.items()}, t, temb, torch.float64)
+    W = [p[f"blocks.{i}.linear.weight"].detach() for i in range(2)] + [p["head.weight"].detach()]
+    bias = [p[f"blocks.{i}.linear.bias"].detach() for i in range(2)] + [p["head.bias"].detach()]
+    gamma = [p[f"blocks.{i}.norm.weight"].detach() for i in range(2)]
+    beta = [p[f"blocks.{i}.norm.bias"].detach() for i in range(2)]
+    xt2, us, hs, pred2, loss2, g64, b64 = chain_restatement(x0, eps, t, tabs["sqrt_ab"], tabs["sqrt_1mab"], e, W, bias, gamma,
+                                                          beta, lambda v: v)
+    close(xt2, xt.reshape(B * T, D), 1e-12)
+    close(pred2.detach(), pred.detach().reshape(B * T, D), 1e-12)
+    close(loss2.detach(), loss.detach(), 1e-12)
+    close(pred2.grad, pred.grad.reshape(B * T, D), 1e-12)
+    for i in range(2):
+        close(g64[i].grad, p[f"blocks.{i}.norm.weight"].grad, 1e-10)
+        close(b64[i].grad, p[f"blocks.{i}.norm.bias"].grad, 1e-10)
+        # d loss / d u_i summed over the tokens = the block's bias gradient
+        close(us[i].grad.sum(0), p[f"blocks.{i}.linear.bias"].grad, 1e-10)
