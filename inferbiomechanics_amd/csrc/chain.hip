@@ -89,6 +89,9 @@ __device__ __forceinline__ bf16x4_t pack4(float a, float b, float c, float d) {
 #ifndef IB_CHAIN_KBMAJOR
 #define IB_CHAIN_KBMAJOR 1
 #endif
+#ifndef IB_CHAIN_EPS_LATE
+#define IB_CHAIN_EPS_LATE 0
+#endif
 // Prefetch ring of 3 k-blocks (2 in flight while one is consumed); the loop is fully unrolled so ring slots are
 // static registers.  `side(kb)` is called once per k-block: the row copies of the neighbouring phases (stores of the
 // previous output image, loads of the next epilogue's operands) are issued a piece per k-block BEHIND the first weight
@@ -1000,13 +1003,6 @@ __global__ __launch_bounds__(CH_THREADS) void mlp_chain2_kernel(ChainParams p) {
   {
     const int ppr = D >> 2;
     uint2 re[CH_ROWS / CH_WAVES][2];
-#pragma unroll
-    for (int j = 0; j < CH_ROWS / CH_WAVES; ++j) {
-      const int rc = min(wave_s + CH_WAVES * j, nrows - 1);
-      const bf16_t* er_ = in_eps + (int64_t)(r0 + rc) * D;
-#pragma unroll
-      for (int q = 0; q < 2; ++q) re[j][q] = *reinterpret_cast<const uint2*>(er_ + min(lane + 64 * q, ppr - 1) * 4);
-    }
     f32x4_t acc[4][NTD];
     zero_acc<NTD>(acc);
     const int colb = wave * 16 * NTD + 4 * g;
@@ -1015,6 +1011,19 @@ __global__ __launch_bounds__(CH_THREADS) void mlp_chain2_kernel(ChainParams p) {
     float4 hb4[NTD];
     auto side = [&](int kb, auto kbc) {
       constexpr int KB = decltype(kbc)::value;
+#if IB_CHAIN_EPS_LATE
+      // the panel's eps rows (the loss target), requested BEHIND the weight stream, four k-blocks before the GEMM ends:
+      // ahead of it (vmcnt retires in order) the first weight k-blocks waited for these 16 row pieces' round trip
+      if (kb == KB - 4) {
+#pragma unroll
+        for (int j = 0; j < CH_ROWS / CH_WAVES; ++j) {
+          const int rc = min(wave_s + CH_WAVES * j, nrows - 1);
+          const bf16_t* er_ = in_eps + (int64_t)(r0 + rc) * D;
+#pragma unroll
+          for (int q = 0; q < 2; ++q) re[j][q] = *reinterpret_cast<const uint2*>(er_ + min(lane_id_now() + 64 * q, ppr - 1) * 4);
+        }
+      }
+#endif
       if (kb == KB - 1) {
 #pragma unroll
         for (int u = 0; u < NTD; ++u) {
@@ -1023,6 +1032,15 @@ __global__ __launch_bounds__(CH_THREADS) void mlp_chain2_kernel(ChainParams p) {
         }
       }
     };
+#if !IB_CHAIN_EPS_LATE
+#pragma unroll
+    for (int j = 0; j < CH_ROWS / CH_WAVES; ++j) {
+      const int rc = min(wave_s + CH_WAVES * j, nrows - 1);
+      const bf16_t* er_ = in_eps + (int64_t)(r0 + rc) * D;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) re[j][q] = *reinterpret_cast<const uint2*>(er_ + min(lane + 64 * q, ppr - 1) * 4);
+    }
+#endif
     chain_gemm<NTD, C::KBH>(p.wf[p.L], wave_s * NTD, imgA, RS, lane_id_now(), acc, side);
     CH_STAMP(2 + 3 * p.L);
 #pragma unroll
