@@ -89,8 +89,10 @@ __device__ __forceinline__ bf16x4_t pack4(float a, float b, float c, float d) {
 #ifndef IB_CHAIN_KBMAJOR
 #define IB_CHAIN_KBMAJOR 1
 #endif
+// IB_CHAIN_EPS_LATE (round 4): the head phase requests the panel's eps rows (the loss target) four k-blocks before its GEMM
+// ends instead of ahead of it, and sums the loss with DPP adds; = 0 rebuilds the round-3 head for the A/B (59.9 -> 57.8-58.4 us)
 #ifndef IB_CHAIN_EPS_LATE
-#define IB_CHAIN_EPS_LATE 0
+#define IB_CHAIN_EPS_LATE 1
 #endif
 // Prefetch ring of 3 k-blocks (2 in flight while one is consumed); the loop is fully unrolled so ring slots are
 // static registers.  `side(kb)` is called once per k-block: the row copies of the neighbouring phases (stores of the
@@ -1082,7 +1084,11 @@ __global__ __launch_bounds__(CH_THREADS) void mlp_chain2_kernel(ChainParams p) {
       for (int r = 0; r < 4; ++r) cs[r] = row16_sum(cs[r]);
       if (l16 == 0) *reinterpret_cast<float4*>(prow + 3 * p.L * H + col) = make_float4(cs[0], cs[1], cs[2], cs[3]);
     }
+#if IB_CHAIN_EPS_LATE
+    lsum = group_sum<64>(lsum, lane);      // DPP only (six ds_bpermute round trips through the LDS crossbar before)
+#else
     lsum = ib_wave_sum(lsum);
+#endif
     if (lane == 0) lossred[wave] = lsum;
     __syncthreads();                       // dpred image complete
     if (tid == 0) {
