@@ -268,8 +268,9 @@ int ib_optim_ticket_words(void);
  * LayerNorm1 in front of it (:12-13,29-31), and their autograd.  One launch over panels of <= 64 token rows
  * (ib_ffn_chain_workgroups), the hidden width walked in chunks of 512 columns, weights streamed from a packed image:
  *   ib_ffn_chain_pack   packed[l] (ib_ffn_chain_packed_elems bf16 elements each) <- w1[l] = feedforward.0.weight [ffn, d],
- *                       w2[l] = feedforward.2.weight [d, ffn], wo[l] = out_proj.weight [d, d] (wo / wo[l] may be NULL): the
- *                       forward and transposed fragment-major images of each, all layers in ONE launch;
+ *                       w2[l] = feedforward.2.weight [d, ffn], wo[l] = out_proj.weight [d, d], wqkv[l] = in_proj_weight [3 d, d]
+ *                       (wo / wqkv and their entries may be NULL): the forward and transposed fragment-major images of each,
+ *                       all layers in ONE launch;
  *   ib_ffn_chain_fwd    y = LN2(x1 + relu(x1 W1^T + b1) W2^T + b2); also stores f1 = relu(..) [M, ffn] (weight-gradient
  *                       operand), s2 = the LayerNorm2 input [M, d], mean / rstd [M], the ReLU bits (`mask`,
  *                       ib_ffn_chain_mask_bytes).  attn != NULL (attention epilogue): the first argument is the LAYER input x
@@ -284,16 +285,22 @@ size_t ib_ffn_chain_packed_elems(int64_t d, int64_t ffn);
 int ib_ffn_chain_workgroups(int64_t M, int64_t d, int64_t ffn, int* rows_per_wg);
 size_t ib_ffn_chain_mask_bytes(int64_t M, int64_t d, int64_t ffn);
 int ib_ffn_chain_pack(const void* const* w1, const int64_t* ld1, const void* const* w2, const int64_t* ld2,
-                      const void* const* wo, const int64_t* ldo, void* const* packed, int layers, int64_t d, int64_t ffn,
-                      ib_stream_t stream);
+                      const void* const* wo, const int64_t* ldo, const void* const* wqkv, const int64_t* ldq,
+                      void* const* packed, int layers, int64_t d, int64_t ffn, ib_stream_t stream);
+/* qkv_next != NULL (needs the attention epilogue): the NEXT layer's in-projection rides behind LayerNorm2 --
+ * qkv_next [M, 3 d] = y . Wqkv_next^T + bqkv_next, from `packed_next` (that layer's packed image, wqkv given to the pack). */
 int ib_ffn_chain_fwd(const void* x1, const void* packed, const float* b1, const float* b2, const float* gamma,
                      const float* beta, void* f1, void* s2, void* y, float* mean, float* rstd, void* mask,
                      const void* attn, const float* bo, const float* gamma1, const float* beta1, void* s1, void* x1_out,
-                     float* mean1, float* rstd1, int64_t M, int64_t d, int64_t ffn, float ln_eps, ib_stream_t stream);
+                     float* mean1, float* rstd1, const void* packed_next, const float* bqkv_next, void* qkv_next,
+                     int64_t M, int64_t d, int64_t ffn, float ln_eps, ib_stream_t stream);
+/* dqkv_next != NULL (needs the attention epilogue): dy is not read (may be NULL) but computed in front of LayerNorm2's
+ * backward = dqkv_next [M, 3 d] . Wqkv_next + ds1_next [M, d]: the next layer's in-projection dgrad + its residual addend. */
 int ib_ffn_chain_bwd(const void* dy, const void* s2, const float* mean, const float* rstd, const float* gamma,
                      const void* packed, const void* mask, void* ds2, void* dz1, void* dx1, float* partial,
                      const void* s1, const float* mean1, const float* rstd1, const float* gamma1, void* ds1, void* dattn,
-                     int64_t M, int64_t d, int64_t ffn, ib_stream_t stream);
+                     const void* packed_next, const void* dqkv_next, const void* ds1_next, int64_t M, int64_t d, int64_t ffn,
+                     ib_stream_t stream);
 
 /* ---- diffusion wrapper [BUILD-DEFINED]: DDPM q_sample, DDIM eta=0 update, table gathers ----- */
 /* ---- tiny matrix products: C[M,N] (+)= sum_k A(m,k) B(k,n), A(m,k) = A[m*sam + k*sak], B(k,n) = B[k*sbk + n*sbn], each

@@ -103,9 +103,9 @@ _SIGS = {
     "ib_ffn_chain_packed_elems": (_sz, [_i64, _i64]),
     "ib_ffn_chain_workgroups": (_c.c_int, [_i64, _i64, _i64, _vp]),
     "ib_ffn_chain_mask_bytes": (_sz, [_i64, _i64, _i64]),
-    "ib_ffn_chain_pack": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _c.c_int, _i64, _i64, _vp]),
-    "ib_ffn_chain_fwd": (_c.c_int, [_vp] * 20 + [_i64, _i64, _i64, _f32, _vp]),
-    "ib_ffn_chain_bwd": (_c.c_int, [_vp] * 17 + [_i64, _i64, _i64, _vp]),
+    "ib_ffn_chain_pack": (_c.c_int, [_vp] * 9 + [_c.c_int, _i64, _i64, _vp]),
+    "ib_ffn_chain_fwd": (_c.c_int, [_vp] * 23 + [_i64, _i64, _i64, _f32, _vp]),
+    "ib_ffn_chain_bwd": (_c.c_int, [_vp] * 20 + [_i64, _i64, _i64, _vp]),
     "ib_sqdiff_mean": (_c.c_int, [_vp, _vp, _vp, _i64, _i64, _c.c_int, _vp]),
     "ib_sqdiff_mean_bwd": (_c.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _c.c_int, _vp]),
     "ib_mask_by_threes": (_c.c_int, [_vp, _vp, _i64, _f32, _c.c_int, _vp]),
@@ -1311,8 +1311,9 @@ def ffn_chain_mask_bytes(M: int, d: int, ffn: int) -> int:
 
 
 def ffn_chain_pack(layers):
-    """layers: [(w1 [ffn, d] bf16, w2 [d, ffn] bf16, packed bf16 [ffn_chain_packed_elems])] or with a 4th element, the
-    attention out-projection weight [d, d] (the attention epilogue's images) -- ONE launch for all of them"""
+    """layers: [(w1 [ffn, d] bf16, w2 [d, ffn] bf16, packed bf16 [ffn_chain_packed_elems])], optionally with a 4th element,
+    the attention out-projection weight [d, d] (the attention epilogue's images), and a 5th, the layer's in-projection
+    weight [3 d, d] (the QKV tail / head of the NEIGHBOURING layer's launches) -- ONE launch for all of them"""
     n = len(layers)
     ffn, d = layers[0][0].shape
     for it in layers:
@@ -1327,12 +1328,17 @@ def ffn_chain_pack(layers):
             _mat(it[3], "wo", torch.bfloat16)
             if tuple(it[3].shape) != (d, d):
                 raise HipError("ffn_chain_pack: the out-projection weight must be [d, d]")
+        if len(it) > 4 and it[4] is not None:
+            _mat(it[4], "wqkv", torch.bfloat16)
+            if tuple(it[4].shape) != (3 * d, d):
+                raise HipError("ffn_chain_pack: the in-projection weight must be [3 d, d]")
     arr = lambda ts: ctypes.cast((ctypes.c_void_p * n)(*[(t.data_ptr() if t is not None else None) for t in ts]), ctypes.c_void_p)
     lds = lambda ts: ctypes.cast((ctypes.c_int64 * n)(*[(t.stride(0) if t is not None else 0) for t in ts]), ctypes.c_void_p)
     w1s, w2s, pks = [l[0] for l in layers], [l[1] for l in layers], [l[2] for l in layers]
     wos = [(l[3] if len(l) > 3 else None) for l in layers]
-    _check(lib().ib_ffn_chain_pack(arr(w1s), lds(w1s), arr(w2s), lds(w2s), arr(wos), lds(wos), arr(pks), n, d, ffn,
-                                   stream_ptr()), "ib_ffn_chain_pack")
+    wqs = [(l[4] if len(l) > 4 else None) for l in layers]
+    _check(lib().ib_ffn_chain_pack(arr(w1s), lds(w1s), arr(w2s), lds(w2s), arr(wos), lds(wos), arr(wqs), lds(wqs), arr(pks), n,
+                                   d, ffn, stream_ptr()), "ib_ffn_chain_pack")
 
 
 def _ffn_rows(t, name, M, N, dtype=torch.bfloat16):
@@ -1347,9 +1353,12 @@ def _ffn_vec(t, name, n):
         raise HipError(f"{name} must be contiguous fp32 [{n}]")
 
 
-def ffn_chain_fwd(x1, packed, b1, b2, gamma, beta, f1, s2, y, mean, rstd, mask, eps: float = 1e-5, attn_out=None):
+def ffn_chain_fwd(x1, packed, b1, b2, gamma, beta, f1, s2, y, mean, rstd, mask, eps: float = 1e-5, attn_out=None,
+                  qkv_next=None):
     """attn_out = (attn [M, d], bo, gamma1, beta1, s1, x1_out, mean1, rstd1): the attention epilogue -- `x1` is then the layer
-    input x and x1_out = LN1(x + attn Wo^T + bo) is computed (and stored) here"""
+    input x and x1_out = LN1(x + attn Wo^T + bo) is computed (and stored) here.
+    qkv_next = (packed image of the NEXT layer, its in-projection bias fp32 [3 d], qkv_out [M, 3 d]): that layer's
+    in-projection of y rides behind LayerNorm2 (needs attn_out)"""
     M, d = x1.shape
     ffn = f1.shape[1]
     for t, n, w in ((x1, "x1", d), (f1, "f1", ffn), (s2, "s2", d), (y, "y", d)):
@@ -1368,18 +1377,32 @@ def ffn_chain_fwd(x1, packed, b1, b2, gamma, beta, f1, s2, y, mean, rstd, mask, 
         for t, n, w in ((bo, "bo", d), (g1, "gamma1", d), (b1n, "beta1", d), (m1, "mean1", M), (r1, "rstd1", M)):
             _ffn_vec(t, n, w)
         extra = [_ptr(t) for t in attn_out]
+    tail = [None] * 3
+    if qkv_next is not None:
+        pk_n, bq, qo = qkv_next
+        if attn_out is None:
+            raise HipError("ffn_chain_fwd: the QKV tail needs the attention epilogue")
+        _req(pk_n, "packed_next", torch.bfloat16, 1)
+        _ffn_vec(bq, "bqkv_next", 3 * d)
+        _ffn_rows(qo, "qkv_next", M, 3 * d)
+        if pk_n.numel() < ffn_chain_packed_elems(d, ffn):
+            raise HipError("ffn_chain_fwd: packed image of the next layer too small")
+        tail = [_ptr(pk_n), _ptr(bq), _ptr(qo)]
     _check(lib().ib_ffn_chain_fwd(_ptr(x1), _ptr(packed), _ptr(b1), _ptr(b2), _ptr(gamma), _ptr(beta), _ptr(f1), _ptr(s2),
-                                  _ptr(y), _ptr(mean), _ptr(rstd), _ptr(mask), *extra, M, d, ffn, float(eps), stream_ptr()),
-           "ib_ffn_chain_fwd")
+                                  _ptr(y), _ptr(mean), _ptr(rstd), _ptr(mask), *extra, *tail, M, d, ffn, float(eps),
+                                  stream_ptr()), "ib_ffn_chain_fwd")
     return y
 
 
-def ffn_chain_bwd(dy, s2, mean, rstd, gamma, packed, mask, ds2, dz1, dx1, partial, attn_out=None):
+def ffn_chain_bwd(dy, s2, mean, rstd, gamma, packed, mask, ds2, dz1, dx1, partial, attn_out=None, qkv_head=None):
     """attn_out = (s1, mean1, rstd1, gamma1, ds1, dattn): LayerNorm1 backward + the out-projection's dgrad in the same launch
-    (dx1 may then be None: it is not stored); partial: fp32 [2 x workgroups, d], or [4 x workgroups, d] with attn_out"""
-    M, d = dy.shape
+    (dx1 may then be None: it is not stored); partial: fp32 [2 x workgroups, d], or [4 x workgroups, d] with attn_out.
+    qkv_head = (packed image of the NEXT layer, dqkv_next [M, 3 d], ds1_next [M, d]): dy is computed in front of
+    LayerNorm2's backward = dqkv_next . Wqkv_next + ds1_next (dy may then be None; needs attn_out)"""
+    M, d = s2.shape
     ffn = dz1.shape[1]
-    for t, n, w in ((dy, "dy", d), (s2, "s2", d), (ds2, "ds2", d), (dz1, "dz1", ffn)) + (((dx1, "dx1", d),) if dx1 is not None else ()):
+    for t, n, w in ((s2, "s2", d), (ds2, "ds2", d), (dz1, "dz1", ffn)) + (((dx1, "dx1", d),) if dx1 is not None else ()) \
+            + (((dy, "dy", d),) if dy is not None else ()):
         _ffn_rows(t, n, M, w)
     _req(partial, "partial", torch.float32, 2)
     nq = 4 if attn_out is not None else 2
@@ -1400,8 +1423,22 @@ def ffn_chain_bwd(dy, s2, mean, rstd, gamma, packed, mask, ds2, dz1, dx1, partia
         extra = [_ptr(t) for t in attn_out]
     elif dx1 is None:
         raise HipError("ffn_chain_bwd: dx1 is required without the attention epilogue")
+    head = [None] * 3
+    if qkv_head is not None:
+        pk_n, dq, ds1n = qkv_head
+        if attn_out is None:
+            raise HipError("ffn_chain_bwd: the QKV head needs the attention epilogue")
+        _req(pk_n, "packed_next", torch.bfloat16, 1)
+        _ffn_rows(dq, "dqkv_next", M, 3 * d)
+        _ffn_rows(ds1n, "ds1_next", M, d)
+        if pk_n.numel() < ffn_chain_packed_elems(d, ffn):
+            raise HipError("ffn_chain_bwd: packed image of the next layer too small")
+        head = [_ptr(pk_n), _ptr(dq), _ptr(ds1n)]
+    elif dy is None:
+        raise HipError("ffn_chain_bwd: dy is required without the QKV head")
     _check(lib().ib_ffn_chain_bwd(_ptr(dy), _ptr(s2), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(packed), _ptr(mask), _ptr(ds2),
-                                  _ptr(dz1), _ptr(dx1), _ptr(partial), *extra, M, d, ffn, stream_ptr()), "ib_ffn_chain_bwd")
+                                  _ptr(dz1), _ptr(dx1), _ptr(partial), *extra, *head, M, d, ffn, stream_ptr()),
+           "ib_ffn_chain_bwd")
     return dx1
 
 

@@ -537,6 +537,11 @@ class TransformerLayerPlan:
         # (ib_linear_dgrad_wt -> the 256 x 128 LDS-DMA kernel of csrc/gemm_nt.hip); refreshed once per forward
         self._wt: Dict[str, torch.Tensor] = {}
         self._wt_fresh = False
+        # set by a parent plan that stacks layers: the layer ABOVE this one (its in-projection rides behind this layer's
+        # LayerNorm2 in the fused forward launch) and the layer BELOW (this layer's in-projection dgrad + residual addend
+        # ride in front of that layer's fused backward launch) -- csrc/ffn_chain.hip's QKV tail / head
+        self.qkv_tail_for: Optional["TransformerLayerPlan"] = None
+        self.qkv_dgrad_below: Optional["TransformerLayerPlan"] = None
         self.own_wt = True           # a parent plan refreshes the copies of all its layers in ONE launch instead
         self.join_on_exit = True     # a parent plan sets this False and joins all layers once at the end
         self.inference = False       # forward only (DDIM sampler): Linear + residual + LayerNorm fused, nothing saved
@@ -575,6 +580,9 @@ class TransformerLayerPlan:
             return []
         pairs = []
         skip = ("feedforward.2.weight", "feedforward.0.weight", "multihead_attention.out_proj.weight") if self.ffn_fused(M) else ()
+        if skip and self.qkv_dgrad_below is not None and self.qkv_dgrad_below.ffn_fused(M) \
+                and not os.environ.get("IB_NO_QKV_FUSE"):
+            skip = skip + ("multihead_attention.in_proj_weight",)
         for n in self.WT_NAMES:
             if n in skip:          # the fused feed-forward sublayer streams its own packed images (ffn_pack_item)
                 continue
@@ -594,6 +602,18 @@ class TransformerLayerPlan:
                 and not os.environ.get("IB_NO_FFN_CHAIN") and not os.environ.get("IB_NO_NT")
                 and hip.ffn_chain_supported(self.d, self.ffn))
 
+    def tail_active(self, M: int, training: bool = False) -> bool:
+        """this layer's fused forward launch also computes the in-projection of the layer above"""
+        nxt = self.qkv_tail_for
+        return (nxt is not None and self.ffn_fused(M) and nxt.ffn_fused(M) and not os.environ.get("IB_NO_QKV_FUSE")
+                and not (training and (self.drop_p > 0.0 or nxt.drop_p > 0.0)))
+
+    def head_active(self, M: int) -> bool:
+        """this layer's in-projection dgrad (+ residual addend) is computed by the fused backward launch of the layer below"""
+        low = self.qkv_dgrad_below
+        return (low is not None and self.ffn_fused(M) and low.ffn_fused(M) and not os.environ.get("IB_NO_QKV_FUSE")
+                and getattr(self, "_ffn_fused", False) and getattr(low, "_ffn_fused", False))
+
     def ffn_pack_item(self, P: ParamSource, M: int):
         """(feedforward.0.weight, feedforward.2.weight, this layer's packed image) for ib_ffn_chain_pack -- refreshed once
         per training step, all layers of a parent plan in ONE launch -- or None"""
@@ -601,7 +621,13 @@ class TransformerLayerPlan:
             return None
         pk = self.buf.get(self.tag + ".ffnpk", (hip.ffn_chain_packed_elems(self.d, self.ffn),), self.dtype)
         return (P.w(self.p + "feedforward.0.weight"), P.w(self.p + "feedforward.2.weight"), pk,
-                P.w(self.p + "multihead_attention.out_proj.weight"))
+                P.w(self.p + "multihead_attention.out_proj.weight"), P.w(self.p + "multihead_attention.in_proj_weight"))
+
+    def qkv_buffer(self, B: int, T: int) -> torch.Tensor:
+        return self.buf.get(self.tag + ".qkv", (B, T, 3 * self.d), self.dtype)
+
+    def packed_image(self) -> torch.Tensor:
+        return self.buf.get(self.tag + ".ffnpk", (hip.ffn_chain_packed_elems(self.d, self.ffn),), self.dtype)
 
     def _dgrad(self, P: ParamSource, dz, wname: str, dx, act_below="none", aux=None, addend=None):
         wt = self._wt.get(wname) if self._wt_fresh else None
@@ -610,7 +636,8 @@ class TransformerLayerPlan:
         hip.linear_dgrad(dz, P.w(self.p + wname), dx, act_below=act_below, aux=aux, addend=addend)
 
     def forward(self, x3: torch.Tensor, P: ParamSource, out: Optional[torch.Tensor] = None, training: bool = False,
-                step: int = 0, step_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
+                step: int = 0, step_dev: Optional[torch.Tensor] = None, qkv_ready: bool = False) -> torch.Tensor:
+        """qkv_ready: the layer below already wrote this layer's in-projection into `qkv_buffer` (its fused launch's tail)"""
         B, T, d = x3.shape
         M = B * T
         g, dt, p, tg = self.buf.get, self.dtype, self.p, self.tag
@@ -628,8 +655,9 @@ class TransformerLayerPlan:
                 hip.ffn_chain_pack([self.ffn_pack_item(P, M)])
         x = x3.view(M, d)
         qkv = g(tg + ".qkv", (B, T, 3 * d), dt)
-        hip.linear_fwd(x, P.w(p + "multihead_attention.in_proj_weight"), P.v(p + "multihead_attention.in_proj_bias"),
-                       qkv.view(M, 3 * d))
+        if not qkv_ready:
+            hip.linear_fwd(x, P.w(p + "multihead_attention.in_proj_weight"), P.v(p + "multihead_attention.in_proj_bias"),
+                           qkv.view(M, 3 * d))
         attn = g(tg + ".attn", (B, T, d), dt)
         lse = g(tg + ".lse", (B, self.h, T), torch.float32)
         hip.attention_fwd(qkv, attn, lse, self.h, drop=drop)
@@ -667,7 +695,11 @@ class TransformerLayerPlan:
                               P.v(p + "feedforward.0.bias"), P.v(p + "feedforward.2.bias"), P.v(p + "norm2.weight"),
                               P.v(p + "norm2.bias"), f1, f2, x2.view(M, d), m2, r2, mask,
                               attn_out=(attn.view(M, d), P.v(p + "multihead_attention.out_proj.bias"),
-                                        P.v(p + "norm1.weight"), P.v(p + "norm1.bias"), a, x1, m1, r1))
+                                        P.v(p + "norm1.weight"), P.v(p + "norm1.bias"), a, x1, m1, r1),
+                              qkv_next=None if not self.tail_active(M, training) else
+                              (self.qkv_tail_for.packed_image(),
+                               P.v(self.qkv_tail_for.p + "multihead_attention.in_proj_bias"),
+                               self.qkv_tail_for.qkv_buffer(B, T).view(M, 3 * d)))
             self.ctx = (x, qkv, attn, lse, a, x1, m1, r1, f1, f2, m2, r2, B, T, drop)
             return x2
         if not (fuse and lin_ln(attn.view(M, d), "multihead_attention.out_proj.weight",
@@ -697,9 +729,13 @@ class TransformerLayerPlan:
                                 "multihead_attention.out_proj.weight", "multihead_attention.out_proj.bias",
                                 "multihead_attention.in_proj_weight", "multihead_attention.in_proj_bias")]
 
-    def backward(self, dx2: torch.Tensor, P: ParamSource, accumulate=False) -> torch.Tensor:
+    def backward(self, dx2: Optional[torch.Tensor], P: ParamSource, accumulate=False, qkv_head=None) -> Optional[torch.Tensor]:
+        """qkv_head = (packed image, dqkv [M, 3 d], ds1 [M, d]) of the layer ABOVE: dx2 (may be None) is then computed inside
+        this layer's fused launch.  Returns dx, or None when this layer's own in-projection dgrad is left to the layer below
+        (`head_active`; `self.pending_head` then holds the triple to hand down)."""
         x, qkv, attn, lse, a, x1, m1, r1, f1, f2, m2, r2, B, T, drop = self.ctx
         M, d = x.shape
+        self.pending_head = None
         g, dt, p, tg = self.buf.get, self.dtype, self.p, self.tag
         lnws = self.buf.bytes("ln.ws", hip.layernorm_bwd_workspace_bytes(M, max(d, 1)))
         defer, later = self.defer, self.later
@@ -774,15 +810,17 @@ class TransformerLayerPlan:
                 raise hip.HipError("fused feed-forward backward needs the deferred partial-sum path (bf16, M >= 4096)")
             nwg = hip.ffn_chain_workgroups(M, d, self.ffn)
             part = self.buf.get(tg + ".ffnpart", (4 * nwg, d), torch.float32)
-            hip.ffn_chain_bwd(dx2.view(M, d), f2, m2, r2, P.v(p + "norm2.weight"),
+            hip.ffn_chain_bwd(None if qkv_head is not None else dx2.view(M, d), f2, m2, r2, P.v(p + "norm2.weight"),
                               self.buf.get(tg + ".ffnpk", (hip.ffn_chain_packed_elems(d, self.ffn),), dt),
                               self.buf.get(tg + ".ffnmask", (hip.ffn_chain_mask_bytes(M, d, self.ffn),), torch.uint8),
                               ds2, dz1, None, part,
-                              attn_out=(a, m1, r1, P.v(p + "norm1.weight"), ds1, dattn.view(M, d)))
+                              attn_out=(a, m1, r1, P.v(p + "norm1.weight"), ds1, dattn.view(M, d)), qkv_head=qkv_head)
             later.append((part[:nwg], nwg, P.g(p + "norm2.weight")))
             later.append((part[nwg:2 * nwg], nwg, P.g(p + "norm2.bias")))
             P.ready(p + "norm2.weight"); P.ready(p + "norm2.bias")
         else:
+            if qkv_head is not None:
+                raise hip.HipError("TransformerLayerPlan.backward: a QKV head needs the fused token-local launch")
             ln_bwd("norm2", dx2.view(M, d), f2, m2, r2, ds2, x1)
         # ds2 = d(x1 + Drop(f2)): the residual path takes it as is, the feedforward path through dropout2's mask
         df2 = ds2
@@ -829,8 +867,12 @@ class TransformerLayerPlan:
             wgrad(dq2, x, "multihead_attention.in_proj_weight", tg + ".wsi",
                   bias=(tg + ".bi", "multihead_attention.in_proj_bias"))
         side(g_in)
-        dx = g(tg + ".dx", (B, T, d), dt)
-        self._dgrad(P, dq2, "multihead_attention.in_proj_weight", dx.view(M, d), addend=ds1)
+        if self.head_active(M):
+            dx = None                  # dq2 . Wqkv + ds1 is computed in front of the layer below's fused backward launch
+            self.pending_head = (self.packed_image(), dq2, ds1)
+        else:
+            dx = g(tg + ".dx", (B, T, d), dt)
+            self._dgrad(P, dq2, "multihead_attention.in_proj_weight", dx.view(M, d), addend=ds1)
         if group:
             def run_group():
                 # problems the grouped launch could not take sum their bias gradient the plain way (P.ready already said)
@@ -1234,6 +1276,8 @@ class DenoiserTransformerPlan:
         for lp in self.layers:
             lp.join_on_exit = False          # joined once, at the end of the whole backward
             lp.own_wt = False                # the transposed weight copies of ALL layers are refreshed by one launch
+        for lo, hi in zip(self.layers[:-1], self.layers[1:]):
+            lo.qkv_tail_for, hi.qkv_dgrad_below = hi, lo     # the upper layer's in-projection rides in the lower layer's launches
         self.ctx = None
         self._posproj_T = None
         self.fuse_reduce_into_optimizer = False         # set by HipTrainer for single-GPU steps
@@ -1399,8 +1443,10 @@ class DenoiserTransformerPlan:
         h = h0
         if ffn_items and not self.inference:
             self.br_wt.join()                         # layer 0's fused feed-forward sublayer reads the packed images
+        ready = False
         for lp in self.layers:
-            h = lp.forward(h, P)
+            h = lp.forward(h, P, qkv_ready=ready)
+            ready = (not self.inference) and lp.tail_active(M)       # it wrote the next layer's in-projection
         out = out if out is not None else g("dt.out", (B, T, D), dt)
         if padded:
             hip.linear_fwd(h.view(M, self.d), w_out_pad, b_out_pad, out.as_strided((M, Kp), (Kp, 1)))
@@ -1444,10 +1490,12 @@ class DenoiserTransformerPlan:
             hip.linear_dgrad(dout, P.w("out_proj.weight"), dh.view(M, self.d))
         P.flush()
         prev = None                                   # (layer plan, closure, names) whose launches lag one layer
+        head = None
         for lp in reversed(self.layers):
             if prev is not None:
                 prev[0].branch.run(prev[1])           # beside this layer's backward
-            dh = lp.backward(dh, P, accumulate)
+            dh = lp.backward(dh, P, accumulate, qkv_head=head)
+            head = lp.pending_head                    # its in-projection dgrad is left to the next (lower) layer's launch
             lg = lp.take_lagged()                     # None unless the layers report through this plan (data parallel)
             if prev is not None:
                 prev[0].branch.join()

@@ -126,10 +126,13 @@ def test_ffn_chain_matches_the_restatement(M, ffn):
     assert rel(y, yy.detach()) < 6e-3 and rel(dx1, x.grad) < 1.5e-2, (rel(y, yy.detach()), rel(dx1, x.grad))
 
 
-@pytest.mark.parametrize("M,ffn", [(100, 1024), (12800, 2048)])
-def test_attention_epilogue_form_matches_the_restatement(M, ffn):
+@pytest.mark.parametrize("M,ffn,qkv", [(100, 1024, False), (12800, 2048, False), (100, 1024, True), (777, 512, True),
+                                       (12800, 2048, True)])
+def test_attention_epilogue_form_matches_the_restatement(M, ffn, qkv):
     """attn != NULL: x1 = LN1(x + attn Wo^T + bo) is computed inside the launch (TransformerBaseline.py:29-31) and the backward
-    continues through LayerNorm1 and the out-projection's dgrad; every stage held to the kernel's own previous stage"""
+    continues through LayerNorm1 and the out-projection's dgrad; every stage held to the kernel's own previous stage.
+    qkv: the NEXT layer's in-projection rides behind LayerNorm2 (forward) and its dgrad + residual addend in front of
+    LayerNorm2's backward (the launch computes its own dy)"""
     from inferbiomechanics_amd import hip
     d = 512
     pr = problem(M, ffn, seed=7 * M + ffn)
@@ -141,11 +144,19 @@ def test_attention_epilogue_form_matches_the_restatement(M, ffn):
     packed = torch.zeros(hip.ffn_chain_packed_elems(d, ffn), dtype=BF, device=DEV)
     hip.ffn_chain_pack([(dev["w1"], dev["w2"], packed, wo.to(DEV))])
     nan = lambda *sh: torch.full(sh, float("nan"), dtype=BF, device=DEV)
+    # the layer above: only its in-projection matters here (its packed image holds just those six blocks)
+    wq, bq = q(3 * d, d, sc=d ** -0.5), torch.randn(3 * d, generator=g) * 0.1
+    dqkv_n, ds1_n = q(M, 3 * d, sc=0.5), q(M, d)
+    packed_n = torch.zeros(hip.ffn_chain_packed_elems(d, ffn), dtype=BF, device=DEV)
+    if qkv:
+        hip.ffn_chain_pack([(dev["w1"], dev["w2"], packed_n, None, wq.to(DEV))])
+    qkv_out = nan(M, 3 * d)
     f1, s2, y, s1, x1o = nan(M, ffn), nan(M, d), nan(M, d), nan(M, d), nan(M, d)
     mean, rstd, mean1, rstd1 = (torch.zeros(M, device=DEV) for _ in range(4))
     mask = torch.zeros(hip.ffn_chain_mask_bytes(M, d, ffn), dtype=torch.uint8, device=DEV)
     hip.ffn_chain_fwd(x.to(DEV), packed, dev["b1"], dev["b2"], dev["gamma"], dev["beta"], f1, s2, y, mean, rstd, mask,
-                      attn_out=(attn.to(DEV), bo.to(DEV), gamma1.to(DEV), beta1.to(DEV), s1, x1o, mean1, rstd1))
+                      attn_out=(attn.to(DEV), bo.to(DEV), gamma1.to(DEV), beta1.to(DEV), s1, x1o, mean1, rstd1),
+                      qkv_next=(packed_n, bq.to(DEV), qkv_out) if qkv else None)
     torch.cuda.synchronize()
     close(s1, rb(x.double() + attn.double() @ wo.double().t() + bo.double()), 2, "s1")
     pr1 = dict(gamma=gamma1, beta=beta1)
@@ -161,15 +172,22 @@ def test_attention_epilogue_form_matches_the_restatement(M, ffn):
     close(s2, rb(pr2["x1"].double() + got_f1 @ pr["w2"].double().t() + pr["b2"].double()), 2, "s2")
     ey, _, _ = layer_norm_of(s2.cpu().double(), pr)
     close(y, ey, 2, "y")
+    if qkv:       # the next layer's in-projection of the kernel's own (bf16) y
+        close(qkv_out, y.cpu().double() @ wq.double().t() + bq.double(), 2, "qkv_next")
     # backward
     nwg = hip.ffn_chain_workgroups(M, d, ffn)
     ds2, dz1, ds1, dattn = nan(M, d), nan(M, ffn), nan(M, d), nan(M, d)
     part = torch.full((4 * nwg, d), float("nan"), device=DEV)
-    hip.ffn_chain_bwd(dev["dy"], s2, mean, rstd, dev["gamma"], packed, mask, ds2, dz1, None, part,
-                      attn_out=(s1, mean1, rstd1, gamma1.to(DEV), ds1, dattn))
+    hip.ffn_chain_bwd(None if qkv else dev["dy"], s2, mean, rstd, dev["gamma"], packed, mask, ds2, dz1, None, part,
+                      attn_out=(s1, mean1, rstd1, gamma1.to(DEV), ds1, dattn),
+                      qkv_head=(packed_n, dqkv_n.to(DEV), ds1_n.to(DEV)) if qkv else None)
     torch.cuda.synchronize()
+    if qkv:       # dy = dqkv_next . Wqkv_next + ds1_next, rounded to bf16 where the kernel parks it in LDS
+        pr = dict(pr, dy=rb(dqkv_n.double() @ wq.double() + ds1_n.double()))
     eb = restate_bwd(pr, s2.cpu().double(), mean.cpu().double(), rstd.cpu().double(), (got_f1 > 0).double())
-    close(ds2, eb["ds2"], 2, "ds2")
+    # (with the QKV head the kernel's dy is an fp32 sum rounded to bf16 inside the launch and never stored: a few of its 6.5 M
+    # elements round the other way than the float64 restatement's, and LayerNorm's backward moves ds2 by that much)
+    close(ds2, eb["ds2"], 5 if qkv else 2, "ds2")
     dx1 = rb(dz1.cpu().double() @ pr["w1"].double() + ds2.cpu().double())          # the kernel rounds dx1 into its LDS image
     s1k, m1k, r1k = s1.cpu().double(), mean1.cpu().double(), rstd1.cpu().double()
     xh1 = (s1k - m1k[:, None]) * r1k[:, None]
