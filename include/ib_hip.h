@@ -240,14 +240,17 @@ int ib_mse_loss_finalize(const void* workspace, size_t workspace_bytes, float* r
 /* ---- optimizer step: torch.optim.{SGD,Adam,RMSprop,Adagrad,Adadelta,Adamax}(lr) defaults,
  * src/cli/train.py:183-197,284.  One launch over a FLAT fp32 parameter buffer.  g is multiplied by
  * grad_scale first (DDP mean = 1/world, train.py:175).  `step_dev` (optional, int32 device scalar)
- * holds the 1-based step count (advance it with ib_counter_add BEFORE this call) and is used for
- * the bias corrections, so a captured hipGraph replays correctly; if NULL, `step` (1-based) is used.  shadow (optional) receives bf16 copies of p. */
+ * holds the step count and is used for the bias corrections, so a captured hipGraph replays correctly: without a
+ * ticket the step is *step_dev + step (step = 0: the counter was advanced with ib_counter_add BEFORE this call;
+ * step = 1: a launch over PART of the buffer inside a self-counting step, see `ticket`); if NULL, `step` (1-based) is
+ * used.  shadow (optional) receives bf16 copies of p. */
 int ib_optim_step(int opt, float* p, const float* g, float* s1, float* s2, int64_t n, float lr,
                   float grad_scale, int32_t step, int32_t* step_dev, int32_t* ticket, void* shadow_bf16,
                   ib_stream_t stream);
 /* ib_optim_step whose gradient, for up to 28 ranges [start, start+len) of the flat buffer, is still a set of partial sums:
  * kind 1 = split-M slabs (base = [count][len] fp32, `stride` elements apart), kind 2 = column sums over `count` rows of a
- * row-major partial array (base = first column, `stride` = row pitch), times scale.  The optimizer sums them itself in the
+ * row-major partial array (base = first column, `stride` = row pitch), times scale, kind 3 = nothing to do (the range was
+ * updated by an earlier launch of this step over that part of the buffer; base / count ignored).  The optimizer sums them itself in the
  * fixed order of ib_step_reduce; elsewhere it reads g.  Optionally also writes *loss_out = loss_scale * sum of one column.
  * Single-GPU steps only (an all-reduce needs the reduced gradient in memory).  Host arrays; n % 4 == 0. */
 int ib_optim_step_sources(int opt, float* p, const float* g, float* s1, float* s2, int64_t n, float lr,

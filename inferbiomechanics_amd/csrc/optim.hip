@@ -24,7 +24,7 @@ struct GradSrc {
   const float* base;           // slabs: [nslab][len] ; column sums: part + col0
   int64_t stride;              // slabs: elements between slabs ; column sums: row pitch of part
   int count;                   // slabs: nslab ; column sums: rows
-  int kind;                    // 1 = slabs, 2 = column sums
+  int kind;                    // 1 = slabs, 2 = column sums, 3 = none: the range was updated by an earlier launch of this step
   float scale;
 };
 struct OptSources {
@@ -137,7 +137,10 @@ __global__ __launch_bounds__(256) void optim_kernel(OptArgs a, OptSources S, int
   // self-counting mode (ticket != NULL): *step_dev holds the number of COMPLETED steps; every block reads it on
   // entry, and the block that draws the last exit ticket publishes step and resets the ticket -- it exits after
   // every other block has entered (and therefore read the old value), so no block can see the new count.
-  const int step = a.step_dev ? (a.ticket ? *(volatile int32_t*)a.step_dev + 1 : *a.step_dev) : a.step;
+  // step_dev without a ticket: step = *step_dev + a.step, nothing published -- a.step = 1 is how a launch over PART of
+  // the buffer (a layer's range, issued as soon as its gradient is complete) takes part in a self-counting step whose
+  // last launch publishes.
+  const int step = a.step_dev ? *(volatile int32_t*)a.step_dev + (a.ticket ? 1 : a.step) : a.step;
   // bias corrections in double (torch computes them as Python floats) -- Adam / Adamax only: two double-precision pow()
   // are several hundred instructions at the head of every thread, ahead of its first load
   float bc1 = 1.f, bc2s = 1.f;
@@ -306,7 +309,13 @@ extern "C" int ib_optim_step_sources(int opt, float* p, const float* g, float* s
   OptSources S{};
   S.n = nsrc;
   for (int j = 0; j < nsrc; ++j) {
-    if (start[j] < 0 || len[j] <= 0 || start[j] % 4 != 0 || start[j] + len[j] > n || !base[j] || count[j] <= 0) return IB_E_ARG;
+    if (start[j] < 0 || len[j] <= 0 || start[j] % 4 != 0 || start[j] + len[j] > n) return IB_E_ARG;
+    if (kind[j] == 3) {                                     // skipped by every block
+      if (len[j] % 4 != 0) return IB_E_ARG;
+      S.s[j] = GradSrc{start[j], len[j], nullptr, 0, 0, 3, 1.f};
+      continue;
+    }
+    if (!base[j] || count[j] <= 0) return IB_E_ARG;
     if (kind[j] == 1) {
       if (len[j] % 4 != 0 || stride[j] % 4 != 0 || !al16(base[j])) return IB_E_ARG;
     } else if (kind[j] == 2) {

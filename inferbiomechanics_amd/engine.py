@@ -382,6 +382,12 @@ class HipTrainer:
             # operand pieces are then aligned 16-byte loads (the unpadded rows were 8-byte aligned: +11 us per wgrad)
             if hasattr(plan, "fuse_reduce_into_optimizer"):
                 plan.fuse_reduce_into_optimizer = not self.ddp and not os.environ.get("IB_NO_OPT_FUSE")
+            if hasattr(plan, "early_optimizer"):
+                # one GPU: a layer's parameters are updated as soon as its gradient is complete, on the layer's side stream
+                # beside the backward of the layers below, instead of in one launch at the end of the step
+                early = plan.fuse_reduce_into_optimizer and not os.environ.get("IB_NO_EARLY_OPT")
+                plan.early_optimizer = self._early_optimizer if early else None
+                self._early_done = []
             if hasattr(plan, "train_pitch"):
                 Dp = plan.train_pitch(D, M)        # 320 for the transformer denoiser at training batch sizes (plans._train_pad)
             else:
@@ -446,9 +452,41 @@ class HipTrainer:
         src = getattr(self.plan, "pending_sources", None)
         if src is not None:
             self.plan.pending_sources = None
+            done = getattr(self, "_early_done", None)
+            if done:
+                src = tuple(src[:4]) + ([self.grad[lo:hi] for lo, hi in done],)
+                self._early_done = []
+        elif getattr(self, "_early_done", None):
+            raise hip.HipError("layers were updated early but the step's last optimizer launch does not know their ranges")
         hip.optim_step(self.opt_type, self.flat, self.grad, self.s1, self.s2, self.lr, step=0, step_dev=self.step_dev,
                        ticket=self.ticket, grad_scale=1.0 / self.world,
                        shadow=m._shadow if dt == torch.bfloat16 else None, sources=src)
+
+    def _prefix_range(self, prefix: str) -> Tuple[int, int]:
+        """[lo, hi) of the flat buffers holding exactly the parameters whose names start with `prefix`"""
+        cache = self.__dict__.setdefault("_prefix_ranges", {})
+        if prefix not in cache:
+            names = list(self.layout.keys())
+            idx = [i for i, k in enumerate(names) if k.startswith(prefix)]
+            if not idx or idx != list(range(idx[0], idx[-1] + 1)):
+                raise hip.HipError(f"parameters of '{prefix}' are not one contiguous range of the flat buffer")
+            lo = self.layout[names[idx[0]]][0]
+            hi = self.layout[names[idx[-1] + 1]][0] if idx[-1] + 1 < len(names) else self.flat.numel()
+            if lo % 4 or hi % 4:
+                raise hip.HipError("flat ranges must be 16-byte aligned")
+            cache[prefix] = (lo, hi)
+        return cache[prefix]
+
+    def _early_optimizer(self, prefix: str, sources):
+        """the optimizer over ONE layer's range (issued by the plan on that layer's side stream once its gradient sources
+        are complete): same step number as the step's last, self-counting launch (*step_dev + 1), which skips the range"""
+        lo, hi = self._prefix_range(prefix)
+        m, dt = self.model, self.model.compute_dtype
+        sl = lambda t: None if t is None else t[lo:hi]
+        hip.optim_step(self.opt_type, self.flat[lo:hi], self.grad[lo:hi], sl(self.s1), sl(self.s2), self.lr, step=1,
+                       step_dev=self.step_dev, grad_scale=1.0 / self.world,
+                       shadow=sl(m._shadow) if dt == torch.bfloat16 else None, sources=sources)
+        self._early_done.append((lo, hi))
 
     def _stage(self, batch) -> Dict[str, torch.Tensor]:
         """copy the batch into the static input buffers the (captured) launch sequence reads"""

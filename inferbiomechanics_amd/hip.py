@@ -1207,7 +1207,9 @@ def optim_step(opt: str, p, g, s1, s2, lr, step=1, step_dev=None, grad_scale=1.0
                sources=None):
     """sources = (items, part, rows, segs): the gradient of some ranges of g is still partial sums -- items =
     [(slab workspace, nslab, dw view into g)], segs = [(col0, ncols, dst view into g | the loss scalar, dst2, scale)] over
-    part[:rows], or 7-tuples (.., part_i, rows_i) that name their own partial matrix (part may then be None).  The optimizer sums them itself (ib_optim_step_sources) instead of a separate ib_step_reduce launch."""
+    part[:rows], or 7-tuples (.., part_i, rows_i) that name their own partial matrix (part may then be None).  The optimizer sums them itself (ib_optim_step_sources) instead of a separate ib_step_reduce launch.
+    An optional fifth entry lists views into g whose parameters were already updated this step (launches over a slice of
+    the buffers with step_dev, no ticket and step=1: same step number as the self-counting launch that follows)."""
     _req(p, "p", torch.float32, 1)
     _req(g, "g", torch.float32, 1)
     n = p.numel()
@@ -1229,7 +1231,8 @@ def optim_step(opt: str, p, g, s1, s2, lr, step=1, step_dev=None, grad_scale=1.0
         if ticket.numel() < optim_ticket_words() or not ticket.is_contiguous():
             raise HipError(f"ticket: {optim_ticket_words()} contiguous zeroed int32 words required (ib_optim_ticket_words)")
     if sources is not None:
-        items, part, rows, segs = sources
+        items, part, rows, segs = sources[:4]
+        done = sources[4] if len(sources) > 4 else ()       # views into g whose parameters an earlier launch updated
         ld = 0
         if part is not None:
             pr, pc, ld = _mat(part, "part", torch.float32)
@@ -1259,6 +1262,8 @@ def optim_step(opt: str, p, g, s1, s2, lr, step=1, step_dev=None, grad_scale=1.0
             for dd in (d, d2):
                 if dd is not None:
                     ent.append((flat_off(dd, "dst"), nc, 2, part.data_ptr() + 4 * c0, ld, int(rows), float(sc)))
+        for dv in done:
+            ent.append((flat_off(dv, "done range"), dv.numel(), 3, 0, 0, 0, 1.0))
         ent.sort(key=lambda e: e[0])              # the kernel's range scan stops at the first source beyond the element
         m = len(ent)
         cv = lambda a: ctypes.cast(a, ctypes.c_void_p)

@@ -557,6 +557,7 @@ class TransformerLayerPlan:
         # gradients ready and flushes.  A captured graph segment must end with every side stream joined, so without the lag
         # each layer's 100-us launch sat on the critical path once per bucket.
         self.lag_group = False
+        self.split_tail = False       # set by the parent on the layer whose backward runs LAST (see backward())
         self.parent_flushes = False  # set with lag_group on ALL layers of such a parent: gradients are reported to the parent
                                      # (take_lagged), which keeps the ready order and does the flushes
         self._lagged = None
@@ -837,9 +838,6 @@ class TransformerLayerPlan:
         def g_ffn1():
             wgrad(dz1, x1, "feedforward.0.weight", tg + ".ws1", bias=(tg + ".b1", "feedforward.0.bias"))
         side(g_ffn1)
-        # (measured and dropped, round 4: sending the feed-forward half of the group off right here, beside the attention
-        # backward and the QKV dgrad -- two launches per layer with their own split counts, 5 + 10 slabs per weight instead
-        # of 4, one more fork / join per layer: 1.97 -> 2.19 ms per step)
         if fused_ffn:
             later.append((part[2 * nwg:3 * nwg], nwg, P.g(p + "norm1.weight")))
             later.append((part[3 * nwg:], nwg, P.g(p + "norm1.bias")))
@@ -857,6 +855,22 @@ class TransformerLayerPlan:
             wgrad(da, attn.view(M, d), "multihead_attention.out_proj.weight", tg + ".wso",
                   bias=(tg + ".bo", "multihead_attention.out_proj.bias"))
         side(g_out)
+        if self.split_tail and group and fused_ffn and not lag and not os.environ.get("IB_NO_TAIL_SPLIT"):
+            # the layer whose backward runs last has nothing behind it to hide its weight-gradient launch: the three
+            # problems whose operands the fused launch has just written go off NOW, beside the attention backward and the
+            # in-projection's dgrad (measured and dropped for the other layers, round 4: 5 + 10 slabs per weight instead
+            # of 4 and one more fork per layer against launches that already fill the chip: 1.97 -> 2.19 ms per step)
+            early = list(group)
+            del group[:]
+            side = self.branch.run            # the rest of the group follows on the same stream (it may read these slabs)
+
+            def run_early():
+                for pr in _wgrad_group(self.buf, early, defer, later):
+                    btag, bname = pr[5]
+                    bp = self.buf.get(btag + ".colsum", ((pr[0].shape[0] + 127) // 128, pr[0].shape[1]), torch.float32)
+                    hip.segment_colsum(pr[0], bp, seg=128, mode=0)
+                    later.append((bp, bp.shape[0], P.g(p + bname)))
+            self.branch.run(run_early)
         if not fused_ffn:
             self._dgrad(P, da, "multihead_attention.out_proj.weight", dattn.view(M, d))
         dqkv = g(tg + ".dqkv", (B, T, 3 * d), dt)
@@ -1278,10 +1292,12 @@ class DenoiserTransformerPlan:
             lp.own_wt = False                # the transposed weight copies of ALL layers are refreshed by one launch
         for lo, hi in zip(self.layers[:-1], self.layers[1:]):
             lo.qkv_tail_for, hi.qkv_dgrad_below = hi, lo     # the upper layer's in-projection rides in the lower layer's launches
+        self.layers[0].split_tail = True
         self.ctx = None
         self._posproj_T = None
         self.fuse_reduce_into_optimizer = False         # set by HipTrainer for single-GPU steps
         self.pending_sources = None
+        self.early_optimizer = None                     # set by HipTrainer: fn(parameter prefix, sources) -- see backward()
         # the step's head and tail are chains of SMALL launches (time-MLP, frame-embedding projection, weight transposes;
         # their gradients): latency-bound and mutually independent, so they run as sibling branches of the main stream
         # (parallel branches of the captured graph).  The trainer switches them off under data parallelism.
@@ -1476,8 +1492,12 @@ class DenoiserTransformerPlan:
         # launch per weight, one per bias and one per LayerNorm
         fuse = self.fuse_reduce_into_optimizer and not accumulate and 12 * len(self.layers) + 4 <= 60
         defer, later = ([], []) if fuse else (None, None)
+        # one GPU: each layer's sources are its own and its parameters are updated on its side stream right behind its
+        # weight-gradient launch, beside the backward of the layers below (the optimizer is HBM traffic, those are matrix
+        # work); the step's last launch then covers only the projections and the time-MLP
+        early = self.early_optimizer if fuse else None
         for lp in self.layers:
-            lp.defer, lp.later = defer, later
+            lp.defer, lp.later = ([], []) if early else (defer, later)
         self.pending_sources = None
         _wgrad(self.buf, dout, hlast.view(M, self.d), P.g("out_proj.weight"), accumulate, ws_tag="dt.wso", defer=defer)
         P.ready("out_proj.weight")
@@ -1496,6 +1516,11 @@ class DenoiserTransformerPlan:
                 prev[0].branch.run(prev[1])           # beside this layer's backward
             dh = lp.backward(dh, P, accumulate, qkv_head=head)
             head = lp.pending_head                    # its in-projection dgrad is left to the next (lower) layer's launch
+            if early is not None:
+                # no launch issued from here on reads this layer's weights: the dgrad the layer below computes for it goes
+                # through the PACKED image (refreshed at the head of the next step), the transposed copies likewise
+                lp.branch.run(lambda lp=lp: early(lp.p, (lp.defer, None, 0, [(0, part.shape[1], dst, None, 1.0, part, rows)
+                                                                          for part, rows, dst in lp.later])))
             lg = lp.take_lagged()                     # None unless the layers report through this plan (data parallel)
             if prev is not None:
                 prev[0].branch.join()

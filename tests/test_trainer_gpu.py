@@ -276,6 +276,40 @@ def test_transformer_fused_reductions_match_separate_reductions(dtype, monkeypat
         assert (res[0][1][k] - mv).abs().max().item() <= 2e-4 * ref, k
 
 
+@pytest.mark.parametrize("cfg", [("adam", torch.bfloat16, 128, 32, 48, 512, 1024), ("rmsprop", torch.float32, 24, 30, 44, 128, 256)])
+def test_layers_updated_early_are_bitwise_the_single_optimizer_launch(cfg, monkeypatch):
+    """one GPU: every transformer layer's parameters are updated by a launch over that layer's range of the flat buffers on
+    the layer's side stream (step number *step_dev + 1 without publishing), the step's last, self-counting launch skips
+    those ranges (source kind 3).  Same sources summed in the same order: BITWISE the one-launch step (IB_NO_EARLY_OPT=1),
+    eager steps and graph replays, with a step-dependent optimizer (Adam's bias corrections)."""
+    from inferbiomechanics_amd.engine import HipTrainer
+    from inferbiomechanics_amd.models.DiffusionDenoisers import DiffusionTransformer
+    opt, dtype, B, T, D, dm, ff = cfg
+    bs = [(x.to(DEV, dtype), t.to(DEV), e.to(DEV, dtype)) for x, t, e in batches(3, B, T, D, seed=13)]
+    res = []
+    for early in (True, False):
+        if not early:
+            monkeypatch.setenv("IB_NO_EARLY_OPT", "1")
+        torch.manual_seed(0)
+        model = DiffusionTransformer(D, T, d_model=dm, num_heads=4, dim_feedforward=ff, num_layers=3, device=DEV,
+                                     compute_dtype=dtype)
+        tr = HipTrainer(model, "diffusion", opt, 1e-3)
+        losses = []
+        for i in range(7):                                   # warm-up (eager) steps, the capture, replays
+            tr.step(bs[i % 3])
+            losses.append(tr.loss_value())
+        torch.cuda.synchronize()
+        assert (tr.plan.early_optimizer is not None) == early and tr._early_done == []
+        assert int(tr.step_dev.item()) == 7
+        res.append((losses, tr.flat.detach().clone(), None if tr.s1 is None else tr.s1.detach().clone(),
+                    None if model._shadow is None else model._shadow.detach().clone()))
+    assert res[0][0] == res[1][0], (res[0][0], res[1][0])
+    for a, b in zip(res[0][1:], res[1][1:]):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert torch.equal(a, b)
+
+
 def test_bench_data_parallel_launch_sequence_on_one_rank():
     """bench.py end to end in a child process, twice: the single-GPU step (reductions fused into the optimizer, one graph)
     and -- IB_DDP_SELFTEST=1, world size 1 -- the data-parallel sequence (gradient materialised, graph cut around an RCCL
