@@ -189,6 +189,7 @@ __global__ __launch_bounds__(FF_THREADS) void ffn_chain_fwd_kernel(FfnFwdParams 
         }
       };
       ff_gemm<FF_RING_B>(p.wqkvp + (int64_t)c * FF_WELEMS, wave_s * FF_NT, imgH, ff_lane(), acq, sideq);
+      FF_STAMP(3 + 4 * p.nchunk + 2 * c);
       __syncthreads();                   // every wave's row pieces of the previous chunk have been read out of image X
 #pragma unroll
       for (int u = 0; u < FF_NT; ++u) {
@@ -198,11 +199,13 @@ __global__ __launch_bounds__(FF_THREADS) void ffn_chain_fwd_kernel(FfnFwdParams 
               ff_pack4(acq[mt][u][0] + bq[u].x, acq[mt][u][1] + bq[u].y, acq[mt][u][2] + bq[u].z, acq[mt][u][3] + bq[u].w);
       }
       __syncthreads();                   // image X = qkv chunk c complete
+      FF_STAMP(4 + 4 * p.nchunk + 2 * c);
     };
     qkv_chunk(0, FfIntC<0>{});
     for (int c = 1; c < 3; ++c) qkv_chunk(c, FfIntC<1>{});
 #pragma unroll
     for (int j = 0; j < 8; ++j) ff_out_piece(imgX, qg + 2 * FF_CHUNK, 3 * FF_D, nrows, tid + j * FF_THREADS);
+    FF_STAMP(9 + 4 * p.nchunk);
   }
 }
 
