@@ -1499,10 +1499,17 @@ class DenoiserTransformerPlan:
         for lp in self.layers:
             lp.defer, lp.later = ([], []) if early else (defer, later)
         self.pending_sources = None
-        _wgrad(self.buf, dout, hlast.view(M, self.d), P.g("out_proj.weight"), accumulate, ws_tag="dt.wso", defer=defer)
-        P.ready("out_proj.weight")
-        _colsum(self.buf, "dt.bo", dout, P.g("out_proj.bias"), accumulate)
-        P.ready("out_proj.bias")
+        def t_outproj():
+            # the output projection's own gradients: three launches nothing downstream waits for -- on a side stream on one
+            # GPU, so the main stream goes from the loss straight to the dgrad
+            _wgrad(self.buf, dout, hlast.view(M, self.d), P.g("out_proj.weight"), accumulate, ws_tag="dt.wso", defer=defer)
+            P.ready("out_proj.weight")
+            _colsum(self.buf, "dt.bo", dout, P.g("out_proj.bias"), accumulate)
+            P.ready("out_proj.bias")
+        if fuse and not os.environ.get("IB_NO_OUTPROJ_BRANCH"):
+            self.br_wt.run(t_outproj)                 # joined with the tail's branches, before the optimizer
+        else:
+            t_outproj()                               # data parallel: the flush below hands this bucket to the all-reduce
         dh = g("dt.dh", (B, T, self.d), dt)
         tp = self._tp
         if not (tp and dout.stride(0) == tp["Kp"] and dout.stride(1) == 1 and
@@ -1565,7 +1572,7 @@ class DenoiserTransformerPlan:
             P.ready("temporal_embedding.embedding.weight")
         self.br_pos.run(t_pos)
         _wgrad(self.buf, dz0, x, gw_in[:, :D], accumulate)
-        self.br_time.join(); self.br_thid.join(); self.br_pos.join()
+        self.br_time.join(); self.br_thid.join(); self.br_pos.join(); self.br_wt.join()
         P.ready("in_proj.weight")
         for lp in self.layers:
             lp.branch.join()
