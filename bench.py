@@ -242,10 +242,10 @@ def regression_ref_shape_leg(dev, B, gpu_steps=400, cpu_budget_s=4.0):
 
 
 KERNEL_OF = {   # C-ABI entry -> device kernel it launches (names as rocprofv3 --kernel-trace reports them)
-    "ib_mlp_chain_train": "mlp_chain_kernel<4, 3, 10>", "ib_mlp_chain_prep": "time_mlp_fwd_kernel<4, 4> (+ weight packing blocks)",
+    "ib_mlp_chain_train": "mlp_chain2_kernel<4, 3, 10, true>", "ib_mlp_chain_prep": "time_mlp_fwd_kernel<4, 4, 1> (+ weight packing blocks)",
     "ib_linear_wgrad_slabs": "gemm_ring_kernel<false, false, EPI_WGRAD>", "ib_slab_reduce_multi": "slab_reduce_multi_kernel",
     "ib_linear_wgrad_slabs_multi": "gemm_tn_kernel<false> (gemm_ring_wgrad_multi_kernel for short reductions)",
-    "ib_linear_wgrad_slabs_multi_bias": "gemm_tn_kernel<true>", "ib_linear_dgrad_wt": "gemm_nt_kernel",
+    "ib_linear_wgrad_slabs_multi_bias": "gemm_tn256_kernel<true> (gemm_tn_kernel<true> for shapes that are not multiples of 256)", "ib_linear_dgrad_wt": "gemm_nt_kernel",
     "ib_optim_step_sources": "optim_kernel<true>",
     "ib_step_reduce": "step_reduce_kernel",
     "ib_colsum_segments": "colsum_segments_kernel",
@@ -253,7 +253,7 @@ KERNEL_OF = {   # C-ABI entry -> device kernel it launches (names as rocprofv3 -
     "ib_linear_wgrad": "gemm_kernel<T, false, false, EPI_WGRAD> (+ slab_reduce_kernel)",
     "ib_layernorm_fwd": "layernorm_fwd_kernel", "ib_layernorm_bwd": "layernorm_bwd_kernel (+ segment_colsum_kernel)",
     "ib_attention_fwd": "attn_fwd_mfma", "ib_attention_bwd": "attn_bwd_mfma", "ib_segment_colsum": "segment_colsum_kernel",
-    "ib_ffn_chain_fwd": "ffn_chain_fwd_kernel<true>", "ib_ffn_chain_bwd": "ffn_chain_bwd_kernel<true>",
+    "ib_ffn_chain_fwd": "ffn_chain_fwd_kernel<true, true> (<true, false> for the top layer)", "ib_ffn_chain_bwd": "ffn_chain_bwd_kernel<true, true> (<true, false> for the top layer)",
     "ib_ffn_chain_pack": "ffn_pack_kernel", "ib_diffusion_draw": "diffusion_draw_kernel",
     "ib_mse_loss": "mse_partial_kernel (+ mse_final_kernel)", "ib_q_sample": "q_sample_kernel",
     "ib_gather_rows": "gather_rows_kernel", "ib_cast": "cast2d_kernel", "ib_cast2d": "cast2d_kernel"}
