@@ -312,3 +312,64 @@ def test_cli_diffusion_trains_from_the_motion_cache(dry, tmp_path):
     assert calls.count("ib_diffusion_draw") >= 3 + 3            # dev evaluation + training steps
     assert main(['train', '--epochs', '2', '--max-steps', '1'] + base)                       # DataLoader x0, device-drawn t / eps
     assert main(['train', '--epochs', '3', '--max-steps', '1', '--eager'] + base)
+
+
+def test_every_parameter_is_updated_exactly_once_per_step(dry, monkeypatch):
+    """one GPU, transformer denoiser: each layer's range of the flat buffers is updated by its own optimizer launch (issued
+    from the backward), the step's last launch names those ranges as done (source kind 3) -- together they cover the flat
+    buffer exactly once, the early launches use `*step_dev + 1` without a ticket, the last one is the self-counting launch.
+    bf16 at the fused launches' row threshold and fp32 at a small shape; IB_NO_EARLY_OPT=1: one launch, nothing marked."""
+    from inferbiomechanics_amd import hip
+    from inferbiomechanics_amd.engine import HipTrainer
+    from inferbiomechanics_amd.models.DiffusionDenoisers import DiffusionTransformer
+    real = hip.optim_step
+    for dtype, B, T, D, dm, ff in ((torch.bfloat16, 128, 32, 48, 512, 1024), (torch.float32, 6, 10, 44, 64, 128)):
+        for early in (True, False):
+            if early:
+                monkeypatch.delenv("IB_NO_EARLY_OPT", raising=False)
+            else:
+                monkeypatch.setenv("IB_NO_EARLY_OPT", "1")
+            m = DiffusionTransformer(D, T, d_model=dm, num_heads=4, dim_feedforward=ff, num_layers=3, compute_dtype=dtype)
+            tr = HipTrainer(m, "diffusion", "adam", 1e-3, use_graph=False)
+            seen = []
+
+            def rec(opt, p, g, s1, s2, lr, step=1, step_dev=None, grad_scale=1.0, shadow=None, ticket=None, sources=None):
+                lo = (p.data_ptr() - tr.flat.data_ptr()) // 4
+                done = [((v.data_ptr() - tr.grad.data_ptr()) // 4, v.numel()) for v in (sources[4] if sources and len(sources) > 4 else ())]
+                srcs = []
+                if sources:
+                    srcs = [(dw.data_ptr() - tr.grad.data_ptr()) // 4 for _, _, dw in sources[0]]
+                    srcs += [(seg[2].data_ptr() - tr.grad.data_ptr()) // 4 for seg in sources[3]]
+                seen.append({"lo": lo, "n": p.numel(), "step": step, "ticket": ticket is not None, "done": done, "srcs": srcs,
+                             "g_lo": (g.data_ptr() - tr.grad.data_ptr()) // 4, "shadow": shadow is not None})
+                return real(opt, p, g, s1, s2, lr, step=step, step_dev=step_dev, grad_scale=grad_scale, shadow=shadow,
+                            ticket=ticket, sources=sources)
+            monkeypatch.setattr(hip, "optim_step", rec)
+            g = torch.Generator().manual_seed(1)
+            tr.step((torch.randn(B, T, D, generator=g).to(dtype), torch.randint(0, 1000, (B,), generator=g),
+                     torch.randn(B, T, D, generator=g).to(dtype)))
+            monkeypatch.setattr(hip, "optim_step", real)
+            n = tr.flat.numel()
+            last = seen[-1]
+            assert last["lo"] == 0 and last["n"] == n and last["ticket"] and last["step"] == 0
+            if not early:
+                assert len(seen) == 1 and last["done"] == []
+                continue
+            assert len(seen) == 4 and len(last["done"]) == 3                       # three layers + the step's last launch
+            cover = torch.zeros(n, dtype=torch.int32)
+            for e in seen[:-1]:
+                assert not e["ticket"] and e["step"] == 1 and e["g_lo"] == e["lo"] and e["shadow"] == (dtype == torch.bfloat16)
+                assert (e["lo"], e["n"]) in last["done"]
+                assert e["srcs"] and all(e["lo"] <= s < e["lo"] + e["n"] for s in e["srcs"])     # only its own gradients
+                cover[e["lo"]:e["lo"] + e["n"]] += 1
+            rest = torch.ones(n, dtype=torch.int32)
+            for lo, ln in last["done"]:
+                rest[lo:lo + ln] = 0
+            assert all(not any(lo <= s < lo + ln for lo, ln in last["done"]) for s in last["srcs"])
+            assert torch.equal(cover + rest, torch.ones(n, dtype=torch.int32))
+            # the ranges are exactly the layers' parameters
+            for li in range(3):
+                lo, hi = tr._prefix_range(f"transformer_layers.{li}.")
+                names = [k for k in tr.layout if k.startswith(f"transformer_layers.{li}.")]
+                assert lo == min(tr.layout[k][0] for k in names) and (lo, hi - lo) in last["done"]
+                assert all(not (lo <= tr.layout[k][0] < hi) for k in tr.layout if k not in names)
