@@ -102,6 +102,16 @@ int ib_linear_ln_fwd(const void* x, int64_t ldx, const void* w, int64_t ldw, con
                      int64_t ldres, const float* gamma, const float* beta, void* y, int64_t ldy, void* a_out,
                      float* mean, float* rstd, void* workspace, size_t workspace_bytes, int64_t M, int64_t N,
                      int64_t K, float eps, int dtype, ib_stream_t stream);
+/* The same operation for d = 512 projections (N == K == 512) as ONE launch over panels of ceil(M / 256) <= 32 rows
+ * (csrc/linln_panel.hip; the sampler's attention out-projection + residual + LayerNorm1, TransformerBaseline.py:12-13,
+ * 29-31): the fp32 GEMM result stays in LDS and is normalised in place -- no slabs, no second launch.  `w_packed` = the
+ * weight's [512 x 512] fragment-major image (ib_ffn_chain_pack: the out-projection's image sits at element offset
+ * 4 * (ffn / 512) * 512 * 512 of a layer's packed buffer).  bias / res optional.  ib_linear_ln_panel_workgroups returns the
+ * workgroup count (0: shape not supported -- M > 8192 or N, K != 512) and the rows per workgroup. */
+int ib_linear_ln_panel_workgroups(int64_t M, int64_t N, int64_t K, int32_t* rows_out);
+int ib_linear_ln_panel_fwd(const void* x, int64_t ldx, const void* w_packed, const float* bias, const void* res,
+                           int64_t ldres, const float* gamma, const float* beta, void* y, int64_t ldy, int64_t M, int64_t N,
+                           int64_t K, float eps, ib_stream_t stream);
 /* Deferred form for a step that computes several weight gradients: ib_linear_wgrad_slabs writes only the split-M
  * partial slabs ([*nslab_out][N][K] fp32, workspace of ib_linear_wgrad_slabs_workspace bytes); ONE
  * ib_slab_reduce_multi launch (n <= 8 gradients, K % 4 == 0, host arrays) then sums every slab set into its dw. */
@@ -517,7 +527,8 @@ enum {
   IB_PATH_CHAIN1 = 11,      /* chain.hip: the round-2 chain kernel (IB_CHAIN_V1=1) */
   IB_PATH_TN256 = 12,       /* gemm_tn256.hip: 256 x 256 weight-gradient kernel, grouped, one split count per group */
   IB_PATH_NT_SPLITK = 13,   /* gemm_nt.hip in split-K form (fp32 slabs) under the sampler's Linear + LayerNorm */
-  IB_PATH_FFN_CHAIN = 14    /* ffn_chain.hip: fused feed-forward sublayer (Linear + ReLU + Linear + residual + LayerNorm) */
+  IB_PATH_FFN_CHAIN = 14,   /* ffn_chain.hip: fused feed-forward sublayer (Linear + ReLU + Linear + residual + LayerNorm) */
+  IB_PATH_LINLN_PANEL = 15  /* linln_panel.hip: Linear + residual + LayerNorm over row panels, one launch (sampler) */
 };
 int ib_debug_last_path(void);
 int ib_selftest_tr16(const void* in_bf16_64x16, void* out_bf16_64x4, ib_stream_t stream);

@@ -1,0 +1,189 @@
+// y = LayerNorm(res + x . W^T + bias) for d = 512 x 512 projections at FEW THOUSAND rows and below (the DDIM sampler's
+// attention out-projection + residual + LayerNorm1, TransformerBaseline.py:12-13,29-31, at B = 1 ... 16 windows of 200 frames),
+// bf16, gfx950 -- ONE launch over panels of rows, the design of the fused training launches (ffn_chain.hip) cut down to its
+// first phase.
+//
+// What it replaces at these row counts: a split-K GEMM into fp32 slabs + a reduction / LayerNorm launch (ib_linear_ln_fwd:
+// 4 slabs of [3200, 512] fp32 written and read back = 52 MB of traffic and a kernel boundary for a 1.7-GFLOP product: 19.3 us
+// at M = 3200, 11.5 us at M = 200).  Here a 512-thread workgroup owns a panel of P = ceil(M / 256) rows (13 at M = 3200: 247
+// workgroups, one round), keeps the GEMM's fp32 result in LDS and normalises it in place: the rows are read once and written
+// once.  Bound: the 512 KB of packed weights every workgroup streams through its CU's L2 port (6-7 us at the ~80 GB/s a CU
+// takes in, ffn_chain.h), i.e. the launch is as long as ONE GEMM phase of the training kernels plus its row traffic.
+// Panels are at most 32 rows (two MFMA row tiles): more rows per workgroup would leave CUs idle long before the matrix pipes
+// matter.  The weights come from the layer's packed image (ib_ffn_chain_pack: block (nt, kb) of 1 KiB at (kb * 32 + nt) KiB).
+#include "ffn_chain.h"
+
+namespace {
+
+constexpr int LP_XS = FF_D * 4 + 16;                       // bytes per fp32 exchange row
+
+struct LinLnPanelParams {
+  const bf16_t* x; int64_t ldx;                            // [M, 512] GEMM input rows
+  const bf16_t* wp;                                        // packed [512 x 512] weight image (W_eff[n][k] = W[n][k])
+  const float* bias;                                       // [512] or NULL
+  const bf16_t* res; int64_t ldres;                        // [M, 512] residual rows or NULL
+  const float* gamma; const float* beta;
+  bf16_t* y; int64_t ldy;
+  int M, P;
+  float eps;
+};
+
+// ff_gemm (ffn_chain.h) over MT row tiles instead of four: same packed-weight stream, same 3-deep register ring, the issue
+// point of every k-block's prefetch pinned by a scheduling barrier
+template <int MT, int KB_, class Side>
+__device__ __forceinline__ void lp_gemm_step(const bf16x8_t* __restrict__ wl, const unsigned char* arow,
+                                             bf16x8_t (&wr)[3][FF_NT], f32x4_t (&acc)[MT][FF_NT], Side&& side) {
+  constexpr int RING = 3, PD = RING - 1, SK = FF_WAVES * FF_NT;
+  if constexpr (KB_ + PD < FF_KB) {
+#pragma unroll
+    for (int u = 0; u < FF_NT; ++u) wr[(KB_ + PD) % RING][u] = wl[(u + (KB_ + PD) * SK) * 64];
+  }
+  side(FfIntC<KB_>{});
+  __builtin_amdgcn_sched_barrier(0);
+  bf16x8_t fa[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) fa[mt] = *reinterpret_cast<const bf16x8_t*>(arow + 16 * mt * FF_RS + 64 * KB_);
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int u = 0; u < FF_NT; ++u)
+      acc[mt][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[KB_ % RING][u], fa[mt], acc[mt][u], 0, 0, 0);
+}
+template <int MT, class Side, int... KBs>
+__device__ __forceinline__ void lp_gemm_seq(const bf16x8_t* __restrict__ wl, const unsigned char* arow, bf16x8_t (&wr)[3][FF_NT],
+                                            f32x4_t (&acc)[MT][FF_NT], Side&& side, std::integer_sequence<int, KBs...>) {
+  (lp_gemm_step<MT, KBs>(wl, arow, wr, acc, side), ...);
+}
+
+template <int MT>
+__global__ __launch_bounds__(FF_THREADS) void linln_panel_kernel(LinLnPanelParams p) {
+  constexpr int ROWS = 16 * MT, PIECES = ROWS * 64 / FF_THREADS;          // 16-byte pieces of the input rows per thread
+  __shared__ __attribute__((aligned(16))) unsigned char img[ROWS * FF_RS];
+  __shared__ __attribute__((aligned(16))) unsigned char exch[ROWS * LP_XS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  const int g = lane >> 4, l16 = lane & 15;
+  const int r0 = blockIdx.x * p.P;
+  const int nrows = min(p.P, p.M - r0);
+  const int colb = wave * 16 * FF_NT + 4 * g;
+  // ---- the weight ring's first two k-blocks are requested ahead of the rows (nothing else is in flight yet)
+  const bf16x8_t* wl = reinterpret_cast<const bf16x8_t*>(p.wp) + (int64_t)(wave_s * FF_NT) * 64 + ff_lane();
+  bf16x8_t wr[3][FF_NT];
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int u = 0; u < FF_NT; ++u) wr[s][u] = wl[(u + s * (FF_WAVES * FF_NT)) * 64];
+  // ---- the panel's input rows -> LDS image (rows beyond the panel: copies of its last row, finite and never stored)
+  {
+    uint4 v[PIECES];
+#pragma unroll
+    for (int j = 0; j < PIECES; ++j) {
+      const int idx = tid + j * FF_THREADS, r = min(idx >> 6, nrows - 1);
+      v[j] = *reinterpret_cast<const uint4*>(p.x + (int64_t)(r0 + r) * p.ldx + (idx & 63) * 8);
+    }
+#pragma unroll
+    for (int j = 0; j < PIECES; ++j) {
+      const int idx = tid + j * FF_THREADS;
+      *reinterpret_cast<uint4*>(img + (idx >> 6) * FF_RS + (idx & 63) * 16) = v[j];
+    }
+  }
+  __syncthreads();
+  f32x4_t acc[MT][FF_NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int u = 0; u < FF_NT; ++u) acc[mt][u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  // side jobs behind the weight stream: the bias of this lane's columns and the residual values of its accumulator positions
+  float4 b4[FF_NT];
+  bf16x4_t rv[MT][FF_NT];
+#pragma unroll
+  for (int u = 0; u < FF_NT; ++u) b4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int u = 0; u < FF_NT; ++u) rv[mt][u] = ff_pack4(0.f, 0.f, 0.f, 0.f);
+  auto side = [&](auto kbc) {
+    constexpr int kb = decltype(kbc)::value;
+    if constexpr (kb == FF_KB - 4) {
+      if (p.bias) {
+#pragma unroll
+        for (int u = 0; u < FF_NT; ++u) b4[u] = *reinterpret_cast<const float4*>(p.bias + colb + 16 * u);
+      }
+    }
+    if constexpr (kb >= FF_KB - 4 && kb - (FF_KB - 4) < MT) {
+      constexpr int mt = kb - (FF_KB - 4);
+      if (p.res) {
+        const int64_t row = r0 + min(16 * mt + l16, nrows - 1);
+#pragma unroll
+        for (int u = 0; u < FF_NT; ++u) rv[mt][u] = *reinterpret_cast<const bf16x4_t*>(p.res + row * p.ldres + colb + 16 * u);
+      }
+    }
+  };
+  const unsigned char* arow = img + l16 * FF_RS + 16 * g;
+  lp_gemm_seq<MT>(wl, arow, wr, acc, side, std::make_integer_sequence<int, FF_KB>{});
+  // ---- LayerNorm input rows, fp32, into the exchange (a GEMM lane owns 4 columns of 16 MT rows; a LayerNorm wave owns rows)
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int u = 0; u < FF_NT; ++u) {
+      float4 t;
+      t.x = (acc[mt][u][0] + b4[u].x) + (float)rv[mt][u][0];
+      t.y = (acc[mt][u][1] + b4[u].y) + (float)rv[mt][u][1];
+      t.z = (acc[mt][u][2] + b4[u].z) + (float)rv[mt][u][2];
+      t.w = (acc[mt][u][3] + b4[u].w) + (float)rv[mt][u][3];
+      *reinterpret_cast<float4*>(exch + (16 * mt + l16) * LP_XS + (colb + 16 * u) * 4) = t;
+    }
+  float gm[8], bt[8];
+  ff_load8f(p.gamma + lane * 8, gm);
+  ff_load8f(p.beta + lane * 8, bt);
+  __syncthreads();
+  const float invH = 1.f / (float)FF_D;
+  for (int row = wave_s; row < nrows; row += FF_WAVES) {
+    const float4 a = *reinterpret_cast<const float4*>(exch + row * LP_XS + lane * 32);
+    const float4 b = *reinterpret_cast<const float4*>(exch + row * LP_XS + lane * 32 + 16);
+    float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    const float mu = ff_row_sum(((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]))) * invH;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { v[k] -= mu; q += v[k] * v[k]; }
+    const float rs = 1.f / sqrtf(ff_row_sum(q) * invH + p.eps);
+    float o[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = v[k] * rs * gm[k] + bt[k];
+    *reinterpret_cast<uint4*>(p.y + (int64_t)(r0 + row) * p.ldy + lane * 8) = ff_pack8(o);
+  }
+}
+
+}  // namespace
+
+// rows per workgroup and workgroup count: ceil(M / 256) rows while that is at most 32, else unsupported (large batches take
+// the tile GEMM + LayerNorm: they fill the chip without streaming the whole weight per 32 rows)
+extern "C" int ib_linear_ln_panel_workgroups(int64_t M, int64_t N, int64_t K, int32_t* rows_out) {
+  if (M <= 0 || N != FF_D || K != FF_D) return 0;
+  const int64_t P = (M + 255) / 256;
+  if (P > 32) return 0;
+  if (rows_out) *rows_out = (int32_t)P;
+  return (int)((M + P - 1) / P);
+}
+
+extern "C" int ib_linear_ln_panel_fwd(const void* x, int64_t ldx, const void* w_packed, const float* bias, const void* res,
+                                      int64_t ldres, const float* gamma, const float* beta, void* y, int64_t ldy, int64_t M,
+                                      int64_t N, int64_t K, float eps, ib_stream_t stream) {
+  if (!x || !w_packed || !gamma || !beta || !y || M <= 0) return IB_E_ARG;
+  int32_t P = 0;
+  const int nwg = ib_linear_ln_panel_workgroups(M, N, K, &P);
+  if (!nwg) return IB_E_UNSUPPORTED;
+  if (ldx < K || ldy < N || (res && ldres < N) || ldx % 8 != 0 || ldy % 8 != 0 || (res && ldres % 4 != 0)) return IB_E_ARG;
+  if (!ff_al16({x, w_packed, gamma, beta, y}) || (bias && !ff_al16({bias})) ||
+      (res && (reinterpret_cast<uintptr_t>(res) % 8) != 0))
+    return IB_E_ARG;
+  LinLnPanelParams p{};
+  p.x = (const bf16_t*)x; p.ldx = ldx; p.wp = (const bf16_t*)w_packed; p.bias = bias;
+  p.res = (const bf16_t*)res; p.ldres = ldres; p.gamma = gamma; p.beta = beta; p.y = (bf16_t*)y; p.ldy = ldy;
+  p.M = (int)M; p.P = P; p.eps = eps;
+  IB_PATH(IB_PATH_LINLN_PANEL);
+  if (P <= 16) hipLaunchKernelGGL(linln_panel_kernel<1>, dim3(nwg), dim3(FF_THREADS), 0, ib_s(stream), p);
+  else hipLaunchKernelGGL(linln_panel_kernel<2>, dim3(nwg), dim3(FF_THREADS), 0, ib_s(stream), p);
+  IB_CHECK_LAUNCH();
+  return IB_OK;
+}

@@ -54,6 +54,8 @@ _SIGS = {
     "ib_linear_ln_fwd_workspace": (_sz, [_i64, _i64, _i64]),
     "ib_linear_ln_fwd": (_c.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _sz,
                                     _i64, _i64, _i64, _f32, _c.c_int, _vp]),
+    "ib_linear_ln_panel_workgroups": (_c.c_int, [_i64, _i64, _i64, _vp]),
+    "ib_linear_ln_panel_fwd": (_c.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _f32, _vp]),
     "ib_linear_wgrad_slabs_workspace": (_sz, [_i64, _i64, _i64]),
     "ib_linear_wgrad_slabs": (_c.c_int, [_vp, _i64, _vp, _i64, _vp, _sz, _vp, _i64, _i64, _i64, _c.c_int, _vp]),
     "ib_linear_wgrad_slabs_multi": (_c.c_int, [_c.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _c.c_int, _vp]),
@@ -264,7 +266,7 @@ class _RecordingLib:
 
 
 PATH_NAMES = {0: "-", 1: "nt256x128", 2: "tn256x128", 3: "ring128", 4: "generic", 5: "smallm", 6: "skinny", 7: "wgrad_small",
-              8: "ring_multi", 9: "linear_ln", 10: "chain_v2", 11: "chain_v1", 12: "tn256x256", 13: "nt_splitk", 14: "ffn_chain"}
+              8: "ring_multi", 9: "linear_ln", 10: "chain_v2", 11: "chain_v1", 12: "tn256x256", 13: "nt_splitk", 14: "ffn_chain", 15: "linear_ln_panel"}
 _work_note = None     # set by a wrapper right before a grouped launch: (flops, bytes) of that launch, for bench.py
 
 
@@ -666,6 +668,36 @@ def linear_ln_fwd(x, w, bias, res, gamma, beta, y, workspace, eps=1e-5) -> bool:
     if rc == -5:
         return False
     _check(rc, "ib_linear_ln_fwd")
+    return True
+
+
+def linear_ln_panel_ok(M: int, N: int, K: int) -> bool:
+    return bool(lib().ib_linear_ln_panel_workgroups(int(M), int(N), int(K), None))
+
+
+def linear_ln_panel_fwd(x, w_packed, bias, res, gamma, beta, y, eps=1e-5) -> bool:
+    """y = LayerNorm(res + x W^T + bias) for a [512, 512] weight given as its packed image (ffn_chain_pack), one launch over
+    row panels (csrc/linln_panel.hip).  Returns False when the shape does not qualify."""
+    dt = torch.bfloat16
+    M, K, ldx = _mat(x, "x", dt)
+    My, N, ldy = _mat(y, "y", dt)
+    _req(w_packed, "w_packed", dt, 1)
+    if My != M or w_packed.numel() < N * K or not w_packed.is_contiguous():
+        raise HipError("linear_ln_panel_fwd: y must be [M, N], w_packed the [N x K] image")
+    ldres = 0
+    if res is not None:
+        Mr, Nr, ldres = _mat(res, "res", dt)
+        if (Mr, Nr) != (M, N):
+            raise HipError("linear_ln_panel_fwd: res must be [M, N]")
+    for t, n in ((gamma, "gamma"), (beta, "beta")) + (((bias, "bias"),) if bias is not None else ()):
+        _req(t, n, torch.float32, 1)
+        if t.numel() != N:
+            raise HipError(f"linear_ln_panel_fwd: {n} must be fp32 [N]")
+    rc = lib().ib_linear_ln_panel_fwd(_ptr(x), ldx, _ptr(w_packed), _ptr(bias), _ptr(res), ldres, _ptr(gamma), _ptr(beta),
+                                      _ptr(y), ldy, M, N, K, float(eps), stream_ptr())
+    if rc == -5:
+        return False
+    _check(rc, "ib_linear_ln_panel_fwd")
     return True
 
 

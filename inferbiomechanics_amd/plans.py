@@ -558,6 +558,7 @@ class TransformerLayerPlan:
         # each layer's 100-us launch sat on the critical path once per bucket.
         self.lag_group = False
         self.split_tail = False       # set by the parent on the layer whose backward runs LAST (see backward())
+        self.infer_packed = False     # set by the parent's prepare_inference: packed_image() holds the frozen weights
         self.parent_flushes = False  # set with lag_group on ALL layers of such a parent: gradients are reported to the parent
                                      # (take_lagged), which keeps the ready order and does the flushes
         self._lagged = None
@@ -703,8 +704,19 @@ class TransformerLayerPlan:
                                self.qkv_tail_for.qkv_buffer(B, T).view(M, 3 * d)))
             self.ctx = (x, qkv, attn, lse, a, x1, m1, r1, f1, f2, m2, r2, B, T, drop)
             return x2
-        if not (fuse and lin_ln(attn.view(M, d), "multihead_attention.out_proj.weight",
-                                "multihead_attention.out_proj.bias", "norm1", x, x1, ".lnws1")):
+        def panel_ln():
+            """out-projection + residual + LayerNorm1 as one launch over row panels (sampler, frozen packed weights)"""
+            if not (fuse and self.infer_packed and d == 512 and hip.linear_ln_panel_ok(M, d, d)
+                    and M < int(os.environ.get("IB_LINLN_PANEL_MAX_M", "4096"))):
+                return False
+            nc = self.ffn // 512
+            wo_img = self.packed_image()[4 * nc * 512 * 512:(4 * nc + 1) * 512 * 512]
+            return hip.linear_ln_panel_fwd(attn.view(M, d), wo_img, P.v(p + "multihead_attention.out_proj.bias"), x,
+                                           P.v(p + "norm1.weight"), P.v(p + "norm1.bias"), x1)
+        if panel_ln():
+            pass
+        elif not (fuse and lin_ln(attn.view(M, d), "multihead_attention.out_proj.weight",
+                                  "multihead_attention.out_proj.bias", "norm1", x, x1, ".lnws1")):
             a = g(tg + ".a", (M, d), dt)
             hip.linear_fwd(attn.view(M, d), P.w(p + "multihead_attention.out_proj.weight"),
                            P.v(p + "multihead_attention.out_proj.bias"), a)
@@ -1323,6 +1335,7 @@ class DenoiserTransformerPlan:
         self._e_all = None
         for lp in self.layers:
             lp.inference = bool(on)
+            lp.infer_packed = False                       # prepare_inference packs the (then frozen) weights again
 
     def prepare_inference(self, P: ParamSource, T: int, D: int, table: Optional[torch.Tensor] = None):
         """once per sampling loop (weights frozen from here on): the frame-embedding half of the input projection, and --
@@ -1349,6 +1362,17 @@ class DenoiserTransformerPlan:
             hip.cast2d(P.w("out_proj.weight"), w_out_pad[:D])
             b_out_pad[:D].copy_(P.v("out_proj.bias"))
             self._pad = (Kp, w_in_pad, w_out_pad, b_out_pad)
+        # frozen weights: every layer's packed image once per sampling loop -- the attention out-projection + residual +
+        # LayerNorm1 of a denoise step is then ONE launch over row panels (csrc/linln_panel.hip) while the step has at most a
+        # few thousand rows, instead of a split-K GEMM into fp32 slabs + a reduction launch
+        for lp in self.layers:
+            lp.infer_packed = False
+        if (self.dtype == torch.bfloat16 and self.d == 512 and not os.environ.get("IB_NO_LINLN_PANEL")
+                and all(hip.ffn_chain_supported(self.d, lp.ffn) for lp in self.layers)):
+            hip.ffn_chain_pack([(P.w(lp.p + "feedforward.0.weight"), P.w(lp.p + "feedforward.2.weight"), lp.packed_image(),
+                                 P.w(lp.p + "multihead_attention.out_proj.weight")) for lp in self.layers])
+            for lp in self.layers:
+                lp.infer_packed = True
         if table is not None and not os.environ.get("IB_NO_TIME_TABLE"):
             steps = table.shape[0]
             every_t = torch.arange(steps, dtype=torch.int64, device=table.device)

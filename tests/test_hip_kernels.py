@@ -468,6 +468,50 @@ def test_linear_ln_fwd_matches_unfused(hip, M, N, K):
                                  torch.zeros(96, device=DEV), y2, ws2)
 
 
+@pytest.mark.parametrize("M,opts", [(3200, "br"), (200, "br"), (3201, "br"), (1, "br"), (5000, "br"), (8192, "b"), (777, "r"),
+                                    (300, "")])
+def test_linear_ln_panel_fwd_matches_float64(hip, M, opts):
+    """csrc/linln_panel.hip: y = LayerNorm(res + x W^T + bias) for a [512, 512] weight from its packed image, one launch over
+    panels of ceil(M / 256) rows (ragged last panel, one and two MFMA row tiles per panel, bias / residual optional, pitched
+    input / residual / output rows) against a float64 restatement; 8193 rows and other widths are reported as unsupported"""
+    bf = torch.bfloat16
+    d, ffn = 512, 1024
+    x_p = rnd((M, d + 8), 1, 1.0, bf).to(DEV)                  # row pitch 520 elements
+    x = x_p[:, :d]
+    w = rnd((d, d), 2, d ** -0.5, bf).to(DEV)
+    b = rnd((d,), 3, 0.1).to(DEV) if "b" in opts else None
+    res_p = rnd((M, d + 4), 4, 1.0, bf).to(DEV)
+    res = res_p[:, :d] if "r" in opts else None
+    g = (1.0 + rnd((d,), 5, 0.2)).to(torch.float32).to(DEV)
+    be = rnd((d,), 6, 0.1).to(DEV)
+    y_p = torch.full((M, d + 16), 7.0, dtype=bf, device=DEV)
+    y = y_p[:, :d]
+    packed = torch.zeros(hip.ffn_chain_packed_elems(d, ffn), dtype=bf, device=DEV)
+    hip.ffn_chain_pack([(rnd((ffn, d), 8, 0.05, bf).to(DEV), rnd((d, ffn), 9, 0.05, bf).to(DEV), packed, w)])
+    nc = ffn // 512
+    wo_img = packed[4 * nc * d * d:(4 * nc + 1) * d * d]
+    assert hip.linear_ln_panel_ok(M, d, d)
+    assert hip.linear_ln_panel_fwd(x, wo_img, b, res, g, be, y)
+    assert hip.lib().ib_debug_last_path() == 15
+    torch.cuda.synchronize()
+    z = x.double().cpu() @ w.double().cpu().T
+    if b is not None:
+        z = z + b.double().cpu()
+    if res is not None:
+        z = z + res.double().cpu()
+    mu = z.mean(-1, keepdim=True)
+    exp = (z - mu) / torch.sqrt(((z - mu) ** 2).mean(-1, keepdim=True) + 1e-5) * g.double().cpu() + be.double().cpu()
+    close(y, exp, 2e-2, "linear_ln_panel_fwd")
+    assert torch.all(y_p[:, d:] == 7.0)                          # nothing written beside the rows
+    # the same numbers as the split-K form it replaces in the sampler, up to one bf16 rounding of the output
+    if M <= 4096:
+        y2 = torch.zeros(M, d, dtype=bf, device=DEV)
+        ws = torch.zeros(int(hip.lib().ib_linear_ln_fwd_workspace(M, d, d)), dtype=torch.uint8, device=DEV)
+        assert hip.linear_ln_fwd(x, w, b, res, g, be, y2, ws)
+        assert (y.float() - y2.float()).abs().max().item() <= 2 ** -6 * max(1.0, exp.abs().max().item())
+    assert not hip.linear_ln_panel_ok(8193, d, d) and not hip.linear_ln_panel_ok(M, 256, d) and not hip.linear_ln_panel_ok(M, d, 1024)
+
+
 @pytest.mark.parametrize("M,N,K", [(256, 512, 1470), (256, 300, 512), (32, 512, 512), (1, 300, 512), (100, 72, 200),
                                    (1000, 512, 512), (64, 16, 64)])
 @pytest.mark.parametrize("act", ["none", "sigmoid", "elu"])
