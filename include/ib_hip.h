@@ -112,6 +112,18 @@ int ib_linear_ln_panel_workgroups(int64_t M, int64_t N, int64_t K, int32_t* rows
 int ib_linear_ln_panel_fwd(const void* x, int64_t ldx, const void* w_packed, const float* bias, const void* res,
                            int64_t ldres, const float* gamma, const float* beta, void* y, int64_t ldy, int64_t M, int64_t N,
                            int64_t K, float eps, ib_stream_t stream);
+/* The feed-forward sublayer of a frozen-weight forward, y = LayerNorm2(x1 + W2 ReLU(W1 x1 + b1) + b2)
+ * (TransformerBaseline.py:15-19,33-36), d == 512, ffn a multiple of 512, at most 64 * (256 / (ffn / 512)) rows
+ * (csrc/linln_panel.hip): a panel of rows is shared by the ffn / 512 workgroups of its hidden chunks, each leaves an fp32
+ * partial product in `workspace` (ib_ffn_infer_workspace bytes); the slab reduction of ib_linear_ln_fwd (bias + residual +
+ * LayerNorm, partials added in chunk order) finishes it: two launches, no [M, ffn] activation in HBM.  x1 / y: contiguous
+ * [M, 512] bf16; `packed`: the layer's image from ib_ffn_chain_pack.  ib_ffn_infer_workgroups returns the workgroup count
+ * of the first launch (0: unsupported), the rows per panel and the panel count. */
+size_t ib_ffn_infer_workspace(int64_t M, int64_t d, int64_t ffn);
+int ib_ffn_infer_workgroups(int64_t M, int64_t d, int64_t ffn, int32_t* rows_out, int32_t* panels_out);
+int ib_ffn_infer_fwd(const void* x1, const void* packed, const float* b1, const float* b2, const float* gamma,
+                     const float* beta, void* y, void* workspace, size_t workspace_bytes, int64_t M, int64_t d, int64_t ffn,
+                     float eps, ib_stream_t stream);
 /* Deferred form for a step that computes several weight gradients: ib_linear_wgrad_slabs writes only the split-M
  * partial slabs ([*nslab_out][N][K] fp32, workspace of ib_linear_wgrad_slabs_workspace bytes); ONE
  * ib_slab_reduce_multi launch (n <= 8 gradients, K % 4 == 0, host arrays) then sums every slab set into its dw. */
@@ -528,7 +540,8 @@ enum {
   IB_PATH_TN256 = 12,       /* gemm_tn256.hip: 256 x 256 weight-gradient kernel, grouped, one split count per group */
   IB_PATH_NT_SPLITK = 13,   /* gemm_nt.hip in split-K form (fp32 slabs) under the sampler's Linear + LayerNorm */
   IB_PATH_FFN_CHAIN = 14,   /* ffn_chain.hip: fused feed-forward sublayer (Linear + ReLU + Linear + residual + LayerNorm) */
-  IB_PATH_LINLN_PANEL = 15  /* linln_panel.hip: Linear + residual + LayerNorm over row panels, one launch (sampler) */
+  IB_PATH_LINLN_PANEL = 15, /* linln_panel.hip: Linear + residual + LayerNorm over row panels, one launch (sampler) */
+  IB_PATH_FFN_INFER = 16    /* linln_panel.hip: feed-forward sublayer, panels shared by their hidden chunks (sampler) */
 };
 int ib_debug_last_path(void);
 int ib_selftest_tr16(const void* in_bf16_64x16, void* out_bf16_64x4, ib_stream_t stream);

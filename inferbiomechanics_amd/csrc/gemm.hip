@@ -1807,6 +1807,16 @@ int linear_ln_split(int64_t M, int64_t N, int64_t K, int* chunk_out) {
 }
 }  // namespace
 
+// the reduction / LayerNorm launch on its own, for N = 512: slabs of another producer (linln_panel.hip's feed-forward launch)
+int ib_slab_ln512_launch(const float* slabs, int nslab, int64_t slab_stride, const float* bias, const void* res, int64_t ldres,
+                         const float* gamma, const float* beta, void* y, int64_t ldy, int64_t M, float eps, hipStream_t s) {
+  hipLaunchKernelGGL((slab_ln_kernel<64, 2>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, slabs, nslab, slab_stride, bias,
+                     reinterpret_cast<const bf16_t*>(res), ldres, gamma, beta, reinterpret_cast<bf16_t*>(y), ldy,
+                     (bf16_t*)nullptr, (float*)nullptr, (float*)nullptr, (int)M, eps);
+  IB_CHECK_LAUNCH();
+  return IB_OK;
+}
+
 extern "C" size_t ib_linear_ln_fwd_workspace(int64_t M, int64_t N, int64_t K) {
   int chunk;
   int split = linear_ln_split(M, N, K, &chunk);

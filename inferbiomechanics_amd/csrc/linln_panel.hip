@@ -154,6 +154,99 @@ __global__ __launch_bounds__(FF_THREADS) void linln_panel_kernel(LinLnPanelParam
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The feed-forward sublayer of a frozen-weight forward at a few thousand rows and below:
+//     y = LayerNorm2( x1 + W2 . ReLU(W1 . x1 + b1) + b2 )                       TransformerBaseline.py:15-19,33-36
+// It replaces Linear + ReLU ([M, 2048] hidden activation through HBM) and the split-K Linear + LayerNorm pair (12.7 + 23.7 us
+// at M = 3200, 7.6 + 15.1 us at M = 200).  The training launch (ffn_chain.hip) gives every 50-row panel to ONE workgroup, which
+// streams all 4 MB of W1 / W2: right when 256 panels fill the chip, 76 us when there are 64.  Here a panel is shared by the
+// `nchunk` workgroups of its hidden chunks: workgroup (panel, c) computes h_c = ReLU(x1 . W1[c]^T + b1[c]) into LDS and the
+// partial product y_c = h_c . W2[:, c]^T (1 MB of weights: two GEMM phases) and leaves y_c as an fp32 slab [c][M][512]; the
+// slab reduction that finishes it IS the LayerNorm launch of gemm.hip (bias + residual + statistics + affine, slabs added in
+// chunk order): two launches, no hidden activation in HBM.
+// (Built first with the reduction inside the launch -- a ticket per panel, the last arriver normalises, agent-scope fences
+// around the ticket: the fences write back and invalidate the XCD's WHOLE L2, every workgroup's weight stream then missed:
+// 106 us instead of 36.  Per-access sc1 loads would need hand-scheduled waits; the kernel boundary is the cheap fence.)
+// Workgroups of one panel have consecutive ids = different XCDs; an XCD sees only chunks id % 8 % nchunk: 1-2 MB of weights
+// in its L2 instead of all of them.
+struct FfnCoopParams {
+  const bf16_t* x1;                 // [M, 512]
+  const bf16_t* w1p; const bf16_t* w2p;      // packed images, chunk c at + c * FF_WELEMS
+  const float* b1;
+  float* part;                      // [nchunk][M][512] fp32 partial products (the slabs of the LayerNorm launch)
+  int M, P, nchunk;
+};
+
+__global__ __launch_bounds__(FF_THREADS) void ffn_coop_kernel(FfnCoopParams p) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * FF_BUF];
+  unsigned char* imgX = smem;
+  unsigned char* imgH = smem + FF_BUF;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  const int g = lane >> 4, l16 = lane & 15;
+  const int panel = (int)blockIdx.x / p.nchunk, c = (int)blockIdx.x % p.nchunk;
+  const int r0 = panel * p.P;
+  const int nrows = min(p.P, p.M - r0);
+  const int colb = wave * 16 * FF_NT + 4 * g;
+  ff_panel_in(p.x1 + (int64_t)r0 * FF_D, imgX, nrows, tid);
+  __syncthreads();
+  {
+    f32x4_t acc1[4][FF_NT];
+    ff_zero(acc1);
+    float4 b4[FF_NT];
+    auto side1 = [&](auto, int kb) {
+      if (kb == FF_KB - 1) {
+#pragma unroll
+        for (int u = 0; u < FF_NT; ++u) b4[u] = *reinterpret_cast<const float4*>(p.b1 + c * FF_CHUNK + colb + 16 * u);
+      }
+    };
+    ff_gemm<FF_RING_A>(p.w1p + (int64_t)c * FF_WELEMS, wave_s * FF_NT, imgX, ff_lane(), acc1, side1);
+#pragma unroll
+    for (int u = 0; u < FF_NT; ++u) {
+      const float bb[4] = {b4[u].x, b4[u].y, b4[u].z, b4[u].w};
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc1[mt][u][r] + bb[r], 0.f);
+        *reinterpret_cast<bf16x4_t*>(imgH + (16 * mt + l16) * FF_RS + (colb + 16 * u) * 2) = ff_pack4(v[0], v[1], v[2], v[3]);
+      }
+    }
+  }
+  __syncthreads();                       // image H = this chunk's hidden activation
+  {
+    f32x4_t accy[4][FF_NT];
+    ff_zero(accy);
+    auto side2 = [&](auto, int) {};
+    ff_gemm<FF_RING_B>(p.w2p + (int64_t)c * FF_WELEMS, wave_s * FF_NT, imgH, ff_lane(), accy, side2);
+    float* pc = p.part + ((int64_t)c * p.M + r0) * FF_D;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const int row = 16 * mt + l16;
+      if (row < nrows) {
+#pragma unroll
+        for (int u = 0; u < FF_NT; ++u)
+          *reinterpret_cast<f32x4_t*>(pc + (int64_t)row * FF_D + colb + 16 * u) = accy[mt][u];
+      }
+    }
+  }
+}
+
+// rows per panel: panels x nchunk workgroups should fill the chip once (256 / nchunk panels), at least 16 rows (one MFMA
+// row tile), at most 64 (the LDS images)
+inline int ffn_coop_geometry(int64_t M, int64_t d, int64_t ffn, int* P, int* nchunk) {
+  if (M <= 0 || d != FF_D || ffn <= 0 || ffn % FF_CHUNK != 0 || ffn / FF_CHUNK > FF_MAXCHUNK) return 0;
+  const int nc = (int)(ffn / FF_CHUNK);
+  const int64_t panels_max = 256 / nc;
+  int64_t rows = (M + panels_max - 1) / panels_max;
+  if (rows < 16) rows = 16;
+  if (rows > FF_ROWS) return 0;
+  if (P) *P = (int)rows;
+  if (nchunk) *nchunk = nc;
+  return (int)((M + rows - 1) / rows);                      // panels
+}
+
 }  // namespace
 
 // rows per workgroup and workgroup count: ceil(M / 256) rows while that is at most 32, else unsupported (large batches take
@@ -186,4 +279,40 @@ extern "C" int ib_linear_ln_panel_fwd(const void* x, int64_t ldx, const void* w_
   else hipLaunchKernelGGL(linln_panel_kernel<2>, dim3(nwg), dim3(FF_THREADS), 0, ib_s(stream), p);
   IB_CHECK_LAUNCH();
   return IB_OK;
+}
+
+extern "C" size_t ib_ffn_infer_workspace(int64_t M, int64_t d, int64_t ffn) {
+  int nc = 0;
+  if (!ffn_coop_geometry(M, d, ffn, nullptr, &nc)) return 0;
+  return (size_t)nc * (size_t)M * FF_D * sizeof(float);
+}
+extern "C" int ib_ffn_infer_workgroups(int64_t M, int64_t d, int64_t ffn, int32_t* rows_out, int32_t* panels_out) {
+  int P = 0, nc = 0;
+  const int panels = ffn_coop_geometry(M, d, ffn, &P, &nc);
+  if (!panels) return 0;
+  if (rows_out) *rows_out = P;
+  if (panels_out) *panels_out = panels;
+  return panels * nc;
+}
+int ib_slab_ln512_launch(const float* slabs, int nslab, int64_t slab_stride, const float* bias, const void* res, int64_t ldres,
+                         const float* gamma, const float* beta, void* y, int64_t ldy, int64_t M, float eps, hipStream_t s);   // gemm.hip
+
+extern "C" int ib_ffn_infer_fwd(const void* x1, const void* packed, const float* b1, const float* b2, const float* gamma,
+                                const float* beta, void* y, void* workspace, size_t workspace_bytes, int64_t M, int64_t d,
+                                int64_t ffn, float eps, ib_stream_t stream) {
+  if (!x1 || !packed || !b1 || !b2 || !gamma || !beta || !y || !workspace) return IB_E_ARG;
+  int P = 0, nc = 0;
+  const int panels = ffn_coop_geometry(M, d, ffn, &P, &nc);
+  if (!panels) return IB_E_UNSUPPORTED;
+  if (workspace_bytes < ib_ffn_infer_workspace(M, d, ffn)) return IB_E_WORKSPACE;
+  if (!ff_al16({x1, packed, b1, b2, gamma, beta, y, workspace})) return IB_E_ARG;
+  FfnCoopParams p{};
+  const bf16_t* pk = reinterpret_cast<const bf16_t*>(packed);
+  p.x1 = (const bf16_t*)x1; p.w1p = pk; p.w2p = pk + (int64_t)nc * FF_WELEMS;
+  p.b1 = b1; p.part = reinterpret_cast<float*>(workspace);
+  p.M = (int)M; p.P = P; p.nchunk = nc;
+  IB_PATH(IB_PATH_FFN_INFER);
+  hipLaunchKernelGGL(ffn_coop_kernel, dim3(panels * nc), dim3(FF_THREADS), 0, ib_s(stream), p);
+  IB_CHECK_LAUNCH();
+  return ib_slab_ln512_launch(p.part, nc, (int64_t)M * FF_D, b2, x1, FF_D, gamma, beta, y, FF_D, M, eps, ib_s(stream));
 }

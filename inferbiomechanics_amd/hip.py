@@ -56,6 +56,9 @@ _SIGS = {
                                     _i64, _i64, _i64, _f32, _c.c_int, _vp]),
     "ib_linear_ln_panel_workgroups": (_c.c_int, [_i64, _i64, _i64, _vp]),
     "ib_linear_ln_panel_fwd": (_c.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _f32, _vp]),
+    "ib_ffn_infer_workspace": (_sz, [_i64, _i64, _i64]),
+    "ib_ffn_infer_workgroups": (_c.c_int, [_i64, _i64, _i64, _vp, _vp]),
+    "ib_ffn_infer_fwd": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i64, _i64, _i64, _f32, _vp]),
     "ib_linear_wgrad_slabs_workspace": (_sz, [_i64, _i64, _i64]),
     "ib_linear_wgrad_slabs": (_c.c_int, [_vp, _i64, _vp, _i64, _vp, _sz, _vp, _i64, _i64, _i64, _c.c_int, _vp]),
     "ib_linear_wgrad_slabs_multi": (_c.c_int, [_c.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _c.c_int, _vp]),
@@ -266,7 +269,7 @@ class _RecordingLib:
 
 
 PATH_NAMES = {0: "-", 1: "nt256x128", 2: "tn256x128", 3: "ring128", 4: "generic", 5: "smallm", 6: "skinny", 7: "wgrad_small",
-              8: "ring_multi", 9: "linear_ln", 10: "chain_v2", 11: "chain_v1", 12: "tn256x256", 13: "nt_splitk", 14: "ffn_chain", 15: "linear_ln_panel"}
+              8: "ring_multi", 9: "linear_ln", 10: "chain_v2", 11: "chain_v1", 12: "tn256x256", 13: "nt_splitk", 14: "ffn_chain", 15: "linear_ln_panel", 16: "ffn_infer"}
 _work_note = None     # set by a wrapper right before a grouped launch: (flops, bytes) of that launch, for bench.py
 
 
@@ -699,6 +702,36 @@ def linear_ln_panel_fwd(x, w_packed, bias, res, gamma, beta, y, eps=1e-5) -> boo
         return False
     _check(rc, "ib_linear_ln_panel_fwd")
     return True
+
+
+def ffn_infer_panels(M: int, d: int, ffn: int) -> int:
+    """panel count of ffn_infer_fwd (0: the shape is not supported)"""
+    n = ctypes.c_int32(0)
+    return int(n.value) if lib().ib_ffn_infer_workgroups(int(M), int(d), int(ffn), None, ctypes.byref(n)) else 0
+
+
+def ffn_infer_fwd(x1, packed, b1, b2, gamma, beta, y, workspace, eps=1e-5):
+    """y = LayerNorm(x1 + W2 ReLU(W1 x1 + b1) + b2) with frozen weights from a layer's packed image: a launch over
+    (panel, hidden chunk) workgroups leaving fp32 partial products + the slab-reduction LayerNorm launch
+    (csrc/linln_panel.hip::ffn_coop_kernel); workspace: ib_ffn_infer_workspace bytes"""
+    dt = torch.bfloat16
+    M, d, ldx = _mat(x1, "x1", dt)
+    My, dy, ldy = _mat(y, "y", dt)
+    ffn = b1.numel()
+    if (My, dy) != (M, d) or ldx != d or ldy != d:
+        raise HipError("ffn_infer_fwd: x1 / y must be contiguous [M, d]")
+    _req(packed, "packed", dt, 1)
+    for t, n, k in ((b1, "b1", ffn), (b2, "b2", d), (gamma, "gamma", d), (beta, "beta", d)):
+        _req(t, n, torch.float32, 1)
+        if t.numel() != k:
+            raise HipError(f"ffn_infer_fwd: {n} must be fp32 [{k}]")
+    if not ffn_infer_panels(M, d, ffn):
+        raise HipError(f"ffn_infer_fwd: shape [M = {M}, d = {d}, ffn = {ffn}] is not supported")
+    if packed.numel() < ffn_chain_packed_elems(d, ffn):
+        raise HipError("ffn_infer_fwd: packed image too small")
+    wsb = workspace.numel() * workspace.element_size()
+    _check(lib().ib_ffn_infer_fwd(_ptr(x1), _ptr(packed), _ptr(b1), _ptr(b2), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(workspace),
+                                  wsb, M, d, ffn, float(eps), stream_ptr()), "ib_ffn_infer_fwd")
 
 
 def linear_wgrad_slabs(dz, x, workspace) -> int:

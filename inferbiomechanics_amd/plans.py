@@ -724,6 +724,15 @@ class TransformerLayerPlan:
                 hip.dropout(a, a, self.drop_p, self.seed + 1, step, step_dev)
             m1, r1 = g(tg + ".m1", (M,), torch.float32), g(tg + ".r1", (M,), torch.float32)
             hip.layernorm_fwd(a, P.v(p + "norm1.weight"), P.v(p + "norm1.bias"), x1, m1, r1, res=x)
+        if (fuse and self.infer_packed and d == 512 and not os.environ.get("IB_NO_FFN_INFER")
+                and hip.ffn_infer_panels(M, d, self.ffn) and x2.is_contiguous()):
+            # the feed-forward sublayer: a panel of rows is shared by the workgroups of its hidden chunks (both GEMMs, the
+            # hidden activation stays in LDS), the slab-reduction LayerNorm launch finishes it (csrc/linln_panel.hip)
+            ws = self.buf.bytes(tg + ".ffws", int(hip.lib().ib_ffn_infer_workspace(M, d, self.ffn)))
+            hip.ffn_infer_fwd(x1, self.packed_image(), P.v(p + "feedforward.0.bias"), P.v(p + "feedforward.2.bias"),
+                              P.v(p + "norm2.weight"), P.v(p + "norm2.bias"), x2.view(M, d), ws)
+            self.ctx = None
+            return x2
         hip.linear_fwd(x1, P.w(p + "feedforward.0.weight"), P.v(p + "feedforward.0.bias"), f1, act="relu")
         if not (fuse and lin_ln(f1, "feedforward.2.weight", "feedforward.2.bias", "norm2", x1, x2.view(M, d), ".lnws2")):
             f2 = g(tg + ".f2", (M, d), dt)

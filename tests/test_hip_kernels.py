@@ -512,6 +512,44 @@ def test_linear_ln_panel_fwd_matches_float64(hip, M, opts):
     assert not hip.linear_ln_panel_ok(8193, d, d) and not hip.linear_ln_panel_ok(M, 256, d) and not hip.linear_ln_panel_ok(M, d, 1024)
 
 
+@pytest.mark.parametrize("M,ffn", [(3200, 2048), (200, 2048), (4096, 2048), (3201, 1024), (1, 2048), (50, 512), (777, 4096)])
+def test_ffn_infer_fwd_matches_float64_and_is_bitwise_repeatable(hip, M, ffn):
+    """csrc/linln_panel.hip::ffn_coop_kernel: the frozen-weight feed-forward sublayer -- a panel of rows shared by the
+    workgroups of its hidden chunks, fp32 partial products finished by the slab-reduction LayerNorm launch.  Against a
+    float64 restatement with the hidden activation rounded to bf16 (what the kernel keeps in LDS and what the per-op path
+    stores); repeated launches give bitwise the same rows; shapes beyond 64 rows per panel are refused."""
+    bf = torch.bfloat16
+    d = 512
+    x1 = rnd((M, d), 1, 1.0, bf).to(DEV)
+    w1 = rnd((ffn, d), 2, d ** -0.5, bf).to(DEV)
+    w2 = rnd((d, ffn), 3, ffn ** -0.5, bf).to(DEV)
+    b1, b2 = rnd((ffn,), 4, 0.1).to(DEV), rnd((d,), 5, 0.1).to(DEV)
+    g = (1.0 + rnd((d,), 6, 0.2)).to(torch.float32).to(DEV)
+    be = rnd((d,), 7, 0.1).to(DEV)
+    packed = torch.zeros(hip.ffn_chain_packed_elems(d, ffn), dtype=bf, device=DEV)
+    hip.ffn_chain_pack([(w1, w2, packed)])
+    panels = hip.ffn_infer_panels(M, d, ffn)
+    assert panels > 0
+    ws = torch.empty(int(hip.lib().ib_ffn_infer_workspace(M, d, ffn)), dtype=torch.uint8, device=DEV)
+    y = torch.zeros(M, d, dtype=bf, device=DEV)
+    hip.ffn_infer_fwd(x1, packed, b1, b2, g, be, y, ws)
+    assert hip.lib().ib_debug_last_path() == 16
+    torch.cuda.synchronize()
+    h = torch.relu(x1.double().cpu() @ w1.double().cpu().T + b1.double().cpu()).to(bf).double()
+    z = h @ w2.double().cpu().T + b2.double().cpu() + x1.double().cpu()
+    mu = z.mean(-1, keepdim=True)
+    exp = (z - mu) / torch.sqrt(((z - mu) ** 2).mean(-1, keepdim=True) + 1e-5) * g.double().cpu() + be.double().cpu()
+    close(y, exp, 2e-2, "ffn_infer_fwd")
+    first = y.clone()
+    for _ in range(20):
+        y.zero_()
+        hip.ffn_infer_fwd(x1, packed, b1, b2, g, be, y, ws)
+    torch.cuda.synchronize()
+    assert torch.equal(y, first)
+    nc = ffn // 512
+    assert hip.ffn_infer_panels(64 * (256 // nc) + 1, d, ffn) == 0 and hip.ffn_infer_panels(M, 256, ffn) == 0
+
+
 @pytest.mark.parametrize("M,N,K", [(256, 512, 1470), (256, 300, 512), (32, 512, 512), (1, 300, 512), (100, 72, 200),
                                    (1000, 512, 512), (64, 16, 64)])
 @pytest.mark.parametrize("act", ["none", "sigmoid", "elu"])
