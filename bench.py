@@ -413,12 +413,17 @@ def ddim_leg(dev, dtype, B=16, T=200, D=300, steps=100):
     model = build_model("transformer", T, D, dtype, dev)
     sampler = DDIMSampler(model, steps, use_graph=True)
     xT = torch.randn(B, T, D, device=dev)
-    sampler.sample(xT, steps=3)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
+    # one untimed loop of the same length (its buffers, graph and per-loop tables exist afterwards: a first 100-step call
+    # after a 3-step warm-up was sometimes 2x slower -- allocations inside the loop), then three timed loops: the median
     sampler.sample(xT)
     torch.cuda.synchronize()
-    el = time.perf_counter() - t0
+    loops = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        sampler.sample(xT)
+        torch.cuda.synchronize()
+        loops.append(time.perf_counter() - t0)
+    el = sorted(loops)[1]
     # forward FLOPs of one denoise step (the frame-embedding half of the input projection and
     # the time-MLP are computed once per loop, not per step)
     d, ffn, L = 512, 2048, 4
@@ -427,7 +432,7 @@ def ddim_leg(dev, dtype, B=16, T=200, D=300, steps=100):
     dn = "bf16" if dtype == torch.bfloat16 else "f32"
     return {"workload": f"transformer_denoiser_T{T} B={B} {steps}-step DDIM (hipGraph-replayed step)",
             "steps_per_sec": round(steps / el, 1), "window_steps_per_sec": round(B * steps / el, 1),
-            "ms_per_sample_batch": round(el * 1e3, 2),
+            "ms_per_sample_batch": round(el * 1e3, 2), "timed_loops_ms": [round(v * 1e3, 2) for v in loops],
             "roofline": {"bound": "mfma" if B >= 16 else "launch latency (one window: every GEMM is a single wave of "
                          "workgroups; the figure is reported against the MFMA peak all the same)",
                          "achieved": round(ach, 2), "peak": PEAK_TFLOPS[dn], "unit": "TFLOP/s",

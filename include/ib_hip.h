@@ -113,7 +113,7 @@ int ib_linear_ln_panel_fwd(const void* x, int64_t ldx, const void* w_packed, con
                            int64_t ldres, const float* gamma, const float* beta, void* y, int64_t ldy, int64_t M, int64_t N,
                            int64_t K, float eps, ib_stream_t stream);
 /* The feed-forward sublayer of a frozen-weight forward, y = LayerNorm2(x1 + W2 ReLU(W1 x1 + b1) + b2)
- * (TransformerBaseline.py:15-19,33-36), d == 512, ffn a multiple of 512, at most 64 * (256 / (ffn / 512)) rows
+ * (TransformerBaseline.py:15-19,33-36), d == 512, ffn a multiple of 512, at most 32768 rows
  * (csrc/linln_panel.hip): a panel of rows is shared by the ffn / 512 workgroups of its hidden chunks, each leaves an fp32
  * partial product in `workspace` (ib_ffn_infer_workspace bytes); the slab reduction of ib_linear_ln_fwd (bias + residual +
  * LayerNorm, partials added in chunk order) finishes it: two launches, no [M, ffn] activation in HBM.  x1 / y: contiguous

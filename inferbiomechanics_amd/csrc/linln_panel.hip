@@ -233,18 +233,130 @@ __global__ __launch_bounds__(FF_THREADS) void ffn_coop_kernel(FfnCoopParams p) {
   }
 }
 
+// ---- the same for a FEW HUNDRED rows (the sampler at B = 1, 2: M = 200, 400): 16-row panels x nchunk workgroups are 52 / 100
+// workgroups streaming 1 MB each.  Here a hidden chunk is cut into SUB sub-chunks of 512 / SUB columns: workgroup
+// (panel, c, s) computes h = ReLU(x1 . W1[cols]^T + b1[cols]) for its 128 or 256 hidden columns (every wave 16 / SUB ... one
+// or two MFMA column tiles over the 16 k-blocks) and the partial product over THOSE reduction columns (4 or 8 k-blocks, all
+// 512 output columns): 256 / 512 KB of weights per workgroup, nchunk x SUB slabs for the LayerNorm launch.
+template <int NT, int KB0, int KBN, class Side>
+__device__ __forceinline__ void sm_gemm(const bf16x8_t* __restrict__ wl, int kb_first, const unsigned char* arow,
+                                        f32x4_t (&acc)[1][NT], Side&& side) {
+  // block (u, j) of this phase = wl[(u + (kb_first + j) * 32) * 64]; A fragment j at arow + 64 * (KB0 + j)
+  constexpr int RING = 3, PD = RING - 1;
+  bf16x8_t wr[RING][NT];
+#pragma unroll
+  for (int s = 0; s < PD && s < KBN; ++s)
+#pragma unroll
+    for (int u = 0; u < NT; ++u) wr[s][u] = wl[(u + (kb_first + s) * 32) * 64];
+#pragma unroll
+  for (int j = 0; j < KBN; ++j) {
+    if (j + PD < KBN) {
+#pragma unroll
+      for (int u = 0; u < NT; ++u) wr[(j + PD) % RING][u] = wl[(u + (kb_first + j + PD) * 32) * 64];
+    }
+    side(j);
+    __builtin_amdgcn_sched_barrier(0);
+    const bf16x8_t fa = *reinterpret_cast<const bf16x8_t*>(arow + 64 * (KB0 + j));
+#pragma unroll
+    for (int u = 0; u < NT; ++u) acc[0][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[j % RING][u], fa, acc[0][u], 0, 0, 0);
+  }
+}
+
+template <int SUB>
+__global__ __launch_bounds__(FF_THREADS) void ffn_coop_small_kernel(FfnCoopParams p) {
+  constexpr int HC = FF_CHUNK / SUB;                        // hidden columns of this workgroup
+  constexpr int NT1 = HC / (16 * FF_WAVES);                 // column tiles per wave in the first GEMM (1 or 2)
+  constexpr int KB2 = HC / 32;                              // k-blocks of the second GEMM (4 or 8)
+  static_assert(NT1 >= 1 && NT1 * 16 * FF_WAVES == HC, "sub-chunk = whole column tiles per wave");
+  __shared__ __attribute__((aligned(16))) unsigned char imgX[16 * FF_RS];
+  __shared__ __attribute__((aligned(16))) unsigned char imgH[16 * FF_RS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  const int g = lane >> 4, l16 = lane & 15;
+  const int per_panel = p.nchunk * SUB;
+  const int panel = (int)blockIdx.x / per_panel, cs = (int)blockIdx.x % per_panel;
+  const int c = cs / SUB, sb = cs % SUB;
+  const int r0 = panel * 16;
+  const int nrows = min(16, p.M - r0);
+  {
+    uint4 v[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int idx = tid + j * FF_THREADS, r = min(idx >> 6, nrows - 1);
+      v[j] = *reinterpret_cast<const uint4*>(p.x1 + (int64_t)(r0 + r) * FF_D + (idx & 63) * 8);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int idx = tid + j * FF_THREADS;
+      *reinterpret_cast<uint4*>(imgX + (idx >> 6) * FF_RS + (idx & 63) * 16) = v[j];
+    }
+  }
+  __syncthreads();
+  const int ln = ff_lane();
+  {
+    // hidden columns HC * sb + 16 * NT1 * wave ... of chunk c: column tiles nt = (HC / 16) * sb + NT1 * wave + u
+    f32x4_t acc1[1][NT1];
+#pragma unroll
+    for (int u = 0; u < NT1; ++u) acc1[0][u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const int nt0 = (HC / 16) * sb + NT1 * wave_s;
+    const bf16x8_t* wl = reinterpret_cast<const bf16x8_t*>(p.w1p + (int64_t)c * FF_WELEMS) + (int64_t)nt0 * 64 + ln;
+    float4 b4[NT1];
+    const int hcol = HC * sb + 16 * NT1 * wave + 4 * g;     // this lane's first hidden column inside the chunk
+    auto side1 = [&](int j) {
+      if (j == FF_KB - 1) {
+#pragma unroll
+        for (int u = 0; u < NT1; ++u) b4[u] = *reinterpret_cast<const float4*>(p.b1 + c * FF_CHUNK + hcol + 16 * u);
+      }
+    };
+    sm_gemm<NT1, 0, FF_KB>(wl, 0, imgX + l16 * FF_RS + 16 * g, acc1, side1);
+#pragma unroll
+    for (int u = 0; u < NT1; ++u) {
+      // image H holds the sub-chunk's HC columns from column 0
+      const int col = 16 * NT1 * wave + 4 * g + 16 * u;
+      *reinterpret_cast<bf16x4_t*>(imgH + l16 * FF_RS + col * 2) =
+          ff_pack4(fmaxf(acc1[0][u][0] + b4[u].x, 0.f), fmaxf(acc1[0][u][1] + b4[u].y, 0.f),
+                   fmaxf(acc1[0][u][2] + b4[u].z, 0.f), fmaxf(acc1[0][u][3] + b4[u].w, 0.f));
+    }
+  }
+  __syncthreads();
+  {
+    f32x4_t accy[1][FF_NT];
+#pragma unroll
+    for (int u = 0; u < FF_NT; ++u) accy[0][u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const bf16x8_t* wl = reinterpret_cast<const bf16x8_t*>(p.w2p + (int64_t)c * FF_WELEMS) + (int64_t)(wave_s * FF_NT) * 64 + ln;
+    auto side2 = [&](int) {};
+    sm_gemm<FF_NT, 0, KB2>(wl, KB2 * sb, imgH + l16 * FF_RS + 16 * g, accy, side2);
+    const int colb = wave * 16 * FF_NT + 4 * g;
+    float* pc = p.part + ((int64_t)(c * SUB + sb) * p.M + r0) * FF_D;
+    if (l16 < nrows) {
+#pragma unroll
+      for (int u = 0; u < FF_NT; ++u) *reinterpret_cast<f32x4_t*>(pc + (int64_t)l16 * FF_D + colb + 16 * u) = accy[0][u];
+    }
+  }
+}
+
 // rows per panel: panels x nchunk workgroups should fill the chip once (256 / nchunk panels), at least 16 rows (one MFMA
-// row tile), at most 64 (the LDS images)
-inline int ffn_coop_geometry(int64_t M, int64_t d, int64_t ffn, int* P, int* nchunk) {
+// row tile), at most 64 (the LDS images; beyond 64 x 256 / nchunk rows the launch takes several rounds)
+// `sub` (hidden sub-chunks per chunk): 1 unless 16-row panels x nchunk leave most of the chip idle -- then 2 or 4, whichever
+// brings the workgroup count nearest to (and not far beyond) 256
+inline int ffn_coop_geometry(int64_t M, int64_t d, int64_t ffn, int* P, int* nchunk, int* sub = nullptr) {
   if (M <= 0 || d != FF_D || ffn <= 0 || ffn % FF_CHUNK != 0 || ffn / FF_CHUNK > FF_MAXCHUNK) return 0;
   const int nc = (int)(ffn / FF_CHUNK);
   const int64_t panels_max = 256 / nc;
   int64_t rows = (M + panels_max - 1) / panels_max;
   if (rows < 16) rows = 16;
-  if (rows > FF_ROWS) return 0;
+  if (rows > FF_ROWS) rows = FF_ROWS;                       // more than one round of workgroups
+  if (M > 32768) return 0;
+  const int64_t panels = (M + rows - 1) / rows;
+  int sb = 1;
+  if (rows == 16) {
+    if (panels * nc * 4 <= 320) sb = 4;
+    else if (panels * nc * 2 <= 320) sb = 2;
+  }
   if (P) *P = (int)rows;
   if (nchunk) *nchunk = nc;
-  return (int)((M + rows - 1) / rows);                      // panels
+  if (sub) *sub = sb;
+  return (int)panels;
 }
 
 }  // namespace
@@ -282,17 +394,17 @@ extern "C" int ib_linear_ln_panel_fwd(const void* x, int64_t ldx, const void* w_
 }
 
 extern "C" size_t ib_ffn_infer_workspace(int64_t M, int64_t d, int64_t ffn) {
-  int nc = 0;
-  if (!ffn_coop_geometry(M, d, ffn, nullptr, &nc)) return 0;
-  return (size_t)nc * (size_t)M * FF_D * sizeof(float);
+  int nc = 0, sb = 1;
+  if (!ffn_coop_geometry(M, d, ffn, nullptr, &nc, &sb)) return 0;
+  return (size_t)nc * sb * (size_t)M * FF_D * sizeof(float);
 }
 extern "C" int ib_ffn_infer_workgroups(int64_t M, int64_t d, int64_t ffn, int32_t* rows_out, int32_t* panels_out) {
-  int P = 0, nc = 0;
-  const int panels = ffn_coop_geometry(M, d, ffn, &P, &nc);
+  int P = 0, nc = 0, sb = 1;
+  const int panels = ffn_coop_geometry(M, d, ffn, &P, &nc, &sb);
   if (!panels) return 0;
   if (rows_out) *rows_out = P;
   if (panels_out) *panels_out = panels;
-  return panels * nc;
+  return panels * nc * sb;
 }
 int ib_slab_ln512_launch(const float* slabs, int nslab, int64_t slab_stride, const float* bias, const void* res, int64_t ldres,
                          const float* gamma, const float* beta, void* y, int64_t ldy, int64_t M, float eps, hipStream_t s);   // gemm.hip
@@ -301,8 +413,8 @@ extern "C" int ib_ffn_infer_fwd(const void* x1, const void* packed, const float*
                                 const float* beta, void* y, void* workspace, size_t workspace_bytes, int64_t M, int64_t d,
                                 int64_t ffn, float eps, ib_stream_t stream) {
   if (!x1 || !packed || !b1 || !b2 || !gamma || !beta || !y || !workspace) return IB_E_ARG;
-  int P = 0, nc = 0;
-  const int panels = ffn_coop_geometry(M, d, ffn, &P, &nc);
+  int P = 0, nc = 0, sb = 1;
+  const int panels = ffn_coop_geometry(M, d, ffn, &P, &nc, &sb);
   if (!panels) return IB_E_UNSUPPORTED;
   if (workspace_bytes < ib_ffn_infer_workspace(M, d, ffn)) return IB_E_WORKSPACE;
   if (!ff_al16({x1, packed, b1, b2, gamma, beta, y, workspace})) return IB_E_ARG;
@@ -312,7 +424,9 @@ extern "C" int ib_ffn_infer_fwd(const void* x1, const void* packed, const float*
   p.b1 = b1; p.part = reinterpret_cast<float*>(workspace);
   p.M = (int)M; p.P = P; p.nchunk = nc;
   IB_PATH(IB_PATH_FFN_INFER);
-  hipLaunchKernelGGL(ffn_coop_kernel, dim3(panels * nc), dim3(FF_THREADS), 0, ib_s(stream), p);
+  if (sb == 4) hipLaunchKernelGGL(ffn_coop_small_kernel<4>, dim3(panels * nc * 4), dim3(FF_THREADS), 0, ib_s(stream), p);
+  else if (sb == 2) hipLaunchKernelGGL(ffn_coop_small_kernel<2>, dim3(panels * nc * 2), dim3(FF_THREADS), 0, ib_s(stream), p);
+  else hipLaunchKernelGGL(ffn_coop_kernel, dim3(panels * nc), dim3(FF_THREADS), 0, ib_s(stream), p);
   IB_CHECK_LAUNCH();
-  return ib_slab_ln512_launch(p.part, nc, (int64_t)M * FF_D, b2, x1, FF_D, gamma, beta, y, FF_D, M, eps, ib_s(stream));
+  return ib_slab_ln512_launch(p.part, nc * sb, (int64_t)M * FF_D, b2, x1, FF_D, gamma, beta, y, FF_D, M, eps, ib_s(stream));
 }

@@ -707,7 +707,7 @@ class TransformerLayerPlan:
         def panel_ln():
             """out-projection + residual + LayerNorm1 as one launch over row panels (sampler, frozen packed weights)"""
             if not (fuse and self.infer_packed and d == 512 and hip.linear_ln_panel_ok(M, d, d)
-                    and M < int(os.environ.get("IB_LINLN_PANEL_MAX_M", "4096"))):
+                    and M <= int(os.environ.get("IB_LINLN_PANEL_MAX_M", "8192"))):
                 return False
             nc = self.ffn // 512
             wo_img = self.packed_image()[4 * nc * 512 * 512:(4 * nc + 1) * 512 * 512]
@@ -725,7 +725,8 @@ class TransformerLayerPlan:
             m1, r1 = g(tg + ".m1", (M,), torch.float32), g(tg + ".r1", (M,), torch.float32)
             hip.layernorm_fwd(a, P.v(p + "norm1.weight"), P.v(p + "norm1.bias"), x1, m1, r1, res=x)
         if (fuse and self.infer_packed and d == 512 and not os.environ.get("IB_NO_FFN_INFER")
-                and hip.ffn_infer_panels(M, d, self.ffn) and x2.is_contiguous()):
+                and hip.ffn_infer_panels(M, d, self.ffn) and x2.is_contiguous()
+                and M <= int(os.environ.get("IB_FFN_INFER_MAX_M", "8192"))):
             # the feed-forward sublayer: a panel of rows is shared by the workgroups of its hidden chunks (both GEMMs, the
             # hidden activation stays in LDS), the slab-reduction LayerNorm launch finishes it (csrc/linln_panel.hip)
             ws = self.buf.bytes(tg + ".ffws", int(hip.lib().ib_ffn_infer_workspace(M, d, self.ffn)))

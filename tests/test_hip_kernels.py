@@ -512,12 +512,12 @@ def test_linear_ln_panel_fwd_matches_float64(hip, M, opts):
     assert not hip.linear_ln_panel_ok(8193, d, d) and not hip.linear_ln_panel_ok(M, 256, d) and not hip.linear_ln_panel_ok(M, d, 1024)
 
 
-@pytest.mark.parametrize("M,ffn", [(3200, 2048), (200, 2048), (4096, 2048), (3201, 1024), (1, 2048), (50, 512), (777, 4096)])
+@pytest.mark.parametrize("M,ffn", [(3200, 2048), (200, 2048), (400, 2048), (4096, 2048), (3201, 1024), (1, 2048), (50, 512), (100, 1024), (777, 4096), (6400, 2048)])
 def test_ffn_infer_fwd_matches_float64_and_is_bitwise_repeatable(hip, M, ffn):
     """csrc/linln_panel.hip::ffn_coop_kernel: the frozen-weight feed-forward sublayer -- a panel of rows shared by the
     workgroups of its hidden chunks, fp32 partial products finished by the slab-reduction LayerNorm launch.  Against a
     float64 restatement with the hidden activation rounded to bf16 (what the kernel keeps in LDS and what the per-op path
-    stores); repeated launches give bitwise the same rows; shapes beyond 64 rows per panel are refused."""
+    stores); repeated launches give bitwise the same rows (6400 rows: more than one round of workgroups)."""
     bf = torch.bfloat16
     d = 512
     x1 = rnd((M, d), 1, 1.0, bf).to(DEV)
@@ -546,8 +546,7 @@ def test_ffn_infer_fwd_matches_float64_and_is_bitwise_repeatable(hip, M, ffn):
         hip.ffn_infer_fwd(x1, packed, b1, b2, g, be, y, ws)
     torch.cuda.synchronize()
     assert torch.equal(y, first)
-    nc = ffn // 512
-    assert hip.ffn_infer_panels(64 * (256 // nc) + 1, d, ffn) == 0 and hip.ffn_infer_panels(M, 256, ffn) == 0
+    assert hip.ffn_infer_panels(32769, d, ffn) == 0 and hip.ffn_infer_panels(M, 256, ffn) == 0
 
 
 @pytest.mark.parametrize("M,N,K", [(256, 512, 1470), (256, 300, 512), (32, 512, 512), (1, 300, 512), (100, 72, 200),
