@@ -112,6 +112,14 @@ int ib_linear_ln_panel_workgroups(int64_t M, int64_t N, int64_t K, int32_t* rows
 int ib_linear_ln_panel_fwd(const void* x, int64_t ldx, const void* w_packed, const float* bias, const void* res,
                            int64_t ldres, const float* gamma, const float* beta, void* y, int64_t ldy, int64_t M, int64_t N,
                            int64_t K, float eps, ib_stream_t stream);
+/* y = x W^T + bias for K == 512 and N a multiple of 512 (a frozen-weight layer's in-projection, TransformerBaseline.py:12-13)
+ * at up to 8192 rows as a launch over (panel of rows, 512-column chunk) workgroups, each streaming one packed [512 x 512]
+ * image (`w_packed`: N / 512 consecutive images, ib_ffn_chain_pack puts the in-projection's at element offset
+ * (4 * (ffn / 512) + 2) * 512 * 512); chunks are cut into 128-column blocks when there are few panels.
+ * ib_linear_panel_workgroups: the workgroup count, 0 = unsupported. */
+int ib_linear_panel_workgroups(int64_t M, int64_t N, int64_t K);
+int ib_linear_panel_fwd(const void* x, int64_t ldx, const void* w_packed, const float* bias, void* y, int64_t ldy, int64_t M,
+                        int64_t N, int64_t K, ib_stream_t stream);
 /* The feed-forward sublayer of a frozen-weight forward, y = LayerNorm2(x1 + W2 ReLU(W1 x1 + b1) + b2)
  * (TransformerBaseline.py:15-19,33-36), d == 512, ffn a multiple of 512, at most 32768 rows
  * (csrc/linln_panel.hip): a panel of rows is shared by the ffn / 512 workgroups of its hidden chunks, each leaves an fp32
@@ -541,7 +549,8 @@ enum {
   IB_PATH_NT_SPLITK = 13,   /* gemm_nt.hip in split-K form (fp32 slabs) under the sampler's Linear + LayerNorm */
   IB_PATH_FFN_CHAIN = 14,   /* ffn_chain.hip: fused feed-forward sublayer (Linear + ReLU + Linear + residual + LayerNorm) */
   IB_PATH_LINLN_PANEL = 15, /* linln_panel.hip: Linear + residual + LayerNorm over row panels, one launch (sampler) */
-  IB_PATH_FFN_INFER = 16    /* linln_panel.hip: feed-forward sublayer, panels shared by their hidden chunks (sampler) */
+  IB_PATH_FFN_INFER = 16,   /* linln_panel.hip: feed-forward sublayer, panels shared by their hidden chunks (sampler) */
+  IB_PATH_LIN_PANEL = 17    /* linln_panel.hip: Linear over (row panel, 512-column chunk) workgroups (sampler in-projection) */
 };
 int ib_debug_last_path(void);
 int ib_selftest_tr16(const void* in_bf16_64x16, void* out_bf16_64x4, ib_stream_t stream);

@@ -156,6 +156,111 @@ __global__ __launch_bounds__(FF_THREADS) void linln_panel_kernel(LinLnPanelParam
 
 
 // ---------------------------------------------------------------------------------------------------------------------
+// y[:, 512 c ..] = x . W[512 c ..]^T + bias for a [3 x 512, 512] weight (the in-projection of a frozen-weight layer,
+// TransformerBaseline.py:12-13) at a few thousand rows and below: workgroup (panel, chunk c) streams ONE packed [512 x 512]
+// image for its <= 64 rows; with few panels (a few hundred rows) a chunk is cut into four blocks of 128 output columns
+// (NTW = 1: one column tile per wave) so that the launch still covers most of the chip.  bf16 rows straight from the
+// accumulators (8-byte stores: a lane owns 4 consecutive columns of a row).
+struct LinPanelParams {
+  const bf16_t* x; int64_t ldx;                            // [M, 512]
+  const bf16_t* wp;                                        // packed images, chunk c at + c * FF_WELEMS
+  const float* bias;                                       // [chunks * 512] or NULL
+  bf16_t* y; int64_t ldy;                                  // [M, chunks * 512]
+  int M, P, chunks;
+};
+
+template <int MT, int NTW>
+__global__ __launch_bounds__(FF_THREADS) void linear_panel_kernel(LinPanelParams p) {
+  constexpr int ROWS = 16 * MT, PIECES = ROWS * 64 / FF_THREADS, SUBS = FF_NT / NTW;
+  __shared__ __attribute__((aligned(16))) unsigned char img[ROWS * FF_RS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+  const int g = lane >> 4, l16 = lane & 15;
+  const int per_panel = p.chunks * SUBS;
+  const int panel = (int)blockIdx.x / per_panel, cs = (int)blockIdx.x % per_panel;
+  const int c = cs / SUBS, sb = cs % SUBS;
+  const int r0 = panel * p.P;
+  const int nrows = min(p.P, p.M - r0);
+  // column tiles of this wave inside chunk c: NTW consecutive ones from nt0; its first output column inside the chunk
+  const int nt0 = (32 / SUBS) * sb + NTW * wave_s;
+  const int col0 = 16 * ((32 / SUBS) * sb + NTW * wave) + 4 * g;
+  const bf16x8_t* wl = reinterpret_cast<const bf16x8_t*>(p.wp + (int64_t)c * FF_WELEMS) + (int64_t)nt0 * 64 + ff_lane();
+  bf16x8_t wr[3][NTW];
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int u = 0; u < NTW; ++u) wr[s][u] = wl[(u + s * 32) * 64];
+  {
+    uint4 v[PIECES];
+#pragma unroll
+    for (int j = 0; j < PIECES; ++j) {
+      const int idx = tid + j * FF_THREADS, r = min(idx >> 6, nrows - 1);
+      v[j] = *reinterpret_cast<const uint4*>(p.x + (int64_t)(r0 + r) * p.ldx + (idx & 63) * 8);
+    }
+#pragma unroll
+    for (int j = 0; j < PIECES; ++j) {
+      const int idx = tid + j * FF_THREADS;
+      *reinterpret_cast<uint4*>(img + (idx >> 6) * FF_RS + (idx & 63) * 16) = v[j];
+    }
+  }
+  __syncthreads();
+  f32x4_t acc[MT][NTW];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int u = 0; u < NTW; ++u) acc[mt][u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float4 b4[NTW];
+#pragma unroll
+  for (int u = 0; u < NTW; ++u) b4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const unsigned char* arow = img + l16 * FF_RS + 16 * g;
+#pragma unroll
+  for (int kb = 0; kb < FF_KB; ++kb) {
+    if (kb + 2 < FF_KB) {
+#pragma unroll
+      for (int u = 0; u < NTW; ++u) wr[(kb + 2) % 3][u] = wl[(u + (kb + 2) * 32) * 64];
+    }
+    if (kb == FF_KB - 2 && p.bias) {
+#pragma unroll
+      for (int u = 0; u < NTW; ++u) b4[u] = *reinterpret_cast<const float4*>(p.bias + c * FF_CHUNK + col0 + 16 * u);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    bf16x8_t fa[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) fa[mt] = *reinterpret_cast<const bf16x8_t*>(arow + 16 * mt * FF_RS + 64 * kb);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int u = 0; u < NTW; ++u)
+        acc[mt][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[kb % 3][u], fa[mt], acc[mt][u], 0, 0, 0);
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int row = 16 * mt + l16;
+    if (row < nrows) {
+      bf16_t* yr = p.y + (int64_t)(r0 + row) * p.ldy + c * FF_CHUNK + col0;
+#pragma unroll
+      for (int u = 0; u < NTW; ++u)
+        *reinterpret_cast<bf16x4_t*>(yr + 16 * u) = ff_pack4(acc[mt][u][0] + b4[u].x, acc[mt][u][1] + b4[u].y,
+                                                             acc[mt][u][2] + b4[u].z, acc[mt][u][3] + b4[u].w);
+    }
+  }
+}
+
+// rows per panel / column blocks per chunk of the launch above: panels x chunks workgroups ~ one round of the chip, at least
+// 16 rows; 16-row panels that leave most CUs idle take four 128-column blocks per chunk
+inline int lin_panel_geometry(int64_t M, int64_t chunks, int* P, int* subs) {
+  if (M <= 0 || chunks < 1 || chunks > 8 || M > 8192) return 0;
+  const int64_t panels_max = 256 / chunks;
+  int64_t rows = (M + panels_max - 1) / panels_max;
+  if (rows < 16) rows = 16;
+  if (rows > FF_ROWS) rows = FF_ROWS;
+  const int64_t panels = (M + rows - 1) / rows;
+  if (P) *P = (int)rows;
+  if (subs) *subs = (rows == 16 && panels * chunks * 4 <= 320) ? 4 : 1;
+  return (int)panels;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // The feed-forward sublayer of a frozen-weight forward at a few thousand rows and below:
 //     y = LayerNorm2( x1 + W2 . ReLU(W1 . x1 + b1) + b2 )                       TransformerBaseline.py:15-19,33-36
 // It replaces Linear + ReLU ([M, 2048] hidden activation through HBM) and the split-K Linear + LayerNorm pair (12.7 + 23.7 us
@@ -429,4 +534,35 @@ extern "C" int ib_ffn_infer_fwd(const void* x1, const void* packed, const float*
   else hipLaunchKernelGGL(ffn_coop_kernel, dim3(panels * nc), dim3(FF_THREADS), 0, ib_s(stream), p);
   IB_CHECK_LAUNCH();
   return ib_slab_ln512_launch(p.part, nc * sb, (int64_t)M * FF_D, b2, x1, FF_D, gamma, beta, y, FF_D, M, eps, ib_s(stream));
+}
+
+extern "C" int ib_linear_panel_workgroups(int64_t M, int64_t N, int64_t K) {
+  if (K != FF_D || N <= 0 || N % FF_CHUNK != 0) return 0;
+  int P = 0, subs = 1;
+  const int panels = lin_panel_geometry(M, N / FF_CHUNK, &P, &subs);
+  return panels * (int)(N / FF_CHUNK) * subs;
+}
+
+extern "C" int ib_linear_panel_fwd(const void* x, int64_t ldx, const void* w_packed, const float* bias, void* y, int64_t ldy,
+                                   int64_t M, int64_t N, int64_t K, ib_stream_t stream) {
+  if (!x || !w_packed || !y || M <= 0) return IB_E_ARG;
+  if (K != FF_D || N <= 0 || N % FF_CHUNK != 0) return IB_E_UNSUPPORTED;
+  int P = 0, subs = 1;
+  const int chunks = (int)(N / FF_CHUNK);
+  const int panels = lin_panel_geometry(M, chunks, &P, &subs);
+  if (!panels) return IB_E_UNSUPPORTED;
+  if (ldx < K || ldy < N || ldx % 8 != 0 || ldy % 4 != 0) return IB_E_ARG;
+  if (!ff_al16({x, w_packed}) || (bias && !ff_al16({bias})) || (reinterpret_cast<uintptr_t>(y) % 8) != 0) return IB_E_ARG;
+  LinPanelParams p{};
+  p.x = (const bf16_t*)x; p.ldx = ldx; p.wp = (const bf16_t*)w_packed; p.bias = bias; p.y = (bf16_t*)y; p.ldy = ldy;
+  p.M = (int)M; p.P = P; p.chunks = chunks;
+  IB_PATH(IB_PATH_LIN_PANEL);
+  const dim3 grid((unsigned)(panels * chunks * subs));
+  hipStream_t s = ib_s(stream);
+  if (subs == 4) hipLaunchKernelGGL((linear_panel_kernel<1, 1>), grid, dim3(FF_THREADS), 0, s, p);
+  else if (P <= 16) hipLaunchKernelGGL((linear_panel_kernel<1, 4>), grid, dim3(FF_THREADS), 0, s, p);
+  else if (P <= 32) hipLaunchKernelGGL((linear_panel_kernel<2, 4>), grid, dim3(FF_THREADS), 0, s, p);
+  else hipLaunchKernelGGL((linear_panel_kernel<4, 4>), grid, dim3(FF_THREADS), 0, s, p);
+  IB_CHECK_LAUNCH();
+  return IB_OK;
 }

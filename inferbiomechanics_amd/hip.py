@@ -56,6 +56,8 @@ _SIGS = {
                                     _i64, _i64, _i64, _f32, _c.c_int, _vp]),
     "ib_linear_ln_panel_workgroups": (_c.c_int, [_i64, _i64, _i64, _vp]),
     "ib_linear_ln_panel_fwd": (_c.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _f32, _vp]),
+    "ib_linear_panel_workgroups": (_c.c_int, [_i64, _i64, _i64]),
+    "ib_linear_panel_fwd": (_c.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp]),
     "ib_ffn_infer_workspace": (_sz, [_i64, _i64, _i64]),
     "ib_ffn_infer_workgroups": (_c.c_int, [_i64, _i64, _i64, _vp, _vp]),
     "ib_ffn_infer_fwd": (_c.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i64, _i64, _i64, _f32, _vp]),
@@ -269,7 +271,7 @@ class _RecordingLib:
 
 
 PATH_NAMES = {0: "-", 1: "nt256x128", 2: "tn256x128", 3: "ring128", 4: "generic", 5: "smallm", 6: "skinny", 7: "wgrad_small",
-              8: "ring_multi", 9: "linear_ln", 10: "chain_v2", 11: "chain_v1", 12: "tn256x256", 13: "nt_splitk", 14: "ffn_chain", 15: "linear_ln_panel", 16: "ffn_infer"}
+              8: "ring_multi", 9: "linear_ln", 10: "chain_v2", 11: "chain_v1", 12: "tn256x256", 13: "nt_splitk", 14: "ffn_chain", 15: "linear_ln_panel", 16: "ffn_infer", 17: "linear_panel"}
 _work_note = None     # set by a wrapper right before a grouped launch: (flops, bytes) of that launch, for bench.py
 
 
@@ -701,6 +703,29 @@ def linear_ln_panel_fwd(x, w_packed, bias, res, gamma, beta, y, eps=1e-5) -> boo
     if rc == -5:
         return False
     _check(rc, "ib_linear_ln_panel_fwd")
+    return True
+
+
+def linear_panel_ok(M: int, N: int, K: int) -> bool:
+    return bool(lib().ib_linear_panel_workgroups(int(M), int(N), int(K)))
+
+
+def linear_panel_fwd(x, w_packed, bias, y) -> bool:
+    """y = x W^T + bias, K = 512, N a multiple of 512, W given as N / 512 packed [512 x 512] images (csrc/linln_panel.hip)"""
+    dt = torch.bfloat16
+    M, K, ldx = _mat(x, "x", dt)
+    My, N, ldy = _mat(y, "y", dt)
+    _req(w_packed, "w_packed", dt, 1)
+    if My != M or w_packed.numel() < N * K or not w_packed.is_contiguous():
+        raise HipError("linear_panel_fwd: y must be [M, N], w_packed the N / 512 images")
+    if bias is not None:
+        _req(bias, "bias", torch.float32, 1)
+        if bias.numel() != N:
+            raise HipError("linear_panel_fwd: bias must be fp32 [N]")
+    rc = lib().ib_linear_panel_fwd(_ptr(x), ldx, _ptr(w_packed), _ptr(bias), _ptr(y), ldy, M, N, K, stream_ptr())
+    if rc == -5:
+        return False
+    _check(rc, "ib_linear_panel_fwd")
     return True
 
 

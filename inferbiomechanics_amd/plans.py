@@ -658,8 +658,13 @@ class TransformerLayerPlan:
         x = x3.view(M, d)
         qkv = g(tg + ".qkv", (B, T, 3 * d), dt)
         if not qkv_ready:
-            hip.linear_fwd(x, P.w(p + "multihead_attention.in_proj_weight"), P.v(p + "multihead_attention.in_proj_bias"),
-                           qkv.view(M, 3 * d))
+            nc = self.ffn // 512
+            if not (self.inference and self.infer_packed and d == 512 and dt == torch.bfloat16
+                    and not os.environ.get("IB_NO_QKV_PANEL") and M <= int(os.environ.get("IB_QKV_PANEL_MAX_M", "1600"))
+                    and hip.linear_panel_fwd(x, self.packed_image()[(4 * nc + 2) * 512 * 512:(4 * nc + 5) * 512 * 512],
+                                             P.v(p + "multihead_attention.in_proj_bias"), qkv.view(M, 3 * d))):
+                hip.linear_fwd(x, P.w(p + "multihead_attention.in_proj_weight"), P.v(p + "multihead_attention.in_proj_bias"),
+                               qkv.view(M, 3 * d))
         attn = g(tg + ".attn", (B, T, d), dt)
         lse = g(tg + ".lse", (B, self.h, T), torch.float32)
         hip.attention_fwd(qkv, attn, lse, self.h, drop=drop)
@@ -1380,7 +1385,8 @@ class DenoiserTransformerPlan:
         if (self.dtype == torch.bfloat16 and self.d == 512 and not os.environ.get("IB_NO_LINLN_PANEL")
                 and all(hip.ffn_chain_supported(self.d, lp.ffn) for lp in self.layers)):
             hip.ffn_chain_pack([(P.w(lp.p + "feedforward.0.weight"), P.w(lp.p + "feedforward.2.weight"), lp.packed_image(),
-                                 P.w(lp.p + "multihead_attention.out_proj.weight")) for lp in self.layers])
+                                 P.w(lp.p + "multihead_attention.out_proj.weight"),
+                                 P.w(lp.p + "multihead_attention.in_proj_weight")) for lp in self.layers])
             for lp in self.layers:
                 lp.infer_packed = True
         if table is not None and not os.environ.get("IB_NO_TIME_TABLE"):

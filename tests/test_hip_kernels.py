@@ -512,6 +512,32 @@ def test_linear_ln_panel_fwd_matches_float64(hip, M, opts):
     assert not hip.linear_ln_panel_ok(8193, d, d) and not hip.linear_ln_panel_ok(M, 256, d) and not hip.linear_ln_panel_ok(M, d, 1024)
 
 
+@pytest.mark.parametrize("M", [3200, 200, 1, 17, 800, 2000, 8192])
+def test_linear_panel_fwd_matches_float64(hip, M):
+    """csrc/linln_panel.hip::linear_panel_kernel: the frozen-weight in-projection [M, 512] -> [M, 1536] over (row panel,
+    512-column chunk) workgroups from the layer's packed image (128-column blocks at a few hundred rows; one / two / four
+    MFMA row tiles per panel), pitched input rows, against float64; other shapes are reported as unsupported"""
+    bf = torch.bfloat16
+    d, ffn = 512, 1024
+    x = rnd((M, d + 8), 1, 1.0, bf).to(DEV)[:, :d]
+    wq = rnd((3 * d, d), 2, d ** -0.5, bf).to(DEV)
+    b = rnd((3 * d,), 3, 0.1).to(DEV)
+    packed = torch.zeros(hip.ffn_chain_packed_elems(d, ffn), dtype=bf, device=DEV)
+    hip.ffn_chain_pack([(rnd((ffn, d), 8, 0.05, bf).to(DEV), rnd((d, ffn), 9, 0.05, bf).to(DEV), packed,
+                         rnd((d, d), 10, 0.05, bf).to(DEV), wq)])
+    nc = ffn // 512
+    img = packed[(4 * nc + 2) * d * d:(4 * nc + 5) * d * d]
+    y = torch.full((M, 3 * d + 8), 7.0, dtype=bf, device=DEV)
+    assert hip.linear_panel_ok(M, 3 * d, d)
+    assert hip.linear_panel_fwd(x, img, b, y[:, :3 * d])
+    assert hip.lib().ib_debug_last_path() == 17
+    torch.cuda.synchronize()
+    exp = x.double().cpu() @ wq.double().cpu().T + b.double().cpu()
+    close(y[:, :3 * d], exp, 1e-2, "linear_panel_fwd")
+    assert torch.all(y[:, 3 * d:] == 7.0)
+    assert not hip.linear_panel_ok(8193, 3 * d, d) and not hip.linear_panel_ok(M, 3 * d, 256) and not hip.linear_panel_ok(M, 300, d)
+
+
 @pytest.mark.parametrize("M,ffn", [(3200, 2048), (200, 2048), (400, 2048), (4096, 2048), (3201, 1024), (1, 2048), (50, 512), (100, 1024), (777, 4096), (6400, 2048)])
 def test_ffn_infer_fwd_matches_float64_and_is_bitwise_repeatable(hip, M, ffn):
     """csrc/linln_panel.hip::ffn_coop_kernel: the frozen-weight feed-forward sublayer -- a panel of rows shared by the
