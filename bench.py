@@ -6,9 +6,12 @@
         bench.py --gpus N --steps K --warmup W
 
 A "step" = one fused training step (q_sample -> denoiser fwd -> eps-MSE -> bwd -> [RCCL grad all-reduce] ->
-fused optimizer) over one batch of synthetic motion windows already resident in HBM.  N = 1 workload =
-BASELINE.json configs[1]: token-wise MLP denoiser 300->512->512->300 (+ time MLP), T = 50, bf16 storage /
-fp32 accumulate, per-GPU batch 256 (weak scaling for N > 1).  Rank 0 prints ONE JSON line.
+fused optimizer) over one batch of synthetic motion windows already resident in HBM.  Headline workload = the
+largest single-GPU training configuration of BASELINE.json: configs[2], the 4-layer d_model = 512 transformer denoiser at
+T = 50, D = 300, bf16 storage / fp32 accumulate, per-GPU batch 256; at N > 1 the same model data-parallel = configs[3]
+(weak scaling: global batch 256 N).  The MLP denoiser (configs[1]), the DDIM loop (configs[4]) and the reference-shape
+regression step (configs[0]) ride as extra keys; a compact `summary` object comes LAST in the line, so a truncated tail
+still carries every headline figure.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -65,13 +68,17 @@ def make_batches(nb, B, T, D, dtype, dev, seed):
     return out
 
 
-def cpu_baseline(kind, T, D, B, dev, budget_s=12.0, ncmp=20):
+def cpu_baseline(kind, T, D, B, dev, budget_s=12.0, ncmp=None):
     """The oracle (torch-eager CPU port of the reference arithmetic + build-defined diffusion wrapper), fp32, one GPU's
     share of the host cores, same workload shape; bounded sample.  "At matched diffusion loss" (north_star): the CPU run and
     the fused GPU trainer (fp32 parity mode and the benchmarked bf16 mode) start from the SAME initial weights and take the
     SAME batches; the loss each computes at step `ncmp` is reported side by side."""
     from inferbiomechanics_amd.engine import HipTrainer
     from oracle import ref_cpu as R
+    if ncmp is None:
+        # the oracle's transformer step at batch 256 takes seconds on the host: the losses are compared after 3 steps and
+        # the timed sample is bounded by `budget_s` (at least 2 steps); the MLP affords 20 + up to 200
+        ncmp = 20 if kind == "mlp" else 3
     # one GPU's share of the host (the GPU box gives 16 worker CPUs per GPU); all 256 logical CPUs of the box
     # on these small GEMMs is 80x SLOWER (thread oversubscription: 9.8 windows/s measured)
     torch.set_num_threads(min(os.cpu_count() or 1, 16))
@@ -117,7 +124,7 @@ def cpu_baseline(kind, T, D, B, dev, budget_s=12.0, ncmp=20):
         step(ncmp + 1 + n)
         n += 1
         el = time.perf_counter() - t0
-        if el > budget_s or n >= 200:
+        if (el > budget_s and n >= 2) or n >= 200:
             break
     rel = lambda a: round(abs(a - cpu_loss) / max(abs(cpu_loss), 1e-30), 6)
     return {"value": round(B * n / el, 1), "unit": "windows/s", "cores": torch.get_num_threads(), "kind": "port",
@@ -552,7 +559,7 @@ def train_leg(workload, a, dev, world, rank, steps, warmup, sync, with_roofline=
         if xg is not None:
             out["xgmi"] = xg
         if rec is not None:
-            rl, breakdown, dev_us = roofline_leg(rec, a.dtype, gemm_family=(kind != "mlp"), workload=workload)
+            rl, breakdown, dev_us = roofline_leg(rec, a.dtype, gemm_family=False, workload=workload)
             out["roofline"] = rl
             out["step_sum_of_kernel_us"] = round(dev_us, 1)
             out["step_breakdown"] = breakdown
@@ -595,7 +602,7 @@ def self_launch(n):
     return p.returncode
 
 
-def graph_collectives_child(n, steps=60, warmup=10, timeout_s=240):
+def graph_collectives_child(n, workload, steps=60, warmup=10, timeout_s=240):
     """Data-parallel runs only: the SAME main workload once more with the gradient all-reduces CAPTURED inside the step's
     hipGraph (IB_GRAPH_COLLECTIVES=1: one graph per step, no graph cut and no host action per collective) -- in FRESH child
     processes (a new torch.distributed.run launch of n ranks; nothing that has touched a GPU is ever re-exec'd), bounded by a
@@ -613,7 +620,7 @@ def graph_collectives_child(n, steps=60, warmup=10, timeout_s=240):
     env.update(IB_GRAPH_COLLECTIVES="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__), "--gpus", str(n), "--steps", str(steps), "--warmup",
-           str(warmup), "--no-transformer", "--no-ddim", "--no-cpu-baseline", "--no-variant-child", "--no-roofline"]
+           str(warmup), "--workload", workload, "--no-mlp", "--no-ddim", "--no-cpu-baseline", "--no-variant-child", "--no-roofline"]
     t0 = time.perf_counter()
     try:
         p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, start_new_session=True)
@@ -643,9 +650,9 @@ def graph_collectives_child(n, steps=60, warmup=10, timeout_s=240):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--workload", default="mlp_denoiser_T50", choices=list(WORKLOADS))
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="transformer_denoiser_T50", choices=list(WORKLOADS))
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--opt-type", default="rmsprop")
     ap.add_argument("--no-graph", action="store_true")
@@ -656,7 +663,7 @@ def main():
     ap.add_argument("--no-variant-child", action="store_true",
                     help="[N > 1] skip the captured-collectives variant (IB_GRAPH_COLLECTIVES=1) run in child processes")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-launch roofline leg (child runs)")
-    ap.add_argument("--no-transformer", action="store_true", help="skip the configs[2] / configs[3] transformer leg")
+    ap.add_argument("--no-mlp", action="store_true", help="skip the configs[1] MLP denoiser leg (extra key `mlp_T50`)")
     ap.add_argument("--bucket-mb", type=float, default=13.0,
                     help="gradient bucket size when all-reduces overlap the backward: each bucket boundary cuts the captured "
                          "graph (about 15 us); 13 MiB = one transformer layer of the T=50 denoiser")
@@ -721,26 +728,26 @@ def main():
     kind, T, D, B = WORKLOADS[a.workload]
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     main_leg = train_leg(a.workload, a, dev, world, rank, a.steps, a.warmup, sync, with_roofline=not a.no_roofline)
-    # BASELINE configs[2] (one GPU) / configs[3] (data parallel, per-GPU batch 256): the 4-layer d = 512 transformer
-    # denoiser at T = 50, its own step count (3 ms steps), every rank takes part (the step holds the all-reduces)
-    tr_leg = None
-    if kind == "mlp" and not a.no_transformer:
-        # (rehearsal on one GPU: the 53-MB gradient goes through gloo on the host every step -- a few steps show the
-        # control flow just as well)
-        tr_leg = train_leg("transformer_denoiser_T50", a, dev, world, rank, 8 if rehearsal else 100, 2 if rehearsal else 10,
-                           sync)
+    # BASELINE configs[1]: the token-wise MLP denoiser at T = 50, its own step count (0.13 ms steps); every rank takes part
+    # (under data parallelism the step holds the all-reduces)
+    mlp_leg = None
+    if kind != "mlp" and not a.no_mlp:
+        mlp_leg = train_leg("mlp_denoiser_T50", a, dev, world, rank, 8 if rehearsal else 2000, 2 if rehearsal else 200, sync,
+                            with_roofline=not a.no_roofline)
     variant = None
     # (IB_BENCH_FORCE_VARIANT=1 with IB_DDP_SELFTEST=1: the same mechanism on a one-GPU box, a 1-rank child)
     want_variant = world > 1 or (selftest and os.environ.get("IB_BENCH_FORCE_VARIANT") == "1")
     if want_variant and not rehearsal and not a.no_variant_child and os.environ.get("IB_GRAPH_COLLECTIVES") != "1":
         sync()
         if rank == 0:
-            variant = graph_collectives_child(world)
+            variant = graph_collectives_child(world, a.workload)
         if host_group is not None:
             dist.barrier(group=host_group)             # the other ranks wait on the HOST (gloo), their GPUs idle
     if rank == 0:
         cfg = dict(main_leg["config"])
-        cfg["workload"] = main_leg["workload"] + (" (BASELINE.json configs[1])" if kind == "mlp" else "")
+        which = {"mlp": "configs[1]", "transformer": "configs[2]" if world == 1 else
+                 "configs[3]: configs[2] data-parallel, 256 windows per GPU"}[kind] if T == 50 else "configs[4] model, training"
+        cfg["workload"] = main_leg["workload"] + f" (BASELINE.json {which})"
         line = {
             "metric": "motion-windows/sec training (+ DDIM steps/sec)", "value": main_leg["value"], "unit": "windows/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": main_leg["ms_per_step"],
@@ -750,31 +757,64 @@ def main():
             "rccl_world": dist.get_world_size() if backend else 1, "backend": backend,
         }
         for k in ("step_ms", "final_loss", "train_tflops", "captures_in_timed_region", "step_fractions", "xgmi", "roofline",
-                  "step_sum_of_kernel_us", "step_breakdown"):
+                  "step_sum_of_kernel_us"):
             if k in main_leg:
                 line[k] = main_leg[k]
+        summary = {"headline": {"workload": cfg["workload"], "windows_per_s": main_leg["value"],
+                                "ms_per_step": main_leg["ms_per_step"], "n_gpus": world,
+                                "mfma_frac_step": main_leg["step_fractions"]["mfma"]}}
+        if "roofline" in main_leg:
+            rl = main_leg["roofline"]
+            summary["roofline"] = {k: rl.get(k) for k in ("entry", "bound", "achieved", "peak", "unit", "frac", "avg_launch_us",
+                                                          "traffic", "launches_per_step")}
         if variant is not None:
             variant["what"] = ("same workload, IB_GRAPH_COLLECTIVES=1 (all-reduces captured inside the step's hipGraph) in fresh "
-                               "child processes; the headline value above is the default cut-graph form")
+                               "child processes; the headline value above is the default form")
             line["graph_collectives_variant"] = variant
-        if tr_leg is not None:
-            tr_leg["workload"] += " (BASELINE.json configs[2]" + ("; configs[3] data-parallel form)" if world > 1 else ")")
-            line["transformer_T50"] = tr_leg
-        if not a.no_ddim:
-            line["ddim"] = ddim_leg(dev, dtype)                                  # B = 16: the quoted figure
-            line["ddim_batches"] = [ddim_leg(dev, dtype, B=b) for b in (1, 256)]   # B in {1,16,256}
+            summary["graph_collectives_variant_ms"] = variant.get("ms_per_step", variant.get("error"))
         if not a.no_cpu_baseline and world == 1:            # rank 0 at N=1 only (the other ranks wait at the barrier)
             line["cpu_baseline"] = cpu_baseline(kind, T, D, B, dev)
-            if kind == "mlp" and not a.no_cli_path:
-                cp = cli_path_leg()
-                cp["fraction_of_bench_value"] = round(cp["windows_per_s"] / main_leg["value"], 3)
-                line["cli_path"] = cp
+            ml = line["cpu_baseline"]["matched_loss"]
+            summary["cpu_baseline"] = {"windows_per_s": line["cpu_baseline"]["value"], "cores": line["cpu_baseline"]["cores"],
+                                       "speedup": round(main_leg["value"] / max(line["cpu_baseline"]["value"], 1e-9), 1),
+                                       "matched_loss_rel_diff_f32": ml["rel_diff_f32"],
+                                       "matched_loss_rel_diff_bf16": ml["rel_diff_bf16"]}
+        if mlp_leg is not None:
+            mlp_leg["workload"] += " (BASELINE.json configs[1])"
+            summary["mlp_T50"] = {"windows_per_s": mlp_leg["value"], "ms_per_step": mlp_leg["ms_per_step"],
+                                  "mfma_frac_step": mlp_leg["step_fractions"]["mfma"]}
+            if "roofline" in mlp_leg:
+                summary["mlp_T50"]["chain_kernel_frac"] = mlp_leg["roofline"].get("frac")
+            if not a.no_cpu_baseline and world == 1:
+                mlp_leg["cpu_baseline"] = cpu_baseline("mlp", 50, 300, 256, dev)
+                summary["mlp_T50"]["cpu_windows_per_s"] = mlp_leg["cpu_baseline"]["value"]
+                summary["mlp_T50"]["matched_loss_rel_diff_bf16"] = mlp_leg["cpu_baseline"]["matched_loss"]["rel_diff_bf16"]
+                if not a.no_cli_path:
+                    cp = cli_path_leg()
+                    cp["fraction_of_bench_value"] = round(cp["windows_per_s"] / mlp_leg["value"], 3)
+                    mlp_leg["cli_path"] = cp
+                    summary["mlp_T50"]["cli_path_windows_per_s"] = cp["windows_per_s"]
+            mlp_leg.pop("step_breakdown", None)             # the per-launch tables live in profiles/ (keeps the line short)
+            line["mlp_T50"] = mlp_leg
+        if not a.no_ddim:
+            legs = [ddim_leg(dev, dtype, B=b) for b in (1, 16, 256)]          # B in {1, 16, 256}
+            line["ddim"] = legs[1]                                            # B = 16: the quoted figure
+            line["ddim_batches"] = [legs[0], legs[2]]
+            summary["ddim_T200_steps_per_s"] = {f"B{b}": lg["steps_per_sec"] for b, lg in zip((1, 16, 256), legs)}
+            summary["ddim_T200_mfma_frac"] = {f"B{b}": lg["roofline"]["frac"] for b, lg in zip((1, 16, 256), legs)}
+        if not a.no_cpu_baseline and world == 1:
             # BASELINE.json configs[0]: the reference's own CPU-runnable case (plumbing; launch-latency bound on the GPU)
             line["regression_ref_shape"] = {
                 "workload": "FeedForwardBaseline([512,512], sigmoid) 1470->300, fp32, RMSprop 1e-4, reference loss "
                             "(BASELINE.json configs[0]; SURVEY.md 8d Config 1; src/cli/train.py:240-284)",
                 "bound": "launch latency (11 dependent launches of a few us each; 7 MFLOP per window)",
                 "legs": [regression_ref_shape_leg(dev, b) for b in (4, 64)]}
+            summary["regression_ref_shape"] = {f"B{lg['batch']}": {"gpu_ms": lg["gpu_ms_per_step"], "cpu_ms": lg["cpu_ms_per_step"],
+                                                                    "loss_rel_diff": lg["loss_at_step_20"]["rel_diff"]}
+                                               for lg in line["regression_ref_shape"]["legs"]}
+        if "step_breakdown" in main_leg:
+            line["step_breakdown"] = main_leg["step_breakdown"][:10]
+        line["summary"] = summary                           # LAST: an 8-KB tail of the line still holds every headline figure
         sys.stdout.flush()
         os.write(out_fd, (json.dumps(line) + "\n").encode())
     if world > 1 or selftest:

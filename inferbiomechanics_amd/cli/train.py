@@ -169,6 +169,11 @@ class TrainCommand(AbstractCommand):
             trainer = HipTrainer(model, "diffusion" if diffusion else "regression", args.opt_type, args.learning_rate,
                                  args=args, use_graph=not args.no_graph, bucket_mb=args.bucket_mb)
 
+        if getattr(args, 'loss_every', 1) < 1:
+            raise SystemExit("--loss-every must be >= 1")
+        if args.window_cache == 'hbm' and not (diffusion and getattr(args, 'synthetic_windows', 0) > 0):
+            raise SystemExit("--window-cache hbm names the device-resident synthetic table: it needs a diffusion model type "
+                             "and --synthetic-windows N (a cache FILE takes a path)")
         cache = None
         if args.window_cache and trainer is not None:
             from ..data.WindowCache import DeviceMotionCache, DeviceWindowCache, PackedWindows, wait_for_file
@@ -176,23 +181,26 @@ class TrainCommand(AbstractCommand):
             # only then enter the barrier -- packing a full training set can outlast the process group's collective timeout
             # (~10 min under RCCL), so no collective may span it; none of them can open a file that is still being written
             in_hbm = diffusion and args.window_cache == 'hbm' and getattr(args, 'synthetic_windows', 0) > 0
+            # the failure marker carries this launch's id (every rank of a torchrun launch sees the same one): the marker a
+            # previous, failed launch left behind has another name and is never mistaken for this run's
+            run_id = os.environ.get("TORCHELASTIC_RUN_ID", "none") + "." + os.environ.get("MASTER_PORT", "0")
+            failed_marker = f"{args.window_cache}.failed.{run_id}"
             if in_hbm:
                 pass                  # synthetic windows are drawn straight into HBM below: no file, no host pass
             elif not os.path.exists(args.window_cache) and rank == 0:
                 print(f"Packing {len(train_dataset)} training windows into {args.window_cache} ...")
                 try:
-                    if os.path.exists(args.window_cache + ".failed"):
-                        os.remove(args.window_cache + ".failed")
                     if diffusion:
                         save_motion_windows(train_dataset, args.window_cache)
                     else:
                         PackedWindows.from_dataset(train_dataset, workers=args.data_loading_workers).save(args.window_cache)
                 except BaseException as exc:      # the waiting ranks poll for this instead of sitting out their timeout
-                    with open(args.window_cache + ".failed", "w") as f:
+                    with open(failed_marker, "w") as f:
                         f.write(repr(exc))
                     raise
             if distributed and not in_hbm:
-                wait_for_file(args.window_cache, float(os.environ.get("IB_WINDOW_CACHE_WAIT_S", 6 * 3600)))
+                wait_for_file(args.window_cache, float(os.environ.get("IB_WINDOW_CACHE_WAIT_S", 6 * 3600)),
+                              failed=failed_marker)
                 dist.barrier()
             if in_hbm:
                 cache = DeviceMotionCache.synthetic(len(train_dataset), window, train_dataset.feat, device,
@@ -210,18 +218,19 @@ class TrainCommand(AbstractCommand):
                                                           checkpoint_dir=checkpoint_dir)
         from .. import hip
         noise_seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
-        draws = [0]
 
-        def device_batch(x0, stream_id):
+        def device_batch(x0, stream_id, draw):
             """x0 [B, T, D] (host or device) -> (x0, t, eps) on the device in the model's dtype; t / eps from the
-            counter-based generator (csrc/noise.hip): the dev-set evaluation and the --eager loop draw like the fused
-            trainer does, nothing random is made on the host"""
+            counter-based generator (csrc/noise.hip), counter `draw`: the dev-set evaluation and the --eager loop draw like
+            the fused trainer does, nothing random is made on the host.  Two counters: the dev set's starts at 0 before
+            every epoch (the same noise every time: comparable reports); the --eager training loop's is the global step
+            epoch * batches-per-epoch + i, which only ever increases and is right again after a resume -- a window meets
+            fresh (t, eps) in every epoch, as with the host generator of the reference-style loop"""
             xd = x0.to(device, model.compute_dtype).contiguous()
             ed = torch.empty_like(xd)
             td = torch.empty(xd.shape[0], dtype=torch.int64, device=device)
-            hip.diffusion_draw(noise_seed, step=draws[0], stream_id=stream_id, eps=ed, t=td,
+            hip.diffusion_draw(noise_seed, step=int(draw), stream_id=stream_id, eps=ed, t=td,
                                num_train_steps=model.num_train_steps)
-            draws[0] += 1
             return xd, td, ed
 
         adopted = False
@@ -233,8 +242,7 @@ class TrainCommand(AbstractCommand):
                 model.eval()
                 for i, batch in enumerate(dev_dataloader):
                     if diffusion:
-                        draws[0] = i                     # the dev set sees the same noise before every epoch
-                        xd, td, ed = device_batch(batch, 0x80000000 | rank)
+                        xd, td, ed = device_batch(batch, 0x80000000 | rank, i)   # the same noise before every epoch
                         tabs = model.tables(device)
                         xt = torch.empty_like(xd)
                         hip.q_sample(xd, ed, td, tabs.sqrt_ab, tabs.sqrt_1mab, xt)
@@ -275,7 +283,7 @@ class TrainCommand(AbstractCommand):
                     else:
                         optimizer.zero_grad()
                         tabs = model.tables(device)
-                        xd, td, ed = device_batch(batch, rank)
+                        xd, td, ed = device_batch(batch, rank, epoch * n_batches + i)
                         xt = torch.empty_like(xd)
                         hip.q_sample(xd, ed, td, tabs.sqrt_ab, tabs.sqrt_1mab, xt)
                         loss = train_eval(ddp_model(xt, td), ed)

@@ -184,6 +184,28 @@ class AddBiomechanicsDataset(Dataset):
         self.windows = np.concatenate(index).astype(np.int64) if index else np.zeros((0, 3), np.int64)
         self._contact_cache: Dict[int, List[int]] = {}
 
+    def inspect_dof_indices(self):
+        """the reference's consistency check over the loaded skeletons (AddBiomechanicsDataset.py:141-156): every skeleton
+        has the same 23 degrees of freedom, and index j names the same joint coordinate in all of them.  Same prints, same
+        assertion messages; the names are gathered per skeleton first, so a failure names the index it is about."""
+        num_skeletons = len(self.skeletons)
+        names = []
+        for i, skeleton in enumerate(self.skeletons):
+            print(f'Skeleton {i + 1}/{num_skeletons} joints:')
+            num_dofs = skeleton.getNumDofs()
+            row = [skeleton.getDofByIndex(j).getName() for j in range(num_dofs)]
+            for j, dof_name in enumerate(row):
+                print(f'  - Dof Index {j}/{num_dofs - 1}: {dof_name}')
+            names.append(row)
+        print('-' * 80)
+        width = max((len(row) for row in names), default=0)
+        assert width == 23, f'{width} unique dof indices found, expected 23'
+        for j in range(width):
+            at_j = [row[j] for row in names if j < len(row)]
+            assert len(at_j) == num_skeletons, f'{len(at_j)} entries found at dof index {j}, expected {num_skeletons}'
+            print(f' - Set of names at dof index {j}: {set(at_j)}')
+            assert len(set(at_j)) == 1, f'{len(set(at_j))} distinct dof names found at dof index {j}, expected 1'
+
     def __len__(self) -> int:
         return int(self.windows.shape[0])
 

@@ -35,15 +35,18 @@ MAGIC = b"IBWINDOWS1\n"
 HEADER_BYTES = 4096
 
 
-def wait_for_file(path: str, timeout_s: float, poll_s: float = 2.0) -> None:
+def wait_for_file(path: str, timeout_s: float, poll_s: float = 2.0, failed: str = None) -> None:
     """Sleep-poll until `path` exists.  PackedWindows.save renames the finished file into place, so existence means
     complete.  Used by the ranks that do not pack (cli/train.py): waiting here instead of inside a collective keeps the
-    process group's watchdog timeout out of a phase whose length depends on the data set."""
+    process group's watchdog timeout out of a phase whose length depends on the data set.  `failed`: the marker file the
+    packing rank of THIS launch writes on an exception (its name carries the launch id: a marker left behind by an earlier,
+    failed launch is a different file and is ignored)."""
     import time
+    failed = failed if failed is not None else path + ".failed"
     t0 = time.monotonic()
     while not os.path.exists(path):
-        if os.path.exists(path + ".failed"):           # the packing rank died (cli/train.py writes it on any exception)
-            raise RuntimeError(f"window cache {path!r}: the packing rank failed: " + open(path + ".failed").read()[:500])
+        if os.path.exists(failed):                     # the packing rank died (cli/train.py writes it on any exception)
+            raise RuntimeError(f"window cache {path!r}: the packing rank failed: " + open(failed).read()[:500])
         if time.monotonic() - t0 > timeout_s:
             raise TimeoutError(f"window cache {path!r} did not appear within {timeout_s:.0f} s (is the packing rank alive?)")
         time.sleep(poll_s)

@@ -386,6 +386,14 @@ class HipTrainer:
                 # one GPU: a layer's parameters are updated as soon as its gradient is complete, on the layer's side stream
                 # beside the backward of the layers below, instead of in one launch at the end of the step
                 early = plan.fuse_reduce_into_optimizer and not os.environ.get("IB_NO_EARLY_OPT")
+                if early:
+                    # probed HERE, before the first launch of the step: a layer whose parameters are not one aligned range
+                    # of the flat buffer falls back to the single end-of-step launch instead of failing mid-step
+                    try:
+                        for lp in getattr(plan, "layers", ()):
+                            self._prefix_range(lp.p)
+                    except hip.HipError:
+                        early = False
                 plan.early_optimizer = self._early_optimizer if early else None
                 self._early_done = []
             if hasattr(plan, "train_pitch"):

@@ -1293,13 +1293,17 @@ def optim_ticket_words() -> int:
     return int(lib().ib_optim_ticket_words())
 
 
-def optim_step(opt: str, p, g, s1, s2, lr, step=1, step_dev=None, grad_scale=1.0, shadow=None, ticket=None,
+def optim_step(opt: str, p, g, s1, s2, lr, step=None, step_dev=None, grad_scale=1.0, shadow=None, ticket=None,
                sources=None):
-    """sources = (items, part, rows, segs): the gradient of some ranges of g is still partial sums -- items =
+    """step: the step number of the bias corrections; with `step_dev` the kernel uses `*step_dev + step`, so the default is
+    0 there (the device counter alone) and 1 without a device counter.
+    sources = (items, part, rows, segs): the gradient of some ranges of g is still partial sums -- items =
     [(slab workspace, nslab, dw view into g)], segs = [(col0, ncols, dst view into g | the loss scalar, dst2, scale)] over
     part[:rows], or 7-tuples (.., part_i, rows_i) that name their own partial matrix (part may then be None).  The optimizer sums them itself (ib_optim_step_sources) instead of a separate ib_step_reduce launch.
     An optional fifth entry lists views into g whose parameters were already updated this step (launches over a slice of
     the buffers with step_dev, no ticket and step=1: same step number as the self-counting launch that follows)."""
+    if step is None:
+        step = 0 if step_dev is not None else 1
     _req(p, "p", torch.float32, 1)
     _req(g, "g", torch.float32, 1)
     n = p.numel()

@@ -84,17 +84,19 @@ class _RegressionLossFn(torch.autograd.Function):
 
 
 class _SqDiffMean(torch.autograd.Function):
-    """mean((o - l)^2, dim=(0, 1)) of device tensors through the library, differentiable w.r.t. the output"""
+    """mean((o - l)^2, dim=(0, 1)) of device tensors through the library, differentiable w.r.t. the output and (the same
+    gradient negated) the label; the result has the inputs' dtype, as the torch expression of the host path has"""
 
     @staticmethod
     def forward(ctx, o, l):
         ctx.save_for_backward(o, l)
-        return hip.sqdiff_mean(o, l)
+        return hip.sqdiff_mean(o, l).to(o.dtype)
 
     @staticmethod
     def backward(ctx, dout):
         o, l = ctx.saved_tensors
-        return hip.sqdiff_mean_bwd(o, l, dout.detach().to(torch.float32).contiguous()), None
+        g = hip.sqdiff_mean_bwd(o, l, dout.detach().to(torch.float32).contiguous())
+        return g, (-g if ctx.needs_input_grad[1] else None)
 
 
 class RegressionLossEvaluator:
@@ -123,6 +125,16 @@ class RegressionLossEvaluator:
     # ib_mean_norm_error; `get_squared_diff_mean_vector` stays differentiable through ib_sqdiff_mean_bwd).  HOST tensors --
     # what the reference's own unit tests pass -- take the explicit host path below: a few torch expressions on the CPU,
     # an API shim outside the GPU hot path (the training step never calls these; it uses the fused ib_regression_loss).
+    @staticmethod
+    def _metric_no_grad(*tensors):
+        """the reported metrics (mean norm errors) are read, never differentiated: the library computes them without a
+        graph.  A caller that wants gradients through them on the device is told so instead of silently getting a constant
+        (the host path, like the reference statics, is differentiable)."""
+        if torch.is_grad_enabled() and any(t.requires_grad for t in tensors):
+            raise hip.HipError("get_mean_norm_error / get_com_acc_error on device tensors are metrics computed without an "
+                               "autograd graph: detach the inputs (or call under torch.no_grad()); the differentiable loss "
+                               "terms are get_squared_diff_mean_vector and the evaluator's __call__")
+
     @staticmethod
     def _on_device(*tensors) -> bool:
         return all(isinstance(t, torch.Tensor) and t.is_cuda for t in tensors) and \
@@ -166,6 +178,7 @@ class RegressionLossEvaluator:
         if output_tensor.shape[-1] % vec_size != 0:
             raise ValueError('Tensors must have a final dimension divisible by vec_size=' + str(vec_size))
         if RegressionLossEvaluator._on_device(output_tensor, label_tensor):
+            RegressionLossEvaluator._metric_no_grad(output_tensor, label_tensor)
             with torch.no_grad():
                 return hip.mean_norm_error(output_tensor.contiguous(), label_tensor.contiguous(), vec_size)
         diffs = output_tensor - label_tensor                                                          # host tensors
@@ -183,6 +196,7 @@ class RegressionLossEvaluator:
         if output_force_tensor.shape[-1] != 6:
             raise ValueError('Output and label tensors must have a 6 dimensional final dimension')
         if RegressionLossEvaluator._on_device(output_force_tensor, label_force_tensor):
+            RegressionLossEvaluator._metric_no_grad(output_force_tensor, label_force_tensor)
             with torch.no_grad():
                 return hip.mean_norm_error(output_force_tensor.contiguous(), label_force_tensor.contiguous(), 3,
                                            fold_halves=True)

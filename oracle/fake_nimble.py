@@ -91,18 +91,32 @@ class _BodyNode:
         return self._name
 
 
+class _Dof:
+    def __init__(self, name: str):
+        self._name = name
+
+    def getName(self) -> str:
+        return self._name
+
+
 class _Skeleton:
     """what `compute_report=True` calls on a skeleton (src/loss/RegressionLossEvaluator.py:265-286); the inverse dynamics
-    is a closed form of its arguments -- enough to check the plumbing, not physics"""
+    is a closed form of its arguments -- enough to check the plumbing, not physics.  `dof_names`: what
+    `inspect_dof_indices` walks (src/data/AddBiomechanicsDataset.py:141-156); the default is the same 23 names for every
+    subject, a test may hand a skeleton another list"""
 
-    def __init__(self, mass: float = 70.0):
+    def __init__(self, mass: float = 70.0, dof_names=None):
         self._mass, self._q, self._dq = mass, np.zeros(NUM_DOFS), np.zeros(NUM_DOFS)
+        self._dofs = list(dof_names) if dof_names is not None else [f"dof_{j}" for j in range(NUM_DOFS)]
 
     def getBodyNode(self, name: str) -> _BodyNode:
         return _BodyNode(name)
 
     def getNumDofs(self) -> int:
-        return NUM_DOFS
+        return len(self._dofs)
+
+    def getDofByIndex(self, j: int) -> _Dof:
+        return _Dof(self._dofs[j])
 
     def getMass(self) -> float:
         return self._mass

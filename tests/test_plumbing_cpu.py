@@ -314,6 +314,38 @@ def test_cli_diffusion_trains_from_the_motion_cache(dry, tmp_path):
     assert main(['train', '--epochs', '3', '--max-steps', '1', '--eager'] + base)
 
 
+def test_eager_diffusion_loop_draws_fresh_noise_every_epoch(dry, tmp_path, monkeypatch):
+    """`--eager`: the training loop's draw counter is the global step (epoch * batches + i) -- epoch 1 draws with other
+    counters than epoch 0 -- while the dev evaluation before every epoch starts at 0 again (its own stream id)"""
+    from inferbiomechanics_amd import hip
+    from inferbiomechanics_amd.main import main
+    seen = []
+    real = hip.diffusion_draw
+
+    def rec(seed, step=0, step_dev=None, stream_id=0, **kw):
+        seen.append((int(stream_id), int(step), step_dev is not None))
+        return real(seed, step=step, step_dev=step_dev, stream_id=stream_id, **kw)
+    monkeypatch.setattr(hip, "diffusion_draw", rec)
+    base = ['--no-wandb', '--synthetic-windows', '24', '--batch-size', '8', '--checkpoint-dir', str(tmp_path / "ck"),
+            '--data-loading-workers', '0', '--model-type', 'diffusion-mlp', '--feat-dim', '24', '--hidden-dims', '32', '32',
+            '--stride', '1', '--history-len', '6', '--compute-dtype', 'bf16', '--seed', '7']
+    assert main(['train', '--epochs', '2', '--eager'] + base)
+    dev = [s for sid, s, _ in seen if sid & 0x80000000]
+    train = [s for sid, s, _ in seen if not sid & 0x80000000]
+    assert dev == [0, 1, 2, 0, 1, 2]                               # the same dev noise before every epoch
+    assert train == [0, 1, 2, 3, 4, 5]                             # epoch 1 = steps 3..5, not 0..2 again
+    assert not any(d for _, _, d in seen)                          # host-side counters only on this path
+    # resumed run: the counter starts at the global step of the first epoch it runs, not at 0
+    del seen[:]
+    assert main(['train', '--epochs', '3', '--eager'] + base)
+    assert [s for sid, s, _ in seen if not sid & 0x80000000] == [6, 7, 8]
+    with pytest.raises(SystemExit, match="loss-every"):
+        main(['train', '--epochs', '1', '--loss-every', '0'] + base)
+    with pytest.raises(SystemExit, match="synthetic-windows"):
+        main(['train', '--epochs', '1', '--window-cache', 'hbm', '--model-type', 'feedforward', '--no-wandb',
+              '--synthetic-windows', '0', '--checkpoint-dir', str(tmp_path / "ck2")])
+
+
 def test_every_parameter_is_updated_exactly_once_per_step(dry, monkeypatch):
     """one GPU, transformer denoiser: each layer's range of the flat buffers is updated by its own optimizer launch (issued
     from the backward), the step's last launch names those ranges as done (source kind 3) -- together they cover the flat

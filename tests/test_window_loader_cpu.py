@@ -130,6 +130,29 @@ def test_skeletons_loaded_unless_skipped(tmp_path, nimble):
     assert open_case(root, LOADER_CASES[0]).skeletons == []
 
 
+def test_inspect_dof_indices(tmp_path, nimble, capsys):
+    """AddBiomechanicsDataset.py:141-156: 23 DoFs, the same name at every index across the skeletons; the three failure
+    messages of the reference for a short skeleton, a renamed coordinate and a 24-DoF set"""
+    root = str(tmp_path / "train")
+    fake_nimble.make_tree(root)
+    ds = AddBiomechanicsDataset(root, 50, "geom/", stride=5)
+    ds.inspect_dof_indices()
+    out = capsys.readouterr().out
+    assert "Skeleton 3/3 joints:" in out and "  - Dof Index 22/22: dof_22" in out
+    assert " - Set of names at dof index 0: {'dof_0'}" in out
+    good = [f"dof_{j}" for j in range(23)]
+    ds.skeletons[1] = fake_nimble._Skeleton(70.0, good[:22])
+    with pytest.raises(AssertionError, match="2 entries found at dof index 22, expected 3"):
+        ds.inspect_dof_indices()
+    ds.skeletons[1] = fake_nimble._Skeleton(70.0, good[:5] + ["knee_r"] + good[6:])
+    with pytest.raises(AssertionError, match="2 distinct dof names found at dof index 5, expected 1"):
+        ds.inspect_dof_indices()
+    ds.skeletons = [fake_nimble._Skeleton(70.0, good + ["extra"]) for _ in range(3)]
+    with pytest.raises(AssertionError, match="24 unique dof indices found, expected 23"):
+        ds.inspect_dof_indices()
+    assert open_case(root, LOADER_CASES[0]).skeletons == []
+
+
 def test_worker_copy_reopens_subjects(tmp_path, nimble):
     """DataLoader workers get a pickled copy: the SubjectOnDisk handles are dropped and re-opened (:287-303)"""
     root = str(tmp_path / "train")
