@@ -260,7 +260,9 @@ KERNEL_OF = {   # C-ABI entry -> device kernel it launches (names as rocprofv3 -
     "ib_linear_wgrad": "gemm_kernel<T, false, false, EPI_WGRAD> (+ slab_reduce_kernel)",
     "ib_layernorm_fwd": "layernorm_fwd_kernel", "ib_layernorm_bwd": "layernorm_bwd_kernel (+ segment_colsum_kernel)",
     "ib_attention_fwd": "attn_fwd_mfma", "ib_attention_bwd": "attn_bwd_mfma", "ib_segment_colsum": "segment_colsum_kernel",
-    "ib_ffn_chain_fwd": "ffn_chain_fwd_kernel<true, true> (<true, false> for the top layer)", "ib_ffn_chain_bwd": "ffn_chain_bwd_kernel<true, true> (<true, false> for the top layer)",
+    "ib_ffn_chain_fwd": "ffn_chain_fwd_kernel<true, true, false> (<true, false, false> for the top layer)", "ib_ffn_chain_bwd": "ffn_chain_bwd_kernel<true, true, false> (<true, false, false> for the top layer)",
+    "ib_ffn_chain_fwd_attn": "ffn_chain_fwd_kernel<true, true, true> (one-window panels: the layer's token-local half + the next layer's in-projection and attention; <true, false, false> for the top layer)",
+    "ib_ffn_chain_bwd_attn": "ffn_chain_bwd_kernel<true, false, true> (one-window panels: the whole layer's backward incl. attention backward and in-projection dgrad)",
     "ib_ffn_chain_pack": "ffn_pack_kernel", "ib_diffusion_draw": "diffusion_draw_kernel",
     "ib_mse_loss": "mse_partial_kernel (+ mse_final_kernel)", "ib_q_sample": "q_sample_kernel",
     "ib_gather_rows": "gather_rows_kernel", "ib_cast": "cast2d_kernel", "ib_cast2d": "cast2d_kernel"}
@@ -368,6 +370,9 @@ def roofline_leg(rec, dtype_name, gemm_family=False, workload=None):
     else:
         kernel = KERNEL_OF.get(top_e, top_e)
         shapes = [(r["dims"][-5:] if top_e == "ib_mlp_chain_train" else r["dims"][-4:-1]) for r in top["rows"]]
+        if top["rows"][0]["_note"] is not None:          # launch forms described by the wrapper (fused layer launches)
+            shapes = [dict(r["_note"][2], launches=r["launches_per_step"], us=r["avg_launch_us"], tflops=r["tflops"])
+                      if isinstance(r["_note"][2], dict) else r["_note"][2] for r in top["rows"]]
     out = {"kernel": kernel, "entry": top_e, "launches_per_step": top["launches"],
            "avg_launch_us": round(avg_us, 2), "share_of_step_device_time": round(top["us"] / total, 3),
            "shapes": shapes, "traffic": None}

@@ -335,6 +335,32 @@ int ib_ffn_chain_bwd(const void* dy, const void* s2, const float* mean, const fl
                      const void* packed_next, const void* dqkv_next, const void* ds1_next, int64_t M, int64_t d, int64_t ffn,
                      ib_stream_t stream);
 
+/* ---- the temporal self-attention INSIDE the two launches above (round 5): panels of exactly one window of T frames
+ * (16 <= T <= 64, M % T == 0; ib_ffn_chain_attn_workgroups = M / T, 0 = unsupported), d = 512 = eight heads of 64.  Wave w of a
+ * panel's workgroup owns the 64 in-projection columns of head w, so softmax(Q K^T / 8) V of a (window, head) and its
+ * backward (nn.MultiheadAttention's core, TransformerBaseline.py:12-13,29) are wave-private work between the GEMM phases:
+ *   ib_ffn_chain_fwd_attn   ib_ffn_chain_fwd (all of its arguments, same meaning) over one-window panels and, with
+ *                           attn_next != NULL (needs the QKV tail), the NEXT layer's attention behind the tail:
+ *                           attn_next [M, 512], lse_next [M / T, 8, T] (row log-sum-exp, fp32);
+ *   ib_ffn_chain_bwd_attn   the attention epilogue form of ib_ffn_chain_bwd continued through THIS layer's attention
+ *                           backward (qkv [M, 1536] and lse as the forward left them) and in-projection dgrad:
+ *                           dqkv [M, 1536] (the in-projection's weight-gradient operand) and dx [M, 512] = dqkv Wqkv + ds1,
+ *                           the gradient w.r.t. the layer input.  dattn is not stored.  `mask` / `partial` sized for
+ *                           ib_ffn_chain_attn_workgroups panels (ib_ffn_chain_attn_mask_bytes). */
+int ib_ffn_chain_attn_workgroups(int64_t M, int64_t d, int64_t ffn, int64_t T);
+size_t ib_ffn_chain_attn_mask_bytes(int64_t M, int64_t d, int64_t ffn, int64_t T);
+int ib_ffn_chain_fwd_attn(const void* x, const void* packed, const float* b1, const float* b2, const float* gamma,
+                          const float* beta, void* f1, void* s2, void* y, float* mean, float* rstd, void* mask,
+                          const void* attn, const float* bo, const float* gamma1, const float* beta1, void* s1, void* x1_out,
+                          float* mean1, float* rstd1, const void* packed_next, const float* bqkv_next, void* qkv_next,
+                          void* attn_next, float* lse_next, int64_t T, int64_t M, int64_t d, int64_t ffn, float ln_eps,
+                          ib_stream_t stream);
+int ib_ffn_chain_bwd_attn(const void* dy, const void* s2, const float* mean, const float* rstd, const float* gamma,
+                          const void* packed, const void* mask, void* ds2, void* dz1, float* partial, const void* s1,
+                          const float* mean1, const float* rstd1, const float* gamma1, void* ds1, const void* qkv,
+                          const float* lse, void* dqkv, void* dx, int64_t T, int64_t M, int64_t d, int64_t ffn,
+                          ib_stream_t stream);
+
 /* ---- diffusion wrapper [BUILD-DEFINED]: DDPM q_sample, DDIM eta=0 update, table gathers ----- */
 /* ---- tiny matrix products: C[M,N] (+)= sum_k A(m,k) B(k,n), A(m,k) = A[m*sam + k*sak], B(k,n) = B[k*sbk + n*sbn], each
  * operand with its own storage dtype (IB_F32 / IB_BF16), fp32 accumulation in a fixed order.  The frame-embedding

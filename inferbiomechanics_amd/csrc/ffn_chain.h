@@ -6,6 +6,10 @@
 #include <initializer_list>
 #include <utility>
 
+#ifdef IB_AB
+extern long long* g_ffn_prof;        // ffn_chain.hip
+#endif
+
 namespace {
 
 constexpr int FF_ROWS = 64, FF_WAVES = 8, FF_THREADS = 512, FF_D = 512, FF_CHUNK = 512, FF_MAXCHUNK = 8;
@@ -297,11 +301,73 @@ __device__ __forceinline__ void ff_panel_out(const unsigned char* img, bf16_t* g
 
 #define FF_TIDV ((wave_s << 6) | ff_lane())
 
-inline int ffn_geometry(int64_t M, int64_t d, int64_t ffn, int* P, int* nchunk) {
+// ---- temporal self-attention INSIDE the panel launches (round 5).  With a panel = one window (P == T <= 64 frames) and
+// d = 512 = 8 heads x 64, wave w's 64 output columns of the in-projection GEMMs ARE head w: its Q, K, V (and, in the
+// backward, the dattn columns the out-projection's dgrad leaves in its accumulators) never concern another wave.  The whole
+// softmax(Q K^T / 8) V of a (window, head) and its backward are wave-private: operands come from the wave's own accumulators
+// or from its own 64-column slice of the two LDS images, no workgroup barrier inside.
+// Lane map of v_mfma_f32_16x16x32_bf16 (attention_mfma.hip): A[row = lane % 16][k = 8 (lane / 16) + j],
+// B[k][col = lane % 16], D[row = 4 (lane / 16) + r][col = lane % 16].
+constexpr int FF_HEADS = FF_D / 64;                       // = FF_WAVES: one head per wave
+constexpr float FF_ATT_SCALE = 0.125f;                    // 1 / sqrt(64)
+typedef __attribute__((address_space(3))) s16x4_t ff_lds_s16x4_t;
+typedef __attribute__((ext_vector_type(8))) short ff_s16x8_t;
+
+// accumulator pair -> operand of the next product: elements 0..3 <- tile a, 4..7 <- tile b (the reduction index of the next
+// product is permuted identically on both of its operands)
+__device__ __forceinline__ bf16x8_t ff_acc_frag(const f32x4_t& a, const f32x4_t& b) {
+  bf16x8_t f;
+  f[0] = (bf16_t)a[0]; f[1] = (bf16_t)a[1]; f[2] = (bf16_t)a[2]; f[3] = (bf16_t)a[3];
+  f[4] = (bf16_t)b[0]; f[5] = (bf16_t)b[1]; f[6] = (bf16_t)b[2]; f[7] = (bf16_t)b[3];
+  return f;
+}
+__device__ __forceinline__ bf16x8_t ff_cat4(const bf16x4_t& a, const bf16x4_t& b) {
+  bf16x8_t f;
+  f[0] = a[0]; f[1] = a[1]; f[2] = a[2]; f[3] = a[3]; f[4] = b[0]; f[5] = b[1]; f[6] = b[2]; f[7] = b[3];
+  return f;
+}
+__device__ __forceinline__ float ff_g4_max(float v) {
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float ff_g4_sum(float v) {
+  v += __shfl_xor(v, 16, 64);
+  return v + __shfl_xor(v, 32, 64);
+}
+// `sl` = the wave's 64-column slice of an image (image + 128 * wave bytes, rows FF_RS bytes apart).
+// 8 consecutive columns of one slice row: operand of a product that reduces over the head dimension
+__device__ __forceinline__ bf16x8_t ff_sl_row(const unsigned char* sl, int row, int ks, int lane) {
+  return *reinterpret_cast<const bf16x8_t*>(sl + row * FF_RS + 64 * ks + 16 * (lane >> 4));
+}
+// transposed operand A[i = column 16 dt + lane % 16][k = slice rows row_lo + 4 g + (0..3) | row_hi + 4 g + (0..3)]
+__device__ __forceinline__ bf16x8_t ff_sl_tr(const unsigned char* sl, int row_lo, int row_hi, int dt, int lane) {
+  const int qq = (lane & 15) >> 2, pp = lane & 3, g = lane >> 4;
+  const unsigned char* a0 = sl + (row_lo + 4 * g + qq) * FF_RS + dt * 32 + 8 * pp;
+  const unsigned char* a1 = sl + (row_hi + 4 * g + qq) * FF_RS + dt * 32 + 8 * pp;
+  s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ff_lds_s16x4_t*)(a0));
+  s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ff_lds_s16x4_t*)(a1));
+  ff_s16x8_t v;
+  v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+  v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+// LDS written by some lanes of this wave, read by others: order the wave's own accesses (no workgroup barrier)
+__device__ __forceinline__ void ff_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// T_att > 0: panels of exactly one window (the launches with the attention inside); 0: the token-count rule
+inline int ffn_geometry(int64_t M, int64_t d, int64_t ffn, int* P, int* nchunk, int64_t T_att = 0) {
   if (d != FF_D || ffn <= 0 || ffn % FF_CHUNK != 0 || ffn / FF_CHUNK > FF_MAXCHUNK || M <= 0) return 0;
   int64_t rows = (M + 255) / 256;                         // one workgroup per CU when the token count allows it
   if (rows > FF_ROWS) rows = FF_ROWS;
   if (rows < 16) rows = M < 16 ? M : 16;
+  if (T_att > 0) {
+    if (T_att < 16 || T_att > FF_ROWS || M % T_att != 0) return 0;
+    rows = T_att;
+  }
   *P = (int)rows;
   *nchunk = (int)(ffn / FF_CHUNK);
   return (int)((M + rows - 1) / rows);

@@ -25,10 +25,11 @@
 // L2 -> CU weight stream (4 MB per workgroup and direction).
 #include "ffn_chain.h"
 
-namespace {
 #ifdef IB_AB
-long long* g_ffn_prof = nullptr;     // TIMING-ONLY (tools/ffn_prof.py): [workgroups][64] wall-clock stamps, measurement builds
+long long* g_ffn_prof = nullptr;     // TIMING-ONLY (tools/ffn_prof.py, tools/layer_prof.py): [workgroups][64] wall-clock stamps,
+                                     // measurement builds; shared with ffn_chain_bwd.hip (declared in ffn_chain.h)
 #endif
+namespace {
 
 struct FfnFwdParams {
   const bf16_t* x1;                 // [M, 512] sublayer input (plain form) -- or, with the attention epilogue, the LAYER input
@@ -45,13 +46,17 @@ struct FfnFwdParams {
   bf16_t* s1; bf16_t* x1out; float* mean1; float* rstd1;
   // QKV tail (QKV): the NEXT layer's in-projection qkv = y . Wqkv^T + bqkv, three 512-column chunks
   const bf16_t* wqkvp; const float* bqkv; bf16_t* qkv;     // qkv: [M, 1536]
+  // attention of the next layer (ATT; panel = one window of P = T frames): attn_next [M, 512] = softmax(Q K^T / 8) V per
+  // (window, head), lse_next [windows, 8, T] = the rows' log-sum-exp (the backward recomputes the probabilities from it)
+  bf16_t* attn_next; float* lse_next;
   int M, P, FF, nchunk;
   float ln_eps;
   long long* prof;
 };
 
-template <bool OUT, bool QKV>
+template <bool OUT, bool QKV, bool ATT>
 __global__ __launch_bounds__(FF_THREADS) void ffn_chain_fwd_kernel(FfnFwdParams p) {
+  static_assert(!ATT || QKV, "the attention rides behind the QKV tail");
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * FF_BUF];
   unsigned char* imgX = smem;
   unsigned char* imgH = smem + FF_BUF;
@@ -172,10 +177,16 @@ __global__ __launch_bounds__(FF_THREADS) void ffn_chain_fwd_kernel(FfnFwdParams 
     // into image X (free now), whose rows leave for qkv[:, 512 c ..] as the side job of the NEXT chunk's GEMM
     __syncthreads();                     // image H = y complete
     bf16_t* qg = p.qkv + (int64_t)r0 * (3 * FF_D);
+    // ATT: wave w's 64 columns of every chunk are head w.  The bf16 values it stores into image X are kept as MFMA operands
+    // too: qf / kf[tile][k-step] = rows 16 tile + lane % 16, head columns {32 ks + 4 g + (0..3), 32 ks + 16 + 4 g + (0..3)} --
+    // the same permutation of the head dimension on both, which is all a product that reduces over it needs
+    bf16x8_t qf[ATT ? 4 : 1][2], pf[ATT ? 4 : 1][2];
+    float inv_l[ATT ? 4 : 1];
     // chunk c's GEMM carries the row stores of chunk c - 1 as its side job; the first trip has none (peeled, so that no
     // runtime branch sits around a store inside the k-loop)
-    auto qkv_chunk = [&](int c, auto with_store) {
+    auto qkv_chunk = [&](int c, auto with_store, auto keep) {
       constexpr bool STORE = decltype(with_store)::value != 0;
+      constexpr int KEEP = decltype(keep)::value;          // 1: Q -> qf, 2: K -> scores + softmax -> pf, 0: nothing kept
       f32x4_t acq[4][FF_NT];
       ff_zero(acq);
       float4 bq[FF_NT];
@@ -191,24 +202,95 @@ __global__ __launch_bounds__(FF_THREADS) void ffn_chain_fwd_kernel(FfnFwdParams 
       ff_gemm<FF_RING_B>(p.wqkvp + (int64_t)c * FF_WELEMS, wave_s * FF_NT, imgH, ff_lane(), acq, sideq);
       FF_STAMP(3 + 4 * p.nchunk + 2 * c);
       __syncthreads();                   // every wave's row pieces of the previous chunk have been read out of image X
+      bf16x8_t kf[KEEP == 2 ? 4 : 1][2];
 #pragma unroll
-      for (int u = 0; u < FF_NT; ++u) {
+      for (int mt = 0; mt < 4; ++mt) {
+        bf16x4_t pk[FF_NT];
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-          *reinterpret_cast<bf16x4_t*>(imgX + (16 * mt + l16) * FF_RS + (colb + 16 * u) * 2) =
-              ff_pack4(acq[mt][u][0] + bq[u].x, acq[mt][u][1] + bq[u].y, acq[mt][u][2] + bq[u].z, acq[mt][u][3] + bq[u].w);
+        for (int u = 0; u < FF_NT; ++u) {
+          pk[u] = ff_pack4(acq[mt][u][0] + bq[u].x, acq[mt][u][1] + bq[u].y, acq[mt][u][2] + bq[u].z, acq[mt][u][3] + bq[u].w);
+          *reinterpret_cast<bf16x4_t*>(imgX + (16 * mt + l16) * FF_RS + (colb + 16 * u) * 2) = pk[u];
+        }
+        if constexpr (KEEP == 1) { qf[mt][0] = ff_cat4(pk[0], pk[1]); qf[mt][1] = ff_cat4(pk[2], pk[3]); }
+        if constexpr (KEEP == 2) { kf[mt][0] = ff_cat4(pk[0], pk[1]); kf[mt][1] = ff_cat4(pk[2], pk[3]); }
+      }
+      if constexpr (KEEP == 2) {
+        // S^T[key][query] = K . Q^T per (key tile, query tile): the lane owns query 16 it + lane % 16 and, per key tile, the
+        // keys 16 jt + 4 g + (0..3); softmax over the keys in registers + two xor-shuffles across the four lane groups;
+        // the unnormalised probabilities go straight into the operand form of P . V (attention_mfma.hip)
+        float* lse = p.lse_next + ((int64_t)blockIdx.x * FF_HEADS + wave_s) * p.P;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          f32x4_t sc[4];
+          float m = -INFINITY;
+#pragma unroll
+          for (int jt = 0; jt < 4; ++jt) {
+            f32x4_t a = {0.f, 0.f, 0.f, 0.f};
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[jt][0], qf[it][0], a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[jt][1], qf[it][1], a, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              a[r] = (16 * jt + 4 * g + r) < nrows ? a[r] * FF_ATT_SCALE : -INFINITY;
+              m = fmaxf(m, a[r]);
+            }
+            sc[jt] = a;
+          }
+          m = ff_g4_max(m);
+          float l = 0.f;
+#pragma unroll
+          for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float pv = __expf(sc[jt][r] - m);      // -inf -> 0
+              l += pv;
+              sc[jt][r] = pv;
+            }
+          l = ff_g4_sum(l);
+          inv_l[it] = 1.f / l;
+          pf[it][0] = ff_acc_frag(sc[0], sc[1]);
+          pf[it][1] = ff_acc_frag(sc[2], sc[3]);
+          const int q = 16 * it + l16;
+          if (g == 0 && q < nrows) lse[q] = m + logf(l);
+        }
       }
       __syncthreads();                   // image X = qkv chunk c complete
       FF_STAMP(4 + 4 * p.nchunk + 2 * c);
     };
-    qkv_chunk(0, FfIntC<0>{});
-    for (int c = 1; c < 3; ++c) qkv_chunk(c, FfIntC<1>{});
+    qkv_chunk(0, FfIntC<0>{}, FfIntC<ATT ? 1 : 0>{});
+    qkv_chunk(1, FfIntC<1>{}, FfIntC<ATT ? 2 : 0>{});
+    qkv_chunk(2, FfIntC<1>{}, FfIntC<0>{});
+    if constexpr (ATT) {
+      // O^T[d][query] = V^T . P^T: V's transposed fragments from the wave's own columns of image X (all eight, once), P from
+      // the registers; the normalised rows -> this wave's columns of image H (y is no longer read: every wave is past the
+      // last GEMM), from where they leave as whole rows beside V's
+      const unsigned char* slV = imgX + 128 * wave_s;
+      bf16x8_t vt[2][4];
+#pragma unroll
+      for (int kp = 0; kp < 2; ++kp)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) vt[kp][dt] = ff_sl_tr(slV, 32 * kp, 32 * kp + 16, dt, lane);
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        f32x4_t o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          o[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+          o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt[0][dt], pf[it][0], o[dt], 0, 0, 0);
+          o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt[1][dt], pf[it][1], o[dt], 0, 0, 0);
+          *reinterpret_cast<bf16x4_t*>(imgH + (16 * it + l16) * FF_RS + (colb + 16 * dt) * 2) =
+              ff_pack4(o[dt][0] * inv_l[it], o[dt][1] * inv_l[it], o[dt][2] * inv_l[it], o[dt][3] * inv_l[it]);
+        }
+      }
+      __syncthreads();                   // image H = the attention output of all eight heads
+      bf16_t* ag = p.attn_next + (int64_t)r0 * FF_D;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ff_out_piece(imgH, ag, FF_D, nrows, tid + j * FF_THREADS);
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) ff_out_piece(imgX, qg + 2 * FF_CHUNK, 3 * FF_D, nrows, tid + j * FF_THREADS);
     FF_STAMP(9 + 4 * p.nchunk);
   }
 }
-
 
 
 // ---- weight packing: [512 x 512] sub-matrices of the row-major bf16 weights -> fragment-major 1-KiB blocks
@@ -278,6 +360,16 @@ extern "C" size_t ib_ffn_chain_mask_bytes(int64_t M, int64_t d, int64_t ffn) {
   const int n = ffn_geometry(M, d, ffn, &P, &nc);
   return (size_t)n * nc * FF_THREADS * sizeof(uint2);
 }
+// the launches with the attention inside: panels of exactly one window of T frames (0 workgroups: not supported)
+extern "C" int ib_ffn_chain_attn_workgroups(int64_t M, int64_t d, int64_t ffn, int64_t T) {
+  int P = 0, nc = 0;
+  return T > 0 ? ffn_geometry(M, d, ffn, &P, &nc, T) : 0;
+}
+extern "C" size_t ib_ffn_chain_attn_mask_bytes(int64_t M, int64_t d, int64_t ffn, int64_t T) {
+  int P = 0, nc = 0;
+  const int n = T > 0 ? ffn_geometry(M, d, ffn, &P, &nc, T) : 0;
+  return (size_t)n * nc * FF_THREADS * sizeof(uint2);
+}
 
 extern "C" int ib_ffn_chain_pack(const void* const* w1, const int64_t* ld1, const void* const* w2, const int64_t* ld2,
                                  const void* const* wo, const int64_t* ldo, const void* const* wqkv, const int64_t* ldq,
@@ -333,16 +425,19 @@ extern "C" int ib_ffn_chain_pack(const void* const* w1, const int64_t* ld1, cons
 }
 
 
-extern "C" int ib_ffn_chain_fwd(const void* x1, const void* packed, const float* b1, const float* b2, const float* gamma,
-                                const float* beta, void* f1, void* s2, void* y, float* mean, float* rstd, void* mask,
-                                const void* attn, const float* bo, const float* gamma1, const float* beta1, void* s1,
-                                void* x1_out, float* mean1, float* rstd1, const void* packed_next, const float* bqkv_next,
-                                void* qkv_next, int64_t M, int64_t d, int64_t ffn, float ln_eps, ib_stream_t stream) {
+namespace {
+int ffn_chain_fwd_launch(const void* x1, const void* packed, const float* b1, const float* b2, const float* gamma,
+                         const float* beta, void* f1, void* s2, void* y, float* mean, float* rstd, void* mask,
+                         const void* attn, const float* bo, const float* gamma1, const float* beta1, void* s1,
+                         void* x1_out, float* mean1, float* rstd1, const void* packed_next, const float* bqkv_next,
+                         void* qkv_next, void* attn_next, float* lse_next, int64_t T, int64_t M, int64_t d, int64_t ffn,
+                         float ln_eps, ib_stream_t stream) {
   FfnFwdParams p{};
   int P = 0, nc = 0;
-  const int nwg = ffn_geometry(M, d, ffn, &P, &nc);
+  const bool att = attn_next != nullptr;
+  const int nwg = ffn_geometry(M, d, ffn, &P, &nc, T);
   if (!nwg) return IB_E_UNSUPPORTED;
-  if (!x1 || !packed || !b1 || !b2 || !gamma || !beta || !f1 || !s2 || !y || !mean || !rstd) return IB_E_ARG;
+  if (!x1 || !packed || !b1 || !b2 || !gamma || !beta || !f1 || !s2 || !y || !mean || !rstd || !mask) return IB_E_ARG;
   if (!ff_al16({x1, packed, b1, b2, gamma, beta, f1, s2, y, mask})) return IB_E_ARG;
   const bool out = attn != nullptr;
   if (out && (!bo || !gamma1 || !beta1 || !s1 || !x1_out || !mean1 || !rstd1 || !ff_al16({attn, bo, gamma1, beta1, s1, x1_out})))
@@ -355,15 +450,42 @@ extern "C" int ib_ffn_chain_fwd(const void* x1, const void* packed, const float*
   p.s1 = (bf16_t*)s1; p.x1out = (bf16_t*)x1_out; p.mean1 = mean1; p.rstd1 = rstd1;
   const bool tail = qkv_next != nullptr;
   if (tail && (!out || !packed_next || !bqkv_next || !ff_al16({packed_next, bqkv_next, qkv_next}))) return IB_E_ARG;
+  if (att && (!tail || !lse_next || T <= 0 || P != T || !ff_al16({attn_next}))) return IB_E_ARG;
+  // the packed images of both layers are addressed with THIS layer's chunk count: the neighbour must have the same width
   p.wqkvp = tail ? reinterpret_cast<const bf16_t*>(packed_next) + (int64_t)(4 * nc + 2) * FF_WELEMS : nullptr;
   p.bqkv = bqkv_next; p.qkv = (bf16_t*)qkv_next;
+  p.attn_next = (bf16_t*)attn_next; p.lse_next = lse_next;
   p.M = (int)M; p.P = P; p.FF = (int)ffn; p.nchunk = nc; p.ln_eps = ln_eps;
   p.prof = IB_AB_PROF(g_ffn_prof);
   IB_PATH(IB_PATH_FFN_CHAIN);
-  if (tail) hipLaunchKernelGGL((ffn_chain_fwd_kernel<true, true>), dim3(nwg), dim3(FF_THREADS), 0, ib_s(stream), p);
-  else if (out) hipLaunchKernelGGL((ffn_chain_fwd_kernel<true, false>), dim3(nwg), dim3(FF_THREADS), 0, ib_s(stream), p);
-  else hipLaunchKernelGGL((ffn_chain_fwd_kernel<false, false>), dim3(nwg), dim3(FF_THREADS), 0, ib_s(stream), p);
+  if (att) hipLaunchKernelGGL((ffn_chain_fwd_kernel<true, true, true>), dim3(nwg), dim3(FF_THREADS), 0, ib_s(stream), p);
+  else if (tail) hipLaunchKernelGGL((ffn_chain_fwd_kernel<true, true, false>), dim3(nwg), dim3(FF_THREADS), 0, ib_s(stream), p);
+  else if (out) hipLaunchKernelGGL((ffn_chain_fwd_kernel<true, false, false>), dim3(nwg), dim3(FF_THREADS), 0, ib_s(stream), p);
+  else hipLaunchKernelGGL((ffn_chain_fwd_kernel<false, false, false>), dim3(nwg), dim3(FF_THREADS), 0, ib_s(stream), p);
   IB_CHECK_LAUNCH();
   return IB_OK;
 }
+}  // namespace
 
+extern "C" int ib_ffn_chain_fwd(const void* x1, const void* packed, const float* b1, const float* b2, const float* gamma,
+                                const float* beta, void* f1, void* s2, void* y, float* mean, float* rstd, void* mask,
+                                const void* attn, const float* bo, const float* gamma1, const float* beta1, void* s1,
+                                void* x1_out, float* mean1, float* rstd1, const void* packed_next, const float* bqkv_next,
+                                void* qkv_next, int64_t M, int64_t d, int64_t ffn, float ln_eps, ib_stream_t stream) {
+  return ffn_chain_fwd_launch(x1, packed, b1, b2, gamma, beta, f1, s2, y, mean, rstd, mask, attn, bo, gamma1, beta1, s1, x1_out,
+                              mean1, rstd1, packed_next, bqkv_next, qkv_next, nullptr, nullptr, 0, M, d, ffn, ln_eps, stream);
+}
+// The same launch over panels of exactly one window of T frames (16 <= T <= 64; the geometry of a layer whose attention rides
+// inside its launches -- its backward uses the same panels) and, with attn_next != NULL, the NEXT layer's temporal
+// self-attention behind the QKV tail (eight heads of 64): attn_next [M, 512], lse_next [M / T, 8, T]
+// (TransformerBaseline.py:12-13,29).
+extern "C" int ib_ffn_chain_fwd_attn(const void* x, const void* packed, const float* b1, const float* b2, const float* gamma,
+                                     const float* beta, void* f1, void* s2, void* y, float* mean, float* rstd, void* mask,
+                                     const void* attn, const float* bo, const float* gamma1, const float* beta1, void* s1,
+                                     void* x1_out, float* mean1, float* rstd1, const void* packed_next,
+                                     const float* bqkv_next, void* qkv_next, void* attn_next, float* lse_next, int64_t T,
+                                     int64_t M, int64_t d, int64_t ffn, float ln_eps, ib_stream_t stream) {
+  if (T <= 0) return IB_E_ARG;
+  return ffn_chain_fwd_launch(x, packed, b1, b2, gamma, beta, f1, s2, y, mean, rstd, mask, attn, bo, gamma1, beta1, s1, x1_out,
+                              mean1, rstd1, packed_next, bqkv_next, qkv_next, attn_next, lse_next, T, M, d, ffn, ln_eps, stream);
+}

@@ -30,6 +30,7 @@ import torch
 import torch.distributed as dist
 
 from . import hip
+from ._tuning import tuning as TU
 from .data.AddBiomechanicsDataset import INPUT_KEY_ORDER, LOSS_KEY_ORDER, LOSS_KEY_WIDTHS
 from .loss.RegressionLossEvaluator import component_weights
 from .module import HipModule, flat_layout
@@ -130,7 +131,7 @@ class GradBuckets:
         t = self.flat[lo:hi]
         if self.on_gpu and not torch.cuda.is_current_stream_capturing():
             self.collective_streams.add(torch.cuda.current_stream().cuda_stream)
-        if inline and self.on_gpu and not os.environ.get("IB_ASYNC_INLINE"):
+        if inline and self.on_gpu and not TU.async_inline:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)      # runs on the caller's stream: no event hops
             return
         w = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
@@ -370,7 +371,7 @@ class HipTrainer:
                                    num_train_steps=m.num_train_steps, table=None if mc is None else mc.table,
                                    idx=st.get("widx"), x0=x0 if mc is not None else None)
             if hasattr(plan, "chain_ok") and plan.chain_ok(D):
-                plan.fuse_reduce_into_optimizer = not self.ddp and not os.environ.get("IB_NO_OPT_FUSE")
+                plan.fuse_reduce_into_optimizer = not self.ddp and not TU.no_opt_fuse
                 # MLP denoiser, bf16: q_sample + forward + loss + the dgrad chain are ONE launch (csrc/chain.hip)
                 if self._slots is None:
                     self._slots = torch.zeros(4, dtype=torch.int64, device=self.device)
@@ -381,11 +382,11 @@ class HipTrainer:
             # activations that are D (= 300) wide live in buffers with a 16-byte-aligned row pitch (304): the GEMM
             # operand pieces are then aligned 16-byte loads (the unpadded rows were 8-byte aligned: +11 us per wgrad)
             if hasattr(plan, "fuse_reduce_into_optimizer"):
-                plan.fuse_reduce_into_optimizer = not self.ddp and not os.environ.get("IB_NO_OPT_FUSE")
+                plan.fuse_reduce_into_optimizer = not self.ddp and not TU.no_opt_fuse
             if hasattr(plan, "early_optimizer"):
                 # one GPU: a layer's parameters are updated as soon as its gradient is complete, on the layer's side stream
                 # beside the backward of the layers below, instead of in one launch at the end of the step
-                early = plan.fuse_reduce_into_optimizer and not os.environ.get("IB_NO_EARLY_OPT")
+                early = plan.fuse_reduce_into_optimizer and not TU.no_early_opt
                 if early:
                     # probed HERE, before the first launch of the step: a layer whose parameters are not one aligned range
                     # of the flat buffer falls back to the single end-of-step launch instead of failing mid-step
@@ -399,7 +400,7 @@ class HipTrainer:
             if hasattr(plan, "train_pitch"):
                 Dp = plan.train_pitch(D, M)        # 320 for the transformer denoiser at training batch sizes (plans._train_pad)
             else:
-                Dp = D if os.environ.get("IB_NO_PAD") else (D + 7) // 8 * 8
+                Dp = D if TU.no_pad else (D + 7) // 8 * 8
             # zeroed once at creation: the pad columns are operands of the padded projections and never written otherwise
             xt = plan.buf.get("tr.xt", (M, Dp), dt, zero=True)[:, :D]
             pred = plan.buf.get("tr.pred", (M, Dp), dt, zero=True)[:, :D]
@@ -423,7 +424,7 @@ class HipTrainer:
             else:
                 hip.concat_keys([st[f"in{i}"] for i in range(len(INPUT_KEY_ORDER))], x)
             if hasattr(plan, "fuse_reduce_into_optimizer"):
-                plan.fuse_reduce_into_optimizer = not self.ddp and not os.environ.get("IB_NO_OPT_FUSE")
+                plan.fuse_reduce_into_optimizer = not self.ddp and not TU.no_opt_fuse
             if hasattr(m, "output_frames_for"):
                 # Groundlink: [B, F', 30] with the four outputs interleaved per frame; the dropout masks are keyed on
                 # the device-resident step counter, so a replayed graph draws fresh masks every step
@@ -532,7 +533,7 @@ class HipTrainer:
                 # chain path: the kernels read the batch through device pointer slots, so a batch that already lies
                 # in HBM in the right dtype is consumed in place (the staging copies were ~15 us of a 0.25 ms step)
                 inplace = self._zero_copy and src.is_cuda and src.device == b.device and src.dtype == d \
-                    and src.is_contiguous() and src.data_ptr() % 16 == 0 and not os.environ.get("IB_NO_ZERO_COPY")
+                    and src.is_contiguous() and src.data_ptr() % 16 == 0 and not TU.no_zero_copy
                 if not inplace:
                     b.copy_(src, non_blocking=True)
                 srcs.append(src if inplace else b)
@@ -703,7 +704,7 @@ class HipTrainer:
         # second appearance such a batch gets a graph of its own that reads the caller's tensors where they lie -- the 14
         # staging copies per step (10 input keys + 4 labels, each a tiny D2D launch issued by the host: ~45 us of the 0.12-ms
         # fp32 reference-shape step) disappear.  Anything else is staged into the static buffers as before.
-        if self.use_graph and self._rec is not None and not os.environ.get("IB_NO_PINNED_GRAPHS") \
+        if self.use_graph and self._rec is not None and not TU.no_pinned_graphs \
                 and not (self.ddp and os.environ.get("IB_GRAPH_COLLECTIVES") == "1"):
             d = self._dict_batch_direct(batch)
             if d is not None:
@@ -747,7 +748,7 @@ class HipTrainer:
             # those pointers for good -- no per-step pointer-update launch ahead of the graph (~5 us of a 0.24 ms step).
             pin = self._pinned.get(key) if key is not None else None
             if pin is None and key is not None and len(self._pinned) < self.MAX_PINNED_GRAPHS \
-                    and not os.environ.get("IB_NO_PINNED_GRAPHS"):
+                    and not TU.no_pinned_graphs:
                 n = self._seen.get(key, 0) + 1
                 if len(self._seen) < 4096 or key in self._seen:
                     self._seen[key] = n
@@ -790,7 +791,7 @@ class HipTrainer:
             for batch in batches:
                 self._srcs = None
                 st = self._stage(batch)
-                if self._slots is None or self._srcs is None or os.environ.get("IB_NO_PINNED_GRAPHS"):
+                if self._slots is None or self._srcs is None or TU.no_pinned_graphs:
                     break
                 key = tuple(t.data_ptr() for t in self._srcs)
                 if key in self._pinned or len(self._pinned) >= self.MAX_PINNED_GRAPHS:

@@ -113,6 +113,10 @@ _SIGS = {
     "ib_ffn_chain_pack": (_c.c_int, [_vp] * 9 + [_c.c_int, _i64, _i64, _vp]),
     "ib_ffn_chain_fwd": (_c.c_int, [_vp] * 23 + [_i64, _i64, _i64, _f32, _vp]),
     "ib_ffn_chain_bwd": (_c.c_int, [_vp] * 20 + [_i64, _i64, _i64, _vp]),
+    "ib_ffn_chain_attn_workgroups": (_c.c_int, [_i64, _i64, _i64, _i64]),
+    "ib_ffn_chain_attn_mask_bytes": (_sz, [_i64, _i64, _i64, _i64]),
+    "ib_ffn_chain_fwd_attn": (_c.c_int, [_vp] * 25 + [_i64, _i64, _i64, _i64, _f32, _vp]),
+    "ib_ffn_chain_bwd_attn": (_c.c_int, [_vp] * 19 + [_i64, _i64, _i64, _i64, _vp]),
     "ib_sqdiff_mean": (_c.c_int, [_vp, _vp, _vp, _i64, _i64, _c.c_int, _vp]),
     "ib_sqdiff_mean_bwd": (_c.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _c.c_int, _vp]),
     "ib_mask_by_threes": (_c.c_int, [_vp, _vp, _i64, _f32, _c.c_int, _vp]),
@@ -1401,11 +1405,16 @@ def ffn_chain_packed_elems(d: int, ffn: int) -> int:
     return int(lib().ib_ffn_chain_packed_elems(int(d), int(ffn)))
 
 
-def ffn_chain_workgroups(M: int, d: int, ffn: int) -> int:
+def ffn_chain_workgroups(M: int, d: int, ffn: int, T: int = 0) -> int:
+    """T > 0: the launches with the attention inside (panels of exactly one window of T frames); 0 = not supported"""
+    if T:
+        return int(lib().ib_ffn_chain_attn_workgroups(int(M), int(d), int(ffn), int(T)))
     return int(lib().ib_ffn_chain_workgroups(int(M), int(d), int(ffn), None))
 
 
-def ffn_chain_mask_bytes(M: int, d: int, ffn: int) -> int:
+def ffn_chain_mask_bytes(M: int, d: int, ffn: int, T: int = 0) -> int:
+    if T:
+        return int(lib().ib_ffn_chain_attn_mask_bytes(int(M), int(d), int(ffn), int(T)))
     return int(lib().ib_ffn_chain_mask_bytes(int(M), int(d), int(ffn)))
 
 
@@ -1453,8 +1462,12 @@ def _ffn_vec(t, name, n):
 
 
 def ffn_chain_fwd(x1, packed, b1, b2, gamma, beta, f1, s2, y, mean, rstd, mask, eps: float = 1e-5, attn_out=None,
-                  qkv_next=None):
-    """attn_out = (attn [M, d], bo, gamma1, beta1, s1, x1_out, mean1, rstd1): the attention epilogue -- `x1` is then the layer
+                  qkv_next=None, attn_next=None, panel_T: int = 0):
+    """panel_T > 0: panels of exactly one window of panel_T frames (`mask` sized with ffn_chain_mask_bytes(.., panel_T)) --
+    the geometry of a layer whose attention rides inside its launches, in both directions.
+    attn_next = (attn_out_next [M, d], lse_next fp32 [M / T, 8, T], T): the NEXT layer's attention core rides behind the
+    QKV tail (needs qkv_next; T = panel_T).
+    attn_out = (attn [M, d], bo, gamma1, beta1, s1, x1_out, mean1, rstd1): the attention epilogue -- `x1` is then the layer
     input x and x1_out = LN1(x + attn Wo^T + bo) is computed (and stored) here.
     qkv_next = (packed image of the NEXT layer, its in-projection bias fp32 [3 d], qkv_out [M, 3 d]): that layer's
     in-projection of y rides behind LayerNorm2 (needs attn_out)"""
@@ -1466,7 +1479,23 @@ def ffn_chain_fwd(x1, packed, b1, b2, gamma, beta, f1, s2, y, mean, rstd, mask, 
         _ffn_vec(t, n, w)
     _req(packed, "packed", torch.bfloat16, 1)
     _req(mask, "mask", torch.uint8, 1)
-    if packed.numel() < ffn_chain_packed_elems(d, ffn) or mask.numel() < ffn_chain_mask_bytes(M, d, ffn):
+    global _work_note
+    if isinstance(_lib, _RecordingLib):
+        # algorithmic work of THIS launch form (bench.py's roofline leg): the token-local GEMMs it contains (out-projection
+        # d^2, feed-forward 2 d ffn, the next layer's in-projection 3 d^2 per row) + 4 T d per row of attention; bytes = what
+        # must cross HBM: rows in (x, attn), rows out (x1, s1, s2, y; f1; qkv, attn_next), the packed images once
+        mac = 2 * d * ffn + (d * d if attn_out is not None else 0) + (3 * d * d if qkv_next is not None else 0)
+        Tn = int(attn_next[2]) if attn_next is not None else 0
+        rows = (6 if attn_out is not None else 3) * d + ffn + (3 * d if qkv_next is not None else 0) + (d if Tn else 0)
+        _work_note = (2 * M * mac + 4 * M * Tn * d, 2 * M * rows + 2 * mac,
+                      {"M": M, "d": d, "ffn": ffn, "out_proj": attn_out is not None, "qkv_tail": qkv_next is not None,
+                       "attention_T": Tn, "panel_T": int(panel_T)})
+    T_att = int(attn_next[2]) if attn_next is not None else int(panel_T)
+    if panel_T and T_att != int(panel_T):
+        raise HipError("ffn_chain_fwd: attn_next's T must equal panel_T")
+    if T_att and not ffn_chain_workgroups(M, d, ffn, T_att):
+        raise HipError(f"ffn_chain_fwd: no one-window panels for M = {M}, T = {T_att} (16 <= T <= 64, M % T == 0)")
+    if packed.numel() < ffn_chain_packed_elems(d, ffn) or mask.numel() < ffn_chain_mask_bytes(M, d, ffn, T_att):
         raise HipError("ffn_chain_fwd: packed image / mask buffer too small")
     extra = [None] * 8
     if attn_out is not None:
@@ -1487,14 +1516,32 @@ def ffn_chain_fwd(x1, packed, b1, b2, gamma, beta, f1, s2, y, mean, rstd, mask, 
         if pk_n.numel() < ffn_chain_packed_elems(d, ffn):
             raise HipError("ffn_chain_fwd: packed image of the next layer too small")
         tail = [_ptr(pk_n), _ptr(bq), _ptr(qo)]
+    if T_att:
+        ao = lse = None
+        if attn_next is not None:
+            ao, lse, _ = attn_next
+            if qkv_next is None:
+                raise HipError("ffn_chain_fwd: the attention tail needs the QKV tail")
+            _ffn_rows(ao, "attn_next", M, d)
+            _req(lse, "lse_next", torch.float32)
+            if lse.numel() != (M // T_att) * 8 * T_att or not lse.is_contiguous() or d != 512:
+                raise HipError("ffn_chain_fwd: lse_next must be contiguous fp32 [M / T, 8, T] (d = 512: eight heads of 64)")
+        _check(lib().ib_ffn_chain_fwd_attn(_ptr(x1), _ptr(packed), _ptr(b1), _ptr(b2), _ptr(gamma), _ptr(beta), _ptr(f1),
+                                           _ptr(s2), _ptr(y), _ptr(mean), _ptr(rstd), _ptr(mask), *extra, *tail, _ptr(ao),
+                                           _ptr(lse), T_att, M, d, ffn, float(eps), stream_ptr()), "ib_ffn_chain_fwd_attn")
+        return y
     _check(lib().ib_ffn_chain_fwd(_ptr(x1), _ptr(packed), _ptr(b1), _ptr(b2), _ptr(gamma), _ptr(beta), _ptr(f1), _ptr(s2),
                                   _ptr(y), _ptr(mean), _ptr(rstd), _ptr(mask), *extra, *tail, M, d, ffn, float(eps),
                                   stream_ptr()), "ib_ffn_chain_fwd")
     return y
 
 
-def ffn_chain_bwd(dy, s2, mean, rstd, gamma, packed, mask, ds2, dz1, dx1, partial, attn_out=None, qkv_head=None):
-    """attn_out = (s1, mean1, rstd1, gamma1, ds1, dattn): LayerNorm1 backward + the out-projection's dgrad in the same launch
+def ffn_chain_bwd(dy, s2, mean, rstd, gamma, packed, mask, ds2, dz1, dx1, partial, attn_out=None, qkv_head=None,
+                  attn_bwd=None):
+    """attn_bwd = (qkv [M, 3 d], lse fp32 [M / T, 8, T], dqkv [M, 3 d], dx [M, d], T): the launch continues through this
+    layer's attention backward and in-projection dgrad (needs attn_out, whose dattn entry may be None: it is not stored;
+    no qkv_head; mask / partial sized for the one-window panels: ffn_chain_workgroups(.., T)).
+    attn_out = (s1, mean1, rstd1, gamma1, ds1, dattn): LayerNorm1 backward + the out-projection's dgrad in the same launch
     (dx1 may then be None: it is not stored); partial: fp32 [2 x workgroups, d], or [4 x workgroups, d] with attn_out.
     qkv_head = (packed image of the NEXT layer, dqkv_next [M, 3 d], ds1_next [M, d]): dy is computed in front of
     LayerNorm2's backward = dqkv_next . Wqkv_next + ds1_next (dy may then be None; needs attn_out)"""
@@ -1505,17 +1552,30 @@ def ffn_chain_bwd(dy, s2, mean, rstd, gamma, packed, mask, ds2, dz1, dx1, partia
         _ffn_rows(t, n, M, w)
     _req(partial, "partial", torch.float32, 2)
     nq = 4 if attn_out is not None else 2
-    if tuple(partial.shape) != (nq * ffn_chain_workgroups(M, d, ffn), d) or not partial.is_contiguous():
+    T_att = int(attn_bwd[4]) if attn_bwd is not None else 0
+    global _work_note
+    if isinstance(_lib, _RecordingLib):
+        # dgrad GEMMs of this launch form: feed-forward 2 d ffn, out-projection d^2, in-projection 3 d^2 (own, behind the
+        # attention backward, or the next layer's in front) per row + 10 T d per row of attention backward (recompute of
+        # S and dP twice, dQ, dK, dV); bytes: rows in (dy | dqkv + ds1, s2, s1; qkv), rows out (ds2, ds1; dz1; dqkv, dx | dattn)
+        mac = 2 * d * ffn + (d * d if attn_out is not None else 0) + (3 * d * d if (qkv_head is not None or T_att) else 0)
+        rows = (5 if attn_out is not None else 4) * d + ffn + (3 * d if qkv_head is not None else 0) + ((7 * d) if T_att else (d if attn_out is not None else 0))
+        _work_note = (2 * M * mac + 10 * M * T_att * d, 2 * M * rows + 2 * mac,
+                      {"M": M, "d": d, "ffn": ffn, "out_proj": attn_out is not None, "qkv_head": qkv_head is not None,
+                       "attention_T": T_att})
+    if T_att and not ffn_chain_workgroups(M, d, ffn, T_att):
+        raise HipError(f"ffn_chain_bwd: no one-window panels for M = {M}, T = {T_att} (16 <= T <= 64, M % T == 0)")
+    if tuple(partial.shape) != (nq * ffn_chain_workgroups(M, d, ffn, T_att), d) or not partial.is_contiguous():
         raise HipError(f"ffn_chain_bwd: partial must be contiguous fp32 [{nq} x workgroups, d]")
     for t, n, w in ((mean, "mean", M), (rstd, "rstd", M), (gamma, "gamma", d)):
         _ffn_vec(t, n, w)
     _req(mask, "mask", torch.uint8, 1)
-    if packed.numel() < ffn_chain_packed_elems(d, ffn) or mask.numel() < ffn_chain_mask_bytes(M, d, ffn):
+    if packed.numel() < ffn_chain_packed_elems(d, ffn) or mask.numel() < ffn_chain_mask_bytes(M, d, ffn, T_att):
         raise HipError("ffn_chain_bwd: packed image / mask buffer too small")
     extra = [None] * 6
     if attn_out is not None:
         s1, m1, r1, g1, ds1, dattn = attn_out
-        for t, n in ((s1, "s1"), (ds1, "ds1"), (dattn, "dattn")):
+        for t, n in ((s1, "s1"), (ds1, "ds1")) + (((dattn, "dattn"),) if not (T_att and dattn is None) else ()):
             _ffn_rows(t, n, M, d)
         for t, n, w in ((m1, "mean1", M), (r1, "rstd1", M), (g1, "gamma1", d)):
             _ffn_vec(t, n, w)
@@ -1535,6 +1595,20 @@ def ffn_chain_bwd(dy, s2, mean, rstd, gamma, packed, mask, ds2, dz1, dx1, partia
         head = [_ptr(pk_n), _ptr(dq), _ptr(ds1n)]
     elif dy is None:
         raise HipError("ffn_chain_bwd: dy is required without the QKV head")
+    if attn_bwd is not None:
+        qkv, lse, dqkv, dx, _ = attn_bwd
+        if attn_out is None or qkv_head is not None or d != 512:
+            raise HipError("ffn_chain_bwd: the attention tail needs the attention epilogue, no QKV head and d = 512")
+        _ffn_rows(qkv, "qkv", M, 3 * d)
+        _ffn_rows(dqkv, "dqkv", M, 3 * d)
+        _ffn_rows(dx, "dx", M, d)
+        _req(lse, "lse", torch.float32)
+        if lse.numel() != (M // T_att) * 8 * T_att or not lse.is_contiguous():
+            raise HipError("ffn_chain_bwd: lse must be contiguous fp32 [M / T, 8, T]")
+        _check(lib().ib_ffn_chain_bwd_attn(_ptr(dy), _ptr(s2), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(packed), _ptr(mask),
+                                           _ptr(ds2), _ptr(dz1), _ptr(partial), *extra[:5], _ptr(qkv), _ptr(lse), _ptr(dqkv),
+                                           _ptr(dx), T_att, M, d, ffn, stream_ptr()), "ib_ffn_chain_bwd_attn")
+        return dx
     _check(lib().ib_ffn_chain_bwd(_ptr(dy), _ptr(s2), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(packed), _ptr(mask), _ptr(ds2),
                                   _ptr(dz1), _ptr(dx1), _ptr(partial), *extra, *head, M, d, ffn, stream_ptr()),
            "ib_ffn_chain_bwd")
@@ -1879,7 +1953,8 @@ def mlp_chain_train(x0, eps, t, sqrt_ab, sqrt_1mab, e, packed, bias, gamma, beta
     M, L = B * T, len(h)
     H = h[0].shape[1]
     u = [None] * L if u is None else list(u)
-    if any(a is None for a in u) and (L > 2 or os.environ.get("IB_CHAIN_V1")):
+    from ._tuning import tuning as TU
+    if any(a is None for a in u) and (L > 2 or TU.chain_v1):
         raise HipError("mlp_chain_train: u buffers are optional only for L <= 2 (pre-activations kept in registers)")
     _req(t, "t", torch.int64, 1); _req(sqrt_ab, "sqrt_ab", torch.float32, 1); _req(sqrt_1mab, "sqrt_1mab", torch.float32, 1)
     er, ec, lde = _mat(e, "e", bt)

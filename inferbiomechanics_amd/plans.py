@@ -22,6 +22,7 @@ from typing import Callable, Dict, List, Optional, Sequence, Tuple
 import torch
 
 from . import hip
+from ._tuning import tuning as TU
 
 
 
@@ -94,7 +95,7 @@ class Branch:
     def __init__(self, device, enabled: bool = True, name: str = ""):
         import os
         self.name = name
-        off = [n for n in os.environ.get("IB_NO_BRANCH", "").split(",") if n]
+        off = [n for n in TU.no_branch.split(",") if n]
         enabled = enabled and name not in off and "all" not in off
         self.on = enabled and torch.device(device).type == "cuda" and not hip._dry_run
         self.stream = torch.cuda.Stream(device=device) if self.on else None
@@ -168,7 +169,7 @@ def _wgrad_group(buf: Buffers, problems, defer: list, later: Optional[list] = No
     ns = [None] * len(items)
     parts = [None] * len(items)
     if 1 < len(grp) <= 6:
-        if later is not None and not os.environ.get("IB_NO_WGRAD_BIAS"):
+        if later is not None and not TU.no_wgrad_bias:
             for i in grp:
                 if len(problems[i]) > 4 and problems[i][4] is not None:
                     parts[i] = buf.get(problems[i][3] + ".bpart", (32, items[i][0].shape[1]), torch.float32)
@@ -531,8 +532,8 @@ class TransformerLayerPlan:
         # end of the whole backward).  Everything else runs them inline: as separate launches on a side stream they were
         # slower (3.059 vs 3.123 ms with the round-1 kernels), and a data-parallel layer joins right away for its bucket.
         # IB_LAYER_BRANCH=1 forces the side stream for every shape, IB_NO_LAYER_BRANCH=1 forces inline.
-        self.branch = Branch(device, enabled=not os.environ.get("IB_NO_LAYER_BRANCH"), name="layer")
-        self._always_fork = bool(os.environ.get("IB_LAYER_BRANCH"))
+        self.branch = Branch(device, enabled=not TU.no_layer_branch, name="layer")
+        self._always_fork = bool(TU.layer_branch)
         # transposed bf16 copies of the four weight matrices: the dgrad GEMMs of large batches read them k-contiguously
         # (ib_linear_dgrad_wt -> the 256 x 128 LDS-DMA kernel of csrc/gemm_nt.hip); refreshed once per forward
         self._wt: Dict[str, torch.Tensor] = {}
@@ -578,12 +579,12 @@ class TransformerLayerPlan:
         """[(weight, its transposed copy)] to refresh before a training forward, or [] when the large-M dgrad path does not
         apply (fp32 parity mode, inference, small token counts)"""
         self._wt_fresh = False
-        if self.dtype != torch.bfloat16 or self.inference or M < 4096 or os.environ.get("IB_NO_NT"):
+        if self.dtype != torch.bfloat16 or self.inference or M < 4096 or TU.no_nt:
             return []
         pairs = []
         skip = ("feedforward.2.weight", "feedforward.0.weight", "multihead_attention.out_proj.weight") if self.ffn_fused(M) else ()
         if skip and self.qkv_dgrad_below is not None and self.qkv_dgrad_below.ffn_fused(M) \
-                and not os.environ.get("IB_NO_QKV_FUSE"):
+                and not TU.no_qkv_fuse:
             skip = skip + ("multihead_attention.in_proj_weight",)
         for n in self.WT_NAMES:
             if n in skip:          # the fused feed-forward sublayer streams its own packed images (ffn_pack_item)
@@ -601,20 +602,38 @@ class TransformerLayerPlan:
         ONE launch each (csrc/ffn_chain.hip): bf16 training at chip-filling token counts, d = 512, a hidden width of whole
         512-column chunks, no dropout between the Linears and the residuals"""
         return (self.dtype == torch.bfloat16 and not self.inference and M >= 4096 and self.drop_p == 0.0
-                and not os.environ.get("IB_NO_FFN_CHAIN") and not os.environ.get("IB_NO_NT")
+                and not TU.no_ffn_chain and not TU.no_nt
                 and hip.ffn_chain_supported(self.d, self.ffn))
 
+    def attn_T(self, M: int, T: int) -> int:
+        """T when the attention core rides INSIDE the layer's fused launches (round 5; csrc/ffn_chain.h): the panels are then
+        exactly one window of T frames (16 <= T <= 64) whose eight 64-column heads belong to the eight waves -- forward
+        attention of the layer above behind the QKV tail, this layer's attention backward + in-projection dgrad behind the
+        out-projection's dgrad: the whole layer is one launch per direction.  0: the token-count panels, separate
+        attention launches."""
+        if (self.ffn_fused(M) and not TU.no_attn_fuse and not TU.no_qkv_fuse and self.d == 512 and self.h == 8
+                and 16 <= T <= 64 and M % T == 0 and hip.ffn_chain_workgroups(M, self.d, self.ffn, T) > 0):
+            return T
+        return 0
+
     def tail_active(self, M: int, training: bool = False) -> bool:
-        """this layer's fused forward launch also computes the in-projection of the layer above"""
+        """this layer's fused forward launch also computes the in-projection of the layer above (both packed images are
+        addressed with one chunk count: the two layers must have the same hidden width)"""
         nxt = self.qkv_tail_for
-        return (nxt is not None and self.ffn_fused(M) and nxt.ffn_fused(M) and not os.environ.get("IB_NO_QKV_FUSE")
+        return (nxt is not None and self.ffn_fused(M) and nxt.ffn_fused(M) and not TU.no_qkv_fuse and nxt.ffn == self.ffn
                 and not (training and (self.drop_p > 0.0 or nxt.drop_p > 0.0)))
+
+    def attn_tail_active(self, M: int, T: int, training: bool = False) -> bool:
+        """... and that layer's attention core behind it"""
+        nxt = self.qkv_tail_for
+        return bool(self.tail_active(M, training) and self.attn_T(M, T) and nxt.attn_T(M, T) and nxt.h == self.h)
 
     def head_active(self, M: int) -> bool:
         """this layer's in-projection dgrad (+ residual addend) is computed by the fused backward launch of the layer below"""
         low = self.qkv_dgrad_below
-        return (low is not None and self.ffn_fused(M) and low.ffn_fused(M) and not os.environ.get("IB_NO_QKV_FUSE")
-                and getattr(self, "_ffn_fused", False) and getattr(low, "_ffn_fused", False))
+        return (low is not None and self.ffn_fused(M) and low.ffn_fused(M) and not TU.no_qkv_fuse and low.ffn == self.ffn
+                and getattr(self, "_ffn_fused", False) and getattr(low, "_ffn_fused", False)
+                and not getattr(self, "_att_T", 0))
 
     def ffn_pack_item(self, P: ParamSource, M: int):
         """(feedforward.0.weight, feedforward.2.weight, this layer's packed image) for ib_ffn_chain_pack -- refreshed once
@@ -628,6 +647,10 @@ class TransformerLayerPlan:
     def qkv_buffer(self, B: int, T: int) -> torch.Tensor:
         return self.buf.get(self.tag + ".qkv", (B, T, 3 * self.d), self.dtype)
 
+    def attn_buffers(self, B: int, T: int):
+        return (self.buf.get(self.tag + ".attn", (B, T, self.d), self.dtype),
+                self.buf.get(self.tag + ".lse", (B, self.h, T), torch.float32))
+
     def packed_image(self) -> torch.Tensor:
         return self.buf.get(self.tag + ".ffnpk", (hip.ffn_chain_packed_elems(self.d, self.ffn),), self.dtype)
 
@@ -638,8 +661,10 @@ class TransformerLayerPlan:
         hip.linear_dgrad(dz, P.w(self.p + wname), dx, act_below=act_below, aux=aux, addend=addend)
 
     def forward(self, x3: torch.Tensor, P: ParamSource, out: Optional[torch.Tensor] = None, training: bool = False,
-                step: int = 0, step_dev: Optional[torch.Tensor] = None, qkv_ready: bool = False) -> torch.Tensor:
-        """qkv_ready: the layer below already wrote this layer's in-projection into `qkv_buffer` (its fused launch's tail)"""
+                step: int = 0, step_dev: Optional[torch.Tensor] = None, qkv_ready: bool = False,
+                attn_ready: bool = False) -> torch.Tensor:
+        """qkv_ready: the layer below already wrote this layer's in-projection into `qkv_buffer` (its fused launch's tail);
+        attn_ready: ... and this layer's attention output + row log-sum-exp (`attn_buffers`) behind it"""
         B, T, d = x3.shape
         M = B * T
         g, dt, p, tg = self.buf.get, self.dtype, self.p, self.tag
@@ -660,18 +685,18 @@ class TransformerLayerPlan:
         if not qkv_ready:
             nc = self.ffn // 512
             if not (self.inference and self.infer_packed and d == 512 and dt == torch.bfloat16
-                    and not os.environ.get("IB_NO_QKV_PANEL") and M <= int(os.environ.get("IB_QKV_PANEL_MAX_M", "1600"))
+                    and not TU.no_qkv_panel and M <= TU.qkv_panel_max_m
                     and hip.linear_panel_fwd(x, self.packed_image()[(4 * nc + 2) * 512 * 512:(4 * nc + 5) * 512 * 512],
                                              P.v(p + "multihead_attention.in_proj_bias"), qkv.view(M, 3 * d))):
                 hip.linear_fwd(x, P.w(p + "multihead_attention.in_proj_weight"), P.v(p + "multihead_attention.in_proj_bias"),
                                qkv.view(M, 3 * d))
-        attn = g(tg + ".attn", (B, T, d), dt)
-        lse = g(tg + ".lse", (B, self.h, T), torch.float32)
-        hip.attention_fwd(qkv, attn, lse, self.h, drop=drop)
+        attn, lse = self.attn_buffers(B, T)
+        if not attn_ready:
+            hip.attention_fwd(qkv, attn, lse, self.h, drop=drop)
         x1 = g(tg + ".x1", (M, d), dt)
         x2 = out if out is not None else g(tg + ".x2", (B, T, d), dt)
         f1 = g(tg + ".f1", (M, self.ffn), dt)
-        fuse = self.inference and dt == torch.bfloat16 and not os.environ.get("IB_NO_LINEAR_LN")
+        fuse = self.inference and dt == torch.bfloat16 and not TU.no_linear_ln
 
         def lin_ln(inp, wname, bname, nname, res, y, wtag):
             """Linear -> +res -> LayerNorm as one K-split GEMM + fused reduction (small M); False = not applicable"""
@@ -681,9 +706,9 @@ class TransformerLayerPlan:
             # B = 2 / 4 / 8 +4 / +6 / +2 % steps/s; M = 3200: -6 % on the ring kernel).  Round 3: from 640 rows the GEMM of
             # the fused form is the 256 x 128 kernel in split-K form (ib_gemm_nt_splitk): K = 2048 31.2 -> 24.0 us at
             # M = 3200, B = 4 / 8 / 16 +7.5 / +8 / +7 % steps/s; K = 512 fused now pays up to M < 4096 too (+1-2 %)
-            if w.shape[1] < 512 or (w.shape[1] < 1024 and M > int(os.environ.get("IB_LINLN_K512_MAX_M", "4095"))):
+            if w.shape[1] < 512 or (w.shape[1] < 1024 and M > TU.linln_k512_max_m):
                 return False
-            if M >= int(os.environ.get("IB_LINLN_MAX_M", "4096")) and not os.environ.get("IB_NO_NT"):
+            if M >= TU.linln_max_m and not TU.no_nt:
                 return False           # large batches fill the chip without a K split: the 256 x 128 NT kernel + LayerNorm
                                        # (M = 51200: 120 + 30 us against 235 us fused)
             ws = self.buf.bytes(tg + wtag, int(hip.lib().ib_linear_ln_fwd_workspace(M, w.shape[0], w.shape[1])))
@@ -691,28 +716,35 @@ class TransformerLayerPlan:
 
         a = m1 = r1 = f2 = m2 = r2 = None
         self._ffn_fused = ffn_fused
+        # one-window panels in BOTH directions of this layer (the ReLU bit words are laid out per panel)
+        Ta = self._att_T = self.attn_T(M, T) if ffn_fused else 0
         if ffn_fused:
             # a / f2 of the context = the LayerNorm INPUTS x + o and x1 + f2 the kernel stores (its backward normalises
             # those; no `res`)
             a, f2 = g(tg + ".s1", (M, d), dt), g(tg + ".s2", (M, d), dt)
             m1, r1 = g(tg + ".m1", (M,), torch.float32), g(tg + ".r1", (M,), torch.float32)
             m2, r2 = g(tg + ".m2", (M,), torch.float32), g(tg + ".r2", (M,), torch.float32)
-            mask = self.buf.get(tg + ".ffnmask", (hip.ffn_chain_mask_bytes(M, d, self.ffn),), torch.uint8)
+            mask = self.buf.get(tg + ".ffnmask", (hip.ffn_chain_mask_bytes(M, d, self.ffn, Ta),), torch.uint8)
+            nxt = self.qkv_tail_for
+            att_next = None
+            if Ta and self.attn_tail_active(M, T, training):
+                na, nl = nxt.attn_buffers(B, T)
+                att_next = (na.view(M, d), nl, Ta)
             hip.ffn_chain_fwd(x, self.buf.get(tg + ".ffnpk", (hip.ffn_chain_packed_elems(d, self.ffn),), dt),
                               P.v(p + "feedforward.0.bias"), P.v(p + "feedforward.2.bias"), P.v(p + "norm2.weight"),
                               P.v(p + "norm2.bias"), f1, f2, x2.view(M, d), m2, r2, mask,
                               attn_out=(attn.view(M, d), P.v(p + "multihead_attention.out_proj.bias"),
                                         P.v(p + "norm1.weight"), P.v(p + "norm1.bias"), a, x1, m1, r1),
                               qkv_next=None if not self.tail_active(M, training) else
-                              (self.qkv_tail_for.packed_image(),
-                               P.v(self.qkv_tail_for.p + "multihead_attention.in_proj_bias"),
-                               self.qkv_tail_for.qkv_buffer(B, T).view(M, 3 * d)))
+                              (nxt.packed_image(), P.v(nxt.p + "multihead_attention.in_proj_bias"),
+                               nxt.qkv_buffer(B, T).view(M, 3 * d)),
+                              attn_next=att_next, panel_T=Ta)
             self.ctx = (x, qkv, attn, lse, a, x1, m1, r1, f1, f2, m2, r2, B, T, drop)
             return x2
         def panel_ln():
             """out-projection + residual + LayerNorm1 as one launch over row panels (sampler, frozen packed weights)"""
             if not (fuse and self.infer_packed and d == 512 and hip.linear_ln_panel_ok(M, d, d)
-                    and M <= int(os.environ.get("IB_LINLN_PANEL_MAX_M", "8192"))):
+                    and M <= TU.linln_panel_max_m):
                 return False
             nc = self.ffn // 512
             wo_img = self.packed_image()[4 * nc * 512 * 512:(4 * nc + 1) * 512 * 512]
@@ -729,9 +761,9 @@ class TransformerLayerPlan:
                 hip.dropout(a, a, self.drop_p, self.seed + 1, step, step_dev)
             m1, r1 = g(tg + ".m1", (M,), torch.float32), g(tg + ".r1", (M,), torch.float32)
             hip.layernorm_fwd(a, P.v(p + "norm1.weight"), P.v(p + "norm1.bias"), x1, m1, r1, res=x)
-        if (fuse and self.infer_packed and d == 512 and not os.environ.get("IB_NO_FFN_INFER")
+        if (fuse and self.infer_packed and d == 512 and not TU.no_ffn_infer
                 and hip.ffn_infer_panels(M, d, self.ffn) and x2.is_contiguous()
-                and M <= int(os.environ.get("IB_FFN_INFER_MAX_M", "8192"))):
+                and M <= TU.ffn_infer_max_m):
             # the feed-forward sublayer: a panel of rows is shared by the workgroups of its hidden chunks (both GEMMs, the
             # hidden activation stays in LDS), the slab-reduction LayerNorm launch finishes it (csrc/linln_panel.hip)
             ws = self.buf.bytes(tg + ".ffws", int(hip.lib().ib_ffn_infer_workspace(M, d, self.ffn)))
@@ -773,10 +805,10 @@ class TransformerLayerPlan:
         # matrix of the layer finished by ONE reduction launch at the end of the layer (before the layer's bucket is
         # all-reduced) instead of a slab reduction per weight and two column-sum launches per bias
         local = defer is None and dt == torch.bfloat16 and M >= 4096 and not accumulate \
-            and not os.environ.get("IB_NO_LAYER_GROUP")
+            and not TU.no_layer_group
         if local:
             defer, later = [], []
-        group = [] if (defer is not None and dt == torch.bfloat16 and not os.environ.get("IB_NO_LAYER_GROUP")) else None
+        group = [] if (defer is not None and dt == torch.bfloat16 and not TU.no_layer_group) else None
         lag = self.lag_group and self.parent_flushes and local and group is not None
         lag_names: List[str] = []
         if self.parent_flushes:       # gradients are reported ready by the parent, in its order, after its joins
@@ -836,13 +868,24 @@ class TransformerLayerPlan:
             # per-panel partial sums, finished with the layer's other partials.
             if later is None:
                 raise hip.HipError("fused feed-forward backward needs the deferred partial-sum path (bf16, M >= 4096)")
-            nwg = hip.ffn_chain_workgroups(M, d, self.ffn)
+            Ta = getattr(self, "_att_T", 0)
+            nwg = hip.ffn_chain_workgroups(M, d, self.ffn, Ta)
             part = self.buf.get(tg + ".ffnpart", (4 * nwg, d), torch.float32)
+            att_bwd = None
+            if Ta:
+                # the whole layer in this launch: attention backward + in-projection dgrad + residual addend behind the
+                # out-projection's dgrad (dattn never leaves the workgroup)
+                if qkv_head is not None:
+                    raise hip.HipError("TransformerLayerPlan.backward: a QKV head and the attention tail exclude each other")
+                dqkv = g(tg + ".dqkv", (B, T, 3 * d), dt)
+                dx_att = g(tg + ".dx", (B, T, d), dt)
+                att_bwd = (qkv.view(M, 3 * d), lse, dqkv.view(M, 3 * d), dx_att.view(M, d), Ta)
             hip.ffn_chain_bwd(None if qkv_head is not None else dx2.view(M, d), f2, m2, r2, P.v(p + "norm2.weight"),
                               self.buf.get(tg + ".ffnpk", (hip.ffn_chain_packed_elems(d, self.ffn),), dt),
-                              self.buf.get(tg + ".ffnmask", (hip.ffn_chain_mask_bytes(M, d, self.ffn),), torch.uint8),
+                              self.buf.get(tg + ".ffnmask", (hip.ffn_chain_mask_bytes(M, d, self.ffn, Ta),), torch.uint8),
                               ds2, dz1, None, part,
-                              attn_out=(a, m1, r1, P.v(p + "norm1.weight"), ds1, dattn.view(M, d)), qkv_head=qkv_head)
+                              attn_out=(a, m1, r1, P.v(p + "norm1.weight"), ds1, None if Ta else dattn.view(M, d)),
+                              qkv_head=qkv_head, attn_bwd=att_bwd)
             later.append((part[:nwg], nwg, P.g(p + "norm2.weight")))
             later.append((part[nwg:2 * nwg], nwg, P.g(p + "norm2.bias")))
             P.ready(p + "norm2.weight"); P.ready(p + "norm2.bias")
@@ -882,7 +925,8 @@ class TransformerLayerPlan:
             wgrad(da, attn.view(M, d), "multihead_attention.out_proj.weight", tg + ".wso",
                   bias=(tg + ".bo", "multihead_attention.out_proj.bias"))
         side(g_out)
-        if self.split_tail and group and fused_ffn and not lag and not os.environ.get("IB_NO_TAIL_SPLIT"):
+        att_done = fused_ffn and bool(getattr(self, "_att_T", 0))
+        if self.split_tail and group and fused_ffn and not lag and not TU.no_tail_split and not att_done:
             # the layer whose backward runs last has nothing behind it to hide its weight-gradient launch: the three
             # problems whose operands the fused launch has just written go off NOW, beside the attention backward and the
             # in-projection's dgrad (measured and dropped for the other layers, round 4: 5 + 10 slabs per weight instead
@@ -901,14 +945,17 @@ class TransformerLayerPlan:
         if not fused_ffn:
             self._dgrad(P, da, "multihead_attention.out_proj.weight", dattn.view(M, d))
         dqkv = g(tg + ".dqkv", (B, T, 3 * d), dt)
-        hip.attention_bwd(qkv, attn, dattn, lse, dqkv, self.h, drop=drop)
+        if not att_done:
+            hip.attention_bwd(qkv, attn, dattn, lse, dqkv, self.h, drop=drop)
         dq2 = dqkv.view(M, 3 * d)
 
         def g_in():
             wgrad(dq2, x, "multihead_attention.in_proj_weight", tg + ".wsi",
                   bias=(tg + ".bi", "multihead_attention.in_proj_bias"))
         side(g_in)
-        if self.head_active(M):
+        if att_done:
+            dx = g(tg + ".dx", (B, T, d), dt)      # written by the fused launch
+        elif self.head_active(M):
             dx = None                  # dq2 . Wqkv + ds1 is computed in front of the layer below's fused backward launch
             self.pending_head = (self.packed_image(), dq2, ds1)
         else:
@@ -949,7 +996,7 @@ class TimeMLPPlan:
 
     def fused_ok(self, table: torch.Tensor, P: ParamSource) -> bool:
         w1, w2 = P.w("time_mlp.0.weight"), P.w("time_mlp.2.weight")
-        return self.dtype == torch.bfloat16 and not os.environ.get("IB_NO_TIME_FUSE") \
+        return self.dtype == torch.bfloat16 and not TU.no_time_fuse \
             and hip.time_mlp_fwd_supported(table.shape[1], w1.shape[0], w2.shape[0])
 
     def forward(self, t: torch.Tensor, table: torch.Tensor, P: ParamSource, pack=None, slots=None) -> torch.Tensor:
@@ -999,7 +1046,7 @@ class TimeMLPPlan:
     def fused_bwd_ok(self, P: ParamSource, defer, accumulate) -> bool:
         """the one-launch backward of the hidden layer (csrc/chain.hip: ib_time_mlp_bwd) leaves fp32 partial slabs, so it
         needs a deferred reduction to hand them to (the step's optimizer / ib_step_reduce)"""
-        if self.dtype != torch.bfloat16 or defer is None or accumulate or os.environ.get("IB_NO_TIME_BWD_FUSE"):
+        if self.dtype != torch.bfloat16 or defer is None or accumulate or TU.no_time_bwd_fuse:
             return False
         w1, w2 = P.w("time_mlp.0.weight"), P.w("time_mlp.2.weight")
         return hip.time_mlp_bwd_supported(w1.shape[1], w1.shape[0], w2.shape[0])
@@ -1028,7 +1075,7 @@ class TimeMLPPlan:
         de = self._de(de32, de_lp)
         # one row per window: the few-row kernel (16 output columns per workgroup, the bias sums in the same launch);
         # shapes it does not take go through the tiled dgrad + a column-sum launch
-        fused = self.dtype == torch.bfloat16 and not os.environ.get("IB_NO_SKINNY") and \
+        fused = self.dtype == torch.bfloat16 and not TU.no_skinny and \
             hip.linear_dgrad_skinny(de, P.w("time_mlp.2.weight"), du, act_below="silu", aux=zu,
                                     dbias=P.g("time_mlp.0.bias"), accumulate=accumulate)
         if not fused:
@@ -1180,7 +1227,7 @@ class DenoiserMLPPlan:
 
     # ---- fused chain: q_sample + forward + loss + dgrad chain in ONE launch (csrc/chain.hip) ------------------
     def chain_ok(self, D: int) -> bool:
-        if os.environ.get("IB_NO_CHAIN") or self.dtype != torch.bfloat16 or not self.hidden:
+        if TU.no_chain or self.dtype != torch.bfloat16 or not self.hidden:
             return False
         H = self.hidden[0]
         return all(h == H for h in self.hidden) and hip.mlp_chain_supported(D, H, len(self.hidden))
@@ -1211,7 +1258,7 @@ class DenoiserMLPPlan:
         xt = g("ch.xt", (M, Dp), dt)[:, :D]
         dpred = g("ch.dpred", (M, Dp), dt)[:, :D]
         # the pre-activations stay in the chain kernel's registers (L <= 2); deeper stacks pass them through HBM
-        u = None if (L <= 2 and not os.environ.get("IB_CHAIN_V1")) else [g(f"ch.u{i}", (M, H), dt) for i in range(L)]
+        u = None if (L <= 2 and not TU.chain_v1) else [g(f"ch.u{i}", (M, H), dt) for i in range(L)]
         h = [g(f"ch.h{i}", (M, H), dt) for i in range(L)]
         dz = [g(f"ch.dz{i}", (M, H), dt) for i in range(L)]
         nwg = hip.mlp_chain_workgroups(M)
@@ -1229,7 +1276,7 @@ class DenoiserMLPPlan:
         # every gradient operand now sits in HBM.  Issue order = the order the graph's ready nodes get the machine:
         # the time-MLP backward first (a dependent chain of small launches; started late it becomes the step's tail),
         # then the large weight-gradient GEMMs, one branch each; the main stream does the small reductions.
-        defer = None if os.environ.get("IB_NO_DEFER") else []
+        defer = None if TU.no_defer else []
         de32 = None
         if not window_panels:
             de32 = g("dm.de32", (B, Hs), torch.float32)
@@ -1242,7 +1289,7 @@ class DenoiserMLPPlan:
         # (issued AFTER the grouped launch instead, the branch's first kernel only started when the grouped launch had
         # finished -- no overlap at all: 0.232 -> 0.250 ms/step)
         rider_ops = []
-        if os.environ.get("IB_SKIP_TIME_BWD") and hip.measurement_build():
+        if TU.skip_time_bwd and hip.measurement_build():
             # TIMING-ONLY (wrong gradients): an upper bound of what the time-MLP backward costs.  Honoured only while the
             # measurement build of the library is loaded (tools/, IB_HIP_LIB) -- the product ignores the variable
             if defer is not None and getattr(self, "_tb_defer", None):
@@ -1255,7 +1302,7 @@ class DenoiserMLPPlan:
                 # launch of their own on the main stream when that launch does not take them
                 rider_ops = []
                 self.time.backward_hidden(de32, de_lp, P, accumulate, defer=defer, ready=False,
-                                          rider=None if os.environ.get("IB_NO_TB_RIDER") else rider_ops)
+                                          rider=None if TU.no_tb_rider else rider_ops)
             else:
                 self.branch.run(lambda: self.time.backward_hidden(de32, de_lp, P, accumulate, defer=defer, ready=False))
             if defer is not None:
@@ -1336,7 +1383,7 @@ class DenoiserTransformerPlan:
     def flush_each_layer(self, on: bool):
         """overlapped data-parallel steps: keep the layers' side streams, hand completed gradient buckets to the trainer at
         every layer boundary (ParamSource.flush) instead of running the whole backward on one stream"""
-        lag = bool(on) and not os.environ.get("IB_NO_LAG_GROUP")
+        lag = bool(on) and not TU.no_lag_group
         for i, lp in enumerate(self.layers):
             lp.flush_on_exit = bool(on)
             lp.parent_flushes = lag
@@ -1382,14 +1429,14 @@ class DenoiserTransformerPlan:
         # few thousand rows, instead of a split-K GEMM into fp32 slabs + a reduction launch
         for lp in self.layers:
             lp.infer_packed = False
-        if (self.dtype == torch.bfloat16 and self.d == 512 and not os.environ.get("IB_NO_LINLN_PANEL")
+        if (self.dtype == torch.bfloat16 and self.d == 512 and not TU.no_linln_panel
                 and all(hip.ffn_chain_supported(self.d, lp.ffn) for lp in self.layers)):
             hip.ffn_chain_pack([(P.w(lp.p + "feedforward.0.weight"), P.w(lp.p + "feedforward.2.weight"), lp.packed_image(),
                                  P.w(lp.p + "multihead_attention.out_proj.weight"),
                                  P.w(lp.p + "multihead_attention.in_proj_weight")) for lp in self.layers])
             for lp in self.layers:
                 lp.infer_packed = True
-        if table is not None and not os.environ.get("IB_NO_TIME_TABLE"):
+        if table is not None and not TU.no_time_table:
             steps = table.shape[0]
             every_t = torch.arange(steps, dtype=torch.int64, device=table.device)
             e = self.time.forward(every_t, table, P)                                     # [steps, d] in the compute dtype
@@ -1406,9 +1453,9 @@ class DenoiserTransformerPlan:
         """row pitch (elements) of the trainer's D-wide activation buffers (x_t, prediction, dL/dprediction): D rounded up to
         64 when the padded projections below apply (bf16, the large-M kernels), else to 8 (16-byte aligned rows)"""
         if (self.dtype == torch.bfloat16 and M >= 4096 and D % 64 != 0
-                and not (os.environ.get("IB_NO_PAD") or os.environ.get("IB_NO_TRAIN_PAD") or os.environ.get("IB_NO_NT"))):
+                and not (TU.no_pad or TU.no_train_pad or TU.no_nt)):
             return (D + 63) // 64 * 64
-        return D if os.environ.get("IB_NO_PAD") else (D + 7) // 8 * 8
+        return D if TU.no_pad else (D + 7) // 8 * 8
 
     def _train_pad(self, M: int, D: int, x2: torch.Tensor, out: Optional[torch.Tensor]):
         """training step with pitched activation buffers (train_pitch): zero-padded copies of the D-wide projection weights,
@@ -1429,7 +1476,7 @@ class DenoiserTransformerPlan:
     def infer_pitch(D: int) -> int:
         """row pitch (elements) the sampler gives its state / noise buffers: D rounded up to 64 (the K step of the LDS-DMA
         kernels) unless IB_NO_PAD; the pad columns must be zero"""
-        return D if (os.environ.get("IB_NO_PAD") or D % 64 == 0) else (D + 63) // 64 * 64
+        return D if (TU.no_pad or D % 64 == 0) else (D + 63) // 64 * 64
 
     def branches(self) -> List[Branch]:
         return [lp.branch for lp in self.layers] + [self.br_time, self.br_thid, self.br_pos, self.br_wt]
@@ -1484,7 +1531,7 @@ class DenoiserTransformerPlan:
         # sampler with pitched buffers (prepare_inference): both projections over the padded width
         padded = (self.inference and self._pad is not None and out is not None and x2.dim() == 2 and out.dim() == 2
                   and x2.stride(0) == self._pad[0] and out.stride(0) == self._pad[0] and x2.stride(1) == 1
-                  and M >= int(os.environ.get("IB_PAD_MIN_M", "2560")))   # below: B = 4 / 8 -1.6 %, B = 16 / 32 +3 %
+                  and M >= TU.pad_min_m)   # below: B = 4 / 8 -1.6 %, B = 16 / 32 +3 %
         tp = None if self.inference else self._tp
         if padded:
             Kp, w_in_pad, w_out_pad, b_out_pad = self._pad
@@ -1499,10 +1546,11 @@ class DenoiserTransformerPlan:
         h = h0
         if ffn_items and not self.inference:
             self.br_wt.join()                         # layer 0's fused feed-forward sublayer reads the packed images
-        ready = False
+        ready = aready = False
         for lp in self.layers:
-            h = lp.forward(h, P, qkv_ready=ready)
+            h = lp.forward(h, P, qkv_ready=ready, attn_ready=aready)
             ready = (not self.inference) and lp.tail_active(M)       # it wrote the next layer's in-projection
+            aready = ready and bool(getattr(lp, "_att_T", 0)) and lp.attn_tail_active(M, T)   # ... and its attention output
         out = out if out is not None else g("dt.out", (B, T, D), dt)
         if padded:
             hip.linear_fwd(h.view(M, self.d), w_out_pad, b_out_pad, out.as_strided((M, Kp), (Kp, 1)))
@@ -1546,7 +1594,7 @@ class DenoiserTransformerPlan:
             P.ready("out_proj.weight")
             _colsum(self.buf, "dt.bo", dout, P.g("out_proj.bias"), accumulate)
             P.ready("out_proj.bias")
-        if fuse and not os.environ.get("IB_NO_OUTPROJ_BRANCH"):
+        if fuse and not TU.no_outproj_branch:
             self.br_wt.run(t_outproj)                 # joined with the tail's branches, before the optimizer
         else:
             t_outproj()                               # data parallel: the flush below hands this bucket to the all-reduce

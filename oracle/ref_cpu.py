@@ -237,16 +237,13 @@ def layer_norm(x: torch.Tensor, g: torch.Tensor, b: torch.Tensor, eps: float = 1
     return (x - mu) / torch.sqrt(var + eps) * g + b
 
 
-def mha_forward(x: torch.Tensor, in_w: torch.Tensor, in_b: torch.Tensor,
-                out_w: torch.Tensor, out_b: torch.Tensor, num_heads: int,
-                prob_mult: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """nn.MultiheadAttention(batch_first=True) self-attention, no mask
-    (TransformerBaseline.py:12-13,29): packed in-proj [3d,d], per-head
-    softmax(QK^T/sqrt(d_h))V, out-proj.  prob_mult [B,H,T,T] (train mode, dropout=p at :13): the
-    dropout multipliers (0 or 1/(1-p)) applied to the NORMALISED probabilities before P.V."""
-    B, T, d = x.shape
+def attention_core(qkv: torch.Tensor, num_heads: int, prob_mult: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """the core of nn.MultiheadAttention between its two projections (TransformerBaseline.py:12-13,29): qkv [B,T,3d]
+    (packed q | k | v) -> per-head softmax(QK^T/sqrt(d_h))V -> [B,T,d].  Split out of mha_forward so that a test can hold
+    a kernel's attention to the in-projection values the kernel itself stored."""
+    B, T, d3 = qkv.shape
+    d = d3 // 3
     dh = d // num_heads
-    qkv = linear(x, in_w, in_b)                                        # [B,T,3d]
     q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
     q = q.reshape(B, T, num_heads, dh).transpose(1, 2)                 # [B,H,T,dh]
     k = k.reshape(B, T, num_heads, dh).transpose(1, 2)
@@ -257,8 +254,18 @@ def mha_forward(x: torch.Tensor, in_w: torch.Tensor, in_b: torch.Tensor,
     p = p / p.sum(dim=-1, keepdim=True)
     if prob_mult is not None:
         p = p * prob_mult
-    o = (p @ v).transpose(1, 2).reshape(B, T, d)
-    return linear(o, out_w, out_b)
+    return (p @ v).transpose(1, 2).reshape(B, T, d)
+
+
+def mha_forward(x: torch.Tensor, in_w: torch.Tensor, in_b: torch.Tensor,
+                out_w: torch.Tensor, out_b: torch.Tensor, num_heads: int,
+                prob_mult: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """nn.MultiheadAttention(batch_first=True) self-attention, no mask
+    (TransformerBaseline.py:12-13,29): packed in-proj [3d,d], per-head
+    softmax(QK^T/sqrt(d_h))V, out-proj.  prob_mult [B,H,T,T] (train mode, dropout=p at :13): the
+    dropout multipliers (0 or 1/(1-p)) applied to the NORMALISED probabilities before P.V."""
+    qkv = linear(x, in_w, in_b)                                        # [B,T,3d]
+    return linear(attention_core(qkv, num_heads, prob_mult), out_w, out_b)
 
 
 TL_KEYS = [  # state_dict names of the reference TransformerLayer

@@ -4,6 +4,8 @@ bf16 storage points (weights, x_t, u, h, pred, dz are bf16 tensors).  Tolerance:
 import pytest
 import torch
 
+from inferbiomechanics_amd._tuning import tuning as TU
+
 pytestmark = pytest.mark.gpu
 
 from oracle import ref_cpu as R  # noqa: E402
@@ -250,9 +252,9 @@ def test_chain_trainer_tracks_per_op_trainer():
 
     def run(no_chain):
         if no_chain:
-            os.environ["IB_NO_CHAIN"] = "1"
+            TU.no_chain = True
         else:
-            os.environ.pop("IB_NO_CHAIN", None)
+            TU.no_chain = False
         try:
             torch.manual_seed(0)
             m = DiffusionMLP(300, [512, 512], compute_dtype=BF).to(DEV)
@@ -270,7 +272,7 @@ def test_chain_trainer_tracks_per_op_trainer():
                 losses.append(tr.loss_value())
             return losses, {k: v.detach().float().cpu() - p0[k] for k, v in m.state_dict().items()}
         finally:
-            os.environ.pop("IB_NO_CHAIN", None)
+            TU.no_chain = False
 
     la, pa = run(False)
     lb, pb = run(True)
@@ -293,9 +295,9 @@ def test_optimizer_sources_bitwise_equal_to_step_reduce():
 
     def run(fused):
         if fused:
-            os.environ.pop("IB_NO_OPT_FUSE", None)
+            TU.no_opt_fuse = False
         else:
-            os.environ["IB_NO_OPT_FUSE"] = "1"
+            TU.no_opt_fuse = True
         try:
             m = DiffusionMLP(300, [512, 512], compute_dtype=BF).to(DEV)
             sd = R.det_params(R.denoiser_mlp_param_shapes(300, [512, 512]), seed0=7.0)
@@ -311,7 +313,7 @@ def test_optimizer_sources_bitwise_equal_to_step_reduce():
                 losses.append(tr.loss_value())
             return losses, {k: v.detach().float().cpu() for k, v in m.state_dict().items()}
         finally:
-            os.environ.pop("IB_NO_OPT_FUSE", None)
+            TU.no_opt_fuse = False
 
     la, pa = run(True)
     lb, pb = run(False)
@@ -331,9 +333,9 @@ def test_zero_copy_batches_equal_staged_batches():
 
     def run(zero_copy):
         if zero_copy:
-            os.environ.pop("IB_NO_ZERO_COPY", None)
+            TU.no_zero_copy = False
         else:
-            os.environ["IB_NO_ZERO_COPY"] = "1"
+            TU.no_zero_copy = True
         try:
             m = DiffusionMLP(300, [512, 512], compute_dtype=BF).to(DEV)
             sd = R.det_params(R.denoiser_mlp_param_shapes(300, [512, 512]), seed0=9.0)
@@ -352,7 +354,7 @@ def test_zero_copy_batches_equal_staged_batches():
             assert tr._zero_copy                      # the chain path is active in both runs
             return losses
         finally:
-            os.environ.pop("IB_NO_ZERO_COPY", None)
+            TU.no_zero_copy = False
 
     la, lb = run(True), run(False)
     assert la == lb, (la, lb)

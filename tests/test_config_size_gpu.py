@@ -207,13 +207,18 @@ def test_bf16_loss_curve_at_headline_shape_tracks_fp32(kind, B, steps, win):
     assert f32[-1] < f32[0] and b16[-1] < b16[0]
 
 
-def test_transformer_large_batch_paths_match_oracle():
-    """M = B T = 6400 token rows: the sizes at which the 256 x 128 LDS-DMA kernels take over (forward + dgrad through
+@pytest.mark.parametrize("attn_inside", [True, False])
+def test_transformer_large_batch_paths_match_oracle(attn_inside, monkeypatch):
+    """attn_inside: the attention core inside the layers' fused launches (round 5: one-window panels, ib_ffn_chain_*_attn)
+    or as separate launches with the in-projection dgrad on the NT kernel.
+    M = B T = 6400 token rows: the sizes at which the 256 x 128 LDS-DMA kernels take over (forward + dgrad through
     csrc/gemm_nt.hip with transposed weight copies, weight gradients + bias partial sums through csrc/gemm_tn.hip, one
     ib_step_reduce_parts per layer) -- drop-in tier, 2 layers of the d = 512 / 8-head denoiser, bf16, against the float64
     oracle on the same bf16-rounded inputs"""
     from inferbiomechanics_amd.loss.DiffusionLossEvaluator import DiffusionLossEvaluator
     from inferbiomechanics_amd import hip
+    from inferbiomechanics_amd._tuning import tuning as TU
+    monkeypatch.setattr(TU, "no_attn_fuse", not attn_inside)
     T, B, layers, rt = 50, 128, 2, 6e-2
     model = make_transformer(T, torch.bfloat16, layers=layers, seed=21)
     g = torch.Generator().manual_seed(22)
@@ -224,7 +229,11 @@ def test_transformer_large_batch_paths_match_oracle():
         loss = DiffusionLossEvaluator()(pred, eps)
         loss.backward()
     names = {n for n, _ in rec.calls}
-    assert {"ib_linear_dgrad_wt", "ib_transpose_multi", "ib_linear_wgrad_slabs_multi_bias", "ib_step_reduce_parts"} <= names, names
+    assert {"ib_linear_wgrad_slabs_multi_bias", "ib_step_reduce_parts"} <= names, names
+    if attn_inside:
+        assert {"ib_ffn_chain_fwd_attn", "ib_ffn_chain_bwd_attn"} <= names and "ib_attention_bwd" not in names, names
+    else:
+        assert {"ib_linear_dgrad_wt", "ib_transpose_multi", "ib_attention_bwd", "ib_ffn_chain_fwd"} <= names, names
     p = oracle_params(model)
     pe = R.denoiser_transformer_forward(p, x.to(torch.bfloat16).double(), t, layers, HEADS)
     le = R.eps_mse(pe, eps.to(torch.bfloat16).double())

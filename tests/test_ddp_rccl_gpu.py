@@ -15,6 +15,8 @@ import socket
 import pytest
 import torch
 
+from inferbiomechanics_amd._tuning import tuning as TU
+
 pytestmark = pytest.mark.gpu
 
 
@@ -51,9 +53,9 @@ def _lag_worker(port, q):
                     torch.randn(B, T, D, generator=g).to("cuda", dt)) for _ in range(3)]
 
         def run(lag: bool, ddp: bool):
-            os.environ.pop("IB_NO_LAG_GROUP", None)
+            TU.no_lag_group = False
             if not lag:
-                os.environ["IB_NO_LAG_GROUP"] = "1"
+                TU.no_lag_group = True
             os.environ["IB_DDP_SELFTEST"] = "1" if ddp else "0"
             model = _transformer(dt, T, D)
             tr = HipTrainer(model, "diffusion", "sgd", 1e-2, bucket_mb=0.5, overlap_comm=True if ddp else None)

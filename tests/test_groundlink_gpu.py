@@ -8,6 +8,8 @@ import sys
 import numpy as np
 import pytest
 import torch
+
+from inferbiomechanics_amd._tuning import tuning as TU
 import torch.nn.functional as Fn
 
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
@@ -307,7 +309,7 @@ def test_groundlink_fused_reduction_is_bitwise_the_separate_reduction(dtype, mon
     res = []
     for fuse in (True, False):
         if not fuse:
-            monkeypatch.setenv("IB_NO_OPT_FUSE", "1")
+            monkeypatch.setattr(TU, "no_opt_fuse", True)
         torch.manual_seed(0)
         m = Groundlink(23, 12, 10, "all_frames", device=DEV, compute_dtype=dtype)
         m.train()

@@ -9,6 +9,8 @@ import numpy as np
 import pytest
 import torch
 
+from inferbiomechanics_amd._tuning import tuning as TU
+
 pytestmark = pytest.mark.gpu
 
 from oracle import ref_cpu as R  # noqa: E402
@@ -225,11 +227,11 @@ def test_ddim_sampler_loop_matches_oracle(dtype, rt):
         exp = R.ddim_sample(lambda x, t: R.denoiser_transformer_forward(p, x, t, 2, 2), xT.double(), 1000, S)
     close(got, exp, rt, "x_0")
     if dtype == torch.bfloat16:
-        os.environ["IB_NO_LINEAR_LN"] = "1"
+        TU.no_linear_ln = True
         try:
             ref = DDIMSampler(model, S, use_graph=False).sample(xT.to(DEV))
         finally:
-            os.environ.pop("IB_NO_LINEAR_LN", None)
+            TU.no_linear_ln = False
         close(got, ref, 3e-2, "fused vs unfused inference path")
     # a second call reuses the captured step and must reproduce the first bit for bit
     smp = DDIMSampler(model, S, use_graph=True)

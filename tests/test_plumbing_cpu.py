@@ -9,6 +9,8 @@ import os
 import pytest
 import torch
 
+from inferbiomechanics_amd._tuning import tuning as TU
+
 
 @pytest.fixture()
 def dry():
@@ -358,9 +360,9 @@ def test_every_parameter_is_updated_exactly_once_per_step(dry, monkeypatch):
     for dtype, B, T, D, dm, ff in ((torch.bfloat16, 128, 32, 48, 512, 1024), (torch.float32, 6, 10, 44, 64, 128)):
         for early in (True, False):
             if early:
-                monkeypatch.delenv("IB_NO_EARLY_OPT", raising=False)
+                monkeypatch.setattr(TU, "no_early_opt", False)
             else:
-                monkeypatch.setenv("IB_NO_EARLY_OPT", "1")
+                monkeypatch.setattr(TU, "no_early_opt", True)
             m = DiffusionTransformer(D, T, d_model=dm, num_heads=4, dim_feedforward=ff, num_layers=3, compute_dtype=dtype)
             tr = HipTrainer(m, "diffusion", "adam", 1e-3, use_graph=False)
             seen = []

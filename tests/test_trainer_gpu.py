@@ -7,6 +7,8 @@ import argparse
 import pytest
 import torch
 
+from inferbiomechanics_amd._tuning import tuning as TU
+
 pytestmark = pytest.mark.gpu
 
 from oracle import ref_cpu as R  # noqa: E402
@@ -168,9 +170,9 @@ def test_recurring_dict_batches_are_read_in_place_bitwise(dtype, monkeypatch):
         load_det(model)
         tr = HipTrainer(model, "regression", "rmsprop", 1e-3, args=args)
         if mode == "staged":
-            monkeypatch.setenv("IB_NO_PINNED_GRAPHS", "1")
+            monkeypatch.setattr(TU, "no_pinned_graphs", True)
         else:
-            monkeypatch.delenv("IB_NO_PINNED_GRAPHS", raising=False)
+            monkeypatch.setattr(TU, "no_pinned_graphs", False)
         losses = []
         for i in range(10):
             inp, lab = batches[i % 2]
@@ -188,7 +190,7 @@ def test_recurring_dict_batches_are_read_in_place_bitwise(dtype, monkeypatch):
     wide[..., :inp[k0].shape[-1]] = inp[k0]
     odd = dict(inp)
     odd[k0] = wide[..., :inp[k0].shape[-1]]
-    monkeypatch.delenv("IB_NO_PINNED_GRAPHS", raising=False)
+    monkeypatch.setattr(TU, "no_pinned_graphs", False)
     before = len(tr._pinned)
     for _ in range(3):
         tr.step((odd, lab))
@@ -255,7 +257,7 @@ def test_transformer_fused_reductions_match_separate_reductions(dtype, monkeypat
     res = []
     for fuse in (True, False):
         if not fuse:
-            monkeypatch.setenv("IB_NO_OPT_FUSE", "1")
+            monkeypatch.setattr(TU, "no_opt_fuse", True)
         torch.manual_seed(0)
         model = DiffusionTransformer(D, T, d_model=128, num_heads=4, dim_feedforward=256, num_layers=3, device=DEV,
                                      compute_dtype=dtype)
@@ -289,7 +291,7 @@ def test_layers_updated_early_are_bitwise_the_single_optimizer_launch(cfg, monke
     res = []
     for early in (True, False):
         if not early:
-            monkeypatch.setenv("IB_NO_EARLY_OPT", "1")
+            monkeypatch.setattr(TU, "no_early_opt", True)
         torch.manual_seed(0)
         model = DiffusionTransformer(D, T, d_model=dm, num_heads=4, dim_feedforward=ff, num_layers=3, device=DEV,
                                      compute_dtype=dtype)
@@ -334,11 +336,18 @@ def test_bench_data_parallel_launch_sequence_on_one_rank():
         assert len(lines) == 1, r.stdout[:500]
         outs.append(json.loads(lines[0]))
     a, b = outs
-    assert a["config"]["grad_buckets"] == 0 and b["config"]["grad_buckets"] == 1
-    assert a["final_loss"] == b["final_loss"]
+    # headline = the transformer denoiser (BASELINE configs[2]): bucketed all-reduces under data parallelism; the MLP
+    # denoiser rides as `mlp_T50`: one bucket = the whole gradient
+    assert a["config"]["grad_buckets"] == 0 and b["config"]["grad_buckets"] >= 2
+    assert a["mlp_T50"]["config"]["grad_buckets"] == 0 and b["mlp_T50"]["config"]["grad_buckets"] == 1
+    assert "configs[2]" in a["config"]["workload"] and "configs[1]" in a["mlp_T50"]["workload"]
+    assert a["mlp_T50"]["final_loss"] == b["mlp_T50"]["final_loss"]
+    assert abs(a["final_loss"] - b["final_loss"]) <= 5e-3 * abs(a["final_loss"])      # (other summation order of the slabs)
     for o in outs:
         assert o["unit"] == "windows/s" and o["n_gpus"] == 1 and o["steps"] == 40 and o["value"] > 0
         assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(o["roofline"])
+        assert list(o)[-1] == "summary" and o["summary"]["headline"]["ms_per_step"] == o["ms_per_step"]
+        assert o["summary"]["mlp_T50"]["ms_per_step"] == o["mlp_T50"]["ms_per_step"]
 
 
 def test_bench_two_rank_control_flow_rehearsal():
@@ -364,8 +373,10 @@ def test_bench_two_rank_control_flow_rehearsal():
     o = json.loads(lines[0])
     assert o["n_gpus"] == 2 and o["rccl_world"] == 2 and o["backend"] == "gloo"
     assert o["config"]["global_batch"] == 512 and o["config"]["parallelism"] == "dp2"
-    assert o["config"]["grad_buckets"] == 1 and o["value"] > 0 and "roofline" in o and "cpu_baseline" not in o
-    assert o["transformer_T50"]["config"]["parallelism"] == "dp2"
+    assert o["config"]["grad_buckets"] >= 2 and o["value"] > 0 and "roofline" in o and "cpu_baseline" not in o
+    assert "configs[3]" in o["config"]["workload"]
+    assert o["mlp_T50"]["config"]["parallelism"] == "dp2" and o["mlp_T50"]["config"]["grad_buckets"] == 1
+    assert list(o)[-1] == "summary"
 
 
 def test_nested_branch_fork_is_refused():
@@ -465,7 +476,7 @@ def test_captured_collectives_on_one_rank_match_the_cut_graphs():
             if captured:
                 env["IB_GRAPH_COLLECTIVES"] = "1"
             r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", workload, "--steps", "30",
-                                "--warmup", "4", "--no-cpu-baseline", "--no-ddim", "--no-transformer", "--overlap-comm",
+                                "--warmup", "4", "--no-cpu-baseline", "--no-ddim", "--no-mlp", "--overlap-comm",
                                 "on" if "transformer" in workload else "off"],
                                capture_output=True, text=True, env=env, timeout=600)
             assert r.returncode == 0, r.stderr[-3000:]
