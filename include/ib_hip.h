@@ -347,6 +347,12 @@ int ib_ffn_chain_bwd(const void* dy, const void* s2, const float* mean, const fl
  *                           dqkv [M, 1536] (the in-projection's weight-gradient operand) and dx [M, 512] = dqkv Wqkv + ds1,
  *                           the gradient w.r.t. the layer input.  dattn is not stored.  `mask` / `partial` sized for
  *                           ib_ffn_chain_attn_workgroups panels (ib_ffn_chain_attn_mask_bytes). */
+/* frozen-weight forward (DDIM sampler beyond 8192 rows): ib_ffn_chain_fwd's attention-epilogue form (+ optional QKV tail)
+ * with nothing saved for a backward -- only y [M, 512] (and qkv_next [M, 1536]) leave the workgroup */
+int ib_ffn_chain_fwd_infer(const void* x, const void* packed, const float* b1, const float* b2, const float* gamma,
+                           const float* beta, void* y, const void* attn, const float* bo, const float* gamma1,
+                           const float* beta1, const void* packed_next, const float* bqkv_next, void* qkv_next, int64_t M,
+                           int64_t d, int64_t ffn, float ln_eps, ib_stream_t stream);
 int ib_ffn_chain_attn_workgroups(int64_t M, int64_t d, int64_t ffn, int64_t T);
 size_t ib_ffn_chain_attn_mask_bytes(int64_t M, int64_t d, int64_t ffn, int64_t T);
 int ib_ffn_chain_fwd_attn(const void* x, const void* packed, const float* b1, const float* b2, const float* gamma,

@@ -142,9 +142,9 @@ __device__ __forceinline__ void ff_out_piece(const unsigned char* img, bf16_t* g
 // ---- row-wise passes: wave w owns rows w, w + 8, ... of the panel, a lane 8 consecutive columns of the row (one row per
 // wave-instruction); the row sums are DPP-only (ff_row_sum).  Two rows at a time, stage by stage.
 
-// LayerNorm of the bf16 rows of `img` (the saved LayerNorm input): y rows -> HBM (and, if `back`, back into the image: the
-// next GEMM's input), the input rows -> HBM (`sg`), mean / rstd -> HBM.  Rows beyond the panel: computed on whatever
-// finite values the image holds, never stored.
+// LayerNorm of the bf16 rows of `img` (the saved LayerNorm input): y rows -> HBM (`yg`, may be null) (and, if `back`, back
+// into the image: the next GEMM's input), the input rows -> HBM (`sg`; null: neither they nor mean / rstd are stored),
+// mean / rstd -> HBM.  Rows beyond the panel: computed on whatever finite values the image holds, never stored.
 __device__ __forceinline__ void ff_ln_rows_fwd(unsigned char* img, bool back, int nrows, int wave_s, int lane,
                                                const float (&gm)[8], const float (&bt)[8], float eps, bf16_t* yg, bf16_t* sg,
                                                float* mean_g, float* rstd_g) {
@@ -182,9 +182,11 @@ __device__ __forceinline__ void ff_ln_rows_fwd(unsigned char* img, bool back, in
       const uint4 hq = ff_pack8(hv);
       if (back) *reinterpret_cast<uint4*>(img + r * FF_RS + c8 * 2) = hq;
       if (r < nrows) {
-        *reinterpret_cast<uint4*>(yg + (int64_t)r * FF_D + c8) = hq;
-        *reinterpret_cast<uint4*>(sg + (int64_t)r * FF_D + c8) = q[gi];
-        if (lane == 0) { mean_g[r] = mean; rstd_g[r] = rstd; }
+        if (yg) *reinterpret_cast<uint4*>(yg + (int64_t)r * FF_D + c8) = hq;
+        if (sg) {                      // (frozen-weight forward: nothing is saved for a backward)
+          *reinterpret_cast<uint4*>(sg + (int64_t)r * FF_D + c8) = q[gi];
+          if (lane == 0) { mean_g[r] = mean; rstd_g[r] = rstd; }
+        }
       }
     }
   }

@@ -54,9 +54,12 @@ struct FfnFwdParams {
   long long* prof;
 };
 
-template <bool OUT, bool QKV, bool ATT>
+// INFER: the frozen-weight forward (DDIM sampler at batches beyond the row-panel kernels of linln_panel.hip): nothing is saved
+// for a backward -- no f1 / s1 / s2 / x1 rows, no statistics, no ReLU bits leave the workgroup
+template <bool OUT, bool QKV, bool ATT, bool INFER = false>
 __global__ __launch_bounds__(FF_THREADS) void ffn_chain_fwd_kernel(FfnFwdParams p) {
   static_assert(!ATT || QKV, "the attention rides behind the QKV tail");
+  static_assert(!INFER || (OUT && !ATT), "the frozen-weight form: attention epilogue, no attention tail");
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * FF_BUF];
   unsigned char* imgX = smem;
   unsigned char* imgH = smem + FF_BUF;
@@ -99,8 +102,11 @@ __global__ __launch_bounds__(FF_THREADS) void ffn_chain_fwd_kernel(FfnFwdParams 
       }
     }
     __syncthreads();                     // image X = s1 complete
-    ff_ln_rows_fwd(imgX, true, nrows, wave_s, lane, gm1, bt1, p.ln_eps, p.x1out + (int64_t)r0 * FF_D,
-                   p.s1 + (int64_t)r0 * FF_D, p.mean1 + r0, p.rstd1 + r0);
+    if constexpr (INFER)
+      ff_ln_rows_fwd(imgX, true, nrows, wave_s, lane, gm1, bt1, p.ln_eps, nullptr, nullptr, nullptr, nullptr);
+    else
+      ff_ln_rows_fwd(imgX, true, nrows, wave_s, lane, gm1, bt1, p.ln_eps, p.x1out + (int64_t)r0 * FF_D,
+                     p.s1 + (int64_t)r0 * FF_D, p.mean1 + r0, p.rstd1 + r0);
   }
   __syncthreads();
   FF_STAMP(1);
@@ -139,12 +145,16 @@ __global__ __launch_bounds__(FF_THREADS) void ffn_chain_fwd_kernel(FfnFwdParams 
         *reinterpret_cast<bf16x4_t*>(imgH + (16 * mt + l16) * FF_RS + (colb + 16 * u) * 2) = ff_pack4(v[0], v[1], v[2], v[3]);
       }
     }
-    if (p.mask) p.mask[((int64_t)blockIdx.x * p.nchunk + c) * FF_THREADS + tid] = make_uint2(mlo, mhi);
+    if constexpr (!INFER) {
+      if (p.mask) p.mask[((int64_t)blockIdx.x * p.nchunk + c) * FF_THREADS + tid] = make_uint2(mlo, mhi);
+    }
     __syncthreads();                     // image H = ReLU chunk complete
     FF_STAMP(4 + 4 * c);
     bf16_t* f1g = p.f1 + (int64_t)r0 * p.FF + c * FF_CHUNK;
     auto side2 = [&](auto, int kb) {     // the chunk's rows -> HBM: 8 pieces per thread, one per two k-blocks
-      if ((kb & 1) == 0) ff_out_piece(imgH, f1g, p.FF, nrows, FF_TIDV + (kb >> 1) * FF_THREADS);
+      if constexpr (!INFER) {
+        if ((kb & 1) == 0) ff_out_piece(imgH, f1g, p.FF, nrows, FF_TIDV + (kb >> 1) * FF_THREADS);
+      }
     };
     ff_gemm<FF_RING_B>(p.w2p + (int64_t)c * FF_WELEMS, wave_s * FF_NT, imgH, ff_lane(), accy, side2);
     FF_STAMP(5 + 4 * c);
@@ -169,8 +179,11 @@ __global__ __launch_bounds__(FF_THREADS) void ffn_chain_fwd_kernel(FfnFwdParams 
     }
   }
   __syncthreads();
-  ff_ln_rows_fwd(imgH, QKV, nrows, wave_s, lane, gm, bt, p.ln_eps, p.y + (int64_t)r0 * FF_D, p.s2 + (int64_t)r0 * FF_D,
-                 p.mean + r0, p.rstd + r0);
+  if constexpr (INFER)
+    ff_ln_rows_fwd(imgH, QKV, nrows, wave_s, lane, gm, bt, p.ln_eps, p.y + (int64_t)r0 * FF_D, nullptr, nullptr, nullptr);
+  else
+    ff_ln_rows_fwd(imgH, QKV, nrows, wave_s, lane, gm, bt, p.ln_eps, p.y + (int64_t)r0 * FF_D, p.s2 + (int64_t)r0 * FF_D,
+                   p.mean + r0, p.rstd + r0);
   FF_STAMP(2 + 4 * p.nchunk);
   if constexpr (QKV) {
     // ---- the next layer's in-projection on the rows just normalised (image H = y): per 512-column chunk a GEMM, bias, bf16
@@ -474,6 +487,35 @@ extern "C" int ib_ffn_chain_fwd(const void* x1, const void* packed, const float*
                                 void* qkv_next, int64_t M, int64_t d, int64_t ffn, float ln_eps, ib_stream_t stream) {
   return ffn_chain_fwd_launch(x1, packed, b1, b2, gamma, beta, f1, s2, y, mean, rstd, mask, attn, bo, gamma1, beta1, s1, x1_out,
                               mean1, rstd1, packed_next, bqkv_next, qkv_next, nullptr, nullptr, 0, M, d, ffn, ln_eps, stream);
+}
+// The frozen-weight forward of a layer's token-local half in ONE launch (DDIM sampler at batches beyond the row-panel
+// kernels; TransformerBaseline.py:12-19,29-36 forward only): y = LN2(x1 + W2 relu(W1 x1 + b1) + b2) with
+// x1 = LN1(x + attn Wo^T + bo), and -- qkv_next != NULL -- the NEXT layer's in-projection of y.  Nothing is saved.
+extern "C" int ib_ffn_chain_fwd_infer(const void* x, const void* packed, const float* b1, const float* b2, const float* gamma,
+                                      const float* beta, void* y, const void* attn, const float* bo, const float* gamma1,
+                                      const float* beta1, const void* packed_next, const float* bqkv_next, void* qkv_next,
+                                      int64_t M, int64_t d, int64_t ffn, float ln_eps, ib_stream_t stream) {
+  FfnFwdParams p{};
+  int P = 0, nc = 0;
+  const int nwg = ffn_geometry(M, d, ffn, &P, &nc);
+  if (!nwg) return IB_E_UNSUPPORTED;
+  if (!x || !packed || !b1 || !b2 || !gamma || !beta || !y || !attn || !bo || !gamma1 || !beta1) return IB_E_ARG;
+  if (!ff_al16({x, packed, b1, b2, gamma, beta, y, attn, bo, gamma1, beta1})) return IB_E_ARG;
+  const bool tail = qkv_next != nullptr;
+  if (tail && (!packed_next || !bqkv_next || !ff_al16({packed_next, bqkv_next, qkv_next}))) return IB_E_ARG;
+  const bf16_t* pk = reinterpret_cast<const bf16_t*>(packed);
+  p.x1 = (const bf16_t*)x; p.w1p = pk; p.w2p = pk + (int64_t)nc * FF_WELEMS;
+  p.b1 = b1; p.b2 = b2; p.gamma = gamma; p.beta = beta; p.y = (bf16_t*)y;
+  p.attn = (const bf16_t*)attn; p.wop = pk + (int64_t)4 * nc * FF_WELEMS; p.bo = bo; p.gamma1 = gamma1; p.beta1 = beta1;
+  p.wqkvp = tail ? reinterpret_cast<const bf16_t*>(packed_next) + (int64_t)(4 * nc + 2) * FF_WELEMS : nullptr;
+  p.bqkv = bqkv_next; p.qkv = (bf16_t*)qkv_next;
+  p.M = (int)M; p.P = P; p.FF = (int)ffn; p.nchunk = nc; p.ln_eps = ln_eps;
+  p.prof = nullptr;
+  IB_PATH(IB_PATH_FFN_CHAIN);
+  if (tail) hipLaunchKernelGGL((ffn_chain_fwd_kernel<true, true, false, true>), dim3(nwg), dim3(FF_THREADS), 0, ib_s(stream), p);
+  else hipLaunchKernelGGL((ffn_chain_fwd_kernel<true, false, false, true>), dim3(nwg), dim3(FF_THREADS), 0, ib_s(stream), p);
+  IB_CHECK_LAUNCH();
+  return IB_OK;
 }
 // The same launch over panels of exactly one window of T frames (16 <= T <= 64; the geometry of a layer whose attention rides
 // inside its launches -- its backward uses the same panels) and, with attn_next != NULL, the NEXT layer's temporal

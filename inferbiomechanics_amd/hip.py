@@ -113,6 +113,7 @@ _SIGS = {
     "ib_ffn_chain_pack": (_c.c_int, [_vp] * 9 + [_c.c_int, _i64, _i64, _vp]),
     "ib_ffn_chain_fwd": (_c.c_int, [_vp] * 23 + [_i64, _i64, _i64, _f32, _vp]),
     "ib_ffn_chain_bwd": (_c.c_int, [_vp] * 20 + [_i64, _i64, _i64, _vp]),
+    "ib_ffn_chain_fwd_infer": (_c.c_int, [_vp] * 14 + [_i64, _i64, _i64, _f32, _vp]),
     "ib_ffn_chain_attn_workgroups": (_c.c_int, [_i64, _i64, _i64, _i64]),
     "ib_ffn_chain_attn_mask_bytes": (_sz, [_i64, _i64, _i64, _i64]),
     "ib_ffn_chain_fwd_attn": (_c.c_int, [_vp] * 25 + [_i64, _i64, _i64, _i64, _f32, _vp]),
@@ -1534,6 +1535,42 @@ def ffn_chain_fwd(x1, packed, b1, b2, gamma, beta, f1, s2, y, mean, rstd, mask, 
                                   _ptr(y), _ptr(mean), _ptr(rstd), _ptr(mask), *extra, *tail, M, d, ffn, float(eps),
                                   stream_ptr()), "ib_ffn_chain_fwd")
     return y
+
+
+def ffn_chain_fwd_infer(x, packed, b1, b2, gamma, beta, y, attn, bo, gamma1, beta1, qkv_next=None, eps: float = 1e-5):
+    """frozen-weight forward of a layer's token-local half in one launch (csrc/ffn_chain.hip, INFER form): y = LN2(x1 + FFN(x1)),
+    x1 = LN1(x + attn Wo^T + bo); qkv_next = (packed image of the NEXT layer, its in-projection bias, qkv_out [M, 3 d]).
+    Nothing is saved.  False: shape not supported."""
+    M, d = x.shape
+    ffn = b1.numel()
+    if not ffn_chain_supported(d, ffn):
+        return False
+    for t, n in ((x, "x"), (y, "y"), (attn, "attn")):
+        _ffn_rows(t, n, M, d)
+    for t, n, w in ((b1, "b1", ffn), (b2, "b2", d), (gamma, "gamma", d), (beta, "beta", d), (bo, "bo", d), (gamma1, "gamma1", d),
+                    (beta1, "beta1", d)):
+        _ffn_vec(t, n, w)
+    _req(packed, "packed", torch.bfloat16, 1)
+    if packed.numel() < ffn_chain_packed_elems(d, ffn):
+        raise HipError("ffn_chain_fwd_infer: packed image too small")
+    tail = [None] * 3
+    if qkv_next is not None:
+        pk_n, bq, qo = qkv_next
+        _req(pk_n, "packed_next", torch.bfloat16, 1)
+        _ffn_vec(bq, "bqkv_next", 3 * d)
+        _ffn_rows(qo, "qkv_next", M, 3 * d)
+        if pk_n.numel() < ffn_chain_packed_elems(d, ffn):
+            raise HipError("ffn_chain_fwd_infer: packed image of the next layer too small")
+        tail = [_ptr(pk_n), _ptr(bq), _ptr(qo)]
+    global _work_note
+    if isinstance(_lib, _RecordingLib):
+        mac = 2 * d * ffn + d * d + (3 * d * d if qkv_next is not None else 0)
+        _work_note = (2 * M * mac, 2 * M * (3 * d + (3 * d if qkv_next is not None else 0)) + 2 * mac,
+                      {"M": M, "d": d, "ffn": ffn, "qkv_tail": qkv_next is not None, "frozen": True})
+    _check(lib().ib_ffn_chain_fwd_infer(_ptr(x), _ptr(packed), _ptr(b1), _ptr(b2), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(attn),
+                                        _ptr(bo), _ptr(gamma1), _ptr(beta1), *tail, M, d, ffn, float(eps), stream_ptr()),
+           "ib_ffn_chain_fwd_infer")
+    return True
 
 
 def ffn_chain_bwd(dy, s2, mean, rstd, gamma, packed, mask, ds2, dz1, dx1, partial, attn_out=None, qkv_head=None,

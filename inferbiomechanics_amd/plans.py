@@ -558,6 +558,7 @@ class TransformerLayerPlan:
         # gradients ready and flushes.  A captured graph segment must end with every side stream joined, so without the lag
         # each layer's 100-us launch sat on the critical path once per bucket.
         self.lag_group = False
+        self.tail_done = self.attn_tail_done = False
         self.split_tail = False       # set by the parent on the layer whose backward runs LAST (see backward())
         self.infer_packed = False     # set by the parent's prepare_inference: packed_image() holds the frozen weights
         self.parent_flushes = False  # set with lag_group on ALL layers of such a parent: gradients are reported to the parent
@@ -693,8 +694,25 @@ class TransformerLayerPlan:
         attn, lse = self.attn_buffers(B, T)
         if not attn_ready:
             hip.attention_fwd(qkv, attn, lse, self.h, drop=drop)
-        x1 = g(tg + ".x1", (M, d), dt)
         x2 = out if out is not None else g(tg + ".x2", (B, T, d), dt)
+        self.tail_done = self.attn_tail_done = False          # read by a parent plan: what this launch did for the layer above
+        if (self.inference and self.infer_packed and d == 512 and dt == torch.bfloat16 and M >= TU.infer_chain_min_m
+                and not TU.no_infer_chain and x2.is_contiguous() and hip.ffn_chain_supported(d, self.ffn)):
+            # frozen weights, more rows than the row-panel kernels take (DDIM at B = 256: 51200 rows): everything behind the
+            # attention core -- and the next layer's in-projection -- in ONE launch over 64-row panels, the training
+            # launch's form that saves nothing (csrc/ffn_chain.hip, INFER).  Round 5: 8 per-op launches per layer before.
+            nxt = self.qkv_tail_for
+            tail = None
+            if nxt is not None and nxt.infer_packed and nxt.ffn == self.ffn and nxt.d == d and not TU.no_qkv_fuse:
+                tail = (nxt.packed_image(), P.v(nxt.p + "multihead_attention.in_proj_bias"), nxt.qkv_buffer(B, T).view(M, 3 * d))
+            if hip.ffn_chain_fwd_infer(x, self.packed_image(), P.v(p + "feedforward.0.bias"), P.v(p + "feedforward.2.bias"),
+                                       P.v(p + "norm2.weight"), P.v(p + "norm2.bias"), x2.view(M, d), attn.view(M, d),
+                                       P.v(p + "multihead_attention.out_proj.bias"), P.v(p + "norm1.weight"),
+                                       P.v(p + "norm1.bias"), qkv_next=tail):
+                self.tail_done = tail is not None
+                self.ctx = None
+                return x2
+        x1 = g(tg + ".x1", (M, d), dt)
         f1 = g(tg + ".f1", (M, self.ffn), dt)
         fuse = self.inference and dt == torch.bfloat16 and not TU.no_linear_ln
 
@@ -739,6 +757,8 @@ class TransformerLayerPlan:
                               (nxt.packed_image(), P.v(nxt.p + "multihead_attention.in_proj_bias"),
                                nxt.qkv_buffer(B, T).view(M, 3 * d)),
                               attn_next=att_next, panel_T=Ta)
+            self.tail_done = self.tail_active(M, training)
+            self.attn_tail_done = att_next is not None
             self.ctx = (x, qkv, attn, lse, a, x1, m1, r1, f1, f2, m2, r2, B, T, drop)
             return x2
         def panel_ln():
@@ -1549,8 +1569,7 @@ class DenoiserTransformerPlan:
         ready = aready = False
         for lp in self.layers:
             h = lp.forward(h, P, qkv_ready=ready, attn_ready=aready)
-            ready = (not self.inference) and lp.tail_active(M)       # it wrote the next layer's in-projection
-            aready = ready and bool(getattr(lp, "_att_T", 0)) and lp.attn_tail_active(M, T)   # ... and its attention output
+            ready, aready = lp.tail_done, lp.attn_tail_done      # it wrote the next layer's in-projection / attention output
         out = out if out is not None else g("dt.out", (B, T, D), dt)
         if padded:
             hip.linear_fwd(h.view(M, self.d), w_out_pad, b_out_pad, out.as_strided((M, Kp), (Kp, 1)))

@@ -494,13 +494,11 @@ def test_linear_ln_panel_fwd_matches_float64(hip, M, opts):
     assert hip.linear_ln_panel_fwd(x, wo_img, b, res, g, be, y)
     assert hip.lib().ib_debug_last_path() == 15
     torch.cuda.synchronize()
-    z = x.double().cpu() @ w.double().cpu().T
-    if b is not None:
-        z = z + b.double().cpu()
+    # the oracle's functions (oracle/ref_cpu.py: nn.Linear, nn.LayerNorm of TransformerBaseline.py:12-13,29-31) in float64
+    z = R.linear(x.double().cpu(), w.double().cpu(), None if b is None else b.double().cpu())
     if res is not None:
         z = z + res.double().cpu()
-    mu = z.mean(-1, keepdim=True)
-    exp = (z - mu) / torch.sqrt(((z - mu) ** 2).mean(-1, keepdim=True) + 1e-5) * g.double().cpu() + be.double().cpu()
+    exp = R.layer_norm(z, g.double().cpu(), be.double().cpu())
     close(y, exp, 2e-2, "linear_ln_panel_fwd")
     assert torch.all(y_p[:, d:] == 7.0)                          # nothing written beside the rows
     # the same numbers as the split-K form it replaces in the sampler, up to one bf16 rounding of the output
@@ -532,7 +530,7 @@ def test_linear_panel_fwd_matches_float64(hip, M):
     assert hip.linear_panel_fwd(x, img, b, y[:, :3 * d])
     assert hip.lib().ib_debug_last_path() == 17
     torch.cuda.synchronize()
-    exp = x.double().cpu() @ wq.double().cpu().T + b.double().cpu()
+    exp = R.linear(x.double().cpu(), wq.double().cpu(), b.double().cpu())          # oracle/ref_cpu.py
     close(y[:, :3 * d], exp, 1e-2, "linear_panel_fwd")
     assert torch.all(y[:, 3 * d:] == 7.0)
     assert not hip.linear_panel_ok(8193, 3 * d, d) and not hip.linear_panel_ok(M, 3 * d, 256) and not hip.linear_panel_ok(M, 300, d)
@@ -561,10 +559,9 @@ def test_ffn_infer_fwd_matches_float64_and_is_bitwise_repeatable(hip, M, ffn):
     hip.ffn_infer_fwd(x1, packed, b1, b2, g, be, y, ws)
     assert hip.lib().ib_debug_last_path() == 16
     torch.cuda.synchronize()
-    h = torch.relu(x1.double().cpu() @ w1.double().cpu().T + b1.double().cpu()).to(bf).double()
-    z = h @ w2.double().cpu().T + b2.double().cpu() + x1.double().cpu()
-    mu = z.mean(-1, keepdim=True)
-    exp = (z - mu) / torch.sqrt(((z - mu) ** 2).mean(-1, keepdim=True) + 1e-5) * g.double().cpu() + be.double().cpu()
+    # oracle/ref_cpu.py's linear / act / layer_norm (TransformerBaseline.py:15-19,33-36), the hidden activation rounded to bf16
+    h = R.act("relu", R.linear(x1.double().cpu(), w1.double().cpu(), b1.double().cpu())).to(bf).double()
+    exp = R.layer_norm(R.linear(h, w2.double().cpu(), b2.double().cpu()) + x1.double().cpu(), g.double().cpu(), be.double().cpu())
     close(y, exp, 2e-2, "ffn_infer_fwd")
     first = y.clone()
     for _ in range(20):
