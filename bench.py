@@ -607,12 +607,13 @@ def self_launch(n):
     return p.returncode
 
 
-def graph_collectives_child(n, workload, steps=60, warmup=10, timeout_s=240):
-    """Data-parallel runs only: the SAME main workload once more with the gradient all-reduces CAPTURED inside the step's
-    hipGraph (IB_GRAPH_COLLECTIVES=1: one graph per step, no graph cut and no host action per collective) -- in FRESH child
-    processes (a new torch.distributed.run launch of n ranks; nothing that has touched a GPU is ever re-exec'd), bounded by a
-    timeout, and fenced: whatever happens there (non-zero exit, timeout, no JSON) becomes an `error` string in the extra key
-    and never costs the record of the default (cut-graph) run."""
+def graph_collectives_child(n, workload, form, steps=60, warmup=10, timeout_s=240):
+    """Data-parallel runs only: the SAME main workload once more in the OTHER form of the collectives than the headline's
+    (`form` = "1": all-reduces captured inside the step's hipGraph -- one graph per step, no graph cut and no host action per
+    collective; "0": host actions between graph segments) -- in FRESH child processes (a new torch.distributed.run launch
+    of n ranks; nothing that has touched a GPU is ever re-exec'd), bounded by a timeout, and fenced: whatever happens there
+    (non-zero exit, timeout, no JSON) becomes an `error` string in the extra key and never costs the record of the headline
+    run, whose own form was chosen by the start-up probe (inferbiomechanics_amd/ddp_probe.py)."""
     import socket
     import subprocess
     with socket.socket() as sk:
@@ -622,7 +623,9 @@ def graph_collectives_child(n, workload, steps=60, warmup=10, timeout_s=240):
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE",
               "ROLE_WORLD_SIZE", "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS"):
         env.pop(k, None)
-    env.update(IB_GRAPH_COLLECTIVES="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    env.update(IB_GRAPH_COLLECTIVES=form, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    if n == 1:
+        env["IB_DDP_SELFTEST"] = "1"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__), "--gpus", str(n), "--steps", str(steps), "--warmup",
            str(warmup), "--workload", workload, "--no-mlp", "--no-ddim", "--no-cpu-baseline", "--no-variant-child", "--no-roofline"]
@@ -666,7 +669,7 @@ def main():
     ap.add_argument("--no-ddim", action="store_true")
     ap.add_argument("--no-cli-path", action="store_true", help="skip the `main.py train` rate of the same workload")
     ap.add_argument("--no-variant-child", action="store_true",
-                    help="[N > 1] skip the captured-collectives variant (IB_GRAPH_COLLECTIVES=1) run in child processes")
+                    help="[N > 1] skip the run of the collectives' OTHER form (captured in the graph / host actions) in child processes")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-launch roofline leg (child runs)")
     ap.add_argument("--no-mlp", action="store_true", help="skip the configs[1] MLP denoiser leg (extra key `mlp_T50`)")
     ap.add_argument("--bucket-mb", type=float, default=13.0,
@@ -688,6 +691,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    forced_form = os.environ.get("IB_GRAPH_COLLECTIVES")      # set by a caller (the variant child below; tools): no probe
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: start the N ranks ourselves.  This process has made no GPU / HIP
         # call yet (and never will): the ranks are FRESH child processes under torch.distributed.run (subprocess, never
@@ -742,10 +746,16 @@ def main():
     variant = None
     # (IB_BENCH_FORCE_VARIANT=1 with IB_DDP_SELFTEST=1: the same mechanism on a one-GPU box, a 1-rank child)
     want_variant = world > 1 or (selftest and os.environ.get("IB_BENCH_FORCE_VARIANT") == "1")
-    if want_variant and not rehearsal and not a.no_variant_child and os.environ.get("IB_GRAPH_COLLECTIVES") != "1":
+    from inferbiomechanics_amd import ddp_probe
+    coll = ddp_probe.verdict() if (world > 1 or selftest) else None
+    if want_variant and not rehearsal and not a.no_variant_child and forced_form is None and coll is not None:
         sync()
         if rank == 0:
-            variant = graph_collectives_child(world, a.workload)
+            if coll["source"] == "probe" and not coll["captured"]:
+                variant = {"skipped": "the start-up probe of the captured form failed (" + str(coll["why"])[:200] + ")"}
+            else:
+                variant = graph_collectives_child(world, a.workload, "0" if coll["captured"] else "1")
+                variant["form"] = "host actions between graph segments" if coll["captured"] else "captured in the step graph"
         if host_group is not None:
             dist.barrier(group=host_group)             # the other ranks wait on the HOST (gloo), their GPUs idle
     if rank == 0:
@@ -761,6 +771,10 @@ def main():
             # proof that the collective library saw N ranks (a SCALE record must show rccl_world == n_gpus)
             "rccl_world": dist.get_world_size() if backend else 1, "backend": backend,
         }
+        if coll is not None:
+            # how the step's all-reduces are issued, and who decided (ddp_probe.py: a probe in fresh child processes)
+            line["collectives"] = dict(coll, form="captured in the step graph" if coll["captured"] else
+                                       "host actions between graph segments")
         for k in ("step_ms", "final_loss", "train_tflops", "captures_in_timed_region", "step_fractions", "xgmi", "roofline",
                   "step_sum_of_kernel_us"):
             if k in main_leg:
@@ -772,11 +786,13 @@ def main():
             rl = main_leg["roofline"]
             summary["roofline"] = {k: rl.get(k) for k in ("entry", "bound", "achieved", "peak", "unit", "frac", "avg_launch_us",
                                                           "traffic", "launches_per_step")}
+        if coll is not None:
+            summary["collectives"] = {"captured_in_step_graph": coll["captured"], "decided_by": coll["source"]}
         if variant is not None:
-            variant["what"] = ("same workload, IB_GRAPH_COLLECTIVES=1 (all-reduces captured inside the step's hipGraph) in fresh "
-                               "child processes; the headline value above is the default form")
+            variant["what"] = ("same workload with the collectives in the OTHER form than the headline run, in fresh child "
+                               "processes")
             line["graph_collectives_variant"] = variant
-            summary["graph_collectives_variant_ms"] = variant.get("ms_per_step", variant.get("error"))
+            summary["other_collectives_form_ms"] = variant.get("ms_per_step", variant.get("error", variant.get("skipped")))
         if not a.no_cpu_baseline and world == 1:            # rank 0 at N=1 only (the other ranks wait at the barrier)
             line["cpu_baseline"] = cpu_baseline(kind, T, D, B, dev)
             ml = line["cpu_baseline"]["matched_loss"]

@@ -99,6 +99,7 @@ class GradBuckets:
                 lo, cur = end, []
         self._pending = [len(m) for m in self.members]
         self._works: list = []
+        self._work_of: dict = {}
         # raw handles of the streams a collective has been issued from: c10d leaves completion events on them that its
         # watchdog thread polls -- such a stream must never be put into capture mode (_Recorder.begin refuses it)
         self.collective_streams: set = set()
@@ -106,6 +107,7 @@ class GradBuckets:
     def reset(self):
         self._pending = [len(m) for m in self.members]
         self._works = []
+        self._work_of = {}
 
     def mark_ready(self, name: str) -> Optional[int]:
         """returns the bucket index if `name` completed a bucket"""
@@ -139,12 +141,22 @@ class GradBuckets:
             w.wait()
         else:
             self._works.append(w)
+            self._work_of[b] = w
+
+    def take_work(self, b: int):
+        """the outstanding Work of bucket b, handed over to the caller (who waits for it on a stream of its own: the
+        per-bucket optimizer); finish() no longer waits for it"""
+        w = self._work_of.pop(b, None)
+        if w is not None:
+            self._works = [x for x in self._works if x is not w]
+        return w
 
     def finish(self):
         """make the compute stream wait for every outstanding bucket (a stream-level wait on the GPU path: no host block)"""
         for w in self._works:
             w.wait()
         self._works = []
+        self._work_of = {}
 
 
 def broadcast_parameters(flat: torch.Tensor, group=None, src: int = 0):
@@ -219,6 +231,13 @@ class HipTrainer:
         self.use_graph = use_graph and not hip._dry_run
         dev = next(model.parameters()).device
         self.device = dev
+        # data parallel with hipGraphs: are the all-reduces captured INSIDE the step's graph (one graph per step) or issued
+        # as host actions between graph segments?  Decided once per process by a probe in fresh child processes
+        # (ddp_probe.py; IB_GRAPH_COLLECTIVES=0/1 forces the answer) -- a collective call: every rank constructs its trainer
+        self.graph_collectives = False
+        if self.ddp and self.use_graph and dev.type == "cuda":
+            from . import ddp_probe
+            self.graph_collectives = ddp_probe.decide(self.world, dist.get_rank(group), str(dist.get_backend(group)))
         self.plan = self._plan_for(dev)
         # Data-parallel policy.  Small models (gradients < 16 MiB, e.g. the MLP denoiser's 4.7 MB): the step is
         # latency-bound, the forked branches are worth more than comm/backward overlap -> branches stay ON and the
@@ -278,6 +297,13 @@ class HipTrainer:
         self.stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         from .plans import Branch
         self._br_loss = Branch(dev, enabled=not self.overlap_comm, name="loss")
+        # data parallel, bucketed: the optimizer runs PER BUCKET on a side stream as soon as that bucket's all-reduce has
+        # completed (1 / world folded in), beside the backward of the layers below -- the structure of the one-GPU step's
+        # per-layer optimizer; the step's last, self-counting launch then only names the buckets as done (round 5: one
+        # launch over the whole flat buffer behind the last all-reduce before, 70 us on the transformer's critical path)
+        self.bucket_opt = bool(self.ddp and self.overlap_comm and not TU.no_bucket_opt)
+        self._br_opt = Branch(dev, enabled=self.bucket_opt, name="bucket_opt")
+        self._early_done: List[Tuple[int, int]] = []
         # device-side batch draw (step_drawn): Philox key = torch's seed (torch.manual_seed(s) selects the noise as it would
         # for torch.randn), stream = data-parallel rank (ranks must not draw the same noise), step = the device counter
         self.noise_seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
@@ -314,6 +340,8 @@ class HipTrainer:
                 cut(b)
             else:
                 self.buckets.launch(b)
+                if self.bucket_opt:
+                    self._bucket_optimizer(b)
 
         def ready(name: str):
             self._ready_seen.append(name)
@@ -356,6 +384,7 @@ class HipTrainer:
         m, plan, dt = self.model, self.plan, self.model.compute_dtype
         self.buckets.reset()
         self._ready_seen = []
+        self._early_done = []
         P = self._psrc(cut)
         if self.task == "diffusion":
             x0, t, eps = st["x0"], st["t"], st["eps"]
@@ -456,6 +485,7 @@ class HipTrainer:
             elif not self.overlap_comm:
                 self.buckets.launch(0, inline=True)  # one bucket = the whole flat gradient, after all joins
             else:
+                self._br_opt.join()                  # the per-bucket optimizer launches (each waited for its own all-reduce)
                 self.buckets.finish()
         # self-counting optimizer launch: uses *step_dev + 1 and publishes it itself (no separate counter launch)
         src = getattr(self.plan, "pending_sources", None)
@@ -465,11 +495,35 @@ class HipTrainer:
             if done:
                 src = tuple(src[:4]) + ([self.grad[lo:hi] for lo, hi in done],)
                 self._early_done = []
-        elif getattr(self, "_early_done", None):
-            raise hip.HipError("layers were updated early but the step's last optimizer launch does not know their ranges")
+        elif self._early_done:
+            # data parallel, per-bucket optimizer: nothing is left to sum, the launch below skips the buckets' ranges
+            src = ([], None, 0, [], [self.grad[lo:hi] for lo, hi in self._early_done])
+            self._early_done = []
         hip.optim_step(self.opt_type, self.flat, self.grad, self.s1, self.s2, self.lr, step=0, step_dev=self.step_dev,
                        ticket=self.ticket, grad_scale=1.0 / self.world,
                        shadow=m._shadow if dt == torch.bfloat16 else None, sources=src)
+
+    def _bucket_optimizer(self, b: int, issue: bool = True, mark: bool = True):
+        """the optimizer over bucket b's range of the flat buffers, on the `bucket_opt` side stream behind that bucket's
+        all-reduce: same step number as the step's last, self-counting launch (*step_dev + 1), which skips the range.
+        `mark` without `issue`: recording a cut-graph step (the range is named as done in the captured last launch; the
+        launch itself is a host action of the replay, `issue` without `mark`)."""
+        lo, hi = self.buckets.ranges[b]
+        if mark:
+            self._early_done.append((lo, hi))
+        if not issue:
+            return
+        m, dt = self.model, self.model.compute_dtype
+        sl = lambda t: None if t is None else t[lo:hi]
+        w = self.buckets.take_work(b)
+
+        def fn():
+            if w is not None:
+                w.wait()                             # stream-level on the GPU path: the SIDE stream waits, not the backward
+            hip.optim_step(self.opt_type, self.flat[lo:hi], self.grad[lo:hi], sl(self.s1), sl(self.s2), self.lr, step=1,
+                           step_dev=self.step_dev, grad_scale=1.0 / self.world,
+                           shadow=sl(m._shadow) if dt == torch.bfloat16 else None)
+        self._br_opt.run(fn)
 
     def _prefix_range(self, prefix: str) -> Tuple[int, int]:
         """[lo, hi) of the flat buffers holding exactly the parameters whose names start with `prefix`"""
@@ -633,15 +687,16 @@ class HipTrainer:
     def _capture(self, st) -> "_Recorder":
         self.captures += 1
         rec = _Recorder(self.buckets.collective_streams)
-        # IB_GRAPH_COLLECTIVES=1: the all-reduces are CAPTURED (c10d enqueues the RCCL kernels on its communication stream,
-        # which joins the capture through the event edges it records): one graph per step, no graph cut and no host work per
-        # collective.  Validated on the 1-rank RCCL self-test group only (no multi-GPU box in this build's reach), hence a flag.
-        # Limit of the flag: on the bucketed (overlap_comm) path c10d's own communication stream joins the capture, and that
+        # graph_collectives (ddp_probe.py's verdict, or IB_GRAPH_COLLECTIVES=1): the all-reduces are CAPTURED (c10d enqueues
+        # the RCCL kernels on its communication stream, which joins the capture through the event edges it records): one graph
+        # per step, no graph cut and no host work per collective.  The default wherever the start-up probe -- the same two
+        # forms run side by side in fresh child processes on the job's own ranks -- finds that it works.
+        # A hazard of the captured form: on the bucketed (overlap_comm) path c10d's own communication stream joins the capture, and that
         # stream carried the eager warm-up steps' collectives whose completion events the c10d watchdog polls from its own
         # thread -- a poll that lands while the stream captures aborts the process (the hazard _Recorder.begin refuses for
         # the caller's streams; it cannot see c10d's).  So before capturing: wait on every outstanding Work, drain the
         # device, and give the watchdog one reap cycle; afterwards nothing it still polls sits on that stream.
-        graph_collectives = self.ddp and os.environ.get("IB_GRAPH_COLLECTIVES") == "1"
+        graph_collectives = self.ddp and self.graph_collectives
         if graph_collectives:
             self.buckets.finish()
             if self.device.type == "cuda":
@@ -654,15 +709,24 @@ class HipTrainer:
             if graph_collectives:
                 if b >= 0:
                     self.buckets.launch(b)
+                    if self.bucket_opt:
+                        self._bucket_optimizer(b)          # a parallel branch of the graph behind the captured all-reduce
                 elif b == -1:
+                    self._br_opt.join()
                     self.buckets.finish()
                 else:
                     self.buckets.launch(0, inline=True)
                 return
             if b >= 0:
-                rec.cut(lambda: self.buckets.launch(b))
+                if self.bucket_opt:
+                    # the collective and the bucket's optimizer launch are host actions of the replay (eager, between two
+                    # graph segments); the captured last launch names the range as done
+                    self._bucket_optimizer(b, issue=False)
+                    rec.cut(lambda: (self.buckets.launch(b), self._bucket_optimizer(b, mark=False)))
+                else:
+                    rec.cut(lambda: self.buckets.launch(b))
             elif b == -1:
-                rec.cut(self.buckets.finish)
+                rec.cut(lambda: (self._br_opt.join(), self.buckets.finish()))
             else:
                 rec.cut(lambda: self.buckets.launch(0, inline=True))
         # Captured on a stream of its own, launched on the trainer's stream.  c10d's watchdog thread polls the completion
@@ -705,7 +769,7 @@ class HipTrainer:
         # staging copies per step (10 input keys + 4 labels, each a tiny D2D launch issued by the host: ~45 us of the 0.12-ms
         # fp32 reference-shape step) disappear.  Anything else is staged into the static buffers as before.
         if self.use_graph and self._rec is not None and not TU.no_pinned_graphs \
-                and not (self.ddp and os.environ.get("IB_GRAPH_COLLECTIVES") == "1"):
+                and not (self.ddp and self.graph_collectives):
             d = self._dict_batch_direct(batch)
             if d is not None:
                 key, st_d = d

@@ -52,14 +52,22 @@ def _lag_worker(port, q):
         batches = [(torch.randn(B, T, D, generator=g).to("cuda", dt), torch.randint(0, 1000, (B,), generator=g).cuda(),
                     torch.randn(B, T, D, generator=g).to("cuda", dt)) for _ in range(3)]
 
-        def run(lag: bool, ddp: bool):
-            TU.no_lag_group = False
-            if not lag:
-                TU.no_lag_group = True
+        def run(lag: bool, ddp: bool, bopt: bool = True, captured: bool = False):
+            TU.no_lag_group = not lag
+            TU.no_bucket_opt = not bopt
+            os.environ["IB_GRAPH_COLLECTIVES"] = "1" if captured else "0"      # forced: no start-up probe in this test
             os.environ["IB_DDP_SELFTEST"] = "1" if ddp else "0"
             model = _transformer(dt, T, D)
             tr = HipTrainer(model, "diffusion", "sgd", 1e-2, bucket_mb=0.5, overlap_comm=True if ddp else None)
-            info = {"ddp": tr.ddp, "overlap": tr.overlap_comm, "buckets": len(tr.buckets.ranges),
+            from inferbiomechanics_amd import hip
+            nopt = [0]
+            real = hip.optim_step
+
+            def counted(*a, **k):
+                nopt[0] += 1
+                return real(*a, **k)
+            hip.optim_step = counted
+            info = {"ddp": tr.ddp, "overlap": tr.overlap_comm, "buckets": len(tr.buckets.ranges), "bucket_opt": tr.bucket_opt,
                     "fused_ffn": all(lp.ffn_fused(B * T) for lp in tr.plan.layers),
                     "lagging": [bool(lp.lag_group and lp.parent_flushes) for lp in tr.plan.layers]}
             losses = []
@@ -67,13 +75,17 @@ def _lag_worker(port, q):
                 tr.step(batches[i % len(batches)])
                 if i == 0:
                     info["ready_is_layout_order"] = tr._ready_seen == list(tr.layout.keys())
+                    info["optimizer_launches_first_step"] = nopt[0]
                 losses.append(tr.loss_value())
+            hip.optim_step = real
             torch.cuda.synchronize()
             info["captured"] = tr._rec is not None
             info["graph_cuts"] = sum(1 for k, _ in tr._rec.actions if k == "host") if tr._rec is not None else -1
             return tr.flat.detach().cpu().numpy().copy(), losses, info
 
-        out = {"lag": run(True, True), "nolag": run(False, True), "single": run(True, False)}
+        out = {"lag": run(True, True), "nolag": run(False, True), "single": run(True, False),
+               "one_opt_launch": run(True, True, bopt=False), "captured": run(True, True, captured=True)}
+        TU.no_bucket_opt = False
         dist.barrier()
         dist.destroy_process_group()
         q.put(("ok", out))
@@ -108,6 +120,17 @@ def test_lagged_weight_gradient_path_is_bitwise_the_unlagged_and_the_single_gpu_
     assert la == lb and np.array_equal(fa, fb), "lagging a layer's weight-gradient launch changed the numbers"
     # the one-GPU step sums the same slabs inside the optimizer launch instead of ib_step_reduce: same fixed order
     assert la == lc and np.array_equal(fa, fc), (la, lc, float(np.abs(fa - fc).max()))
+    # round 5: the optimizer runs per bucket behind that bucket's all-reduce (one launch per bucket + the self-counting last
+    # launch, eager warm-up, graph replay with the launches as host actions of the cuts) -- bitwise the single launch over
+    # the whole flat buffer behind the last all-reduce
+    fd, ld, idd = out["one_opt_launch"]
+    assert ia["bucket_opt"] and ia["optimizer_launches_first_step"] == ia["buckets"] + 1, ia
+    assert not idd["bucket_opt"] and idd["optimizer_launches_first_step"] == 1, idd
+    assert la == ld and np.array_equal(fa, fd), (la, ld, float(np.abs(fa - fd).max()))
+    # ... and with the all-reduces (and the per-bucket optimizer branches behind them) captured inside ONE graph per step
+    fe, le, ie = out["captured"]
+    assert ie["captured"] and ie["graph_cuts"] == 0 and ie["bucket_opt"], ie
+    assert la == le and np.array_equal(fa, fe), (la, le, float(np.abs(fa - fe).max()))
 
 
 def _eager_ddp_worker(port, q):

@@ -407,3 +407,29 @@ def test_every_parameter_is_updated_exactly_once_per_step(dry, monkeypatch):
                 names = [k for k in tr.layout if k.startswith(f"transformer_layers.{li}.")]
                 assert lo == min(tr.layout[k][0] for k in names) and (lo, hi - lo) in last["done"]
                 assert all(not (lo <= tr.layout[k][0] < hi) for k in tr.layout if k not in names)
+
+
+def test_ddp_probe_decision_rules(monkeypatch):
+    """ddp_probe.decide(): a forced form (IB_GRAPH_COLLECTIVES=0/1) is taken as is; a host-side backend never captures; a
+    probe whose child job fails (here: no GPU -- the child's first HIP call raises) yields the cut-graph form with the
+    reason recorded, and the verdict is remembered in the environment for the trainers that follow"""
+    from inferbiomechanics_amd import ddp_probe
+    monkeypatch.setenv("IB_GRAPH_COLLECTIVES", "1")
+    assert ddp_probe.decide(1, 0, "nccl") is True and ddp_probe.verdict()["source"] == "environment"
+    monkeypatch.setenv("IB_GRAPH_COLLECTIVES", "0")
+    assert ddp_probe.decide(1, 0, "nccl") is False
+    monkeypatch.delenv("IB_GRAPH_COLLECTIVES")
+    monkeypatch.setattr(ddp_probe, "_verdict", None)
+    assert ddp_probe.decide(1, 0, "gloo") is False and ddp_probe.verdict()["source"] == "backend"
+    assert os.environ["IB_GRAPH_COLLECTIVES"] == "0"
+    monkeypatch.delenv("IB_GRAPH_COLLECTIVES")
+    if torch.cuda.is_available():
+        return                                   # (on a GPU box the real probe is exercised by tests/test_trainer_gpu.py)
+    r = ddp_probe.run_child(1, timeout_s=120)
+    assert r["ok"] is False and r["why"] and r["seconds"] >= 0
+    calls = []
+    monkeypatch.setattr(ddp_probe, "run_child", lambda world: (calls.append(world), {"ok": True, "why": "stub", "seconds": 0.0})[1])
+    assert ddp_probe.decide(1, 0, "nccl") is True and calls == [1] and ddp_probe.verdict()["source"] == "probe"
+    assert os.environ["IB_GRAPH_COLLECTIVES"] == "1"
+    assert ddp_probe.decide(1, 0, "nccl") is True and calls == [1]          # remembered: no second probe
+    monkeypatch.delenv("IB_GRAPH_COLLECTIVES")
