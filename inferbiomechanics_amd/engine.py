@@ -165,6 +165,25 @@ def broadcast_parameters(flat: torch.Tensor, group=None, src: int = 0):
         dist.broadcast(flat, src=src, group=group)
 
 
+def _drain_c10d_watchdog(device):
+    """Block until c10d's watchdog thread has reaped every eager collective issued so far.  The watchdog polls the completion
+    event of each outstanding Work (hipEventQuery from its own thread); the events sit on c10d's communication stream, and a
+    poll that lands while that stream is part of a capture fails ("event last recorded in a capturing stream") and takes the
+    process down.  torch keeps a counter of such pending queries for its own graphs -- `CUDAGraph.capture_begin()` waits
+    until it is zero -- so an EMPTY torch capture on a scratch stream is the deterministic form of that wait (round 4 slept
+    for half a second and hoped; a 13-bucket step on a busy host outlasted it once in this round's tests)."""
+    import time
+    try:
+        with torch.cuda.stream(torch.cuda.Stream(device=device)):
+            g = torch.cuda.CUDAGraph()
+            g.capture_begin()                        # returns once no c10d Work is waiting for its watchdog query
+            g.capture_end()
+    except Exception:                                # a torch without that counter: fall back to the timed wait
+        time.sleep(0.5)
+        return
+    time.sleep(0.05)
+
+
 class _Recorder:
     """Records a step as segments: hipGraphs (captured launch runs) interleaved with host actions
     (collective launches), then replays them."""
@@ -301,7 +320,12 @@ class HipTrainer:
         # completed (1 / world folded in), beside the backward of the layers below -- the structure of the one-GPU step's
         # per-layer optimizer; the step's last, self-counting launch then only names the buckets as done (round 5: one
         # launch over the whole flat buffer behind the last all-reduce before, 70 us on the transformer's critical path)
-        self.bucket_opt = bool(self.ddp and self.overlap_comm and not TU.no_bucket_opt)
+        # Only where completed buckets are launched at the plan's FLUSH points (layer boundaries: every launch that reads a
+        # layer's weights has been issued by then -- the later dgrads go through the packed / transposed copies made at the
+        # head of the step).  A plan that launches a bucket the moment its last gradient is reported may still have the
+        # dgrad through those very weights ahead of it: updating them there is a race (caught by
+        # tests/test_ddp_numerics_gpu.py on the MLP denoiser with forced overlap).
+        self.bucket_opt = bool(self.ddp and self.overlap_comm and self._flush_mode and not TU.no_bucket_opt)
         self._br_opt = Branch(dev, enabled=self.bucket_opt, name="bucket_opt")
         self._early_done: List[Tuple[int, int]] = []
         # device-side batch draw (step_drawn): Philox key = torch's seed (torch.manual_seed(s) selects the noise as it would
@@ -695,15 +719,14 @@ class HipTrainer:
         # stream carried the eager warm-up steps' collectives whose completion events the c10d watchdog polls from its own
         # thread -- a poll that lands while the stream captures aborts the process (the hazard _Recorder.begin refuses for
         # the caller's streams; it cannot see c10d's).  So before capturing: wait on every outstanding Work, drain the
-        # device, and give the watchdog one reap cycle; afterwards nothing it still polls sits on that stream.
+        # device, and wait until the watchdog has reaped them all (_drain_c10d_watchdog); afterwards nothing it still polls
+        # sits on that stream.
         graph_collectives = self.ddp and self.graph_collectives
         if graph_collectives:
             self.buckets.finish()
             if self.device.type == "cuda":
                 torch.cuda.synchronize(self.device)
-            if self.overlap_comm:
-                import time
-                time.sleep(0.5)
+                _drain_c10d_watchdog(self.device)
 
         def cut(b: int):
             if graph_collectives:
