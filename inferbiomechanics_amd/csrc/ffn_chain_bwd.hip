@@ -191,7 +191,19 @@ __global__ __launch_bounds__(FF_THREADS) void ffn_chain_bwd_kernel(FfnBwdParams 
     FF_STAMP(3);
     f32x4_t acco[4][FF_NT];
     ff_zero(acco);
-    auto sideo = [&](auto, int) {};
+    // ATT: the K and Q row fragments of this wave's head (16 pieces of 16 bytes per lane) are requested one per k-block
+    // BEHIND the weight prefetch of this phase: their HBM round trip runs under the GEMM
+    bf16x8_t qf[ATT ? 4 : 1][2], kf[ATT ? 4 : 1][2];
+    const bf16_t* qb = ATT ? p.qkv + (int64_t)r0 * (3 * FF_D) + 64 * wave_s + 8 * g : nullptr;
+    auto sideo = [&](auto kbc, int) {
+      if constexpr (ATT) {
+        constexpr int kb = decltype(kbc)::value;
+        constexpr int t = (kb & 7) >> 1, ks = kb & 1;
+        const bf16_t* row = qb + (int64_t)min(16 * t + (ff_lane() & 15), nrows - 1) * (3 * FF_D) + 32 * ks;   // rows beyond the window: duplicates
+        if constexpr (kb < 8) kf[t][ks] = *reinterpret_cast<const bf16x8_t*>(row + FF_D);
+        else qf[t][ks] = *reinterpret_cast<const bf16x8_t*>(row);
+      }
+    };
     ff_gemm<FF_RING_BB>(p.wotp, wave_s * FF_NT, imgZ, ff_lane(), acco, sideo);
 #pragma unroll
     for (int u = 0; u < FF_NT; ++u) {
@@ -205,26 +217,22 @@ __global__ __launch_bounds__(FF_THREADS) void ffn_chain_bwd_kernel(FfnBwdParams 
       ff_panel_out(imgD, p.dattn + (int64_t)r0 * FF_D, nrows, tid);
     } else {
       // ---- attention backward of head `wave` of this window, wave-private (attention_mfma.hip's two phases; all sums in
-      // registers, fixed order).  dO = the dattn columns just written into this wave's slice of image D (SB); Q, K, V row
-      // fragments of the head straight from HBM; K (phase 1), then Q (phase 2) in this wave's slice of image Z (SA) for the
-      // transposed reads.  The slices of other waves are never touched: no workgroup barrier until the results leave.
+      // registers, fixed order).  dO = the dattn columns just written into this wave's slice of image D (SB); K and Q row
+      // fragments arrived under the GEMM above, V's are requested now; K (phase 1), then Q (phase 2) in this wave's slice of
+      // image Z (SA) for the transposed reads.  The slices of other waves are never touched: no workgroup barrier until the
+      // results meet in the images.  dQ, dK, dV stay ON CHIP: bf16 in registers until both slices are free, then dQ -> SA,
+      // dK -> SB (the operands of the in-projection dgrad's first two phases), dV in registers until image Z is free again.
       FF_STAMP(4);
       __syncthreads();                   // every wave is past the out-projection GEMM: image Z (ds1) may be overwritten
       FF_STAMP(5);
       unsigned char* SA = imgZ + 128 * wave_s;
-      const unsigned char* SB = imgD + 128 * wave_s;
-      const bf16_t* qb = p.qkv + (int64_t)r0 * (3 * FF_D) + 64 * wave_s + 8 * g;
-      bf16_t* dqb = p.dqkv + (int64_t)r0 * (3 * FF_D) + 64 * wave_s + 4 * g;
-      bf16x8_t qf[4][2], kf[4][2], vf[4][2];
+      unsigned char* SB = imgD + 128 * wave_s;
+      bf16x8_t vf[4][2];
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        const bf16_t* row = qb + (int64_t)min(16 * t + l16, nrows - 1) * (3 * FF_D);   // rows beyond the window: finite duplicates
+        const bf16_t* row = qb + (int64_t)min(16 * t + l16, nrows - 1) * (3 * FF_D) + 2 * FF_D;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          qf[t][ks] = *reinterpret_cast<const bf16x8_t*>(row + 32 * ks);
-          kf[t][ks] = *reinterpret_cast<const bf16x8_t*>(row + FF_D + 32 * ks);
-          vf[t][ks] = *reinterpret_cast<const bf16x8_t*>(row + 2 * FF_D + 32 * ks);
-        }
+        for (int ks = 0; ks < 2; ++ks) vf[t][ks] = *reinterpret_cast<const bf16x8_t*>(row + 32 * ks);
       }
       attL[wave_s][lane] = lane < nrows ? p.lse[((int64_t)blockIdx.x * FF_HEADS + wave_s) * p.P + lane] : 0.f;
 #pragma unroll
@@ -235,6 +243,7 @@ __global__ __launch_bounds__(FF_THREADS) void ffn_chain_bwd_kernel(FfnBwdParams 
       ff_wave_sync();
       FF_STAMP(6);
       // ---------------- phase 1: dQ per 16-query tile (the lane owns query 16 it + lane % 16)
+      bf16x4_t dqp[4][4], dkp[4][4], dvp[4][4];
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
         const int q = 16 * it + l16;
@@ -276,13 +285,13 @@ __global__ __launch_bounds__(FF_THREADS) void ffn_chain_bwd_kernel(FfnBwdParams 
           for (int dt = 0; dt < 4; ++dt)
             dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ff_sl_tr(SA, 32 * kp, 32 * kp + 16, dt, lane), sf, dq[dt], 0, 0, 0);
         }
-        if (q < nrows) {
-          bf16_t* row = dqb + (int64_t)q * (3 * FF_D);
 #pragma unroll
-          for (int dt = 0; dt < 4; ++dt)
-            *reinterpret_cast<bf16x4_t*>(row + 16 * dt) = ff_pack4(dq[dt][0] * FF_ATT_SCALE, dq[dt][1] * FF_ATT_SCALE,
-                                                                     dq[dt][2] * FF_ATT_SCALE, dq[dt][3] * FF_ATT_SCALE);
-        }
+        for (int dt = 0; dt < 4; ++dt)
+          dqp[it][dt] = ff_pack4(dq[dt][0] * FF_ATT_SCALE, dq[dt][1] * FF_ATT_SCALE, dq[dt][2] * FF_ATT_SCALE,
+                                 dq[dt][3] * FF_ATT_SCALE);
+        // (the tiles are independent: left alone the scheduler interleaves them and the live set outgrows 256 VGPRs --
+        // 124 spilled registers measured; one tile at a time fits)
+        __builtin_amdgcn_sched_barrier(0);
       }
       FF_STAMP(7);
       ff_wave_sync();                    // phase 1 is done reading K out of SA; D of every query is in LDS
@@ -295,7 +304,6 @@ __global__ __launch_bounds__(FF_THREADS) void ffn_chain_bwd_kernel(FfnBwdParams 
       // ---------------- phase 2: dK, dV per 16-key tile (the lane owns key 16 jt + lane % 16)
 #pragma unroll
       for (int jt = 0; jt < 4; ++jt) {
-        const int key = 16 * jt + l16;
         const bf16x8_t k0 = kf[jt][0], k1 = kf[jt][1], v0 = vf[jt][0], v1 = vf[jt][1];
         f32x4_t dv[4], dk[4];
 #pragma unroll
@@ -332,24 +340,89 @@ __global__ __launch_bounds__(FF_THREADS) void ffn_chain_bwd_kernel(FfnBwdParams 
             dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ff_sl_tr(SA, 32 * qp, 32 * qp + 16, dt, lane), sf, dk[dt], 0, 0, 0);
           }
         }
-        if (key < nrows) {
-          bf16_t* row = dqb + (int64_t)key * (3 * FF_D);
 #pragma unroll
-          for (int dt = 0; dt < 4; ++dt) {
-            *reinterpret_cast<bf16x4_t*>(row + FF_D + 16 * dt) = ff_pack4(dk[dt][0] * FF_ATT_SCALE, dk[dt][1] * FF_ATT_SCALE,
-                                                                            dk[dt][2] * FF_ATT_SCALE, dk[dt][3] * FF_ATT_SCALE);
-            *reinterpret_cast<bf16x4_t*>(row + 2 * FF_D + 16 * dt) = ff_pack4(dv[dt][0], dv[dt][1], dv[dt][2], dv[dt][3]);
-          }
+        for (int dt = 0; dt < 4; ++dt) {
+          dkp[jt][dt] = ff_pack4(dk[dt][0] * FF_ATT_SCALE, dk[dt][1] * FF_ATT_SCALE, dk[dt][2] * FF_ATT_SCALE,
+                                 dk[dt][3] * FF_ATT_SCALE);
+          dvp[jt][dt] = ff_pack4(dv[dt][0], dv[dt][1], dv[dt][2], dv[dt][3]);
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
       FF_STAMP(8);
-      __syncthreads();                   // every head's dqkv rows are stored (workgroup scope: visible to the loads below)
+      ff_wave_sync();                    // this wave is done reading Q / dO out of its slices: they take dQ / dK
+      // rows (16 tile + lane % 16), columns (16 dt + 4 g ..) of the slice: the layout every GEMM epilogue writes
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          *reinterpret_cast<bf16x4_t*>(SA + (16 * t + l16) * FF_RS + (16 * dt + 4 * g) * 2) = dqp[t][dt];
+          *reinterpret_cast<bf16x4_t*>(SB + (16 * t + l16) * FF_RS + (16 * dt + 4 * g) * 2) = dkp[t][dt];
+        }
+      __syncthreads();                   // image Z = dQ, image D = dK of all eight heads
       FF_STAMP(9);
-      // ---- dx = dqkv . Wqkv + ds1: this layer's in-projection dgrad + the residual addend, rows -> HBM
-      ff_qkv_dgrad(p.ds1 + (int64_t)r0 * FF_D, p.dqkv + (int64_t)r0 * (3 * FF_D), p.wqkvtp_own, imgZ, imgD, nrows, tid, wave_s,
-                   l16, colb);
+      // ---- dx = dqkv . Wqkv + ds1: the in-projection's dgrad straight from the images; the dqkv rows leave for HBM (the
+      // in-projection's weight-gradient operand) as the side jobs of the phases that read them, one piece per two k-blocks
+      bf16_t* dqg = p.dqkv + (int64_t)r0 * (3 * FF_D);
+      f32x4_t accd[4][FF_NT];
+      ff_zero(accd);
+      auto side_q = [&](auto, int kb) {
+        if ((kb & 1) == 0) ff_out_piece(imgZ, dqg, 3 * FF_D, nrows, FF_TIDV + (kb >> 1) * FF_THREADS);
+      };
+      ff_gemm<FF_RING_BB>(p.wqkvtp_own, wave_s * FF_NT, imgZ, ff_lane(), accd, side_q);
+      auto side_k = [&](auto, int kb) {
+        if ((kb & 1) == 0) ff_out_piece(imgD, dqg + FF_CHUNK, 3 * FF_D, nrows, FF_TIDV + (kb >> 1) * FF_THREADS);
+      };
+      ff_gemm<FF_RING_BB>(p.wqkvtp_own + FF_WELEMS, wave_s * FF_NT, imgD, ff_lane(), accd, side_k);
+      __syncthreads();                   // every wave is past both phases: the images may be rewritten
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+          *reinterpret_cast<bf16x4_t*>(SA + (16 * t + l16) * FF_RS + (16 * dt + 4 * g) * 2) = dvp[t][dt];
+      __syncthreads();                   // image Z = dV
+      // third phase: dV rows out on the even k-blocks, the residual addend's rows (ds1, written by this workgroup's
+      // LayerNorm1 backward above: visible at workgroup scope) requested on the odd ones and parked in named registers
+      const bf16_t* ad = p.ds1 + (int64_t)r0 * FF_D;
+      uint4 n0, n1, n2, n3, n4, n5, n6, n7;
+      n0 = n1 = n2 = n3 = n4 = n5 = n6 = n7 = make_uint4(0u, 0u, 0u, 0u);
+      auto piece = [&](int j) {
+        const int idx = FF_TIDV + j * FF_THREADS;
+        return *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(ad + (int64_t)min(idx >> 6, nrows - 1) * FF_D) + (idx & 63) * 16);
+      };
+      auto side_v = [&](auto kbc, int) {
+        constexpr int kb = decltype(kbc)::value;
+        if constexpr ((kb & 1) == 0) ff_out_piece(imgZ, dqg + 2 * FF_CHUNK, 3 * FF_D, nrows, FF_TIDV + (kb >> 1) * FF_THREADS);
+        if constexpr (kb == 1) n0 = piece(0);
+        if constexpr (kb == 3) n1 = piece(1);
+        if constexpr (kb == 5) n2 = piece(2);
+        if constexpr (kb == 7) n3 = piece(3);
+        if constexpr (kb == 9) n4 = piece(4);
+        if constexpr (kb == 11) n5 = piece(5);
+        if constexpr (kb == 13) n6 = piece(6);
+        if constexpr (kb == 15) n7 = piece(7);
+      };
+      ff_gemm<FF_RING_BB>(p.wqkvtp_own + 2 * FF_WELEMS, wave_s * FF_NT, imgZ, ff_lane(), accd, side_v);
+      {
+        auto put = [&](int j, const uint4& v) {           // image D is free since the barrier behind the second phase
+          const int idx = tid + j * FF_THREADS;
+          *reinterpret_cast<uint4*>(imgD + (idx >> 6) * FF_RS + (idx & 63) * 16) = v;
+        };
+        put(0, n0); put(1, n1); put(2, n2); put(3, n3); put(4, n4); put(5, n5); put(6, n6); put(7, n7);
+      }
+      __syncthreads();                   // image D = ds1 rows
+#pragma unroll
+      for (int u = 0; u < FF_NT; ++u) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          bf16x4_t* slot = reinterpret_cast<bf16x4_t*>(imgD + (16 * mt + l16) * FF_RS + (colb + 16 * u) * 2);
+          const bf16x4_t av = *slot;
+          *slot = ff_pack4(accd[mt][u][0] + (float)av[0], accd[mt][u][1] + (float)av[1], accd[mt][u][2] + (float)av[2],
+                           accd[mt][u][3] + (float)av[3]);
+        }
+      }
+      __syncthreads();                   // image D = dx
       FF_STAMP(10);
-      ff_panel_out(imgZ, p.dx + (int64_t)r0 * FF_D, nrows, tid);
+      ff_panel_out(imgD, p.dx + (int64_t)r0 * FF_D, nrows, tid);
       FF_STAMP(11);
     }
   }
