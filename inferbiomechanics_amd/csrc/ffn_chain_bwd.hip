@@ -191,19 +191,10 @@ __global__ __launch_bounds__(FF_THREADS) void ffn_chain_bwd_kernel(FfnBwdParams 
     FF_STAMP(3);
     f32x4_t acco[4][FF_NT];
     ff_zero(acco);
-    // ATT: the K and Q row fragments of this wave's head (16 pieces of 16 bytes per lane) are requested one per k-block
-    // BEHIND the weight prefetch of this phase: their HBM round trip runs under the GEMM
-    bf16x8_t qf[ATT ? 4 : 1][2], kf[ATT ? 4 : 1][2];
+    // (ATT: requesting the K / Q row fragments of the head as side jobs of this phase was measured a wash -- the phase got
+    // 3.1 us longer, the load step behind it 2.8 us shorter: the same bytes through the same L2 -> CU path, plus 3 spills)
     const bf16_t* qb = ATT ? p.qkv + (int64_t)r0 * (3 * FF_D) + 64 * wave_s + 8 * g : nullptr;
-    auto sideo = [&](auto kbc, int) {
-      if constexpr (ATT) {
-        constexpr int kb = decltype(kbc)::value;
-        constexpr int t = (kb & 7) >> 1, ks = kb & 1;
-        const bf16_t* row = qb + (int64_t)min(16 * t + (ff_lane() & 15), nrows - 1) * (3 * FF_D) + 32 * ks;   // rows beyond the window: duplicates
-        if constexpr (kb < 8) kf[t][ks] = *reinterpret_cast<const bf16x8_t*>(row + FF_D);
-        else qf[t][ks] = *reinterpret_cast<const bf16x8_t*>(row);
-      }
-    };
+    auto sideo = [&](auto, int) {};
     ff_gemm<FF_RING_BB>(p.wotp, wave_s * FF_NT, imgZ, ff_lane(), acco, sideo);
 #pragma unroll
     for (int u = 0; u < FF_NT; ++u) {
@@ -217,8 +208,8 @@ __global__ __launch_bounds__(FF_THREADS) void ffn_chain_bwd_kernel(FfnBwdParams 
       ff_panel_out(imgD, p.dattn + (int64_t)r0 * FF_D, nrows, tid);
     } else {
       // ---- attention backward of head `wave` of this window, wave-private (attention_mfma.hip's two phases; all sums in
-      // registers, fixed order).  dO = the dattn columns just written into this wave's slice of image D (SB); K and Q row
-      // fragments arrived under the GEMM above, V's are requested now; K (phase 1), then Q (phase 2) in this wave's slice of
+      // registers, fixed order).  dO = the dattn columns just written into this wave's slice of image D (SB); Q, K, V row
+      // fragments of the head straight from HBM; K (phase 1), then Q (phase 2) in this wave's slice of
       // image Z (SA) for the transposed reads.  The slices of other waves are never touched: no workgroup barrier until the
       // results meet in the images.  dQ, dK, dV stay ON CHIP: bf16 in registers until both slices are free, then dQ -> SA,
       // dK -> SB (the operands of the in-projection dgrad's first two phases), dV in registers until image Z is free again.
@@ -227,12 +218,16 @@ __global__ __launch_bounds__(FF_THREADS) void ffn_chain_bwd_kernel(FfnBwdParams 
       FF_STAMP(5);
       unsigned char* SA = imgZ + 128 * wave_s;
       unsigned char* SB = imgD + 128 * wave_s;
-      bf16x8_t vf[4][2];
+      bf16x8_t qf[4][2], kf[4][2], vf[4][2];
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        const bf16_t* row = qb + (int64_t)min(16 * t + l16, nrows - 1) * (3 * FF_D) + 2 * FF_D;
+        const bf16_t* row = qb + (int64_t)min(16 * t + l16, nrows - 1) * (3 * FF_D);   // rows beyond the window: finite duplicates
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) vf[t][ks] = *reinterpret_cast<const bf16x8_t*>(row + 32 * ks);
+        for (int ks = 0; ks < 2; ++ks) {
+          qf[t][ks] = *reinterpret_cast<const bf16x8_t*>(row + 32 * ks);
+          kf[t][ks] = *reinterpret_cast<const bf16x8_t*>(row + FF_D + 32 * ks);
+          vf[t][ks] = *reinterpret_cast<const bf16x8_t*>(row + 2 * FF_D + 32 * ks);
+        }
       }
       attL[wave_s][lane] = lane < nrows ? p.lse[((int64_t)blockIdx.x * FF_HEADS + wave_s) * p.P + lane] : 0.f;
 #pragma unroll

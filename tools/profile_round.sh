@@ -7,13 +7,13 @@
 # copies the summaries into profiles/.  The program sits directly after `--` (no env / bash -c hop: rocprofv3's preloaded
 # library has initialised the GPU by then).
 set -o pipefail
-TAG=${1:-r02}
-WL=${2:-mlp_denoiser_T50}
+TAG=${1:-r05_tr}
+WL=${2:-transformer_denoiser_T50}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 python3 $GRAFT_REPO_ROOT/tools/csrc_hash.py > $OUT/csrc_hash.txt     # the build these counters belong to
 cd /tmp && export TMPDIR=/tmp
-ARGS="--workload $WL --steps 40 --warmup 5 --no-cpu-baseline --no-ddim --no-transformer --no-graph"
+ARGS="--workload $WL --steps 40 --warmup 5 --no-cpu-baseline --no-ddim --no-mlp --no-cli-path --no-graph"
 timeout -k 10 280 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $GRAFT_REPO_ROOT/bench.py $ARGS > $OUT/trace.log 2>&1; echo trace_rc=$?
 timeout -k 10 280 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $GRAFT_REPO_ROOT/bench.py $ARGS > $OUT/pmc_fetch.log 2>&1; echo fetch_rc=$?
 timeout -k 10 280 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $GRAFT_REPO_ROOT/bench.py $ARGS > $OUT/pmc_write.log 2>&1; echo write_rc=$?

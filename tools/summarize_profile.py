@@ -23,7 +23,13 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ENTRY_OF = [("ffn_chain_fwd_kernel", "", "ib_ffn_chain_fwd"), ("ffn_chain_bwd_kernel", "", "ib_ffn_chain_bwd"),
+ENTRY_OF = [# round 5: the one-window-panel launches with the attention inside (and the top layer's launch of the same entry point)
+            ("ffn_chain_bwd_kernel<true, false, true", "", "ib_ffn_chain_bwd_attn"),
+            ("ffn_chain_fwd_kernel<true, true, true, false", "", "ib_ffn_chain_fwd_attn"),
+            ("ffn_chain_fwd_kernel<true, false, false, false", "", "ib_ffn_chain_fwd_attn"),
+            ("ffn_chain_fwd_kernel<true, true, false, true", "", "ib_ffn_chain_fwd_infer"),
+            ("ffn_chain_fwd_kernel<true, false, false, true", "", "ib_ffn_chain_fwd_infer"),
+            ("ffn_chain_fwd_kernel", "", "ib_ffn_chain_fwd"), ("ffn_chain_bwd_kernel", "", "ib_ffn_chain_bwd"),
             ("ffn_pack_kernel", "", "ib_ffn_chain_pack"), ("diffusion_draw_kernel", "", "ib_diffusion_draw"),
             ("gemm_tn256_kernel", "", "ib_linear_wgrad_slabs_multi"), ("gemm_tn_kernel", "", "ib_linear_wgrad_slabs_multi"), ("gemm_nt_kernel<0, 0, false", "", "ib_linear_fwd"),
             ("gemm_nt_kernel<1, 0", "", "ib_linear_fwd"), ("gemm_nt_kernel<0, 1", "", "ib_linear_dgrad"),
