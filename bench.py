@@ -668,8 +668,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ddim", action="store_true")
     ap.add_argument("--no-cli-path", action="store_true", help="skip the `main.py train` rate of the same workload")
-    ap.add_argument("--no-variant-child", action="store_true",
-                    help="[N > 1] skip the run of the collectives' OTHER form (captured in the graph / host actions) in child processes")
+    ap.add_argument("--variant-child", action="store_true",
+                    help="[N > 1] also run the collectives' OTHER form (captured in the graph / host actions) in child processes "
+                         "(doubles the processes on the node for its duration: opt-in)")
+    ap.add_argument("--no-variant-child", action="store_true", help="(accepted for older command lines; the variant is opt-in)")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-launch roofline leg (child runs)")
     ap.add_argument("--no-mlp", action="store_true", help="skip the configs[1] MLP denoiser leg (extra key `mlp_T50`)")
     ap.add_argument("--bucket-mb", type=float, default=13.0,
@@ -745,7 +747,7 @@ def main():
                             with_roofline=not a.no_roofline)
     variant = None
     # (IB_BENCH_FORCE_VARIANT=1 with IB_DDP_SELFTEST=1: the same mechanism on a one-GPU box, a 1-rank child)
-    want_variant = world > 1 or (selftest and os.environ.get("IB_BENCH_FORCE_VARIANT") == "1")
+    want_variant = (world > 1 and a.variant_child) or (selftest and os.environ.get("IB_BENCH_FORCE_VARIANT") == "1")
     from inferbiomechanics_amd import ddp_probe
     coll = ddp_probe.verdict() if (world > 1 or selftest) else None
     if want_variant and not rehearsal and not a.no_variant_child and forced_form is None and coll is not None:

@@ -5,13 +5,14 @@ kernels enqueued by c10d can be captured and replayed depends on the RCCL / driv
 there is a hang or an abort, not an exception.  So the question is never asked in a process that matters:
 
     parent (every rank, HipTrainer.__init__ -> decide())
-        rank 0 starts a FRESH child job -- `python -m torch.distributed.run --nproc-per-node <world>
+        rank 0 starts a FRESH child job -- `python -m torch.distributed.run --nproc-per-node min(world, 2)
         -m inferbiomechanics_amd.ddp_probe` (subprocess; nothing that has touched a GPU is ever exec'd) -- bounded by a
         timeout, its process group killed as a whole when it expires;
         the child ranks build two small models, run the cut-graph form and the captured form on the same batches
         (bucketed + overlapped policy and the one-bucket policy) and compare the trajectories bit for bit;
         exit code 0 + the OK line -> every parent rank uses the captured form; anything else -> the cut-graph form.
-    The verdict reaches the other parent ranks over a host-side (gloo) group: their GPUs stay idle while the child runs.
+    The verdict reaches the other parent ranks through the process group's key-value store: no collective is issued and
+    their GPUs stay idle while the child runs.
 
 IB_GRAPH_COLLECTIVES=1 / =0 in the environment skips the probe (forces the form); the verdict of a probe is remembered in
 that variable for the rest of the process.  Reference: the step this is about is DDP's bucketed all-reduce inside
@@ -62,6 +63,9 @@ def run_child(world: int, timeout_s: float = 150.0) -> dict:
         return {"ok": False, "why": repr(exc)[:300], "seconds": round(time.perf_counter() - t0, 1)}
 
 
+PROBE_RANKS = 2       # the child job's size (at most the parent's world): two ranks put RCCL's inter-GPU transport inside
+                      # the captured graph, which is what can fail; a world-sized child would double the processes on the node
+_probe_no = 0
 _verdict = None      # the last decision of this process: {"captured": bool, "source": ..., "why": ...}
 
 
@@ -82,11 +86,27 @@ def decide(world: int, rank: int, backend: str) -> bool:
         _verdict = {"captured": False, "source": "backend", "why": f"backend {backend}: collectives run on the host"}
         os.environ["IB_GRAPH_COLLECTIVES"] = "0"
         return False
+    # the verdict travels through the process group's own key-value store (rank 0 sets a key, the others block on it):
+    # no extra group, no collective, and the other ranks' GPUs stay idle while the child job runs
+    import json
+    global _probe_no
+    _probe_no += 1
+    key = f"ib_ddp_probe_verdict_{_probe_no}"
     res = [None]
+    store = None
+    try:
+        store = dist.distributed_c10d._get_default_store()
+    except Exception:
+        store = None
     if rank == 0:
-        res[0] = run_child(world)
-    if world > 1:
-        g = dist.new_group(backend="gloo")            # host-side wait: the other ranks' GPUs stay idle meanwhile
+        res[0] = run_child(min(world, PROBE_RANKS))
+        if world > 1 and store is not None:
+            store.set(key, json.dumps(res[0]))
+    elif store is not None:
+        store.wait([key])
+        res[0] = json.loads(store.get(key).decode())
+    if world > 1 and store is None:                   # no store to be had: a host-side group for one broadcast
+        g = dist.new_group(backend="gloo")
         dist.broadcast_object_list(res, src=0, group=g)
         dist.destroy_process_group(g)
     r = res[0]
