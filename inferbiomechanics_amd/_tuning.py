@@ -19,6 +19,7 @@ _SPEC = {
     "no_layer_branch": ("IB_NO_LAYER_BRANCH", False),
     "layer_branch": ("IB_LAYER_BRANCH", False),
     "no_outproj_branch": ("IB_NO_OUTPROJ_BRANCH", False),
+    "pos_own_branch": ("IB_POS_OWN_BRANCH", False),   # frame-embedding gradients on a fifth branch of the step's tail (rounds 2-4)
     # ---- GEMM families
     "no_nt": ("IB_NO_NT", False),
     "no_wgrad_bias": ("IB_NO_WGRAD_BIAS", False),

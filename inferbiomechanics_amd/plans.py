@@ -1677,7 +1677,11 @@ class DenoiserTransformerPlan:
             hip.tiny_matmul(dpp32.t(), pos, gw_in[:, D:], accumulate=accumulate)
             hip.tiny_matmul(dpp32, w_in[:, D:], gpos, accumulate=accumulate)
             P.ready("temporal_embedding.embedding.weight")
-        self.br_pos.run(t_pos)
+        # (round 5: behind the time-MLP hidden layer's chain on ITS branch, not on a branch of its own: with the main stream,
+        # layer 0's weight-gradient branch and the two time-MLP branches the tail already has four concurrent branches, a
+        # captured graph runs four at a time, and the fifth -- three small launches -- only started when another had
+        # finished: alone at the end of the step, `profiles/r05_tr_timeline.txt`)
+        (self.br_pos if TU.pos_own_branch else self.br_thid).run(t_pos)
         _wgrad(self.buf, dz0, x, gw_in[:, :D], accumulate)
         self.br_time.join(); self.br_thid.join(); self.br_pos.join(); self.br_wt.join()
         P.ready("in_proj.weight")

@@ -3,7 +3,7 @@
 export IB_HIP_LIB=${IB_HIP_LIB:-$(cd "$(dirname "$0")/.." && pwd)/inferbiomechanics_amd/lib/ab/libib_hip_ab.so}
 for v in "" "IB_NO_LAG_GROUP=1" "" "IB_NO_LAG_GROUP=1"; do
   echo "== $v"
-  env $v IB_DDP_SELFTEST=1 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 MASTER_ADDR=127.0.0.1 MASTER_PORT=29577 python bench.py --workload transformer_denoiser_T50 --steps 300 --warmup 30 --no-cpu-baseline --no-ddim --no-transformer 2>/dev/null | python -c "
+  env $v IB_DDP_SELFTEST=1 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 MASTER_ADDR=127.0.0.1 MASTER_PORT=29577 python bench.py --workload transformer_denoiser_T50 --steps 300 --warmup 30 --no-cpu-baseline --no-ddim --no-mlp 2>/dev/null | python -c "
 import json,sys
 o=json.loads(sys.stdin.read())
 print(o['ms_per_step'], o['final_loss'])

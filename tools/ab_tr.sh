@@ -3,11 +3,10 @@
 export IB_HIP_LIB=${IB_HIP_LIB:-$(cd "$(dirname "$0")/.." && pwd)/inferbiomechanics_amd/lib/ab/libib_hip_ab.so}
 for v in "$@"; do
   echo "== $v"
-  env $v python bench.py --workload transformer_denoiser_T50 --steps 100 --warmup 10 --no-cpu-baseline --no-ddim --no-transformer 2>/dev/null | python -c "
+  env $v python bench.py --workload transformer_denoiser_T50 --steps 100 --warmup 10 --no-cpu-baseline --no-ddim --no-mlp 2>/dev/null | python -c "
 import json,sys
 o=json.loads(sys.stdin.read())
 print(o['ms_per_step'], o['step_ms'], o['final_loss'])
-for b in o['step_breakdown'][:18]: print('   ', b['entry'], b['dims'][-4:], b['launches_per_step'], b['avg_launch_us'])
 print('   sum', o['step_sum_of_kernel_us'])
 "
 done
