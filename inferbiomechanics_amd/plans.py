@@ -614,7 +614,12 @@ class TransformerLayerPlan:
         attention launches."""
         if (self.ffn_fused(M) and not TU.no_attn_fuse and not TU.no_qkv_fuse and self.d == 512 and self.h == 8
                 and 16 <= T <= 64 and M % T == 0 and hip.ffn_chain_workgroups(M, self.d, self.ffn, T) > 0):
-            return T
+            # a panel kernel's time per workgroup is set by the weights it streams, whatever its row count: one-window panels
+            # much shorter than the token-count panels (many short windows: B = 2048, T = 16 -> 2048 workgroups instead of
+            # 512) multiply the rounds of workgroups; there the separate attention launches win
+            natural = min(64, max(16, -(-M // 256)))
+            if 4 * T >= 3 * natural:
+                return T
         return 0
 
     def tail_active(self, M: int, training: bool = False) -> bool:

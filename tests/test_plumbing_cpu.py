@@ -433,3 +433,23 @@ def test_ddp_probe_decision_rules(monkeypatch):
     assert os.environ["IB_GRAPH_COLLECTIVES"] == "1"
     assert ddp_probe.decide(1, 0, "nccl") is True and calls == [1]          # remembered: no second probe
     monkeypatch.delenv("IB_GRAPH_COLLECTIVES")
+
+
+def test_attention_inside_the_layer_launches_is_chosen_by_shape(dry):
+    """plans.TransformerLayerPlan.attn_T: one-window panels (the attention inside the fused layer launches) for bf16,
+    d = 512 = 8 heads x 64, 16 <= T <= 64, whole windows, at least 4096 rows -- and not where one-window panels would be much
+    shorter than the token-count panels (many short windows multiply the rounds of workgroups)"""
+    from inferbiomechanics_amd import plans
+    from inferbiomechanics_amd._tuning import tuning as TU
+    lp = plans.TransformerLayerPlan("l.", 512, 8, 2048, torch.bfloat16, "cpu", tag="tlx")
+    assert lp.attn_T(12800, 50) == 50 and lp.attn_T(4096, 32) == 32 and lp.attn_T(25600, 50) == 50 and lp.attn_T(8192, 64) == 64
+    assert lp.attn_T(32768, 16) == 0            # 2048 workgroups instead of 512
+    assert lp.attn_T(51200, 200) == 0 and lp.attn_T(4000, 50) == 0 and lp.attn_T(12800, 48) == 0      # T > 64; < 4096 rows; M % T
+    assert plans.TransformerLayerPlan("l.", 512, 4, 2048, torch.bfloat16, "cpu").attn_T(12800, 50) == 0          # 4 heads of 128
+    assert plans.TransformerLayerPlan("l.", 512, 8, 2048, torch.float32, "cpu").attn_T(12800, 50) == 0           # parity mode
+    assert plans.TransformerLayerPlan("l.", 512, 8, 2048, torch.bfloat16, "cpu", dropout_p=0.1).attn_T(12800, 50) == 0
+    TU.no_attn_fuse = True
+    try:
+        assert lp.attn_T(12800, 50) == 0
+    finally:
+        TU.no_attn_fuse = False
