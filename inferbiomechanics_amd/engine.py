@@ -446,6 +446,7 @@ class HipTrainer:
                     try:
                         for lp in getattr(plan, "layers", ()):
                             self._prefix_range(lp.p)
+                        self._prefix_range("out_proj.")
                     except hip.HipError:
                         early = False
                 plan.early_optimizer = self._early_optimizer if early else None
@@ -513,19 +514,47 @@ class HipTrainer:
                 self.buckets.finish()
         # self-counting optimizer launch: uses *step_dev + 1 and publishes it itself (no separate counter launch)
         src = getattr(self.plan, "pending_sources", None)
+        done, self._early_done = list(self._early_done), []
         if src is not None:
             self.plan.pending_sources = None
-            done = getattr(self, "_early_done", None)
-            if done:
-                src = tuple(src[:4]) + ([self.grad[lo:hi] for lo, hi in done],)
-                self._early_done = []
-        elif self._early_done:
-            # data parallel, per-bucket optimizer: nothing is left to sum, the launch below skips the buckets' ranges
-            src = ([], None, 0, [], [self.grad[lo:hi] for lo, hi in self._early_done])
-            self._early_done = []
-        hip.optim_step(self.opt_type, self.flat, self.grad, self.s1, self.s2, self.lr, step=0, step_dev=self.step_dev,
-                       ticket=self.ticket, grad_scale=1.0 / self.world,
-                       shadow=m._shadow if dt == torch.bfloat16 else None, sources=src)
+        elif done:
+            src = ([], None, 0, [], [])               # data parallel, per-bucket optimizer: nothing is left to sum
+        # The launch covers only what the earlier launches of this step left: ranges already updated at the head / tail of
+        # the flat buffers are cut off (a launch over the whole 13-M-element buffer whose blocks find most of it done was
+        # 18 us at the very end of the transformer step; over the 1 M elements that are left it is 4), ranges in the middle
+        # are named as done (source kind 3).  Everything updated already: one block that only counts the step.
+        lo, hi, inner = self._last_launch_range(done, src)
+        if src is not None and (inner or len(src) > 4):
+            src = tuple(src[:4]) + ([self.grad[a:b] for a, b in inner],)
+        sl = lambda t: None if t is None else t[lo:hi]
+        hip.optim_step(self.opt_type, self.flat[lo:hi], self.grad[lo:hi], sl(self.s1), sl(self.s2), self.lr, step=0,
+                       step_dev=self.step_dev, ticket=self.ticket, grad_scale=1.0 / self.world,
+                       shadow=sl(m._shadow) if dt == torch.bfloat16 else None, sources=src)
+
+    def _last_launch_range(self, done, src):
+        """[lo, hi) of the flat buffers for the step's last optimizer launch + the done ranges left inside it"""
+        n = self.flat.numel()
+        merged: List[List[int]] = []
+        for a, b in sorted(done):
+            if merged and a <= merged[-1][1]:
+                merged[-1][1] = max(merged[-1][1], b)
+            else:
+                merged.append([a, b])
+        lo, hi = 0, n
+        if merged and merged[0][0] == 0:
+            lo = merged.pop(0)[1]
+        if merged and merged[-1][1] == n:
+            hi = merged.pop()[0]
+        if lo >= hi:                                  # nothing left: a one-block launch that publishes the step number
+            return n - 64, n, [(n - 64, n)]
+        if src is not None:                           # every gradient source of this launch must lie inside the range
+            g0 = self.grad.data_ptr()
+            dsts = [dw for _, _, dw in src[0]] + [seg[2] for seg in src[3]] + [seg[3] for seg in src[3] if seg[3] is not None]
+            for t in dsts:
+                off = (t.data_ptr() - g0) // 4
+                if 0 <= off < n and not (lo <= off and off + t.numel() <= hi):
+                    return 0, n, [(a, b) for a, b in sorted(done)]
+        return lo, hi, [(a, b) for a, b in merged]
 
     def _bucket_optimizer(self, b: int, issue: bool = True, mark: bool = True):
         """the optimizer over bucket b's range of the flat buffers, on the `bucket_opt` side stream behind that bucket's

@@ -1613,11 +1613,15 @@ class DenoiserTransformerPlan:
         self.pending_sources = None
         def t_outproj():
             # the output projection's own gradients: three launches nothing downstream waits for -- on a side stream on one
-            # GPU, so the main stream goes from the loss straight to the dgrad
-            _wgrad(self.buf, dout, hlast.view(M, self.d), P.g("out_proj.weight"), accumulate, ws_tag="dt.wso", defer=defer)
+            # GPU, so the main stream goes from the loss straight to the dgrad.  With the per-layer optimizer its parameters
+            # (the head of the flat buffers) are updated right here too: the step's last launch then starts behind the layers
+            op_defer = [] if early else defer
+            _wgrad(self.buf, dout, hlast.view(M, self.d), P.g("out_proj.weight"), accumulate, ws_tag="dt.wso", defer=op_defer)
             P.ready("out_proj.weight")
             _colsum(self.buf, "dt.bo", dout, P.g("out_proj.bias"), accumulate)
             P.ready("out_proj.bias")
+            box_op.append(op_defer)
+        box_op: list = []
         if fuse and not TU.no_outproj_branch:
             self.br_wt.run(t_outproj)                 # joined with the tail's branches, before the optimizer
         else:
@@ -1627,6 +1631,10 @@ class DenoiserTransformerPlan:
         if not (tp and dout.stride(0) == tp["Kp"] and dout.stride(1) == 1 and
                 hip.linear_dgrad_wt(dout.as_strided((M, tp["Kp"]), (tp["Kp"], 1)), tp["w_outT"], dh.view(M, self.d))):
             hip.linear_dgrad(dout, P.w("out_proj.weight"), dh.view(M, self.d))
+        if early is not None and box_op:
+            # forked AGAIN from here: behind the dgrad above (which may read the weight itself) and behind the gradient
+            # launches already on that branch
+            self.br_wt.run(lambda: early("out_proj.", (box_op[0], None, 0, [])))
         P.flush()
         prev = None                                   # (layer plan, closure, names) whose launches lag one layer
         head = None

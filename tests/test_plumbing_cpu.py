@@ -385,27 +385,30 @@ def test_every_parameter_is_updated_exactly_once_per_step(dry, monkeypatch):
             monkeypatch.setattr(hip, "optim_step", real)
             n = tr.flat.numel()
             last = seen[-1]
-            assert last["lo"] == 0 and last["n"] == n and last["ticket"] and last["step"] == 0
+            assert last["ticket"] and last["step"] == 0                   # the self-counting launch comes last
             if not early:
-                assert len(seen) == 1 and last["done"] == []
+                assert len(seen) == 1 and last["done"] == [] and last["lo"] == 0 and last["n"] == n
                 continue
-            assert len(seen) == 4 and len(last["done"]) == 3                       # three layers + the step's last launch
+            # the output projection (head of the flat buffers) + three layers + the step's last launch, which starts behind
+            # the layers' ranges (nothing in the middle left to skip) and covers the projections' tail and the time-MLP
+            assert len(seen) == 5 and last["done"] == [], [(e["lo"], e["n"]) for e in seen]
             cover = torch.zeros(n, dtype=torch.int32)
             for e in seen[:-1]:
                 assert not e["ticket"] and e["step"] == 1 and e["g_lo"] == e["lo"] and e["shadow"] == (dtype == torch.bfloat16)
-                assert (e["lo"], e["n"]) in last["done"]
                 assert e["srcs"] and all(e["lo"] <= s < e["lo"] + e["n"] for s in e["srcs"])     # only its own gradients
                 cover[e["lo"]:e["lo"] + e["n"]] += 1
-            rest = torch.ones(n, dtype=torch.int32)
-            for lo, ln in last["done"]:
-                rest[lo:lo + ln] = 0
-            assert all(not any(lo <= s < lo + ln for lo, ln in last["done"]) for s in last["srcs"])
-            assert torch.equal(cover + rest, torch.ones(n, dtype=torch.int32))
+            assert last["lo"] == max(e["lo"] + e["n"] for e in seen[:-1]) and last["lo"] + last["n"] == n
+            assert all(last["lo"] <= s for s in last["srcs"])
+            cover[last["lo"]:] += 1
+            assert torch.equal(cover, torch.ones(n, dtype=torch.int32))
+            early_ranges = [(e["lo"], e["n"]) for e in seen[:-1]]
+            lo_o, hi_o = tr._prefix_range("out_proj.")
+            assert (lo_o, hi_o - lo_o) in early_ranges and lo_o == 0
             # the ranges are exactly the layers' parameters
             for li in range(3):
                 lo, hi = tr._prefix_range(f"transformer_layers.{li}.")
                 names = [k for k in tr.layout if k.startswith(f"transformer_layers.{li}.")]
-                assert lo == min(tr.layout[k][0] for k in names) and (lo, hi - lo) in last["done"]
+                assert lo == min(tr.layout[k][0] for k in names) and (lo, hi - lo) in early_ranges
                 assert all(not (lo <= tr.layout[k][0] < hi) for k in tr.layout if k not in names)
 
 
