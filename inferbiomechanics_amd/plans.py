@@ -1608,8 +1608,11 @@ class DenoiserTransformerPlan:
         # weight-gradient launch, beside the backward of the layers below (the optimizer is HBM traffic, those are matrix
         # work); the step's last launch then covers only the projections and the time-MLP
         early = self.early_optimizer if fuse else None
+        # (the layer whose backward runs LAST keeps the step's common source lists: its range of the flat buffers borders the
+        # projections' tail, so the step's last launch takes it along instead of following a launch of its own)
+        last_run = self.layers[0]
         for lp in self.layers:
-            lp.defer, lp.later = ([], []) if early else (defer, later)
+            lp.defer, lp.later = ([], []) if (early and lp is not last_run) else (defer, later)
         self.pending_sources = None
         def t_outproj():
             # the output projection's own gradients: three launches nothing downstream waits for -- on a side stream on one
@@ -1643,7 +1646,7 @@ class DenoiserTransformerPlan:
                 prev[0].branch.run(prev[1])           # beside this layer's backward
             dh = lp.backward(dh, P, accumulate, qkv_head=head)
             head = lp.pending_head                    # its in-projection dgrad is left to the next (lower) layer's launch
-            if early is not None:
+            if early is not None and lp is not last_run:
                 # no launch issued from here on reads this layer's weights: the dgrad the layer below computes for it goes
                 # through the PACKED image (refreshed at the head of the next step), the transposed copies likewise
                 lp.branch.run(lambda lp=lp: early(lp.p, (lp.defer, None, 0, [(0, part.shape[1], dst, None, 1.0, part, rows)

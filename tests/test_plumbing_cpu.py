@@ -389,9 +389,10 @@ def test_every_parameter_is_updated_exactly_once_per_step(dry, monkeypatch):
             if not early:
                 assert len(seen) == 1 and last["done"] == [] and last["lo"] == 0 and last["n"] == n
                 continue
-            # the output projection (head of the flat buffers) + three layers + the step's last launch, which starts behind
-            # the layers' ranges (nothing in the middle left to skip) and covers the projections' tail and the time-MLP
-            assert len(seen) == 5 and last["done"] == [], [(e["lo"], e["n"]) for e in seen]
+            # the output projection (head of the flat buffers) + the two layers whose backward does not run last + the step's
+            # last launch, which starts behind their ranges (nothing in the middle left to skip) and covers the last-run
+            # layer, the projections' tail and the time-MLP
+            assert len(seen) == 4 and last["done"] == [], [(e["lo"], e["n"]) for e in seen]
             cover = torch.zeros(n, dtype=torch.int32)
             for e in seen[:-1]:
                 assert not e["ticket"] and e["step"] == 1 and e["g_lo"] == e["lo"] and e["shadow"] == (dtype == torch.bfloat16)
@@ -405,7 +406,8 @@ def test_every_parameter_is_updated_exactly_once_per_step(dry, monkeypatch):
             lo_o, hi_o = tr._prefix_range("out_proj.")
             assert (lo_o, hi_o - lo_o) in early_ranges and lo_o == 0
             # the ranges are exactly the layers' parameters
-            for li in range(3):
+            assert tr._prefix_range("transformer_layers.0.")[0] == last["lo"]
+            for li in range(1, 3):
                 lo, hi = tr._prefix_range(f"transformer_layers.{li}.")
                 names = [k for k in tr.layout if k.startswith(f"transformer_layers.{li}.")]
                 assert lo == min(tr.layout[k][0] for k in names) and (lo, hi - lo) in early_ranges
