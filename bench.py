@@ -262,7 +262,6 @@ KERNEL_OF = {   # C-ABI entry -> device kernel it launches (names as rocprofv3 -
     "ib_attention_fwd": "attn_fwd_mfma", "ib_attention_bwd": "attn_bwd_mfma", "ib_segment_colsum": "segment_colsum_kernel",
     "ib_ffn_chain_fwd": "ffn_chain_fwd_kernel<true, true, false> (<true, false, false> for the top layer)", "ib_ffn_chain_bwd": "ffn_chain_bwd_kernel<true, true, false> (<true, false, false> for the top layer)",
     "ib_ffn_chain_fwd_attn": "ffn_chain_fwd_kernel<true, true, true> (one-window panels: the layer's token-local half + the next layer's in-projection and attention; <true, false, false> for the top layer)",
-    "ib_ffn_stack_fwd": "ffn_stack_fwd_kernel (all layers' forward launches of ib_ffn_chain_fwd_attn in one: a panel's workgroup walks its window through the stack)",
     "ib_ffn_chain_bwd_attn": "ffn_chain_bwd_kernel<true, false, true> (one-window panels: the whole layer's backward incl. attention backward and in-projection dgrad)",
     "ib_ffn_chain_pack": "ffn_pack_kernel", "ib_diffusion_draw": "diffusion_draw_kernel",
     "ib_mse_loss": "mse_partial_kernel (+ mse_final_kernel)", "ib_q_sample": "q_sample_kernel",

@@ -361,12 +361,6 @@ int ib_ffn_chain_fwd_attn(const void* x, const void* packed, const float* b1, co
                           float* mean1, float* rstd1, const void* packed_next, const float* bqkv_next, void* qkv_next,
                           void* attn_next, float* lse_next, int64_t T, int64_t M, int64_t d, int64_t ffn, float ln_eps,
                           ib_stream_t stream);
-/* `layers` (2 .. 8) consecutive layers' ib_ffn_chain_fwd_attn launches as ONE launch: `args` = layers x 25 pointers, per
- * layer the 25 pointer arguments of ib_ffn_chain_fwd_attn in its order; every layer but the last carries the next layer's
- * in-projection + attention, and layer l + 1's x / attn must be layer l's y / attn_next.  A panel's workgroup walks its rows
- * through all the layers without waiting for the other panels at the layer boundaries. */
-int ib_ffn_stack_fwd(const void* const* args, int layers, int64_t T, int64_t M, int64_t d, int64_t ffn, float ln_eps,
-                     ib_stream_t stream);
 int ib_ffn_chain_bwd_attn(const void* dy, const void* s2, const float* mean, const float* rstd, const float* gamma,
                           const void* packed, const void* mask, void* ds2, void* dz1, float* partial, const void* s1,
                           const float* mean1, const float* rstd1, const float* gamma1, void* ds1, const void* qkv,

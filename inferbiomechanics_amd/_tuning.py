@@ -30,7 +30,6 @@ _SPEC = {
     "no_ffn_chain": ("IB_NO_FFN_CHAIN", False),
     "no_qkv_fuse": ("IB_NO_QKV_FUSE", False),
     "no_attn_fuse": ("IB_NO_ATTN_FUSE", False),        # round 5: attention inside the panel launches
-    "no_layer_stack": ("IB_NO_LAYER_STACK", False),    # round 5: all layers of a direction in one launch
     "no_lag_group": ("IB_NO_LAG_GROUP", False),
     # ---- sampler (frozen-weight forward)
     "no_qkv_panel": ("IB_NO_QKV_PANEL", False),

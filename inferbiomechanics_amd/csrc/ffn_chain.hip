@@ -56,15 +56,11 @@ struct FfnFwdParams {
 
 // INFER: the frozen-weight forward (DDIM sampler at batches beyond the row-panel kernels of linln_panel.hip): nothing is saved
 // for a backward -- no f1 / s1 / s2 / x1 rows, no statistics, no ReLU bits leave the workgroup
-// The body of one layer's launch as a function of the panel's two LDS images, so that a STACK of layers can run in one
-// launch (ffn_stack_fwd_kernel below): rows never mix across panels, so a workgroup can walk its panel through all layers
-// without waiting for the other workgroups at the layer boundaries.  `resident`: the launch's previous layer (this same
-// workgroup) left this layer's attention rows in image H -- they are not loaded again -- and other threads may still be
-// reading the images for their row stores: one barrier before image X takes the layer input.
-template <bool OUT, bool QKV, bool ATT, bool INFER>
-__device__ __forceinline__ void ff_layer_fwd(const FfnFwdParams& p, unsigned char* smem, bool resident) {
+template <bool OUT, bool QKV, bool ATT, bool INFER = false>
+__global__ __launch_bounds__(FF_THREADS) void ffn_chain_fwd_kernel(FfnFwdParams p) {
   static_assert(!ATT || QKV, "the attention rides behind the QKV tail");
   static_assert(!INFER || (OUT && !ATT), "the frozen-weight form: attention epilogue, no attention tail");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * FF_BUF];
   unsigned char* imgX = smem;
   unsigned char* imgH = smem + FF_BUF;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -75,13 +71,12 @@ __device__ __forceinline__ void ff_layer_fwd(const FfnFwdParams& p, unsigned cha
   const int colb = wave * 16 * FF_NT + 4 * g;             // this lane's first column inside a 512-wide GEMM output
   const int c8 = lane * 8;                                // row-wise passes: 8 consecutive columns of the wave's row
   FF_STAMP(0);
-  if (resident) __syncthreads();
   // ---- the panel's input rows -> image X (16-byte pieces, rows beyond the panel = copies of the last row: finite)
   ff_panel_in(p.x1 + (int64_t)r0 * FF_D, imgX, nrows, tid);
   if constexpr (OUT) {
     // attention output rows -> image H; o = attn . Wo^T (GEMM); s1 = x + o + bo written over x in image X (each position is
     // read and written by the same lane); row-wise LayerNorm1 turns image X into x1, the feed-forward input
-    if (!resident) ff_panel_in(p.attn + (int64_t)r0 * FF_D, imgH, nrows, tid);
+    ff_panel_in(p.attn + (int64_t)r0 * FF_D, imgH, nrows, tid);
     __syncthreads();
     f32x4_t acco[4][FF_NT];
     ff_zero(acco);
@@ -310,24 +305,6 @@ __device__ __forceinline__ void ff_layer_fwd(const FfnFwdParams& p, unsigned cha
   }
 }
 
-template <bool OUT, bool QKV, bool ATT, bool INFER = false>
-__global__ __launch_bounds__(FF_THREADS) void ffn_chain_fwd_kernel(FfnFwdParams p) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * FF_BUF];
-  ff_layer_fwd<OUT, QKV, ATT, INFER>(p, smem, false);
-}
-
-// A stack of up to FF_MAXSTACK layers' forward launches as ONE launch (one-window panels, every layer but the last with the
-// next layer's in-projection + attention behind it): layer l + 1 of a panel starts the moment layer l of THAT panel is done
-// -- its attention rows still in LDS, its input rows (written a moment ago by this workgroup) re-read from L2 -- instead of
-// behind the slowest workgroup of layer l, a launch boundary and a cold start.
-constexpr int FF_MAXSTACK = 8;
-struct FfnStackFwdParams { FfnFwdParams l[FF_MAXSTACK]; int L; };
-
-__global__ __launch_bounds__(FF_THREADS) void ffn_stack_fwd_kernel(FfnStackFwdParams sp) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * FF_BUF];
-  for (int l = 0; l + 1 < sp.L; ++l) ff_layer_fwd<true, true, true, false>(sp.l[l], smem, l > 0);
-  ff_layer_fwd<true, false, false, false>(sp.l[sp.L - 1], smem, true);
-}
 
 // ---- weight packing: [512 x 512] sub-matrices of the row-major bf16 weights -> fragment-major 1-KiB blocks
 // (block (nt, kb) at (kb * 32 + nt) * 1 KiB; W_eff[n][k] = src[n * ld + k], or src[k * ld + n] when transposed)
@@ -462,11 +439,6 @@ extern "C" int ib_ffn_chain_pack(const void* const* w1, const int64_t* ld1, cons
 
 
 namespace {
-int ffn_fwd_fill(FfnFwdParams& p, int& nwg, const void* x1, const void* packed, const float* b1, const float* b2,
-                 const float* gamma, const float* beta, void* f1, void* s2, void* y, float* mean, float* rstd, void* mask,
-                 const void* attn, const float* bo, const float* gamma1, const float* beta1, void* s1, void* x1_out,
-                 float* mean1, float* rstd1, const void* packed_next, const float* bqkv_next, void* qkv_next, void* attn_next,
-                 float* lse_next, int64_t T, int64_t M, int64_t d, int64_t ffn, float ln_eps);
 int ffn_chain_fwd_launch(const void* x1, const void* packed, const float* b1, const float* b2, const float* gamma,
                          const float* beta, void* f1, void* s2, void* y, float* mean, float* rstd, void* mask,
                          const void* attn, const float* bo, const float* gamma1, const float* beta1, void* s1,
@@ -474,29 +446,9 @@ int ffn_chain_fwd_launch(const void* x1, const void* packed, const float* b1, co
                          void* qkv_next, void* attn_next, float* lse_next, int64_t T, int64_t M, int64_t d, int64_t ffn,
                          float ln_eps, ib_stream_t stream) {
   FfnFwdParams p{};
-  int nwg = 0;
-  const int rc = ffn_fwd_fill(p, nwg, x1, packed, b1, b2, gamma, beta, f1, s2, y, mean, rstd, mask, attn, bo, gamma1, beta1, s1,
-                              x1_out, mean1, rstd1, packed_next, bqkv_next, qkv_next, attn_next, lse_next, T, M, d, ffn, ln_eps);
-  if (rc != IB_OK) return rc;
-  const bool att = attn_next != nullptr, out = attn != nullptr, tail = qkv_next != nullptr;
-  IB_PATH(IB_PATH_FFN_CHAIN);
-  if (att) hipLaunchKernelGGL((ffn_chain_fwd_kernel<true, true, true>), dim3(nwg), dim3(FF_THREADS), 0, ib_s(stream), p);
-  else if (tail) hipLaunchKernelGGL((ffn_chain_fwd_kernel<true, true, false>), dim3(nwg), dim3(FF_THREADS), 0, ib_s(stream), p);
-  else if (out) hipLaunchKernelGGL((ffn_chain_fwd_kernel<true, false, false>), dim3(nwg), dim3(FF_THREADS), 0, ib_s(stream), p);
-  else hipLaunchKernelGGL((ffn_chain_fwd_kernel<false, false, false>), dim3(nwg), dim3(FF_THREADS), 0, ib_s(stream), p);
-  IB_CHECK_LAUNCH();
-  return IB_OK;
-}
-
-// argument checks + parameter block of one layer's forward launch (shared by the single-layer and the stacked entry points)
-int ffn_fwd_fill(FfnFwdParams& p, int& nwg, const void* x1, const void* packed, const float* b1, const float* b2,
-                 const float* gamma, const float* beta, void* f1, void* s2, void* y, float* mean, float* rstd, void* mask,
-                 const void* attn, const float* bo, const float* gamma1, const float* beta1, void* s1, void* x1_out,
-                 float* mean1, float* rstd1, const void* packed_next, const float* bqkv_next, void* qkv_next, void* attn_next,
-                 float* lse_next, int64_t T, int64_t M, int64_t d, int64_t ffn, float ln_eps) {
   int P = 0, nc = 0;
   const bool att = attn_next != nullptr;
-  nwg = ffn_geometry(M, d, ffn, &P, &nc, T);
+  const int nwg = ffn_geometry(M, d, ffn, &P, &nc, T);
   if (!nwg) return IB_E_UNSUPPORTED;
   if (!x1 || !packed || !b1 || !b2 || !gamma || !beta || !f1 || !s2 || !y || !mean || !rstd || !mask) return IB_E_ARG;
   if (!ff_al16({x1, packed, b1, b2, gamma, beta, f1, s2, y, mask})) return IB_E_ARG;
@@ -518,42 +470,15 @@ int ffn_fwd_fill(FfnFwdParams& p, int& nwg, const void* x1, const void* packed, 
   p.attn_next = (bf16_t*)attn_next; p.lse_next = lse_next;
   p.M = (int)M; p.P = P; p.FF = (int)ffn; p.nchunk = nc; p.ln_eps = ln_eps;
   p.prof = IB_AB_PROF(g_ffn_prof);
-  return IB_OK;
-}
-}  // namespace
-
-// `layers` (2 .. 8) consecutive layers' forward launches of ib_ffn_chain_fwd_attn as ONE launch over the one-window panels:
-// `args` = layers x 25 pointers, per layer the 25 pointer arguments of ib_ffn_chain_fwd_attn in its order (x, packed, b1, b2,
-// gamma, beta, f1, s2, y, mean, rstd, mask, attn, bo, gamma1, beta1, s1, x1_out, mean1, rstd1, packed_next, bqkv_next,
-// qkv_next, attn_next, lse_next).  Every layer but the last carries the next layer's in-projection + attention
-// (qkv_next / attn_next / lse_next given) and layer l + 1's x / attn must be layer l's y / attn_next: a panel's workgroup walks
-// its rows through all the layers (TransformerBaseline.py:24-38 x layers) without waiting at the layer boundaries.
-extern "C" int ib_ffn_stack_fwd(const void* const* args, int layers, int64_t T, int64_t M, int64_t d, int64_t ffn, float ln_eps,
-                                ib_stream_t stream) {
-  if (!args || layers < 2 || layers > FF_MAXSTACK || T <= 0) return IB_E_ARG;
-  FfnStackFwdParams sp{};
-  int nwg = 0;
-  for (int l = 0; l < layers; ++l) {
-    const void* const* a = args + 25 * l;
-    const bool last = l + 1 == layers;
-    if (!a[12] || (last ? (a[20] || a[22] || a[23]) : (!a[20] || !a[22] || !a[23] || !a[24]))) return IB_E_ARG;
-    if (l > 0 && (a[0] != args[25 * (l - 1) + 8] || a[12] != args[25 * (l - 1) + 23])) return IB_E_ARG;   // x = y, attn = attn_next
-    int n = 0;
-    const int rc = ffn_fwd_fill(sp.l[l], n, a[0], a[1], (const float*)a[2], (const float*)a[3], (const float*)a[4], (const float*)a[5],
-                                (void*)a[6], (void*)a[7], (void*)a[8], (float*)a[9], (float*)a[10], (void*)a[11], a[12],
-                                (const float*)a[13], (const float*)a[14], (const float*)a[15], (void*)a[16], (void*)a[17],
-                                (float*)a[18], (float*)a[19], a[20], (const float*)a[21], (void*)a[22], (void*)a[23],
-                                (float*)a[24], T, M, d, ffn, ln_eps);
-    if (rc != IB_OK) return rc;
-    if (l > 0 && n != nwg) return IB_E_ARG;
-    nwg = n;
-  }
-  sp.L = layers;
   IB_PATH(IB_PATH_FFN_CHAIN);
-  hipLaunchKernelGGL(ffn_stack_fwd_kernel, dim3(nwg), dim3(FF_THREADS), 0, ib_s(stream), sp);
+  if (att) hipLaunchKernelGGL((ffn_chain_fwd_kernel<true, true, true>), dim3(nwg), dim3(FF_THREADS), 0, ib_s(stream), p);
+  else if (tail) hipLaunchKernelGGL((ffn_chain_fwd_kernel<true, true, false>), dim3(nwg), dim3(FF_THREADS), 0, ib_s(stream), p);
+  else if (out) hipLaunchKernelGGL((ffn_chain_fwd_kernel<true, false, false>), dim3(nwg), dim3(FF_THREADS), 0, ib_s(stream), p);
+  else hipLaunchKernelGGL((ffn_chain_fwd_kernel<false, false, false>), dim3(nwg), dim3(FF_THREADS), 0, ib_s(stream), p);
   IB_CHECK_LAUNCH();
   return IB_OK;
 }
+}  // namespace
 
 extern "C" int ib_ffn_chain_fwd(const void* x1, const void* packed, const float* b1, const float* b2, const float* gamma,
                                 const float* beta, void* f1, void* s2, void* y, float* mean, float* rstd, void* mask,

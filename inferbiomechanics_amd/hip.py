@@ -117,7 +117,6 @@ _SIGS = {
     "ib_ffn_chain_attn_workgroups": (_c.c_int, [_i64, _i64, _i64, _i64]),
     "ib_ffn_chain_attn_mask_bytes": (_sz, [_i64, _i64, _i64, _i64]),
     "ib_ffn_chain_fwd_attn": (_c.c_int, [_vp] * 25 + [_i64, _i64, _i64, _i64, _f32, _vp]),
-    "ib_ffn_stack_fwd": (_c.c_int, [_vp, _c.c_int, _i64, _i64, _i64, _i64, _f32, _vp]),
     "ib_ffn_chain_bwd_attn": (_c.c_int, [_vp] * 19 + [_i64, _i64, _i64, _i64, _vp]),
     "ib_sqdiff_mean": (_c.c_int, [_vp, _vp, _vp, _i64, _i64, _c.c_int, _vp]),
     "ib_sqdiff_mean_bwd": (_c.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _c.c_int, _vp]),
@@ -1464,10 +1463,8 @@ def _ffn_vec(t, name, n):
 
 
 def ffn_chain_fwd(x1, packed, b1, b2, gamma, beta, f1, s2, y, mean, rstd, mask, eps: float = 1e-5, attn_out=None,
-                  qkv_next=None, attn_next=None, panel_T: int = 0, collect=None):
-    """collect (a list; needs panel_T): nothing is launched -- the checked launch is appended for ffn_stack_fwd, which runs a
-    stack of consecutive layers' launches as one.
-    panel_T > 0: panels of exactly one window of panel_T frames (`mask` sized with ffn_chain_mask_bytes(.., panel_T)) --
+                  qkv_next=None, attn_next=None, panel_T: int = 0):
+    """panel_T > 0: panels of exactly one window of panel_T frames (`mask` sized with ffn_chain_mask_bytes(.., panel_T)) --
     the geometry of a layer whose attention rides inside its launches, in both directions.
     attn_next = (attn_out_next [M, d], lse_next fp32 [M / T, 8, T], T): the NEXT layer's attention core rides behind the
     QKV tail (needs qkv_next; T = panel_T).
@@ -1530,44 +1527,14 @@ def ffn_chain_fwd(x1, packed, b1, b2, gamma, beta, f1, s2, y, mean, rstd, mask, 
             _req(lse, "lse_next", torch.float32)
             if lse.numel() != (M // T_att) * 8 * T_att or not lse.is_contiguous() or d != 512:
                 raise HipError("ffn_chain_fwd: lse_next must be contiguous fp32 [M / T, 8, T] (d = 512: eight heads of 64)")
-        ptrs = [_ptr(x1), _ptr(packed), _ptr(b1), _ptr(b2), _ptr(gamma), _ptr(beta), _ptr(f1), _ptr(s2), _ptr(y), _ptr(mean),
-                _ptr(rstd), _ptr(mask), *extra, *tail, _ptr(ao), _ptr(lse)]
-        if collect is not None:
-            collect.append((ptrs, T_att, M, d, ffn, float(eps), _work_note))
-            _work_note = None
-            return y
-        _check(lib().ib_ffn_chain_fwd_attn(*ptrs, T_att, M, d, ffn, float(eps), stream_ptr()), "ib_ffn_chain_fwd_attn")
+        _check(lib().ib_ffn_chain_fwd_attn(_ptr(x1), _ptr(packed), _ptr(b1), _ptr(b2), _ptr(gamma), _ptr(beta), _ptr(f1),
+                                           _ptr(s2), _ptr(y), _ptr(mean), _ptr(rstd), _ptr(mask), *extra, *tail, _ptr(ao),
+                                           _ptr(lse), T_att, M, d, ffn, float(eps), stream_ptr()), "ib_ffn_chain_fwd_attn")
         return y
     _check(lib().ib_ffn_chain_fwd(_ptr(x1), _ptr(packed), _ptr(b1), _ptr(b2), _ptr(gamma), _ptr(beta), _ptr(f1), _ptr(s2),
                                   _ptr(y), _ptr(mean), _ptr(rstd), _ptr(mask), *extra, *tail, M, d, ffn, float(eps),
                                   stream_ptr()), "ib_ffn_chain_fwd")
     return y
-
-
-def ffn_stack_fwd(launches):
-    """`launches` = what ffn_chain_fwd(..., collect=launches) gathered for 2 .. 8 consecutive layers (same M, T, d, ffn; layer
-    l + 1's x / attn = layer l's y / attn_next): ONE launch in which a panel's workgroup walks its rows through all the layers
-    (csrc/ffn_chain.hip::ffn_stack_fwd_kernel).  A single collected launch is issued as it is."""
-    global _work_note
-    if not launches:
-        return
-    if len(launches) == 1:
-        ptrs, T, M, d, ffn, eps, note = launches[0]
-        _work_note = note
-        _check(lib().ib_ffn_chain_fwd_attn(*ptrs, T, M, d, ffn, eps, stream_ptr()), "ib_ffn_chain_fwd_attn")
-        return
-    _, T, M, d, ffn, eps, _ = launches[0]
-    if any(l[1:6] != (T, M, d, ffn, eps) for l in launches):
-        raise HipError("ffn_stack_fwd: the layers of a stack must agree in shape")
-    flat = [q for l in launches for q in l[0]]
-    arr = (ctypes.c_void_p * len(flat))(*flat)
-    if isinstance(_lib, _RecordingLib):
-        notes = [l[6] for l in launches if l[6] is not None]
-        if notes:
-            _work_note = (sum(n[0] for n in notes), sum(n[1] for n in notes),
-                          {"layers": len(launches), "M": M, "d": d, "ffn": ffn, "attention_T": T, "stacked": True})
-    _check(lib().ib_ffn_stack_fwd(ctypes.cast(arr, ctypes.c_void_p), len(launches), T, M, d, ffn, eps, stream_ptr()),
-           "ib_ffn_stack_fwd")
 
 
 def ffn_chain_fwd_infer(x, packed, b1, b2, gamma, beta, y, attn, bo, gamma1, beta1, qkv_next=None, eps: float = 1e-5):

@@ -668,10 +668,8 @@ class TransformerLayerPlan:
 
     def forward(self, x3: torch.Tensor, P: ParamSource, out: Optional[torch.Tensor] = None, training: bool = False,
                 step: int = 0, step_dev: Optional[torch.Tensor] = None, qkv_ready: bool = False,
-                attn_ready: bool = False, collect: Optional[list] = None) -> torch.Tensor:
-        """collect: a parent plan's list -- the whole-layer launch with the attention inside is not issued but appended, the
-        parent issues the collected layers as one stacked launch (hip.ffn_stack_fwd);
-        qkv_ready: the layer below already wrote this layer's in-projection into `qkv_buffer` (its fused launch's tail);
+                attn_ready: bool = False) -> torch.Tensor:
+        """qkv_ready: the layer below already wrote this layer's in-projection into `qkv_buffer` (its fused launch's tail);
         attn_ready: ... and this layer's attention output + row log-sum-exp (`attn_buffers`) behind it"""
         B, T, d = x3.shape
         M = B * T
@@ -763,7 +761,7 @@ class TransformerLayerPlan:
                               qkv_next=None if not self.tail_active(M, training) else
                               (nxt.packed_image(), P.v(nxt.p + "multihead_attention.in_proj_bias"),
                                nxt.qkv_buffer(B, T).view(M, 3 * d)),
-                              attn_next=att_next, panel_T=Ta, collect=collect if Ta else None)
+                              attn_next=att_next, panel_T=Ta)
             self.tail_done = self.tail_active(M, training)
             self.attn_tail_done = att_next is not None
             self.ctx = (x, qkv, attn, lse, a, x1, m1, r1, f1, f2, m2, r2, B, T, drop)
@@ -1574,20 +1572,9 @@ class DenoiserTransformerPlan:
         if ffn_items and not self.inference:
             self.br_wt.join()                         # layer 0's fused feed-forward sublayer reads the packed images
         ready = aready = False
-        # training with the attention inside the layer launches: the layers' launches are collected and issued as ONE
-        # (a panel's workgroup walks its window through all the layers: no wait for the slowest panel, no launch edge and no
-        # cold start at the layer boundaries) -- provided every layer hands its successor both in-projection and attention
-        stackable = (not self.inference and not TU.no_layer_stack and 2 <= len(self.layers) <= 8
-                     and all(lp.attn_T(M, T) for lp in self.layers)
-                     and all(lp.attn_tail_active(M, T) for lp in self.layers[:-1]))
-        stack = [] if stackable else None
         for lp in self.layers:
-            h = lp.forward(h, P, qkv_ready=ready, attn_ready=aready, collect=stack)
+            h = lp.forward(h, P, qkv_ready=ready, attn_ready=aready)
             ready, aready = lp.tail_done, lp.attn_tail_done      # it wrote the next layer's in-projection / attention output
-        if stack is not None:
-            if len(stack) != len(self.layers):
-                raise hip.HipError("DenoiserTransformerPlan: a layer of a stackable chain launched on its own")
-            hip.ffn_stack_fwd(stack)
         out = out if out is not None else g("dt.out", (B, T, D), dt)
         if padded:
             hip.linear_fwd(h.view(M, self.d), w_out_pad, b_out_pad, out.as_strided((M, Kp), (Kp, 1)))

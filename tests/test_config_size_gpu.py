@@ -231,7 +231,7 @@ def test_transformer_large_batch_paths_match_oracle(attn_inside, monkeypatch):
     names = {n for n, _ in rec.calls}
     assert {"ib_linear_wgrad_slabs_multi_bias", "ib_step_reduce_parts"} <= names, names
     if attn_inside:
-        assert {"ib_ffn_stack_fwd", "ib_ffn_chain_bwd_attn"} <= names and "ib_attention_bwd" not in names, names
+        assert {"ib_ffn_chain_fwd_attn", "ib_ffn_chain_bwd_attn"} <= names and "ib_attention_bwd" not in names, names
     else:
         assert {"ib_linear_dgrad_wt", "ib_transpose_multi", "ib_attention_bwd", "ib_ffn_chain_fwd"} <= names, names
     p = oracle_params(model)

@@ -14,7 +14,7 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 from inferbiomechanics_amd import hip  # noqa: E402
 
-GEMM_LIKE = ("ib_linear_", "ib_mlp_chain_train", "ib_time_mlp", "ib_mlp_chain_prep", "ib_ffn_chain_fwd", "ib_ffn_chain_bwd", "ib_ffn_stack_",
+GEMM_LIKE = ("ib_linear_", "ib_mlp_chain_train", "ib_time_mlp", "ib_mlp_chain_prep", "ib_ffn_chain_fwd", "ib_ffn_chain_bwd",
              "ib_ffn_infer_fwd")      # ("ib_linear_" covers ib_linear_panel_fwd / ib_linear_ln_panel_fwd)
 
 

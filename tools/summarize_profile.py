@@ -24,7 +24,6 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ENTRY_OF = [# round 5: the one-window-panel launches with the attention inside (and the top layer's launch of the same entry point)
-            ("ffn_stack_fwd_kernel", "", "ib_ffn_stack_fwd"), ("ffn_stack_bwd_kernel", "", "ib_ffn_stack_bwd"),
             ("ffn_chain_bwd_kernel<true, false, true", "", "ib_ffn_chain_bwd_attn"),
             ("ffn_chain_fwd_kernel<true, true, true, false", "", "ib_ffn_chain_fwd_attn"),
             ("ffn_chain_fwd_kernel<true, false, false, false", "", "ib_ffn_chain_fwd_attn"),
