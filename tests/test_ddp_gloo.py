@@ -121,3 +121,55 @@ def test_distributed_sampler_sharding_rule():
     b, lb, _, _ = ds[3]
     assert all(torch.equal(a[k], b[k]) for k in a) and a['pos'].shape == (10, 23)
     assert la['groundContactWrenchesInRootFrame'].shape == (10, 12)
+
+
+def _probe_worker(rank, world, port, q):
+    """ddp_probe.decide() across two ranks: rank 0 runs the (here: stubbed) child job, the verdict reaches rank 1 through the
+    process group's store -- no collective -- and both remember it"""
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        os.environ.pop("IB_GRAPH_COLLECTIVES", None)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import sys
+        import time
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from inferbiomechanics_amd import ddp_probe
+        calls = []
+
+        def stub(n, timeout_s=150.0):
+            calls.append(n)
+            time.sleep(0.5)                       # the other rank must WAIT for the verdict, not run ahead
+            return {"ok": True, "why": "stub", "seconds": 0.5}
+        ddp_probe.run_child = stub
+        t0 = time.monotonic()
+        got = ddp_probe.decide(world, rank, "nccl")        # (the backend NAME selects the probe; the store is the group's)
+        waited = time.monotonic() - t0
+        assert got is True and os.environ["IB_GRAPH_COLLECTIVES"] == "1" and ddp_probe.verdict()["source"] == "probe"
+        assert calls == ([2] if rank == 0 else []) and waited >= 0.4, (rank, calls, waited)
+        # a second decision in the same process is answered from the environment: no second child job
+        assert ddp_probe.decide(world, rank, "nccl") is True and calls == ([2] if rank == 0 else [])
+        # a failed probe: every rank falls back to the cut-graph form
+        os.environ.pop("IB_GRAPH_COLLECTIVES")
+        ddp_probe.run_child = lambda n, timeout_s=150.0: {"ok": False, "why": "timed out after 150 s", "seconds": 150.0}
+        assert ddp_probe.decide(world, rank, "nccl") is False and os.environ["IB_GRAPH_COLLECTIVES"] == "0"
+        assert "timed out" in ddp_probe.verdict()["why"]
+        os.environ.pop("IB_GRAPH_COLLECTIVES")
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, "FAIL: " + traceback.format_exc()))
+
+
+def test_probe_verdict_reaches_every_rank_through_the_store():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_probe_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] == "ok" for r in res), res

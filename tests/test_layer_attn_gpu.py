@@ -43,7 +43,7 @@ def rel(a, b):
     return float((a.detach().cpu().double() - b.double()).norm() / b.double().norm())
 
 
-def make(B, T, ffn, seed):
+def make(B, T, ffn, seed, qk_gain=2.0):
     g = torch.Generator().manual_seed(seed)
     M = B * T
     q = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(BF)
@@ -52,14 +52,17 @@ def make(B, T, ffn, seed):
                 w1=q(ffn, D, sc=D ** -0.5), b1=v(ffn), w2=q(D, ffn, sc=ffn ** -0.5), b2=v(D), g2=v(D, 0.2, 1.0), be2=v(D),
                 # the in-projection of the layer above (forward tail) -- also used as THIS layer's for the backward tail;
                 # scaled up so that the softmax is not flat (scores of a few units)
-                wq=q(3 * D, D, sc=2.0 * D ** -0.5), bq=v(3 * D), dy=q(M, D))
+                wq=q(3 * D, D, sc=qk_gain * D ** -0.5), bq=v(3 * D), dy=q(M, D))
 
 
-@pytest.mark.parametrize("B,T,ffn", [(256, 50, 2048), (8, 64, 512), (5, 16, 1024), (3, 37, 512)])
-def test_layer_launches_with_the_attention_inside(B, T, ffn):
+@pytest.mark.parametrize("B,T,ffn,qk_gain", [(256, 50, 2048, 2.0), (8, 64, 512, 2.0), (5, 16, 1024, 2.0), (3, 37, 512, 2.0),
+                                              (8, 50, 512, 5.0)])
+def test_layer_launches_with_the_attention_inside(B, T, ffn, qk_gain):
+    """qk_gain 5: scores of +-25 -- a PEAKED softmax (most rows put > 0.9 on one key), where dS = P (dP - D) cancels and a
+    D taken from the rounded output instead of the recomputed probabilities was 35 % off in round 2"""
     from inferbiomechanics_amd import hip
     M = B * T
-    pr = make(B, T, ffn, seed=1000 * T + B)
+    pr = make(B, T, ffn, seed=1000 * T + B, qk_gain=qk_gain)
     dev = {k: t.to(DEV) for k, t in pr.items()}
     assert hip.ffn_chain_workgroups(M, D, ffn, T) == B
     packed = torch.zeros(hip.ffn_chain_packed_elems(D, ffn), dtype=BF, device=DEV)
@@ -125,9 +128,14 @@ def test_layer_launches_with_the_attention_inside(B, T, ffn):
     want_dqkv = q64.grad.reshape(M, 3 * D)
     # probabilities, dS and the three products' operands are bf16 inside the launch: a few ulps of the largest gradient
     err = (dqkv.cpu().double() - want_dqkv).abs()
-    assert float(err.max()) < 3e-2 * float(want_dqkv.abs().max()), (float(err.max()), float(want_dqkv.abs().max()))
+    sharp = qk_gain > 3
+    if sharp:
+        pmax = torch.softmax(sc, dim=-1).max(-1).values
+        assert float((pmax > 0.9).double().mean()) > 0.3, float((pmax > 0.9).double().mean())     # the case is what it says
+    assert float(err.max()) < (6e-2 if sharp else 3e-2) * float(want_dqkv.abs().max()), (float(err.max()), float(want_dqkv.abs().max()))
     for c, nm in enumerate(("dq", "dk", "dv")):
-        assert rel(dqkv[:, c * D:(c + 1) * D], want_dqkv[:, c * D:(c + 1) * D]) < 8e-3, nm
+        assert rel(dqkv[:, c * D:(c + 1) * D], want_dqkv[:, c * D:(c + 1) * D]) < (2e-2 if sharp else 8e-3), \
+            (nm, rel(dqkv[:, c * D:(c + 1) * D], want_dqkv[:, c * D:(c + 1) * D]))
     close(dx, dqkv.cpu().double() @ f64["wq"] + ds1k, 3, "dx")
     assert bool(torch.isfinite(part).all())
     dgam2 = part[:nwg].sum(0).cpu().double()
