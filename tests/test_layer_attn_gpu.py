@@ -101,7 +101,9 @@ def test_layer_launches_with_the_attention_inside(B, T, ffn, qk_gain):
     assert torch.allclose(lse.cpu().double(), torch.logsumexp(sc, dim=-1), rtol=1e-4, atol=1e-4)
     # ... and of the oracle's attention of the float64 in-projection of the same rows (bf16-model tolerance)
     eye, zero = torch.eye(D, dtype=torch.float64), torch.zeros(D, dtype=torch.float64)
-    assert rel(ao, R.mha_forward(yk.view(B, T, D), f64["wq"], f64["bq"], eye, zero, H).reshape(M, D)) < 1e-2
+    # (a peaked softmax amplifies the bf16 rounding of q and k -- scores of +-25 move by +-0.1 -- which this comparison,
+    # unlike the one above, does not share with the launch)
+    assert rel(ao, R.mha_forward(yk.view(B, T, D), f64["wq"], f64["bq"], eye, zero, H).reshape(M, D)) < (1e-2 if qk_gain < 3 else 3e-2)
 
     # ---- backward: THIS layer's attention = (qkv, lse) just produced (as data), its in-projection = wq (own image)
     nwg = hip.ffn_chain_workgroups(M, D, ffn, T)
