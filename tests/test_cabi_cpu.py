@@ -31,6 +31,38 @@ def test_null_arguments_return_error_codes_not_crashes():
     assert lib.ib_linear_wgrad_workspace(4, 8, 8) == 0
 
 
+def test_whole_layer_launches_validate_their_arguments():
+    """round 5: the launches with the attention inside check shape, panel geometry and pointers on the host and return error
+    codes -- a NULL `mask` would have been a device fault (the forward stores its ReLU bit words through it)"""
+    from inferbiomechanics_amd import hip
+    lib = hip.lib()
+    assert lib.ib_ffn_chain_attn_workgroups(12800, 512, 2048, 50) == 256
+    assert lib.ib_ffn_chain_attn_workgroups(4096, 512, 1024, 64) == 64
+    for M, d, ffn, T in ((12800, 512, 2048, 8), (12800, 512, 2048, 65), (12800, 512, 2048, 48), (12800, 256, 2048, 50),
+                         (12800, 512, 2000, 50), (12800, 512, 2048, 0)):
+        assert lib.ib_ffn_chain_attn_workgroups(M, d, ffn, T) == 0, (M, d, ffn, T)
+    assert lib.ib_ffn_chain_attn_mask_bytes(12800, 512, 2048, 50) == 256 * 4 * 512 * 8
+    buf = ctypes.create_string_buffer(4096)
+    a = ctypes.cast(buf, ctypes.c_void_p).value // 16 * 16 + 16          # any aligned non-NULL address: nothing is launched
+    P = lambda ok=True: ctypes.c_void_p(a) if ok else None
+    fwd = lambda **k: lib.ib_ffn_chain_fwd_attn(*[P(k.get(f"a{i}", True)) for i in range(25)], k.get("T", 50), k.get("M", 12800),
+                                                k.get("d", 512), k.get("ffn", 2048), 1e-5, None)
+    assert fwd(T=0) == -1                                         # IB_E_ARG: no panel geometry
+    assert fwd(T=48) == -5 and fwd(d=256) == -5                   # IB_E_UNSUPPORTED: M % T != 0 / d != 512
+    assert fwd(a11=False) == -1                                   # mask
+    assert fwd(a24=False) == -1                                   # attention tail without lse
+    assert fwd(a22=False) == -1                                   # attention tail without the QKV tail
+    assert lib.ib_ffn_chain_fwd(*[P(i != 11) for i in range(23)], 12800, 512, 2048, 1e-5, None) == -1       # mask NULL
+    bwd = lambda **k: lib.ib_ffn_chain_bwd_attn(*[P(k.get(f"a{i}", True)) for i in range(19)], k.get("T", 50), k.get("M", 12800),
+                                                512, 2048, None)
+    assert bwd(T=0) == -1 and bwd(T=48) == -5
+    for i in (0, 6, 10, 15, 16, 17, 18):                          # dy, mask, s1, qkv, lse, dqkv, dx
+        assert bwd(**{f"a{i}": False}) == -1, i
+    inf = lambda **k: lib.ib_ffn_chain_fwd_infer(*[P(k.get(f"a{i}", True)) for i in range(14)], k.get("M", 51200), k.get("d", 512),
+                                                 2048, 1e-5, None)
+    assert inf(d=256) == -5 and inf(a6=False) == -1 and inf(a7=False) == -1 and inf(a13=True, a11=False) == -1
+
+
 def test_schedule_tables_bit_exact_vs_oracle():
     from inferbiomechanics_amd.diffusion import schedule as S
     ab = S.alphas_cumprod(1000)
