@@ -74,7 +74,9 @@ class GradBuckets:
     slice has been produced.  The division by world_size is folded into the optimizer kernel."""
 
     def __init__(self, flat_grad: torch.Tensor, layout: "OrderedDict[str, Tuple[int, int]]", bucket_bytes: int,
-                 group=None, active: Optional[bool] = None):
+                 group=None, active: Optional[bool] = None, cuts: Sequence[str] = ()):
+        """cuts: parameter names after which a bucket preferably ends (a plan's layer boundaries): a bucket is closed
+        there once it holds at least half of `bucket_bytes`, and otherwise as soon as it reaches `bucket_bytes`"""
         self.flat = flat_grad
         self.group = group
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
@@ -91,7 +93,7 @@ class GradBuckets:
         for i, n in enumerate(names):
             cur.append(n)
             end = layout[names[i + 1]][0] if i + 1 < len(names) else total
-            if (end - lo) * 4 >= bucket_bytes or i + 1 == len(names):
+            if (end - lo) * 4 >= bucket_bytes or i + 1 == len(names) or (n in cuts and (end - lo) * 8 >= bucket_bytes):
                 for m in cur:
                     self.bucket_of[m] = len(self.ranges)
                 self.ranges.append((lo, end))
@@ -304,7 +306,8 @@ class HipTrainer:
         self._gviews = {k: params[k].grad for k in order}
         self._params = params
         self.buckets = GradBuckets(self.grad, self.layout,
-                                   int(bucket_mb * (1 << 20)) if self.overlap_comm else (1 << 62), group, active=self.ddp)
+                                   int(bucket_mb * (1 << 20)) if self.overlap_comm else (1 << 62), group, active=self.ddp,
+                                   cuts=set(self.plan.bucket_cuts()) if hasattr(self.plan, "bucket_cuts") else ())
         self.result = torch.zeros(64, dtype=torch.float32, device=dev)
         self.comp_w = None
         if task == "regression":

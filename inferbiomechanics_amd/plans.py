@@ -1412,7 +1412,7 @@ class DenoiserTransformerPlan:
         for i, lp in enumerate(self.layers):
             lp.flush_on_exit = bool(on)
             lp.parent_flushes = lag
-            lp.lag_group = lag and i > 0            # layer 0's backward runs last: nothing to hide its launch behind
+            lp.lag_group = lag                      # (round 5: layer 0's too -- it runs beside the step's tail of small launches)
 
     def set_inference(self, on: bool):
         """forward-only mode with frozen weights (the DDIM sampler): fused Linear + residual + LayerNorm in every layer,
@@ -1594,6 +1594,12 @@ class DenoiserTransformerPlan:
             o += lp.ready_order()
         return o + ["in_proj.bias"] + TimeMLPPlan.ready_order() + ["temporal_embedding.embedding.weight", "in_proj.weight"]
 
+    def bucket_cuts(self) -> List[str]:
+        """parameter names after which a gradient bucket should end: a layer's gradients become ready together (one grouped
+        weight-gradient launch + one reduction), so a bucket that ends inside the NEXT layer waits a whole layer longer for
+        its all-reduce than its bytes ask for"""
+        return [lp.ready_order()[-1] for lp in self.layers]
+
     def backward(self, dout3: torch.Tensor, P: ParamSource, accumulate=False):
         x, pos, hlast, B, T = self.ctx
         M, D = x.shape
@@ -1625,10 +1631,16 @@ class DenoiserTransformerPlan:
             P.ready("out_proj.bias")
             box_op.append(op_defer)
         box_op: list = []
-        if fuse and not TU.no_outproj_branch:
-            self.br_wt.run(t_outproj)                 # joined with the tail's branches, before the optimizer
+        ddp_overlap = bool(self.layers and self.layers[0].parent_flushes)
+        outproj_pending = False
+        if (fuse or ddp_overlap) and not TU.no_outproj_branch:
+            # one GPU: joined with the tail's branches, before the optimizer.  Overlapped data parallel (round 5): joined in
+            # front of the first flush (the first layer boundary), where its bucket goes out with the top layer's -- inline
+            # its three launches (53 us, one of them the generic kernel for the 300-wide operand) sat on the critical path
+            self.br_wt.run(t_outproj)
+            outproj_pending = ddp_overlap
         else:
-            t_outproj()                               # data parallel: the flush below hands this bucket to the all-reduce
+            t_outproj()                               # the flush below hands this bucket to the all-reduce
         dh = g("dt.dh", (B, T, self.d), dt)
         tp = self._tp
         if not (tp and dout.stride(0) == tp["Kp"] and dout.stride(1) == 1 and
@@ -1654,6 +1666,9 @@ class DenoiserTransformerPlan:
             lg = lp.take_lagged()                     # None unless the layers report through this plan (data parallel)
             if prev is not None:
                 prev[0].branch.join()
+                if outproj_pending:
+                    self.br_wt.join()                 # the output projection's gradients: reported before this layer's (order)
+                    outproj_pending = False
                 for nm in prev[2]:
                     P.ready(nm)
                 prev = None
@@ -1666,8 +1681,18 @@ class DenoiserTransformerPlan:
                     P.flush()
                 else:
                     prev = (lp, lg[0], lg[1])
-        if prev is not None:
-            raise hip.HipError("the last layer's weight-gradient launch must not lag")
+        last_lag, Ptop = prev, P
+        if last_lag is not None:
+            # the last-run layer's grouped weight-gradient launch + reduction lag too (round 5): forked HERE, beside the
+            # step's tail -- a dozen small launches on the main stream and two branches -- instead of in front of it (inline
+            # it put 130 us between the last backward launch and the tail, `profiles/r05_tr_timeline_ddp.txt`).  The tail's
+            # gradients are reported behind the layer's (the ready order is the flat layout), once everything is joined.
+            last_lag[0].branch.run(last_lag[1])
+            tail_names: List[str] = []
+            P = ParamSource(Ptop.w, Ptop.v, Ptop.g, ready=tail_names.append, flush=lambda: None)
+        if outproj_pending:                           # (a one-layer stack: no layer boundary came before the tail)
+            self.br_wt.join()
+            outproj_pending = False
         dz0 = dh.view(M, self.d)
         w_in, gw_in = P.w("in_proj.weight"), P.g("in_proj.weight")
         # tail: three chains of small launches hang off dz0 -- the time-MLP's two halves and the frame-embedding gradients
@@ -1703,6 +1728,10 @@ class DenoiserTransformerPlan:
         P.ready("in_proj.weight")
         for lp in self.layers:
             lp.branch.join()
+        if last_lag is not None:
+            P = Ptop
+            for nm in last_lag[2] + tail_names:
+                P.ready(nm)
         P.flush()
         if fuse:
             self.pending_sources = (defer, None, 0, [(0, part.shape[1], dst, None, 1.0, part, rows)
