@@ -1650,7 +1650,19 @@ class DenoiserTransformerPlan:
             # forked AGAIN from here: behind the dgrad above (which may read the weight itself) and behind the gradient
             # launches already on that branch
             self.br_wt.run(lambda: early("out_proj.", (box_op[0], None, 0, [])))
-        P.flush()
+        Pin = P
+
+        def flush_joined():
+            """every flush of this backward: a flush may end a captured graph segment (a collective goes out between two
+            segments), and a segment must end with every side stream joined -- the output projection's branch included"""
+            nonlocal outproj_pending
+            if outproj_pending:
+                self.br_wt.join()
+                outproj_pending = False
+            Pin.flush()
+        P = ParamSource(Pin.w, Pin.v, Pin.g, ready=Pin.ready, flush=flush_joined)
+        if not outproj_pending:
+            P.flush()                                 # (pending: its bucket goes out at the first layer boundary instead)
         prev = None                                   # (layer plan, closure, names) whose launches lag one layer
         head = None
         for lp in reversed(self.layers):
@@ -1666,9 +1678,6 @@ class DenoiserTransformerPlan:
             lg = lp.take_lagged()                     # None unless the layers report through this plan (data parallel)
             if prev is not None:
                 prev[0].branch.join()
-                if outproj_pending:
-                    self.br_wt.join()                 # the output projection's gradients: reported before this layer's (order)
-                    outproj_pending = False
                 for nm in prev[2]:
                     P.ready(nm)
                 prev = None
@@ -1690,9 +1699,6 @@ class DenoiserTransformerPlan:
             last_lag[0].branch.run(last_lag[1])
             tail_names: List[str] = []
             P = ParamSource(Ptop.w, Ptop.v, Ptop.g, ready=tail_names.append, flush=lambda: None)
-        if outproj_pending:                           # (a one-layer stack: no layer boundary came before the tail)
-            self.br_wt.join()
-            outproj_pending = False
         dz0 = dh.view(M, self.d)
         w_in, gw_in = P.w("in_proj.weight"), P.g("in_proj.weight")
         # tail: three chains of small launches hang off dz0 -- the time-MLP's two halves and the frame-embedding gradients
