@@ -38,7 +38,9 @@ def _transformer(dtype, T, D, seed=7):
 
 def _lag_worker(port, q):
     try:
+        import faulthandler
         import sys
+        faulthandler.dump_traceback_later(240, exit=True)      # a hang shows WHERE (all threads) instead of a silent timeout
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         import torch.distributed as dist
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1",
@@ -57,6 +59,7 @@ def _lag_worker(port, q):
             TU.no_bucket_opt = not bopt
             os.environ["IB_GRAPH_COLLECTIVES"] = "1" if captured else "0"      # forced: no start-up probe in this test
             os.environ["IB_DDP_SELFTEST"] = "1" if ddp else "0"
+            print(f"[arm] lag={lag} ddp={ddp} bucket_opt={bopt} captured={captured}", file=sys.stderr, flush=True)
             model = _transformer(dt, T, D)
             tr = HipTrainer(model, "diffusion", "sgd", 1e-2, bucket_mb=0.5, overlap_comm=True if ddp else None)
             from inferbiomechanics_amd import hip
@@ -100,7 +103,7 @@ def _spawn(target):
     q = ctx.Queue()
     p = ctx.Process(target=target, args=(_free_port(), q))
     p.start()
-    status, out = q.get(timeout=900)
+    status, out = q.get(timeout=400)
     p.join(timeout=120)
     assert status == "ok", status
     return out
