@@ -40,7 +40,11 @@ def _lag_worker(port, q):
     try:
         import faulthandler
         import sys
-        faulthandler.dump_traceback_later(240, exit=True)      # a hang shows WHERE (all threads) instead of a silent timeout
+        # a hang shows WHERE (all threads) instead of a silent timeout: into a file the GPU box hands back
+        root_ = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        os.makedirs(os.path.join(root_, "gpurun_out"), exist_ok=True)
+        _fh = open(os.path.join(root_, "gpurun_out", f"rccl_worker_hang_{os.getpid()}.txt"), "w")
+        faulthandler.dump_traceback_later(150, exit=True, file=_fh)
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         import torch.distributed as dist
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1",
@@ -103,7 +107,7 @@ def _spawn(target):
     q = ctx.Queue()
     p = ctx.Process(target=target, args=(_free_port(), q))
     p.start()
-    status, out = q.get(timeout=400)
+    status, out = q.get(timeout=200)
     p.join(timeout=120)
     assert status == "ok", status
     return out
