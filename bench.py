@@ -690,6 +690,9 @@ def main():
     # the host driver of this pool only supports dmabuf IPC; without this RCCL's cross-process buffer registration fails
     # (hipIpcGetMemHandle: invalid argument).  Must be in the environment before the first HIP call.
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # c10d's completion-event cache off (read when the process group is created): precondition of capturing the all-reduces
+    # inside the step graph (inferbiomechanics_amd/ddp_probe.py)
+    os.environ.setdefault("TORCH_NCCL_CUDA_EVENT_CACHE", "0")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))

@@ -14,6 +14,8 @@ there is a hang or an abort, not an exception.  So the question is never asked i
     The verdict reaches the other parent ranks through the process group's key-value store: no collective is issued and
     their GPUs stay idle while the child runs.
 
+The captured form is only considered when c10d's event cache is off (TORCH_NCCL_CUDA_EVENT_CACHE=0 at process-group
+creation: `prepare_env()`, called by bench.py and `main.py train`) -- see decide().
 IB_GRAPH_COLLECTIVES=1 / =0 in the environment skips the probe (forces the form); the verdict of a probe is remembered in
 that variable for the rest of the process.  Reference: the step this is about is DDP's bucketed all-reduce inside
 backward, src/cli/train.py:99-102,175,281."""
@@ -40,7 +42,7 @@ def run_child(world: int, timeout_s: float = 150.0) -> dict:
               "IB_GRAPH_COLLECTIVES", "IB_BENCH_REHEARSAL"):
         env.pop(k, None)
     env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS=env.get("OMP_NUM_THREADS", "4"),
-               IB_DDP_SELFTEST="1" if world == 1 else "0", IB_DDP_PROBE_CHILD="1")
+               IB_DDP_SELFTEST="1" if world == 1 else "0", IB_DDP_PROBE_CHILD="1", TORCH_NCCL_CUDA_EVENT_CACHE="0")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
@@ -73,6 +75,16 @@ def verdict():
     return _verdict
 
 
+def event_cache_off() -> bool:
+    return os.environ.get("TORCH_NCCL_CUDA_EVENT_CACHE", "1").strip().lower() in ("0", "false", "off", "n", "no")
+
+
+def prepare_env():
+    """call BEFORE dist.init_process_group("nccl"): what the captured form needs from the process group (and dmabuf IPC)"""
+    os.environ.setdefault("TORCH_NCCL_CUDA_EVENT_CACHE", "0")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+
 def decide(world: int, rank: int, backend: str) -> bool:
     """collective over the parent job's ranks: True = capture the all-reduces inside the step graph"""
     global _verdict
@@ -82,6 +94,16 @@ def decide(world: int, rank: int, backend: str) -> bool:
         if _verdict is None or _verdict.get("source") == "environment":
             _verdict = {"captured": forced == "1", "source": "environment", "why": f"IB_GRAPH_COLLECTIVES={forced}"}
         return forced == "1"
+    if backend == "nccl" and not event_cache_off():
+        # c10d recycles the completion events of its Works through a cache; an event last recorded INSIDE a capture that
+        # comes back for an eager collective makes the watchdog's query fail now and then ("operation not permitted on an
+        # event last recorded in a capturing stream": process abort; 2 of 20 runs under load with the cache, 0 of 30 without:
+        # tools/rccl_stress.sh).  The cache is a property of the process group, fixed when it was created.
+        _verdict = {"captured": False, "source": "event-cache",
+                    "why": "TORCH_NCCL_CUDA_EVENT_CACHE was not 0 when the process group was created: captured collectives "
+                           "are only used with c10d's event cache off (bench.py / main.py train set it)"}
+        os.environ["IB_GRAPH_COLLECTIVES"] = "0"
+        return False
     if backend != "nccl" or os.environ.get("IB_DDP_PROBE_CHILD") == "1":
         _verdict = {"captured": False, "source": "backend", "why": f"backend {backend}: collectives run on the host"}
         os.environ["IB_GRAPH_COLLECTIVES"] = "0"
@@ -119,7 +141,7 @@ def main() -> int:
     """the child job's ranks"""
     import torch
     import torch.distributed as dist
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    prepare_env()
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)

@@ -129,6 +129,7 @@ def _probe_worker(rank, world, port, q):
     try:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
         os.environ.pop("IB_GRAPH_COLLECTIVES", None)
+        os.environ["TORCH_NCCL_CUDA_EVENT_CACHE"] = "0"
         dist.init_process_group("gloo", rank=rank, world_size=world)
         import sys
         import time

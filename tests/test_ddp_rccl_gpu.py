@@ -48,7 +48,8 @@ def _lag_worker(port, q):
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         import torch.distributed as dist
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1",
-                          HSA_ENABLE_IPC_MODE_LEGACY="0", IB_DDP_SELFTEST="1")
+                          HSA_ENABLE_IPC_MODE_LEGACY="0", IB_DDP_SELFTEST="1",
+                          TORCH_NCCL_CUDA_EVENT_CACHE=os.environ.get("TORCH_NCCL_CUDA_EVENT_CACHE", "0"))
         torch.cuda.set_device(0)
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
         from inferbiomechanics_amd.engine import HipTrainer

@@ -425,6 +425,11 @@ def test_ddp_probe_decision_rules(monkeypatch):
     assert ddp_probe.decide(1, 0, "nccl") is False
     monkeypatch.delenv("IB_GRAPH_COLLECTIVES")
     monkeypatch.setattr(ddp_probe, "_verdict", None)
+    # c10d's event cache on (the default of a process group the caller created without prepare_env()): never captured
+    monkeypatch.delenv("TORCH_NCCL_CUDA_EVENT_CACHE", raising=False)
+    assert ddp_probe.decide(1, 0, "nccl") is False and ddp_probe.verdict()["source"] == "event-cache"
+    monkeypatch.delenv("IB_GRAPH_COLLECTIVES")
+    monkeypatch.setenv("TORCH_NCCL_CUDA_EVENT_CACHE", "0")
     assert ddp_probe.decide(1, 0, "gloo") is False and ddp_probe.verdict()["source"] == "backend"
     assert os.environ["IB_GRAPH_COLLECTIVES"] == "0"
     monkeypatch.delenv("IB_GRAPH_COLLECTIVES")
