@@ -96,6 +96,9 @@ def _lag_worker(port, q):
         TU.no_bucket_opt = False
         dist.barrier()
         dist.destroy_process_group()
+        faulthandler.cancel_dump_traceback_later()
+        _fh.close()
+        os.unlink(_fh.name)                           # no hang: nothing to hand back
         q.put(("ok", out))
     except Exception:  # pragma: no cover
         import traceback
