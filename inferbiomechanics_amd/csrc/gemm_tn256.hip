@@ -30,7 +30,7 @@ constexpr int ROW = 512;                              // bytes per image row (25
 constexpr int OP_BYTES = BK * ROW, STAGE = 2 * OP_BYTES, LDS_BYTES = NS * STAGE;      // 16 KiB, 32 KiB, 128 KiB
 constexpr int MAXP = 6;
 #ifndef TN256_ABL
-#define TN256_ABL 0      // TIMING-ONLY build variants (tools/build_variant.sh): 1 no MFMA, 2 no LDS-DMA after the prologue, 3 no fragment reads
+#define TN256_ABL 0      // TIMING-ONLY build variants (tools/build_variant.sh): 1 no MFMA, 2 no LDS-DMA after the prologue, 3 no fragment reads, 4 neither (four-wave form)
 #endif
 
 typedef __attribute__((address_space(3))) void lds_void_t;
@@ -254,6 +254,233 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_tn256_kernel(Params P) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Four-wave form (round 5): the same 256 x 256 tile and stage ring, 256 threads as 2 (n) x 2 (k) waves of 128 x 128 =
+// 8 x 8 MFMA tiles (256 accumulator registers per lane: one wave per SIMD, the 512-register budget).
+// Why: the eight-wave form reads (64 + 128) x 32 x 2 B = 12 KiB of fragments per wave and stage = 96 KiB per workgroup
+// against 32 KiB that the LDS-DMA writes -- 1024 LDS cycles (128 B / clk) per stage next to 1024 MFMA cycles: the two pipes
+// could only lose to each other (timing-only ablations: no fragment reads 84 us, no LDS-DMA 86 us, both 102 us).  A
+// 128 x 128 wave tile reads 16 KiB per wave = 64 KiB per workgroup and stage: 768 LDS cycles under the same 1024 MFMA cycles.
+// A stage's sixteen fragments are held whole (64 registers) and the NEXT stage's sixteen are read under the 64 MFMAs, so
+// the stage's slot is free from the barrier at the head of its own step: one barrier per step, at the step boundary.
+struct Frags { bf16x8_t a[8], b[8]; };
+__device__ __forceinline__ void frags_ready(Frags& f) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.a[2]), "+v"(f.a[3]), "+v"(f.a[4]), "+v"(f.a[5]), "+v"(f.a[6]), "+v"(f.a[7]),
+                 "+v"(f.b[0]), "+v"(f.b[1]), "+v"(f.b[2]), "+v"(f.b[3]), "+v"(f.b[4]), "+v"(f.b[5]), "+v"(f.b[6]), "+v"(f.b[7]));
+}
+constexpr int THREADS4 = 256;
+#ifndef TN256_NS4
+#define TN256_NS4 4
+#endif
+constexpr int NS4 = TN256_NS4;          // ring depth of the four-wave form (5 x 32 KiB = the whole LDS measured the same: 104.9-108.5 vs 106.1-107.9 us)
+// accumulators pinned to the AccVGPR half of the wave's 512 registers (left to itself the allocator spreads them over both
+// halves and copies: 179 v_accvgpr moves per 128 MFMAs); volatile: issue order = program order
+__device__ __forceinline__ void mfma_acc(f32x4_t& acc, const bf16x8_t& a, const bf16x8_t& b) {
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+
+template <bool BIAS>
+__global__ __launch_bounds__(THREADS4, 1) void gemm_tn256w4_kernel(Params P) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[NS4 * STAGE];
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int wm = wave & 1, wn = wave >> 1;
+  const int nwg = (int)gridDim.x;
+  const int first = ib_xcd_remap((int)blockIdx.x, nwg);
+  if (first >= P.items) return;
+  const unsigned smem0 = lds_off(smem);
+  const int nk = P.nk;
+
+  unsigned ab0, bb0;
+  {
+    const int lane = lane_now();
+    const int g = lane >> 4, q = (lane & 15) >> 2, pq = lane & 3;
+    const unsigned ro = (unsigned)((8 * g + q) * ROW + 8 * pq);
+    ab0 = smem0 + ro + (unsigned)(32 * ((wm << 3) | ((g & 1) << 2) | q));
+    bb0 = smem0 + OP_BYTES + ro + (unsigned)(32 * ((wn << 3) | ((g & 1) << 2) | q));
+  }
+  [[maybe_unused]] bf16x8_t ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (bf16_t)1.0f;
+
+  for (int item = first; item < P.items; item += nwg) {
+    int e = 0;
+    for (int j = 1; j < P.n; ++j)
+      if (item >= P.pr[j].item0) e = j;
+    const Prob& q = P.pr[e];
+    const int local = item - q.item0;
+    const int split = local / q.per_split, tl = local % q.per_split;
+    const int i0 = (tl / q.tiles_k) * TM, j0 = (tl % q.tiles_k) * TK;
+
+    // LDS-DMA sources.  A wave's piece j (0..3) of an operand = stage rows r0 + 8 j, r0 = 2 wave + (lane >> 5): the row's
+    // swizzle s(m) = (m & 3) | ((m >> 3) & 1) << 2 has its high bit from j's parity, so two per-lane column offsets
+    const bf16_t* pa[2];
+    const bf16_t* pb[2];
+    const unsigned sa = (unsigned)q.lda, sb = (unsigned)q.ldb;
+    {
+      const int lane = lane_now();
+      const int r0 = 2 * wave + (lane >> 5);
+#pragma unroll
+      for (int par = 0; par < 2; ++par) {
+        const int src = (lane & 31) ^ (((r0 & 3) | (par << 2)) << 1);
+        pa[par] = q.A + (size_t)(split * P.chunk + r0) * sa + (size_t)(i0 + 8 * src);
+        pb[par] = q.B + (size_t)(split * P.chunk + r0) * sb + (size_t)(j0 + 8 * src);
+      }
+    }
+    // piece j (0..3: operand A, 4..7: operand B) of stage kt into the slot at `st`
+    auto piece = [&](int j, int kt, unsigned char* st) {
+      if (j < 4)
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(pa[j & 1] + (size_t)((unsigned)(kt * BK + 8 * j) * sa)),
+                                         (lds_void_t*)(st + (wave + 4 * j) * 1024), 16, 0, 0);
+      else
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(pb[j & 1] + (size_t)((unsigned)(kt * BK + 8 * (j - 4)) * sb)),
+                                         (lds_void_t*)(st + OP_BYTES + (wave + 4 * (j - 4)) * 1024), 16, 0, 0);
+    };
+
+    [[maybe_unused]] const bool want_bias = BIAS && q.dbias != nullptr && j0 == 0;
+    f32x4_t acc[8][8];
+    [[maybe_unused]] f32x4_t accb[4];
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc[t][u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    if constexpr (BIAS) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) accb[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+
+    // prologue: NS stages in flight (nk >= 8 by the host's choice of the split), the first one's fragments
+#pragma unroll
+    for (int s = 0; s < NS4; ++s)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) piece(j, s, smem + s * STAGE);
+    wait_vm<8 * (NS4 - 1)>();
+    __builtin_amdgcn_s_barrier();
+    Frags f0, f1;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      f0.a[t] = lds_read_tr(ab0 ^ (unsigned)(t << 5));
+      f0.b[t] = lds_read_tr(bb0 ^ (unsigned)(t << 5));
+    }
+    frags_ready(f0);
+
+    // step kt: the 64 MFMAs of stage kt (fragments in `cur`); under them the fragments of stage kt + 1 are read into `nxt`
+    // (NEXT) and stage kt + NS is requested into the slot stage kt came from (ISSUE).  VM = LDS-DMA instructions that may
+    // still be in flight when stage kt + 1 must have landed (the stages issued behind it, 8 per stage; loads retire in order).
+    // The order below IS the issue order (MFMAs and fragment reads are volatile asm, scheduling barriers pin the rest): the
+    // first row of MFMAs runs ahead of the barrier (it needs neither the freed slot nor the next stage), the sixteen
+    // fragment reads and eight requests are spread over the other seven rows.
+    int slot = 0;                          // the slot stage kt lies in (kt mod NS4)
+    auto step = [&](auto next_c, auto issue_c, auto vm_c, int kt, Frags& cur, Frags& nxt) {
+      constexpr bool NEXT = decltype(next_c)::value, ISSUE = decltype(issue_c)::value;
+      constexpr int VM = decltype(vm_c)::value;
+      const int slot1 = slot == NS4 - 1 ? 0 : slot + 1;
+      const unsigned so1 = (unsigned)(slot1 * STAGE);
+      unsigned char* st = smem + slot * STAGE;
+      auto read_pair = [&](int t) {
+        nxt.a[t] = lds_read_tr((ab0 + so1) ^ (unsigned)(t << 5));
+        nxt.b[t] = lds_read_tr((bb0 + so1) ^ (unsigned)(t << 5));
+      };
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        if (t == 1 && NEXT) {
+          wait_vm<VM>();
+          __builtin_amdgcn_s_barrier();    // every wave holds stage kt in registers (slot free) and stage kt + 1 is visible
+        }
+        if (t >= 1 && NEXT && TN256_ABL != 3 && TN256_ABL != 4) {
+          read_pair(t);
+          if (t == 1) read_pair(0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (TN256_ABL != 1) mfma_acc(acc[t][u], cur.b[u], cur.a[t]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t >= 1 && ISSUE && TN256_ABL != 2 && TN256_ABL != 4) {
+          piece(t, kt + NS4, st);
+          if (t == 1) piece(0, kt + NS4, st);
+        }
+      }
+      if constexpr (BIAS) {
+        if (want_bias) {                   // item-uniform; the two k-half waves of an n half take four row tiles each
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const bf16x8_t fsel = wn ? cur.a[4 + i] : cur.a[i];
+            // (the builtin would take the AccVGPR form and shuttle these four through a[16:19] every step)
+            asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(accb[i]) : "v"(ones), "v"(fsel));
+          }
+        }
+      }
+      if constexpr (NEXT) frags_ready(nxt);
+      slot = slot1;
+    };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    auto vm = [](auto c) { return std::integral_constant<int, 8 * decltype(c)::value>{}; };   // stages -> instructions
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+    // main steps (a request each) in pairs, then the NS4 steps that only drain the ring; nk is even (host), so with an odd
+    // ring the first step stands alone and the fragment buffers swap roles
+    auto run = [&](int kt, Frags& x, Frags& y) {
+      for (; kt < nk - NS4; kt += 2) {
+        step(T_{}, T_{}, vm(std::integral_constant<int, NS4 - 2>{}), kt, x, y);
+        step(T_{}, T_{}, vm(std::integral_constant<int, NS4 - 2>{}), kt + 1, y, x);
+      }
+      if constexpr (NS4 == 4) {
+        step(T_{}, F_{}, vm(I2{}), kt, x, y);
+        step(T_{}, F_{}, vm(I1{}), kt + 1, y, x);
+        step(T_{}, F_{}, vm(I0{}), kt + 2, x, y);
+        step(F_{}, F_{}, vm(I0{}), kt + 3, y, x);
+      } else {
+        static_assert(NS4 == 4 || NS4 == 5, "ring depth");
+        step(T_{}, F_{}, vm(I3{}), kt, x, y);
+        step(T_{}, F_{}, vm(I2{}), kt + 1, y, x);
+        step(T_{}, F_{}, vm(I1{}), kt + 2, x, y);
+        step(T_{}, F_{}, vm(I0{}), kt + 3, y, x);
+        step(F_{}, F_{}, vm(I0{}), kt + 4, x, y);
+      }
+    };
+    if constexpr (NS4 & 1) {
+      step(T_{}, T_{}, vm(std::integral_constant<int, NS4 - 2>{}), 0, f0, f1);
+      run(1, f1, f0);
+    } else {
+      run(0, f0, f1);
+    }
+
+    // ---- epilogue: fp32 accumulators straight to the slab of this split
+    // (the asm MFMAs are opaque to the compiler's hazard recognizer: the last results need 2 + 4 x 2 passes to land)
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    if constexpr (BIAS) {
+      // ALL four registers of each bias accumulator stay live up to here.  Only element 0 is stored, so after the last
+      // step's MFMAs the allocator took elements 2-3 of accb[0] as temporaries for the next MFMA's operand while the
+      // (opaque) MFMA was still writing them: one or two non-finite bias gradients per ~100 training steps.
+      asm volatile("" : "+v"(accb[0]), "+v"(accb[1]), "+v"(accb[2]), "+v"(accb[3]));
+    }
+    {
+      const int lane = lane_now();
+      float* slab = q.C + (size_t)split * (size_t)q.N * (size_t)q.K;
+      const int n0 = i0 + wm * 128 + (lane & 15), k0 = j0 + wn * 128 + 4 * (lane >> 4);
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          *reinterpret_cast<f32x4_t*>(slab + (size_t)(n0 + 16 * t) * q.K + k0 + 16 * u) = acc[t][u];
+      if constexpr (BIAS) {
+        if (want_bias && (lane >> 4) == 0) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) q.dbias[(size_t)split * q.N + n0 + 16 * (4 * wn + i)] = accb[i][0];
+        }
+      }
+    }
+    // the next item's prologue reuses all four slots: every read of them is behind the last step's barrier; its 32 requests
+    // and these 64 stores do not fit the 6-bit counter together, so the stores drain first (one item per workgroup at the
+    // transformer's shapes: this is the kernel's end there)
+    wait_vm<0>();
+  }
+}
+
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
@@ -313,8 +540,14 @@ int ib_gemm_tn256_multi(int n, const void* const* dz, const int64_t* lddz, const
   P.items = items;
   const int grid = items < 256 ? items : 256;
   IB_PATH(IB_PATH_TN256);
-  if (any_bias) hipLaunchKernelGGL(gemm_tn256_kernel<true>, dim3(grid), dim3(THREADS), 0, s, P);
-  else hipLaunchKernelGGL(gemm_tn256_kernel<false>, dim3(grid), dim3(THREADS), 0, s, P);
+  static const bool v8 = ib_ab_set("IB_TN256_W8");     // measurement builds: the eight-wave form
+  if (v8) {
+    if (any_bias) hipLaunchKernelGGL(gemm_tn256_kernel<true>, dim3(grid), dim3(THREADS), 0, s, P);
+    else hipLaunchKernelGGL(gemm_tn256_kernel<false>, dim3(grid), dim3(THREADS), 0, s, P);
+  } else {
+    if (any_bias) hipLaunchKernelGGL(gemm_tn256w4_kernel<true>, dim3(grid), dim3(THREADS4), 0, s, P);
+    else hipLaunchKernelGGL(gemm_tn256w4_kernel<false>, dim3(grid), dim3(THREADS4), 0, s, P);
+  }
   IB_CHECK_LAUNCH();
   return IB_OK;
 }
