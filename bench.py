@@ -690,9 +690,10 @@ def main():
     # the host driver of this pool only supports dmabuf IPC; without this RCCL's cross-process buffer registration fails
     # (hipIpcGetMemHandle: invalid argument).  Must be in the environment before the first HIP call.
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    # c10d's completion-event cache off (read when the process group is created): precondition of capturing the all-reduces
-    # inside the step graph (inferbiomechanics_amd/ddp_probe.py)
-    os.environ.setdefault("TORCH_NCCL_CUDA_EVENT_CACHE", "0")
+    # what capturing the all-reduces inside the step graph needs from the process group (read when it is created): c10d's
+    # completion-event cache off, its flight recorder on (inferbiomechanics_amd/ddp_probe.py, engine._drain_c10d_watchdog)
+    from inferbiomechanics_amd import ddp_probe as _probe_env
+    _probe_env.prepare_env()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))

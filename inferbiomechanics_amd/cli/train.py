@@ -102,7 +102,8 @@ class TrainCommand(AbstractCommand):
             torch.manual_seed(args.seed)
         geometry = self.ensure_geometry(args.geometry_folder)
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC for RCCL (before the first HIP call)
-        os.environ.setdefault("TORCH_NCCL_CUDA_EVENT_CACHE", "0")    # precondition of captured collectives (ddp_probe.py)
+        from .. import ddp_probe
+        ddp_probe.prepare_env()                                      # preconditions of captured collectives (ddp_probe.py)
         device = pick_device(args)
         world_size = int(os.environ.get('WORLD_SIZE', '1'))
         distributed = world_size > 1

@@ -42,7 +42,9 @@ def run_child(world: int, timeout_s: float = 150.0) -> dict:
               "IB_GRAPH_COLLECTIVES", "IB_BENCH_REHEARSAL"):
         env.pop(k, None)
     env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS=env.get("OMP_NUM_THREADS", "4"),
-               IB_DDP_SELFTEST="1" if world == 1 else "0", IB_DDP_PROBE_CHILD="1", TORCH_NCCL_CUDA_EVENT_CACHE="0")
+               IB_DDP_SELFTEST="1" if world == 1 else "0", IB_DDP_PROBE_CHILD="1", TORCH_NCCL_CUDA_EVENT_CACHE="0",
+               TORCH_NCCL_TRACE_BUFFER_SIZE=env.get("TORCH_NCCL_TRACE_BUFFER_SIZE", "2000"),
+               TORCH_FR_BUFFER_SIZE=env.get("TORCH_FR_BUFFER_SIZE", "2000"))
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
@@ -82,6 +84,10 @@ def event_cache_off() -> bool:
 def prepare_env():
     """call BEFORE dist.init_process_group("nccl"): what the captured form needs from the process group (and dmabuf IPC)"""
     os.environ.setdefault("TORCH_NCCL_CUDA_EVENT_CACHE", "0")
+    # c10d's flight recorder on: engine._drain_c10d_watchdog reads it to know when the watchdog has let go of every eager
+    # collective (both spellings: the variable was renamed between torch releases)
+    os.environ.setdefault("TORCH_NCCL_TRACE_BUFFER_SIZE", "2000")
+    os.environ.setdefault("TORCH_FR_BUFFER_SIZE", "2000")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 
@@ -95,10 +101,11 @@ def decide(world: int, rank: int, backend: str) -> bool:
             _verdict = {"captured": forced == "1", "source": "environment", "why": f"IB_GRAPH_COLLECTIVES={forced}"}
         return forced == "1"
     if backend == "nccl" and not event_cache_off():
-        # c10d recycles the completion events of its Works through a cache; an event last recorded INSIDE a capture that
-        # comes back for an eager collective makes the watchdog's query fail now and then ("operation not permitted on an
-        # event last recorded in a capturing stream": process abort; 2 of 20 runs under load with the cache, 0 of 30 without:
-        # tools/rccl_stress.sh).  The cache is a property of the process group, fixed when it was created.
+        # c10d recycles the completion events of its Works through a cache, so a captured Work and a later eager one can
+        # share an event object; with the cache on, the five-arm RCCL test under load still met the watchdog abort ("event
+        # last recorded in a capturing stream") in 1 of 30 runs even with the deterministic drain of
+        # engine._drain_c10d_watchdog; cache off + that drain: 0 of 46 (profiles/r05_rccl_stress.txt).  The cache is a
+        # property of the process group, fixed when it was created.
         _verdict = {"captured": False, "source": "event-cache",
                     "why": "TORCH_NCCL_CUDA_EVENT_CACHE was not 0 when the process group was created: captured collectives "
                            "are only used with c10d's event cache off (bench.py / main.py train set it)"}

@@ -167,23 +167,53 @@ def broadcast_parameters(flat: torch.Tensor, group=None, src: int = 0):
         dist.broadcast(flat, src=src, group=group)
 
 
-def _drain_c10d_watchdog(device):
-    """Block until c10d's watchdog thread has reaped every eager collective issued so far.  The watchdog polls the completion
-    event of each outstanding Work (hipEventQuery from its own thread); the events sit on c10d's communication stream, and a
-    poll that lands while that stream is part of a capture fails ("event last recorded in a capturing stream") and takes the
-    process down.  torch keeps a counter of such pending queries for its own graphs -- `CUDAGraph.capture_begin()` waits
-    until it is zero -- so an EMPTY torch capture on a scratch stream is the deterministic form of that wait (round 4 slept
-    for half a second and hoped; a 13-bucket step on a busy host outlasted it once in this round's tests)."""
-    import time
+_drain_report = {"mode": None, "waited_s": 0.0, "polls": 0}      # the last drain of this process (tests, bench line)
+
+
+def _active_c10d_works():
+    """number of eager c10d Works the watchdog thread has not retired yet, from c10d's flight recorder (every collective that
+    is handed to the watchdog gets an entry, marked retired in the watchdog pass that reaps it; collectives issued under
+    capture are neither handed over nor recorded).  None when the recorder is off or this torch has no such call."""
+    import pickle
     try:
-        with torch.cuda.stream(torch.cuda.Stream(device=device)):
-            g = torch.cuda.CUDAGraph()
-            g.capture_begin()                        # returns once no c10d Work is waiting for its watchdog query
-            g.capture_end()
-    except Exception:                                # a torch without that counter: fall back to the timed wait
-        time.sleep(0.5)
+        c = torch._C._distributed_c10d
+        everything = pickle.loads(c._dump_nccl_trace(True, False, False))
+        if not everything.get("entries"):
+            return None                              # recorder off (TORCH_NCCL_TRACE_BUFFER_SIZE=0): nothing to read
+        active = pickle.loads(c._dump_nccl_trace(True, False, True)).get("entries") or []
+        return sum(1 for e in active if not e.get("retired", False))
+    except Exception:
+        return None
+
+
+def _drain_c10d_watchdog(device, timeout_s: float = 20.0):
+    """Block until c10d's watchdog thread has reaped every eager collective issued so far.  The watchdog wakes every ~100 ms
+    and polls the completion event of each Work it still holds (hipEventQuery from its own thread); the events of the eager
+    warm-up steps' collectives sit on c10d's communication stream, and a poll that lands while that stream is part of a
+    capture fails ("event last recorded in a capturing stream") and takes the process down.  Completed on the GPU is not
+    enough -- the Work leaves the watchdog's list only in its next pass.  So: read the flight recorder until no Work is
+    un-retired (deterministic); without a recorder, sleep for several watchdog periods (rounds 4 / 5a: 0.5 s was outlasted
+    once on a busy host, and the `CUDAGraph.capture_begin()` wait this function used before does not exist in this torch:
+    with only its 50-ms sleep one capture in ten met a watchdog pass)."""
+    import time
+    t0 = time.perf_counter()
+    n = _active_c10d_works()
+    if n is None:
+        time.sleep(0.6)
+        _drain_report.update(mode="sleep", waited_s=round(time.perf_counter() - t0, 3), polls=0)
         return
-    time.sleep(0.05)
+    polls = 1
+    while n:
+        if time.perf_counter() - t0 > timeout_s:
+            raise hip.HipError(f"c10d's watchdog still holds {n} collective(s) after {timeout_s:.0f} s: not capturing "
+                               "collectives beside them (IB_GRAPH_COLLECTIVES=0 selects the cut-graph form)")
+        time.sleep(0.01)
+        n = _active_c10d_works()
+        polls += 1
+        if n is None:                                # the recorder went away under us
+            time.sleep(0.6)
+            break
+    _drain_report.update(mode="flight-recorder", waited_s=round(time.perf_counter() - t0, 3), polls=polls)
 
 
 class _Recorder:

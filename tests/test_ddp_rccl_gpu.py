@@ -49,7 +49,9 @@ def _lag_worker(port, q):
         import torch.distributed as dist
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1",
                           HSA_ENABLE_IPC_MODE_LEGACY="0", IB_DDP_SELFTEST="1",
-                          TORCH_NCCL_CUDA_EVENT_CACHE=os.environ.get("TORCH_NCCL_CUDA_EVENT_CACHE", "0"))
+                          TORCH_NCCL_CUDA_EVENT_CACHE=os.environ.get("TORCH_NCCL_CUDA_EVENT_CACHE", "0"),
+                          TORCH_NCCL_TRACE_BUFFER_SIZE=os.environ.get("TORCH_NCCL_TRACE_BUFFER_SIZE", "2000"),
+                          TORCH_FR_BUFFER_SIZE=os.environ.get("TORCH_FR_BUFFER_SIZE", "2000"))
         torch.cuda.set_device(0)
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
         from inferbiomechanics_amd.engine import HipTrainer
@@ -88,6 +90,8 @@ def _lag_worker(port, q):
             hip.optim_step = real
             torch.cuda.synchronize()
             info["captured"] = tr._rec is not None
+            from inferbiomechanics_amd import engine as _eng
+            info["drain"] = dict(_eng._drain_report)
             info["graph_cuts"] = sum(1 for k, _ in tr._rec.actions if k == "host") if tr._rec is not None else -1
             return tr.flat.detach().cpu().numpy().copy(), losses, info
 
@@ -141,6 +145,8 @@ def test_lagged_weight_gradient_path_is_bitwise_the_unlagged_and_the_single_gpu_
     # ... and with the all-reduces (and the per-bucket optimizer branches behind them) captured inside ONE graph per step
     fe, le, ie = out["captured"]
     assert ie["captured"] and ie["graph_cuts"] == 0 and ie["bucket_opt"], ie
+    # the capture waited until c10d's flight recorder showed no eager collective left with the watchdog (not a timed sleep)
+    assert ie["drain"]["mode"] == "flight-recorder" and ie["drain"]["polls"] >= 1, ie["drain"]
     assert la == le and np.array_equal(fa, fe), (la, le, float(np.abs(fa - fe).max()))
 
 
