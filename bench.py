@@ -252,7 +252,7 @@ KERNEL_OF = {   # C-ABI entry -> device kernel it launches (names as rocprofv3 -
     "ib_mlp_chain_train": "mlp_chain2_kernel<4, 3, 10, true>", "ib_mlp_chain_prep": "time_mlp_fwd_kernel<4, 4, 1> (+ weight packing blocks)",
     "ib_linear_wgrad_slabs": "gemm_ring_kernel<false, false, EPI_WGRAD>", "ib_slab_reduce_multi": "slab_reduce_multi_kernel",
     "ib_linear_wgrad_slabs_multi": "gemm_tn_kernel<false> (gemm_ring_wgrad_multi_kernel for short reductions)",
-    "ib_linear_wgrad_slabs_multi_bias": "gemm_tn256_kernel<true> (gemm_tn_kernel<true> for shapes that are not multiples of 256)", "ib_linear_dgrad_wt": "gemm_nt_kernel",
+    "ib_linear_wgrad_slabs_multi_bias": "gemm_tn256w4_kernel<true> (gemm_tn_kernel<true> for shapes that are not multiples of 256)", "ib_linear_dgrad_wt": "gemm_nt_kernel",
     "ib_optim_step_sources": "optim_kernel<true>",
     "ib_step_reduce": "step_reduce_kernel",
     "ib_colsum_segments": "colsum_segments_kernel",

@@ -31,7 +31,7 @@ ENTRY_OF = [# round 5: the one-window-panel launches with the attention inside (
             ("ffn_chain_fwd_kernel<true, false, false, true", "", "ib_ffn_chain_fwd_infer"),
             ("ffn_chain_fwd_kernel", "", "ib_ffn_chain_fwd"), ("ffn_chain_bwd_kernel", "", "ib_ffn_chain_bwd"),
             ("ffn_pack_kernel", "", "ib_ffn_chain_pack"), ("diffusion_draw_kernel", "", "ib_diffusion_draw"),
-            ("gemm_tn256_kernel", "", "ib_linear_wgrad_slabs_multi"), ("gemm_tn_kernel", "", "ib_linear_wgrad_slabs_multi"), ("gemm_nt_kernel<0, 0, false", "", "ib_linear_fwd"),
+            ("gemm_tn256w4_kernel", "", "ib_linear_wgrad_slabs_multi"), ("gemm_tn256_kernel", "", "ib_linear_wgrad_slabs_multi"), ("gemm_tn_kernel", "", "ib_linear_wgrad_slabs_multi"), ("gemm_nt_kernel<0, 0, false", "", "ib_linear_fwd"),
             ("gemm_nt_kernel<1, 0", "", "ib_linear_fwd"), ("gemm_nt_kernel<0, 1", "", "ib_linear_dgrad"),
             ("gemm_nt_kernel<0, 0, true", "", "ib_linear_dgrad"), ("gemm_nt_kernel", "", "ib_linear_fwd"),
             ("mlp_chain_kernel", "", "ib_mlp_chain_train"), ("mlp_chain2_kernel", "", "ib_mlp_chain_train"),
