@@ -44,6 +44,8 @@ _SPEC = {
     "no_time_table": ("IB_NO_TIME_TABLE", False),
     "no_infer_chain": ("IB_NO_INFER_CHAIN", False),    # round 5: large-batch sampler on the training-shape launches
     "infer_chain_min_m": ("IB_INFER_CHAIN_MIN_M", 8193),
+    "no_infer_split": ("IB_NO_INFER_SPLIT", False),    # round 5: the short last round of panels through the row-panel kernels
+    "infer_split_max_rem": ("IB_INFER_SPLIT_MAX_REM", 96),   # swept: 88 panels +4.7 %, 119 panels -3.4 %
     # ---- padding of the D-wide projections
     "no_pad": ("IB_NO_PAD", False),
     "no_train_pad": ("IB_NO_TRAIN_PAD", False),

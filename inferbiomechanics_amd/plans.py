@@ -1404,6 +1404,39 @@ class DenoiserTransformerPlan:
         self.br_thid = Branch(device, name="tr_thid")
         self.br_pos = Branch(device, name="tr_pos")
         self.br_wt = Branch(device, name="tr_wt")
+        self.br_side = Branch(device, name="tr_side")    # sampler: the windows beyond the fused launch's last full round
+
+    def side_windows(self, B: int, T: int) -> int:
+        """sampler: how many of the batch's last windows take the per-op side stack (0: none) -- the fused launch's last
+        round of panels would fill at most `infer_split_max_rem` of the 256 CUs"""
+        M = B * T
+        if (not self.inference or TU.no_infer_split or TU.no_infer_chain or not self.br_side.on or M < TU.infer_chain_min_m
+                or self.dtype != torch.bfloat16 or self.d != 512 or not all(lp.infer_packed for lp in self.layers)):
+            return 0
+        panels = -(-M // 64)
+        rounds, rem = divmod(panels, 256)
+        if rounds == 0 or rem == 0 or rem > TU.infer_split_max_rem:
+            return 0
+        Bm = (rounds * 256 * 64) // T
+        Bs = B - Bm
+        if Bs <= 0 or Bm * T < TU.infer_chain_min_m or Bs * T > min(TU.linln_panel_max_m, TU.ffn_infer_max_m):
+            return 0
+        return Bs
+
+    def side_layers(self) -> List["TransformerLayerPlan"]:
+        """a second set of layer plans over the same parameters and packed images, with activation buffers of their own"""
+        if self._side is None:
+            self._side = []
+            for lp in self.layers:
+                sl = TransformerLayerPlan(lp.p, lp.d, lp.h, lp.ffn, lp.dtype, self.buf.device, buf=self.buf, tag=lp.tag + "s")
+                sl.join_on_exit, sl.own_wt = False, False
+                sl.packed_image = lp.packed_image             # the main layer's image (packed once per sampling loop)
+                self._side.append(sl)
+        for sl, lp in zip(self._side, self.layers):
+            sl.inference, sl.infer_packed = lp.inference, lp.infer_packed
+        return self._side
+
+    _side = None
 
     def flush_each_layer(self, on: bool):
         """overlapped data-parallel steps: keep the layers' side streams, hand completed gradient buckets to the trainer at
@@ -1504,7 +1537,7 @@ class DenoiserTransformerPlan:
         return D if (TU.no_pad or D % 64 == 0) else (D + 63) // 64 * 64
 
     def branches(self) -> List[Branch]:
-        return [lp.branch for lp in self.layers] + [self.br_time, self.br_thid, self.br_pos, self.br_wt]
+        return [lp.branch for lp in self.layers] + [self.br_time, self.br_thid, self.br_pos, self.br_wt, self.br_side]
 
     def forward(self, x3: torch.Tensor, t: torch.Tensor, table: torch.Tensor, P: ParamSource,
                 out: Optional[torch.Tensor] = None, BT: Optional[Tuple[int, int]] = None) -> torch.Tensor:
@@ -1571,10 +1604,34 @@ class DenoiserTransformerPlan:
         h = h0
         if ffn_items and not self.inference:
             self.br_wt.join()                         # layer 0's fused feed-forward sublayer reads the packed images
-        ready = aready = False
-        for lp in self.layers:
-            h = lp.forward(h, P, qkv_ready=ready, attn_ready=aready)
-            ready, aready = lp.tail_done, lp.attn_tail_done      # it wrote the next layer's in-projection / attention output
+        Bs = self.side_windows(B, T)
+        if Bs:
+            # Sampler, large batch: a 64-row panel of the fused frozen-weight launch costs what its weight stream costs,
+            # so 800 panels (B = 256, T = 200) are FOUR rounds of 256 workgroups for 3.125 rounds of work.  The windows
+            # beyond the last full round go through the whole layer stack on the per-op row-panel kernels (which spread a
+            # weight's columns over the chip) on a side branch -- forked once, joined once -- beside the full rounds.
+            Bm = B - Bs
+            hL = g("dt.hL", (B, T, self.d), dt)
+            side = self.side_layers()
+            hs = h0[Bm:]
+
+            def side_stack():
+                hh = hs
+                for i, sl in enumerate(side):
+                    hh = sl.forward(hh, P, out=hL[Bm:] if i + 1 == len(side) else None)
+            self.br_side.run(side_stack)
+            h = h0[:Bm]
+            ready = aready = False
+            for i, lp in enumerate(self.layers):
+                h = lp.forward(h, P, out=hL[:Bm] if i + 1 == len(self.layers) else None, qkv_ready=ready, attn_ready=aready)
+                ready, aready = lp.tail_done, lp.attn_tail_done
+            self.br_side.join()
+            h = hL
+        else:
+            ready = aready = False
+            for lp in self.layers:
+                h = lp.forward(h, P, qkv_ready=ready, attn_ready=aready)
+                ready, aready = lp.tail_done, lp.attn_tail_done  # it wrote the next layer's in-projection / attention output
         out = out if out is not None else g("dt.out", (B, T, D), dt)
         if padded:
             hip.linear_fwd(h.view(M, self.d), w_out_pad, b_out_pad, out.as_strided((M, Kp), (Kp, 1)))
