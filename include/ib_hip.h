@@ -552,6 +552,12 @@ int ib_graph_end(ib_stream_t stream, void** graph_exec_out);
 int ib_graph_launch(void* graph_exec, ib_stream_t stream);
 int ib_graph_destroy(void* graph_exec);
 
+/* ---- streams of the library's own (non-blocking, current device).  The reference runs everything on the default stream
+ * (SURVEY.md 8b "Threading / processes"); the build's side branches / capture stream / trainer stream must not come from
+ * torch's round-robin pool of 32 streams, which c10d's communication stream shares (engine.py, plans.Branch) */
+int ib_stream_create(void** stream_out);
+int ib_stream_destroy(void* stream);
+
 /* ---- HIP-event timing on the launch stream (bench.py's roofline leg) ------------------------ */
 int ib_event_create(void** ev_out);
 int ib_event_record(void* ev, ib_stream_t stream);

@@ -236,6 +236,7 @@ class TrainCommand(AbstractCommand):
             return xd, td, ed
 
         adopted = False
+        prev_stream = None
         for epoch in range(epoch_checkpoint + 1, args.epochs):
             dev_dataloader.sampler.set_epoch(epoch)
             train_dataloader.sampler.set_epoch(epoch)
@@ -261,7 +262,7 @@ class TrainCommand(AbstractCommand):
             print(f'[rank={rank}] Running Training Epoch {epoch}')
             model.train()
             if trainer is not None and not adopted:
-                trainer.adopt_stream()      # the loop's device work runs on the trainer's stream: no per-step hand-over
+                prev_stream = trainer.adopt_stream()   # the loop's device work runs on the trainer's stream: no per-step hand-over
                 adopted = True
             if cache is not None:
                 train_batches = list(cache.batches(args.batch_size, rank=rank, world=world_size))
@@ -324,6 +325,9 @@ class TrainCommand(AbstractCommand):
             train_eval.print_report(args, log_to_wandb=log_to_wandb) if not diffusion else train_eval.print_report()
             logging.info('-' * 80)
 
+        if prev_stream is not None:                 # in-process callers (tests, tools) get their stream back
+            torch.cuda.current_stream().synchronize()
+            torch.cuda.set_stream(prev_stream)
         if wandb is not None:
             wandb.finish()
         if distributed:

@@ -41,6 +41,22 @@ extern "C" int ib_graph_destroy(void* graph_exec) {
   return hipGraphExecDestroy(reinterpret_cast<hipGraphExec_t>(graph_exec)) == hipSuccess ? IB_OK : IB_E_LAUNCH;
 }
 
+// A stream of the library's own (non-blocking, current device).  The host side runs its side branches, its capture stream
+// and its trainer stream on these instead of torch.cuda.Stream(): torch hands those out round-robin from a pool of 32 per
+// device that c10d's communication stream comes from too -- the 33rd stream of a process IS an earlier one, and a side branch
+// that aliases c10d's stream pulls it into a capture (tests/test_ddp_rccl_gpu.py failed one run in ten that way).
+extern "C" int ib_stream_create(void** stream_out) {
+  if (!stream_out) return IB_E_ARG;
+  hipStream_t s = nullptr;
+  if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess || !s) return IB_E_LAUNCH;
+  *stream_out = s;
+  return IB_OK;
+}
+extern "C" int ib_stream_destroy(void* stream) {
+  if (!stream) return IB_E_ARG;
+  return hipStreamDestroy(reinterpret_cast<hipStream_t>(stream)) == hipSuccess ? IB_OK : IB_E_LAUNCH;
+}
+
 extern "C" int ib_event_create(void** ev_out) {
   if (!ev_out) return IB_E_ARG;
   hipEvent_t e;

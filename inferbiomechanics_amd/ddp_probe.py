@@ -101,11 +101,12 @@ def decide(world: int, rank: int, backend: str) -> bool:
             _verdict = {"captured": forced == "1", "source": "environment", "why": f"IB_GRAPH_COLLECTIVES={forced}"}
         return forced == "1"
     if backend == "nccl" and not event_cache_off():
-        # c10d recycles the completion events of its Works through a cache, so a captured Work and a later eager one can
-        # share an event object; with the cache on, the five-arm RCCL test under load still met the watchdog abort ("event
-        # last recorded in a capturing stream") in 1 of 30 runs even with the deterministic drain of
-        # engine._drain_c10d_watchdog; cache off + that drain: 0 of 46 (profiles/r05_rccl_stress.txt).  The cache is a
-        # property of the process group, fixed when it was created.
+        # A precaution kept from the hunt for the watchdog abort ("event last recorded in a capturing stream"): c10d recycles
+        # the completion events of its Works through a cache, so a captured Work and a later eager one can share an event
+        # object.  The two causes that were found and fixed are elsewhere (engine._drain_c10d_watchdog waits on the flight
+        # recorder's `retired` flags; hip.new_stream keeps the library's streams out of the pool c10d's stream comes from);
+        # with both, 24 stress runs with the cache on and 30 with it off passed (profiles/r05_rccl_stress.txt).  The cache
+        # is a property of the process group, fixed when it was created.
         _verdict = {"captured": False, "source": "event-cache",
                     "why": "TORCH_NCCL_CUDA_EVENT_CACHE was not 0 when the process group was created: captured collectives "
                            "are only used with c10d's event cache off (bench.py / main.py train set it)"}

@@ -44,7 +44,7 @@ class DDIMSampler:
             return self._sample(x_T, steps)
         # hipGraph capture is not allowed on the legacy default stream -> run on a side stream
         if getattr(self, "_stream", None) is None:
-            self._stream = torch.cuda.Stream(device=x_T.device)
+            self._stream = hip.new_stream(x_T.device)
         cur = torch.cuda.current_stream()
         self._stream.wait_stream(cur)
         with torch.cuda.stream(self._stream):

@@ -171,17 +171,19 @@ _drain_report = {"mode": None, "waited_s": 0.0, "polls": 0}      # the last drai
 
 
 def _active_c10d_works():
-    """number of eager c10d Works the watchdog thread has not retired yet, from c10d's flight recorder (every collective that
-    is handed to the watchdog gets an entry, marked retired in the watchdog pass that reaps it; collectives issued under
-    capture are neither handed over nor recorded).  None when the recorder is off or this torch has no such call."""
+    """number of eager c10d Works the watchdog thread still holds, from c10d's flight recorder: every collective handed to
+    the watchdog has an entry whose `retired` flag is set in the watchdog pass that reaps it (measured: 100 ms after the
+    Work completed on the GPU; `state == completed` -- what the recorder's own `onlyActive` filter looks at -- comes from an
+    event query and says nothing about the watchdog).  Collectives issued under capture are neither handed over nor
+    recorded.  None when the recorder is off or this torch has no such call."""
     import pickle
     try:
-        c = torch._C._distributed_c10d
-        everything = pickle.loads(c._dump_nccl_trace(True, False, False))
-        if not everything.get("entries"):
-            return None                              # recorder off (TORCH_NCCL_TRACE_BUFFER_SIZE=0): nothing to read
-        active = pickle.loads(c._dump_nccl_trace(True, False, True)).get("entries") or []
-        return sum(1 for e in active if not e.get("retired", False))
+        entries = pickle.loads(torch._C._distributed_c10d._dump_nccl_trace(True, False, False)).get("entries")
+        if not entries:
+            return None                              # recorder off (TORCH_FR_BUFFER_SIZE=0): nothing to read
+        if "retired" not in entries[-1]:
+            return None
+        return sum(1 for e in entries if not e["retired"])
     except Exception:
         return None
 
@@ -346,7 +348,7 @@ class HipTrainer:
             self.comp_w = torch.tensor(component_weights(args), dtype=torch.float32, device=dev)
         # hipGraph capture is not allowed on the legacy default stream: the step runs on its own stream,
         # ordered after / before the caller's current stream by events
-        self.stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+        self.stream = hip.new_stream(dev) if dev.type == "cuda" else None
         from .plans import Branch
         self._br_loss = Branch(dev, enabled=not self.overlap_comm, name="loss")
         # data parallel, bucketed: the optimizer runs PER BUCKET on a side stream as soon as that bucket's all-reduce has
@@ -818,7 +820,7 @@ class HipTrainer:
         # events of earlier collectives; an event that sits on a stream WHILE that stream is being captured makes the
         # poll fail and aborts the process.  The capture stream carries no real work, so no such event ever sits on it.
         if self._cap_stream is None and self.device.type == "cuda":
-            self._cap_stream = torch.cuda.Stream(device=self.device)
+            self._cap_stream = hip.new_stream(self.device)
         if self._cap_stream is not None:
             with torch.cuda.stream(self._cap_stream):
                 rec.begin()

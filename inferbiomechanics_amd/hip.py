@@ -167,6 +167,8 @@ _SIGS = {
     "ib_graph_end": (_c.c_int, [_vp, _c.POINTER(_vp)]),
     "ib_graph_launch": (_c.c_int, [_vp, _vp]),
     "ib_graph_destroy": (_c.c_int, [_vp]),
+    "ib_stream_create": (_c.c_int, [_c.POINTER(_vp)]),
+    "ib_stream_destroy": (_c.c_int, [_vp]),
     "ib_event_create": (_c.c_int, [_c.POINTER(_vp)]),
     "ib_event_record": (_c.c_int, [_vp, _vp]),
     "ib_event_elapsed_ms": (_c.c_int, [_vp, _vp, _c.POINTER(_f32)]),
@@ -350,11 +352,51 @@ class record_launches:
         return False
 
 
+_free_streams: dict = {}          # device index -> handles whose torch wrapper has died: handed out again, never destroyed
+
+
+class _OwnedStream:
+    """returns an ib_stream_create handle to the free list when its torch wrapper dies.  Not destroyed: a loop that adopted a
+    trainer's stream (HipTrainer.adopt_stream) may have left it as the thread's CURRENT torch stream beyond the trainer's
+    life -- a destroyed handle there is a segfault at the next launch, a recycled one is just a stream."""
+
+    def __init__(self, ptr, index):
+        self.ptr, self.index = ptr, index
+
+    def __del__(self):
+        try:
+            _free_streams.setdefault(self.index, []).append(self.ptr)
+        except Exception:
+            pass
+
+
+def new_stream(device=None) -> "torch.cuda.Stream":
+    """A stream of the library's own (ib_stream_create), seen by torch as an ExternalStream.  NOT torch.cuda.Stream(): torch
+    hands its streams out round-robin from a pool of 32 per device and c10d's communication stream comes from the same pool,
+    so in a process that has made 32 streams (a few trainers: each has a dozen side branches) a new side branch IS an older
+    stream -- possibly c10d's, which a capture then drags in (the watchdog's event query fails: process abort), or a live
+    plan's branch (silently serialised)."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    free = _free_streams.get(dev.index)
+    if free:
+        ptr = free.pop()
+    else:
+        out = ctypes.c_void_p(0)
+        with torch.cuda.device(dev):
+            _check(lib().ib_stream_create(ctypes.byref(out)), "ib_stream_create")
+        ptr = out.value
+    s = torch.cuda.ExternalStream(ptr, device=dev)
+    s._ib_owner = _OwnedStream(ptr, dev.index)
+    return s
+
+
 def time_recorded_call(name: str, args, reps: int = 20, rounds: int = 3) -> float:
     """average device time (us) of one launch of a recorded call: `reps` launches captured in a graph on a side
     stream, replayed `rounds` times between two HIP events recorded on that stream"""
     fn = getattr(lib(), name)
-    s = torch.cuda.Stream()
+    s = new_stream()
     sp = ctypes.c_void_p(s.cuda_stream)
     a = list(args)
     a[-1] = sp                                   # every entry point takes the stream last

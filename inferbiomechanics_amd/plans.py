@@ -98,7 +98,7 @@ class Branch:
         off = [n for n in TU.no_branch.split(",") if n]
         enabled = enabled and name not in off and "all" not in off
         self.on = enabled and torch.device(device).type == "cuda" and not hip._dry_run
-        self.stream = torch.cuda.Stream(device=device) if self.on else None
+        self.stream = hip.new_stream(device) if self.on else None      # never torch's pool (shared with c10d)
         self._forks: List = []
         self._join = torch.cuda.Event() if self.on else None
         self._n = 0
