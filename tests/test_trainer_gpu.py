@@ -409,6 +409,31 @@ def test_nested_branch_fork_is_refused():
     assert Branch._depth == 0
 
 
+def test_library_streams_are_not_torch_pool_streams():
+    """hip.new_stream(): the side branches / capture stream / trainer stream come from ib_stream_create, not from torch's
+    round-robin pool of 32 streams per device (which c10d's communication stream shares: the 33rd torch stream of a process
+    IS an earlier one); handles of dead wrappers are handed out again, never destroyed"""
+    import gc
+    from inferbiomechanics_amd import hip
+    from inferbiomechanics_amd.plans import Branch
+    pool = {torch.cuda.Stream(device=DEV).cuda_stream for _ in range(40)}
+    assert len(pool) <= 32                                  # the pool wraps: torch.cuda.Stream() aliases after 32
+    mine = [hip.new_stream(DEV) for _ in range(40)]
+    ptrs = [s.cuda_stream for s in mine]
+    assert len(set(ptrs)) == 40 and not (set(ptrs) & pool)
+    b = Branch(DEV, name="t")
+    assert b.stream.cuda_stream not in pool
+    x = torch.zeros(8, device=DEV)
+    with torch.cuda.stream(mine[0]):
+        x.add_(1)
+    mine[0].synchronize()
+    assert float(x.sum()) == 8.0
+    gone = ptrs[-1]
+    del mine[-1]
+    gc.collect()
+    assert hip.new_stream(DEV).cuda_stream == gone          # recycled (a dangling current-stream reference stays valid)
+
+
 _CAPTURE_GUARD = r"""
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, sys.argv[1])
