@@ -431,7 +431,9 @@ def test_library_streams_are_not_torch_pool_streams():
     gone = ptrs[-1]
     del mine[-1]
     gc.collect()
-    assert hip.new_stream(DEV).cuda_stream == gone          # recycled (a dangling current-stream reference stays valid)
+    free = list(hip._free_streams.get(torch.cuda.current_device(), []))
+    assert gone in free                                     # recycled, not destroyed: a dangling current-stream reference
+    assert hip.new_stream(DEV).cuda_stream in free          # stays valid, and the next stream is a recycled one
 
 
 _CAPTURE_GUARD = r"""
