@@ -463,3 +463,65 @@ def test_attention_inside_the_layer_launches_is_chosen_by_shape(dry):
         assert lp.attn_T(12800, 50) == 0
     finally:
         TU.no_attn_fuse = False
+
+
+def test_watchdog_drain_waits_for_the_flight_recorders_retired_flags(monkeypatch):
+    """engine._drain_c10d_watchdog: before a capture with collectives it polls c10d's flight recorder until EVERY recorded
+    Work is `retired` (the watchdog thread has let go of it: `state == completed` is not enough), gives up loudly, and
+    falls back to a timed wait when the recorder is off"""
+    import pickle
+    import time
+    from inferbiomechanics_amd import engine, hip
+    c = torch._C._distributed_c10d
+    calls = {"n": 0}
+
+    def entries(retired_after):
+        def dump(include_collectives=None, include_stack=None, only_active=None):
+            calls["n"] += 1
+            done = calls["n"] > retired_after
+            return pickle.dumps({"entries": [{"record_id": 0, "state": "completed", "retired": True},
+                                             {"record_id": 1, "state": "completed", "retired": done}]})
+        return dump
+    monkeypatch.setattr(c, "_dump_nccl_trace", entries(3), raising=False)
+    engine._drain_c10d_watchdog("cpu")
+    assert engine._drain_report["mode"] == "flight-recorder" and engine._drain_report["polls"] == 4 and calls["n"] == 4
+    # a Work the watchdog never lets go of: an error that names the way out, not a capture beside it
+    calls["n"] = 0
+    monkeypatch.setattr(c, "_dump_nccl_trace", entries(10 ** 9), raising=False)
+    with pytest.raises(hip.HipError, match="IB_GRAPH_COLLECTIVES=0"):
+        engine._drain_c10d_watchdog("cpu", timeout_s=0.05)
+    # recorder off (no entries) / a torch without the `retired` field: several watchdog periods of plain waiting
+    slept = []
+    monkeypatch.setattr(time, "sleep", lambda s: slept.append(s))
+    monkeypatch.setattr(c, "_dump_nccl_trace", lambda *a: pickle.dumps({"entries": []}), raising=False)
+    engine._drain_c10d_watchdog("cpu")
+    assert engine._drain_report["mode"] == "sleep" and slept and max(slept) >= 0.5
+    monkeypatch.setattr(c, "_dump_nccl_trace", lambda *a: pickle.dumps({"entries": [{"record_id": 0, "state": "completed"}]}),
+                        raising=False)
+    engine._drain_c10d_watchdog("cpu")
+    assert engine._drain_report["mode"] == "sleep"
+
+
+def test_sampler_row_split_rule():
+    """plans.DenoiserTransformerPlan.side_windows: the windows beyond the fused launch's last FULL round of 256 panels take
+    the per-op side stack when that round would fill at most 96 CUs (frozen bf16 weights, d = 512, >= 8193 rows)"""
+    from inferbiomechanics_amd import plans
+
+    class _On:
+        on = True
+    p = plans.DenoiserTransformerPlan.__new__(plans.DenoiserTransformerPlan)
+    p.inference, p.dtype, p.d, p.br_side = True, torch.bfloat16, 512, _On()
+
+    class _L:
+        infer_packed = True
+    p.layers = [_L(), _L()]
+    assert p.side_windows(256, 200) == 11          # 800 panels = 3 rounds + 32: windows 245 ... 255
+    assert p.side_windows(90, 200) == 9 and p.side_windows(84, 200) == 3
+    assert p.side_windows(128, 200) == 0           # 400 panels: the second round is 144 panels wide
+    assert p.side_windows(120, 200) == 0           # 119 panels: measured -3.4 %
+    assert p.side_windows(110, 200) == 29          # 88 panels: measured +4.7 %
+    assert p.side_windows(256, 50) == 0 and p.side_windows(16, 200) == 0           # one round / below the fused launch
+    p.inference = False
+    assert p.side_windows(256, 200) == 0
+    p.inference, p.dtype = True, torch.float32
+    assert p.side_windows(256, 200) == 0
